@@ -1,0 +1,133 @@
+/*
+ * perseus_ddc.h -- thin C ABI over the MI355X (gfx950) I/Q ingest + decimation
+ * kernels.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * What each entry point stands in for in the reference (libperseus-sdr):
+ *
+ *   pddc_unpack24_f32      examples/perseustest.c:466-502  user_data_callback_c_f
+ *   pddc_unpack24_i32      examples/perseustest.c:432-460  user_data_callback_c_u
+ *                          (dup. examples/simple.c:33-61)
+ *   pddc_nco_freg          perseus-sdr.c:584   tuning word written to the FPGA
+ *   pddc_pipeline_*        the FPGA DDC itself (NCO mix + decimating FIR chain)
+ *                          that perseus_set_sampling_rate() selects by bitstream
+ *                          (perseus-sdr.c:776-867) and perseus_set_ddc_center_freq()
+ *                          tunes (perseus-sdr.c:556-619); no software model of it
+ *                          exists in the reference, so its arithmetic is defined
+ *                          by oracle/perseus_oracle.c.
+ *   pddc_pipeline_push_host   what perseus-in.c:206-207 hands to the client
+ *                          callback, batched (see perseus-sdr.h in this directory
+ *                          for the drop-in callback API built on top of this).
+ *
+ * Sample formats
+ *   packed : 6 bytes / complex sample, I0 I1 I2 Q0 Q1 Q2, 24-bit two's
+ *            complement little endian (examples/perseustest.c:449-455)
+ *   f32    : interleaved float32 I,Q  (8 bytes / sample), range [-1.00000012, 1]
+ *   i32    : interleaved int32 I,Q, MSB aligned (multiples of 256)
+ *
+ * All functions return PDDC_OK (0) or a negative PDDC_E* code, and set a
+ * thread-local message readable through pddc_last_error().  There is NO CPU
+ * fallback: without a usable HIP device every compute entry point fails with
+ * PDDC_ENODEV.
+ *
+ * "d_" pointers are device (HBM) addresses, "h_" pointers host addresses.
+ * `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ */
+#ifndef PERSEUS_DDC_H
+#define PERSEUS_DDC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDDC_OK          0
+#define PDDC_EINVAL     -1   /* bad argument (size, alignment, NULL)          */
+#define PDDC_ENODEV     -2   /* no HIP device / device index out of range      */
+#define PDDC_EHIP       -3   /* a HIP runtime call failed                      */
+#define PDDC_ENOMEM     -4   /* allocation failed                              */
+#define PDDC_ECAPACITY  -5   /* output buffer too small                        */
+#define PDDC_ESTATE     -6   /* call not valid in the pipeline's current state */
+
+#define PDDC_ADC_CLK_HZ        80000000.0   /* perseus-sdr.h:44 */
+#define PDDC_MAX_STAGES        4
+#define PDDC_MAX_TAPS          1024
+#define PDDC_FAST_MAX_TAPS     256          /* fused decimate-by-8 kernel      */
+#define PDDC_PACKED_BYTES      6
+#define PDDC_INPUT_GRANULE     8            /* process(): nsamples % 8 == 0    */
+
+/* pipeline flags */
+#define PDDC_F_MIX         0x1u   /* NCO complex mix before stage 0            */
+#define PDDC_F_TAPS_FP16   0x2u   /* round taps to fp16 storage (config 5)     */
+#define PDDC_F_NO_FAST     0x4u   /* force the generic kernels (testing)       */
+
+typedef struct pddc_pipeline pddc_pipeline;
+
+typedef struct {
+    int          decim;    /* decimation factor D >= 1                         */
+    int          ntaps;    /* 1 .. PDDC_MAX_TAPS                               */
+    const float *taps;     /* h[0..ntaps-1], host memory, copied               */
+} pddc_stage_desc;
+
+/* ---- library ------------------------------------------------------------ */
+int         pddc_version(void);
+const char *pddc_last_error(void);
+int         pddc_device_count(void);                 /* >= 0, or PDDC_E*      */
+
+/* ---- tuning word (perseus-sdr.c:584) ------------------------------------ */
+uint32_t    pddc_nco_freg(double center_freq_hz, double adc_clk_hz);
+
+/* ---- stateless kernels on device-resident buffers ------------------------ */
+/* d_packed must be 16-byte aligned; nsamples may be any value >= 0.          */
+int pddc_unpack24_f32(const void *d_packed, size_t nsamples, void *d_out_f32, void *stream);
+int pddc_unpack24_i32(const void *d_packed, size_t nsamples, void *d_out_i32, void *stream);
+/* synthetic source of BASELINE.md section 3: byte k of the LCG stream
+ * s=s*1664525+1013904223, byte=s>>24, starting `byte_offset` bytes in.        */
+int pddc_synth_lcg(void *d_dst, size_t nbytes, uint32_t seed, uint64_t byte_offset, void *stream);
+
+/* ---- device memory helpers for C hosts (tests/bench use torch instead) ---- */
+int pddc_set_device(int device);
+int pddc_malloc(void **d_ptr, size_t nbytes);
+int pddc_free(void *d_ptr);
+int pddc_memcpy_h2d(void *d_dst, const void *h_src, size_t nbytes, void *stream);
+int pddc_memcpy_d2h(void *h_dst, const void *d_src, size_t nbytes, void *stream);
+int pddc_stream_sync(void *stream);
+
+/* ---- DDC pipeline: [NCO mix] -> stage 0 -> ... -> stage n-1 --------------- */
+int pddc_pipeline_create(pddc_pipeline **out, int device,
+                         const pddc_stage_desc *stages, int nstages, uint32_t flags);
+int pddc_pipeline_destroy(pddc_pipeline *p);
+/* zero FIR histories, decimation phases and the NCO sample counter            */
+int pddc_pipeline_reset(pddc_pipeline *p);
+int pddc_pipeline_set_freg(pddc_pipeline *p, uint32_t freg);
+int pddc_pipeline_set_center_freq(pddc_pipeline *p, double center_freq_hz);
+int pddc_pipeline_set_taps(pddc_pipeline *p, int stage, const float *taps, int ntaps);
+uint32_t pddc_pipeline_get_freg(const pddc_pipeline *p);
+int pddc_pipeline_total_decim(const pddc_pipeline *p);
+/* upper bound of outputs a process() of nsamples_in can produce               */
+size_t pddc_pipeline_max_output(const pddc_pipeline *p, size_t nsamples_in);
+/* 1 if stage 0 runs the fused unpack+mix+polyphase kernel for this geometry   */
+int pddc_pipeline_uses_fused(const pddc_pipeline *p);
+
+/* Device-resident batch: d_packed (16-byte aligned, nsamples % 8 == 0) ->
+ * d_out_f32 (16-byte aligned, capacity in complex samples).  Asynchronous on
+ * `stream`; *n_out (host) is written before return (it depends only on sizes).
+ * Stream state (FIR history, phase, NCO counter) advances by nsamples.        */
+int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsamples,
+                          void *d_out_f32, size_t out_capacity, size_t *n_out, void *stream);
+/* Host batch: H2D copy, process, D2H copy, synchronous.                        */
+int pddc_pipeline_push_host(pddc_pipeline *p, const void *h_packed, size_t nsamples,
+                            void *h_out_f32, size_t out_capacity, size_t *n_out);
+
+/* ---- measurement hooks (bench.py) ----------------------------------------- */
+/* Times `iters` back-to-back launches of the pipeline's stage-0 kernel alone
+ * with HIP events on `stream`; returns average milliseconds per launch.
+ * State is not advanced (history taken as is).                                 */
+int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsamples,
+                              void *d_out_f32, int iters, void *stream, float *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PERSEUS_DDC_H */

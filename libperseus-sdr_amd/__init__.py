@@ -1,0 +1,221 @@
+"""libperseus-sdr_amd -- MI355X-native I/Q ingest + decimation path behind the
+libperseus-sdr API.
+
+This package is only a loader: the product is two C-ABI shared libraries built
+from csrc/ (hand-written HIP for gfx950 + plain C host code):
+
+  libperseus_ddc.so   include/perseus_ddc.h   kernels + stream pipeline
+  libperseus-sdr.so   include/perseus-sdr.h   drop-in perseus_* callback API
+
+Python (ctypes) is used by tests/ and bench.py to drive them; torch only
+supplies device memory, streams and torch.distributed.  The hyphen in the
+package name follows the reference repo's name, so import it with
+importlib.import_module("libperseus-sdr_amd").
+
+There is no CPU fallback anywhere in this package: if the HIP library is not
+built, loading raises; if no GPU is present, compute entry points return
+PDDC_ENODEV and the wrappers raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+DDC_LIB = os.path.join(_HERE, "libperseus_ddc.so")
+SDR_LIB = os.path.join(_HERE, "libperseus-sdr.so")
+
+PDDC_OK, PDDC_EINVAL, PDDC_ENODEV, PDDC_EHIP, PDDC_ENOMEM, PDDC_ECAPACITY, PDDC_ESTATE = 0, -1, -2, -3, -4, -5, -6
+PDDC_F_MIX, PDDC_F_TAPS_FP16, PDDC_F_NO_FAST = 1, 2, 4
+
+
+class PddcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pddc error {code}: {msg}")
+        self.code = code
+
+
+def build(verbose: bool = False) -> None:
+    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "all"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+
+
+class StageDesc(C.Structure):
+    _fields_ = [("decim", C.c_int), ("ntaps", C.c_int), ("taps", C.POINTER(C.c_float))]
+
+
+_ddc = None
+
+
+def ddc_lib() -> C.CDLL:
+    """Load libperseus_ddc.so; raises if it has not been built."""
+    global _ddc
+    if _ddc is not None:
+        return _ddc
+    if not os.path.exists(DDC_LIB):
+        raise FileNotFoundError(
+            f"{DDC_LIB} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+    try:
+        # torch bundles its own libamdhip64.so.7; load it first so that this
+        # process holds ONE HIP runtime and torch streams/pointers are valid here
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(DDC_LIB)
+    vp, sz = C.c_void_p, C.c_size_t
+    L.pddc_version.restype = C.c_int
+    L.pddc_last_error.restype = C.c_char_p
+    L.pddc_device_count.restype = C.c_int
+    L.pddc_nco_freg.argtypes = [C.c_double, C.c_double]
+    L.pddc_nco_freg.restype = C.c_uint32
+    L.pddc_unpack24_f32.argtypes = [vp, sz, vp, vp]
+    L.pddc_unpack24_i32.argtypes = [vp, sz, vp, vp]
+    L.pddc_synth_lcg.argtypes = [vp, sz, C.c_uint32, C.c_uint64, vp]
+    L.pddc_set_device.argtypes = [C.c_int]
+    L.pddc_malloc.argtypes = [C.POINTER(vp), sz]
+    L.pddc_free.argtypes = [vp]
+    L.pddc_memcpy_h2d.argtypes = [vp, vp, sz, vp]
+    L.pddc_memcpy_d2h.argtypes = [vp, vp, sz, vp]
+    L.pddc_stream_sync.argtypes = [vp]
+    L.pddc_pipeline_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(StageDesc), C.c_int, C.c_uint32]
+    L.pddc_pipeline_destroy.argtypes = [vp]
+    L.pddc_pipeline_reset.argtypes = [vp]
+    L.pddc_pipeline_set_freg.argtypes = [vp, C.c_uint32]
+    L.pddc_pipeline_set_center_freq.argtypes = [vp, C.c_double]
+    L.pddc_pipeline_set_taps.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int]
+    L.pddc_pipeline_get_freg.argtypes = [vp]
+    L.pddc_pipeline_get_freg.restype = C.c_uint32
+    L.pddc_pipeline_total_decim.argtypes = [vp]
+    L.pddc_pipeline_max_output.argtypes = [vp, sz]
+    L.pddc_pipeline_max_output.restype = sz
+    L.pddc_pipeline_uses_fused.argtypes = [vp]
+    L.pddc_pipeline_process.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp]
+    L.pddc_pipeline_push_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.pddc_pipeline_time_stage0.argtypes = [vp, vp, sz, vp, C.c_int, vp, C.POINTER(C.c_float)]
+    for name in ("pddc_unpack24_f32", "pddc_unpack24_i32", "pddc_synth_lcg", "pddc_set_device",
+                 "pddc_malloc", "pddc_free", "pddc_memcpy_h2d", "pddc_memcpy_d2h", "pddc_stream_sync",
+                 "pddc_pipeline_create", "pddc_pipeline_destroy", "pddc_pipeline_reset",
+                 "pddc_pipeline_set_freg", "pddc_pipeline_set_center_freq", "pddc_pipeline_set_taps",
+                 "pddc_pipeline_total_decim", "pddc_pipeline_uses_fused", "pddc_pipeline_process",
+                 "pddc_pipeline_push_host", "pddc_pipeline_time_stage0"):
+        getattr(L, name).restype = C.c_int
+    _ddc = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise PddcError(rc, ddc_lib().pddc_last_error().decode(errors="replace"))
+    return rc
+
+
+class Pipeline:
+    """Thin handle over pddc_pipeline_* (include/perseus_ddc.h)."""
+
+    def __init__(self, stages, device: int = 0, mix: bool = False, taps_fp16: bool = False,
+                 no_fast: bool = False):
+        import numpy as np
+        L = ddc_lib()
+        self._taps = [np.ascontiguousarray(h, dtype=np.float32) for _, h in stages]
+        arr = (StageDesc * len(stages))()
+        for i, (d, _) in enumerate(stages):
+            arr[i].decim = int(d)
+            arr[i].ntaps = int(self._taps[i].size)
+            arr[i].taps = self._taps[i].ctypes.data_as(C.POINTER(C.c_float))
+        flags = (PDDC_F_MIX if mix else 0) | (PDDC_F_TAPS_FP16 if taps_fp16 else 0) | \
+                (PDDC_F_NO_FAST if no_fast else 0)
+        h = C.c_void_p()
+        check(L.pddc_pipeline_create(C.byref(h), device, arr, len(stages), flags))
+        self._h = h
+        self.decim = L.pddc_pipeline_total_decim(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            ddc_lib().pddc_pipeline_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self):
+        check(ddc_lib().pddc_pipeline_reset(self._h))
+
+    def set_freg(self, freg: int):
+        check(ddc_lib().pddc_pipeline_set_freg(self._h, freg & 0xFFFFFFFF))
+
+    def set_center_freq(self, hz: float):
+        check(ddc_lib().pddc_pipeline_set_center_freq(self._h, float(hz)))
+
+    @property
+    def freg(self) -> int:
+        return int(ddc_lib().pddc_pipeline_get_freg(self._h))
+
+    @property
+    def fused(self) -> bool:
+        return bool(ddc_lib().pddc_pipeline_uses_fused(self._h))
+
+    def max_output(self, n: int) -> int:
+        return int(ddc_lib().pddc_pipeline_max_output(self._h, n))
+
+    def process_ptr(self, d_in: int, nsamples: int, d_out: int, out_cap: int, stream: int = 0) -> int:
+        n = C.c_size_t(0)
+        check(ddc_lib().pddc_pipeline_process(self._h, d_in, nsamples, d_out, out_cap, C.byref(n), stream))
+        return n.value
+
+    def process(self, packed_u8, out_f32=None, stream=None):
+        """packed_u8: torch uint8 CUDA tensor; returns torch float32 tensor [n_out, 2]."""
+        import torch
+        ns = packed_u8.numel() // 6
+        cap = self.max_output(ns) + 1
+        if out_f32 is None:
+            out_f32 = torch.empty((cap, 2), dtype=torch.float32, device=packed_u8.device)
+        st = stream if stream is not None else torch.cuda.current_stream(packed_u8.device).cuda_stream
+        n = self.process_ptr(packed_u8.data_ptr(), ns, out_f32.data_ptr(), out_f32.numel() // 2, st)
+        return out_f32[:n]
+
+    def push_host(self, packed_np):
+        import numpy as np
+        b = np.ascontiguousarray(packed_np, dtype=np.uint8)
+        ns = b.size // 6
+        cap = self.max_output(ns) + 1
+        out = np.empty((cap, 2), dtype=np.float32)
+        n = C.c_size_t(0)
+        check(ddc_lib().pddc_pipeline_push_host(self._h, b.ctypes.data, ns, out.ctypes.data, cap, C.byref(n)))
+        return out[:n.value]
+
+    def time_stage0(self, d_in: int, nsamples: int, d_out: int, iters: int, stream: int = 0) -> float:
+        ms = C.c_float(0)
+        check(ddc_lib().pddc_pipeline_time_stage0(self._h, d_in, nsamples, d_out, iters, stream, C.byref(ms)))
+        return float(ms.value)
+
+
+def unpack24_f32(packed_u8, stream=None):
+    """torch uint8 CUDA tensor -> float32 [ns, 2] via the HIP kernel."""
+    import torch
+    ns = packed_u8.numel() // 6
+    out = torch.empty((ns, 2), dtype=torch.float32, device=packed_u8.device)
+    st = stream if stream is not None else torch.cuda.current_stream(packed_u8.device).cuda_stream
+    check(ddc_lib().pddc_unpack24_f32(packed_u8.data_ptr(), ns, out.data_ptr(), st))
+    return out
+
+
+def unpack24_i32(packed_u8, stream=None):
+    import torch
+    ns = packed_u8.numel() // 6
+    out = torch.empty((ns, 2), dtype=torch.int32, device=packed_u8.device)
+    st = stream if stream is not None else torch.cuda.current_stream(packed_u8.device).cuda_stream
+    check(ddc_lib().pddc_unpack24_i32(packed_u8.data_ptr(), ns, out.data_ptr(), st))
+    return out
+
+
+def synth_lcg(nbytes: int, seed: int = 12345, byte_offset: int = 0, device="cuda:0", stream=None):
+    import torch
+    out = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    st = stream if stream is not None else torch.cuda.current_stream(out.device).cuda_stream
+    check(ddc_lib().pddc_synth_lcg(out.data_ptr(), nbytes, seed & 0xFFFFFFFF, byte_offset, st))
+    return out

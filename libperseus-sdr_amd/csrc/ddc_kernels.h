@@ -1,0 +1,55 @@
+/*
+ * ddc_kernels.h -- internal launch interface between the host-side pipeline
+ * (ddc_pipeline.cpp) and the gfx950 kernels (ddc_kernels.hip).
+ * Not part of the public ABI (that is include/perseus_ddc.h).
+ */
+#ifndef PDDC_DDC_KERNELS_H
+#define PDDC_DDC_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pddc {
+
+enum InFmt { IN_PACKED24 = 0, IN_F32C = 1 };
+
+/* arguments of the fused decimate-by-8 kernel (k_fir8) */
+struct Fir8Args {
+    const void *in;          /* batch start: packed bytes or float2            */
+    const void *hist;        /* 8*ntb samples that precede the batch           */
+    float      *out;         /* float2 outputs                                 */
+    const float *taps_blk;   /* [ntb][8] block-reversed taps (device)          */
+    long long   n_in;        /* samples in the batch, multiple of 8            */
+    unsigned long long n0;   /* absolute index of batch sample 0 (NCO phase)   */
+    uint32_t    freg;        /* NCO tuning word                                */
+    float       lo_c[8];     /* cos/sin of step e*freg, e=0..7 (host, double)  */
+    float       lo_s[8];
+};
+
+/* tile geometry of k_fir8<NTB,R>: inputs per block tile */
+constexpr int fir8_tile_inputs(int R) { return 1024 * R; }
+size_t fir8_lds_bytes(int ntb, int R);
+bool   fir8_supported(int ntb, int R);
+
+/* returns hipSuccess or the launch error */
+hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s);
+
+hipError_t launch_unpack24(const void *d_in, long long nsamples, void *d_out, bool to_i32,
+                           bool mix, unsigned long long n0, uint32_t freg,
+                           const float *lo_c, const float *lo_s, hipStream_t s);
+
+/* generic decimating FIR on float2: out[q] = sum_k h[k]*x[first + q*D - k],
+ * x indexed relative to `in`, valid down to in[-(ntaps-1)] (history is
+ * contiguous in front of the batch). */
+hipError_t launch_fir_generic(const float *in, long long first, long long n_out, int D,
+                              const float *taps, int ntaps, float *out, hipStream_t s);
+
+/* new_hist = last H elements of [hist(H) | batch(n)], elem_bytes each (H*elem_bytes <= 16 KiB) */
+hipError_t launch_hist_update(void *hist, int H, const void *batch, long long n, int elem_bytes,
+                              hipStream_t s);
+
+hipError_t launch_synth_lcg(void *dst, size_t nbytes, uint32_t seed, uint64_t byte_offset,
+                            hipStream_t s);
+
+} // namespace pddc
+#endif

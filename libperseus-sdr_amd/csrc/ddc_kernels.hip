@@ -1,0 +1,636 @@
+/*
+ * ddc_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the I/Q ingest +
+ * decimation hot path.  Written for wave64 / 160 KiB LDS / HBM3E directly;
+ * there is no other target.
+ *
+ *   k_unpack24   24-bit packed I/Q -> float32 (or MSB-aligned int32), optional
+ *                NCO mix.  Bit-exact restatement of the reference client
+ *                callbacks (examples/perseustest.c:432-502): float =
+ *                (float)(v24*256) / 2147483392.0f == (float)v24 * RN(1/8388607),
+ *                one v_cvt + one v_mul (exhaustively equal).
+ *   k_fir8       fused  unpack -> [NCO mix] -> polyphase decimate-by-8 FIR.
+ *                The 8 B/sample float intermediate never touches HBM:
+ *                algorithmic traffic 6 B in + 1 B out per input sample.
+ *   k_fir_generic  any-D decimating FIR on float2 (later cascade stages).
+ *   k_hist_update  carries the FIR history between batches.
+ *   k_synth_lcg    device-side synthetic source.
+ *
+ * k_fir8 design (DESIGN.md "Kernels"):
+ *   - block = 256 threads = 4 waves; tile = 1024*R input samples (+8*NTB halo)
+ *   - load phase: every thread pulls whole 48-byte groups (8 samples) with
+ *     3x global_load_dwordx4, unpacks in registers (v_bfe_i32 / v_alignbit),
+ *     optionally mixes with the NCO, and writes PLANAR I / Q floats to LDS,
+ *     rotated by one sample so that FIR windows are 16-byte aligned
+ *   - FIR phase: waves 0,2 filter the I plane, waves 1,3 the Q plane; each
+ *     lane owns R consecutive outputs (a register sliding window over
+ *     R+NTB-1 aligned 8-sample LDS groups, 2x ds_read_b128 each, conflict
+ *     free through a 4-float pad per lane segment); taps are wave-uniform and
+ *     come through the scalar cache into SGPRs (s_load), so an FMA costs one
+ *     VALU slot and no VGPR/LDS traffic for the coefficient
+ *   - store phase: results are transposed through LDS (XOR-swizzled 16-byte
+ *     chunks) into interleaved float2 and leave as coalesced dwordx4 stores
+ *   No MFMA: 9 flop/B, a memory-bound stream (BASELINE.json north_star).
+ */
+#include "ddc_kernels.h"
+
+#define PDDC_CONSTANT __attribute__((address_space(4)))
+
+namespace pddc {
+
+static constexpr float kUnpackScale = 0x1.000002p-23f;   /* RN(1/8388607) */
+
+/* ------------------------------------------------------------------------ */
+/* 12 dwords (48 bytes) = 8 packed samples -> sign-extended 24-bit integers  */
+__device__ __forceinline__ void unpack8_i24(const uint32_t (&w)[12], int32_t (&I)[8], int32_t (&Q)[8])
+{
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const uint32_t a = w[3 * h], b = w[3 * h + 1], c = w[3 * h + 2];
+        I[2 * h]     = ((int32_t)(a << 8)) >> 8;                                        /* bytes 0..2  */
+        Q[2 * h]     = ((int32_t)(__builtin_amdgcn_alignbit(b, a, 24) << 8)) >> 8;      /* bytes 3..5  */
+        I[2 * h + 1] = ((int32_t)(__builtin_amdgcn_alignbit(c, b, 16) << 8)) >> 8;      /* bytes 6..8  */
+        Q[2 * h + 1] = ((int32_t)c) >> 8;                                               /* bytes 9..11 */
+    }
+}
+
+/* exp(-j*2*pi*phase/2^32) from the exact 32-bit phase: quadrant reduction in
+ * integers, then minimax polynomials on [-pi/4, pi/4] (abs error < 1e-7). */
+__device__ __forceinline__ void nco_lo(uint32_t phase, float &c, float &s)
+{
+    const uint32_t q = (phase + 0x20000000u) >> 30;
+    const int32_t  r = (int32_t)(phase - (q << 30));
+    const float t  = (float)r * 1.4629180792671596e-9f;          /* pi / 2^31 */
+    const float t2 = t * t;
+    float sn = fmaf(t2, fmaf(t2, fmaf(t2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), 0.0f);
+    sn = fmaf(sn, t, t);
+    float cs = fmaf(t2, fmaf(t2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
+    cs = fmaf(t2 * t2, cs, fmaf(t2, -0.5f, 1.0f));
+    float cc, ss;
+    switch (q & 3u) {
+    case 0:  cc = cs;  ss = sn;  break;
+    case 1:  cc = -sn; ss = cs;  break;
+    case 2:  cc = -cs; ss = -sn; break;
+    default: cc = sn;  ss = -cs; break;
+    }
+    c = cc;
+    s = -ss;     /* exp(-j theta) */
+}
+
+/* mix 8 consecutive samples starting at absolute index nabs */
+template <typename P>
+__device__ __forceinline__ void mix8(float (&xi)[8], float (&xq)[8], unsigned long long nabs, const P &p)
+{
+    float cb, sb;
+    nco_lo((uint32_t)nabs * p.freg, cb, sb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        /* LO(nabs+e) = LO(nabs) * step[e] */
+        const float c = cb * p.lo_c[e] - sb * p.lo_s[e];
+        const float s = cb * p.lo_s[e] + sb * p.lo_c[e];
+        const float r = xi[e] * c - xq[e] * s;
+        const float i = xi[e] * s + xq[e] * c;
+        xi[e] = r;
+        xq[e] = i;
+    }
+}
+
+/* ======================================================================== */
+/* k_unpack24                                                               */
+/* ======================================================================== */
+struct UnpackArgs {
+    const uint8_t *in;
+    void          *out;
+    long long      ns;
+    unsigned long long n0;
+    uint32_t       freg;
+    float          lo_c[8];
+    float          lo_s[8];
+};
+
+template <bool TO_I32, bool MIX>
+__global__ __launch_bounds__(256) void k_unpack24(UnpackArgs p)
+{
+    const long long ngroups = (p.ns + 7) >> 3;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < ngroups;
+         g += (long long)gridDim.x * 256) {
+        const long long s0 = g << 3;
+        uint32_t w[12];
+        if (s0 + 8 <= p.ns) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.in + s0 * 6);
+            const uint4 a = src[0], b = src[1], c = src[2];
+            w[0] = a.x; w[1] = a.y; w[2] = a.z;  w[3] = a.w;
+            w[4] = b.x; w[5] = b.y; w[6] = b.z;  w[7] = b.w;
+            w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+        } else {            /* ragged tail: byte loads, zero fill */
+            const long long nb = (p.ns - s0) * 6;
+#pragma unroll
+            for (int d = 0; d < 12; ++d) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (4 * d + b < nb)
+                        v |= (uint32_t)p.in[s0 * 6 + 4 * d + b] << (8 * b);
+                w[d] = v;
+            }
+        }
+        int32_t I[8], Q[8];
+        unpack8_i24(w, I, Q);
+        uint32_t o[16];
+        if (TO_I32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[2 * e]     = (uint32_t)I[e] << 8;
+                o[2 * e + 1] = (uint32_t)Q[e] << 8;
+            }
+        } else {
+            float xi[8], xq[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xi[e] = (float)I[e] * kUnpackScale;
+                xq[e] = (float)Q[e] * kUnpackScale;
+            }
+            if (MIX)
+                mix8(xi, xq, p.n0 + (unsigned long long)s0, p);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[2 * e]     = __float_as_uint(xi[e]);
+                o[2 * e + 1] = __float_as_uint(xq[e]);
+            }
+        }
+        uint32_t *dst = reinterpret_cast<uint32_t *>(p.out) + s0 * 2;
+        if (s0 + 8 <= p.ns) {
+            uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                d4[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+        } else {
+            const int rem = (int)(p.ns - s0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < rem) {
+                    dst[2 * e]     = o[2 * e];
+                    dst[2 * e + 1] = o[2 * e + 1];
+                }
+        }
+    }
+}
+
+hipError_t launch_unpack24(const void *d_in, long long ns, void *d_out, bool to_i32, bool mix,
+                           unsigned long long n0, uint32_t freg, const float *lo_c,
+                           const float *lo_s, hipStream_t s)
+{
+    if (ns <= 0)
+        return hipSuccess;
+    UnpackArgs a;
+    a.in = static_cast<const uint8_t *>(d_in);
+    a.out = d_out;
+    a.ns = ns;
+    a.n0 = n0;
+    a.freg = freg;
+    for (int e = 0; e < 8; ++e) {
+        a.lo_c[e] = lo_c ? lo_c[e] : 1.0f;
+        a.lo_s[e] = lo_s ? lo_s[e] : 0.0f;
+    }
+    const long long ngroups = (ns + 7) >> 3;
+    long long blocks = (ngroups + 255) / 256;
+    if (blocks > 256 * 16)
+        blocks = 256 * 16;
+    const dim3 grid((unsigned)blocks), blk(256);
+    if (to_i32)
+        hipLaunchKernelGGL((k_unpack24<true, false>), grid, blk, 0, s, a);
+    else if (mix)
+        hipLaunchKernelGGL((k_unpack24<false, true>), grid, blk, 0, s, a);
+    else
+        hipLaunchKernelGGL((k_unpack24<false, false>), grid, blk, 0, s, a);
+    return hipGetLastError();
+}
+
+/* ======================================================================== */
+/* k_fir8 : fused unpack + mix + polyphase decimate-by-8                    */
+/* ======================================================================== */
+/* LDS plane layout: group G (8 samples) lives at float offset
+ *   goff(G) = 8 + 8*G + 4*(G/R)      (G >= 0),   group -1 at offset 0.
+ * Sample position p = i + 8*NTB - 1 (i = input index relative to the tile),
+ * group = p >> 3, slot = p & 7: the one-sample rotation puts the window
+ * x[8m-7 .. 8m] of every output m into ONE aligned group.
+ * The 4-float pad every R groups makes the lane stride of the FIR reads
+ * 8R+4 floats = 4 (mod 8) banks-of-4: conflict-free ds_read_b128.            */
+template <int R>
+__device__ __forceinline__ int goff(int G)
+{
+    return 8 + 8 * G + 4 * (G / R);
+}
+
+template <int NTB, int R>
+struct Fir8Geom {
+    static constexpr int TI      = 1024 * R;            /* inputs per tile          */
+    static constexpr int TO      = 128 * R;             /* outputs per tile         */
+    static constexpr int NG      = TI / 8 + NTB;        /* groups incl. history     */
+    static constexpr int PLANE   = 8 + 8 * NG + 4 * (NG / R) + 8;   /* floats      */
+    static constexpr int LDS_FLT = 2 * PLANE;
+};
+
+size_t fir8_lds_bytes(int ntb, int R)
+{
+    const int NG = 1024 * R / 8 + ntb;
+    const int plane = 8 + 8 * NG + 4 * (NG / R) + 8;
+    return (size_t)2 * plane * sizeof(float);
+}
+
+template <int NTB, int R, int INFMT, bool MIX>
+__global__ __launch_bounds__(256) void k_fir8(Fir8Args p)
+{
+    using G = Fir8Geom<NTB, R>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sI = smem;
+    float *sQ = smem + G::PLANE;
+
+    const int tid = threadIdx.x;
+    const long long tile_in0 = (long long)blockIdx.x * G::TI;      /* first input of the tile */
+
+    /* ---------------- load phase: groups v = 0 .. NG-1 -------------------- */
+    /* group v holds inputs i = 8v - 8*NTB + e (e=0..7) relative to the tile.
+     * All global loads of the thread are issued before the first unpack so
+     * that one HBM latency covers the whole tile (NITER groups in flight).   */
+    constexpr int NITER = (G::NG + 255) / 256;
+    constexpr int NW    = (INFMT == IN_PACKED24) ? 3 : 4;          /* 16-byte words per group */
+    uint4 raw[NITER][NW];
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+        const int v = tid + 256 * it;
+        const long long s_abs = tile_in0 + 8LL * v - 8 * NTB;      /* relative to batch start */
+        const bool have = (v < G::NG) && (s_abs < p.n_in);
+        constexpr int ES = (INFMT == IN_PACKED24) ? 6 : 8;         /* bytes per sample */
+        const uint8_t *src = (s_abs < 0)
+                                 ? static_cast<const uint8_t *>(p.hist) + (s_abs + 8 * NTB) * ES
+                                 : static_cast<const uint8_t *>(p.in) + s_abs * ES;
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+            raw[it][k] = have ? reinterpret_cast<const uint4 *>(src)[k] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+        const int v = tid + 256 * it;
+        if (v < G::NG) {
+            const long long s_abs = tile_in0 + 8LL * v - 8 * NTB;
+            float xi[8], xq[8];
+            if (INFMT == IN_PACKED24) {
+                const uint32_t w[12] = { raw[it][0].x, raw[it][0].y, raw[it][0].z, raw[it][0].w,
+                                         raw[it][1].x, raw[it][1].y, raw[it][1].z, raw[it][1].w,
+                                         raw[it][2].x, raw[it][2].y, raw[it][2].z, raw[it][2].w };
+                int32_t I[8], Q[8];
+                unpack8_i24(w, I, Q);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xi[e] = (float)I[e] * kUnpackScale;
+                    xq[e] = (float)Q[e] * kUnpackScale;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint4 f = raw[it][k < NW ? k : 0];
+                    xi[2 * k]     = __uint_as_float(f.x);
+                    xq[2 * k]     = __uint_as_float(f.y);
+                    xi[2 * k + 1] = __uint_as_float(f.z);
+                    xq[2 * k + 1] = __uint_as_float(f.w);
+                }
+            }
+            if (MIX)     /* zero-filled groups stay zero; index wraps correctly for s_abs<0 */
+                mix8(xi, xq, p.n0 + (unsigned long long)s_abs, p);
+            /* rotated write: e=0 -> slot 7 of group v-1 ; e=1..7 -> slots 0..6 of group v */
+            const int o_prev = (v == 0) ? 7 : goff<R>(v - 1) + 7;
+            const int o_cur  = goff<R>(v);
+            sI[o_prev] = xi[0];
+            sQ[o_prev] = xq[0];
+            *reinterpret_cast<float4 *>(sI + o_cur) = make_float4(xi[1], xi[2], xi[3], xi[4]);
+            *reinterpret_cast<float4 *>(sQ + o_cur) = make_float4(xq[1], xq[2], xq[3], xq[4]);
+            *reinterpret_cast<float2 *>(sI + o_cur + 4) = make_float2(xi[5], xi[6]);
+            *reinterpret_cast<float2 *>(sQ + o_cur + 4) = make_float2(xq[5], xq[6]);
+            sI[o_cur + 6] = xi[7];
+            sQ[o_cur + 6] = xq[7];
+        }
+    }
+    __syncthreads();
+
+    /* ---------------- FIR phase ------------------------------------------ */
+    const int wave  = tid >> 6;
+    const int lane  = tid & 63;
+    const int plane = wave & 1;
+    const int L     = (wave >> 1) * 64 + lane;                     /* 0..127 */
+    const float *base = (plane ? sQ : sI) + 8 + L * (8 * R + 4);   /* goff(R*L) */
+    const float PDDC_CONSTANT *hb = (const float PDDC_CONSTANT *)p.taps_blk;
+
+    float accA[R], accB[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        accA[r] = 0.0f;
+        accB[r] = 0.0f;
+    }
+#pragma unroll
+    for (int ub = 0; ub < R + NTB - 1; ++ub) {
+        const int go = 8 * ub + 4 * (ub / R);
+        const float4 d0 = *reinterpret_cast<const float4 *>(base + go);
+        const float4 d1 = *reinterpret_cast<const float4 *>(base + go + 4);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = r + NTB - 1 - ub;
+            if (j >= 0 && j < NTB) {
+                const float PDDC_CONSTANT *h = hb + 8 * j;
+                float a = (j & 1) ? accB[r] : accA[r];
+                a = fmaf(h[0], d0.x, a);
+                a = fmaf(h[1], d0.y, a);
+                a = fmaf(h[2], d0.z, a);
+                a = fmaf(h[3], d0.w, a);
+                a = fmaf(h[4], d1.x, a);
+                a = fmaf(h[5], d1.y, a);
+                a = fmaf(h[6], d1.z, a);
+                a = fmaf(h[7], d1.w, a);
+                if (j & 1)
+                    accB[r] = a;
+                else
+                    accA[r] = a;
+            }
+        }
+    }
+    __syncthreads();          /* every wave is done reading the sample planes */
+
+    /* ---------------- store phase: transpose through LDS ------------------ */
+    float *ot = smem;         /* overlays sI */
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int f  = 2 * (R * L + r) + plane;
+        const int q  = f >> 2;
+        const int qs = q ^ ((q >> 3) & 7);
+        ot[4 * qs + (f & 3)] = accA[r] + accB[r];
+    }
+    __syncthreads();
+    const long long n_out    = p.n_in >> 3;
+    const long long tile_o0  = (long long)blockIdx.x * G::TO;
+    constexpr int NCH = G::TO / 2;                                  /* 16-byte chunks */
+#pragma unroll
+    for (int it = 0; it < (NCH + 255) / 256; ++it) {
+        const int q = tid + 256 * it;
+        if (q < NCH) {
+            const int qs = q ^ ((q >> 3) & 7);
+            const float4 v = *reinterpret_cast<const float4 *>(ot + 4 * qs);
+            const long long m = tile_o0 + 2LL * q;
+            if (m + 1 < n_out)
+                *reinterpret_cast<float4 *>(p.out + 2 * m) = v;
+            else if (m < n_out)
+                *reinterpret_cast<float2 *>(p.out + 2 * m) = make_float2(v.x, v.y);
+        }
+    }
+}
+
+bool fir8_supported(int ntb, int R)
+{
+    return (R == 4 || R == 8) && (ntb == 4 || ntb == 8 || ntb == 16 || ntb == 32);
+}
+
+template <int NTB, int R>
+static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s)
+{
+    using G = Fir8Geom<NTB, R>;
+    const size_t lds = (size_t)G::LDS_FLT * sizeof(float);
+    const long long ntiles = (a.n_in + G::TI - 1) / G::TI;
+    if (ntiles <= 0)
+        return hipSuccess;
+    const dim3 grid((unsigned)ntiles), blk(256);
+#define PDDC_LAUNCH(FMT, MIXV)                                                                    \
+    do {                                                                                          \
+        static bool attr_done = false;                                                            \
+        if (!attr_done) {                                                                         \
+            hipError_t e = hipFuncSetAttribute(                                                   \
+                reinterpret_cast<const void *>(&k_fir8<NTB, R, FMT, MIXV>),                       \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+            if (e != hipSuccess)                                                                  \
+                return e;                                                                         \
+            attr_done = true;                                                                     \
+        }                                                                                         \
+        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV>), grid, blk, lds, s, a);                    \
+    } while (0)
+    if (fmt == IN_PACKED24) {
+        if (mix)
+            PDDC_LAUNCH(IN_PACKED24, true);
+        else
+            PDDC_LAUNCH(IN_PACKED24, false);
+    } else {
+        PDDC_LAUNCH(IN_F32C, false);
+    }
+#undef PDDC_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s)
+{
+    if (fmt == IN_F32C && mix)
+        return hipErrorInvalidValue;
+#define PDDC_CASE(N, RR)                                                                          \
+    if (ntb == N && R == RR)                                                                      \
+        return launch_fir8_t<N, RR>(fmt, mix, a, s)
+    PDDC_CASE(4, 8);
+    PDDC_CASE(8, 8);
+    PDDC_CASE(16, 8);
+    PDDC_CASE(32, 8);
+    PDDC_CASE(4, 4);
+    PDDC_CASE(8, 4);
+    PDDC_CASE(16, 4);
+    PDDC_CASE(32, 4);
+#undef PDDC_CASE
+    return hipErrorInvalidValue;
+}
+
+/* ======================================================================== */
+/* k_fir_generic : any decimation, any tap count, float2 in / float2 out    */
+/* ======================================================================== */
+/* One output per thread, 256 outputs per block.  The block's input span
+ * (255*D + ntaps samples) is staged planar in LDS with a pad that makes the
+ * lane stride odd, the taps sit in LDS and are read as broadcasts.  This is
+ * the low-rate path (stages 2.. of a cascade, and odd first stages).        */
+__global__ __launch_bounds__(256) void k_fir_generic(const float *__restrict__ in, long long first,
+                                                      long long n_out, int D, const float *__restrict__ taps,
+                                                      int ntaps, float *__restrict__ out, int span, int padshift)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    /* layout: taps[ntaps_pad] | I plane | Q plane */
+    const int ntp = (ntaps + 3) & ~3;
+    float *sT = smem;
+    const int plane = span + (padshift >= 0 ? (span >> padshift) : 0) + 4;
+    float *sI = sT + ntp;
+    float *sQ = sI + plane;
+    const int tid = threadIdx.x;
+    const long long q0 = (long long)blockIdx.x * 256;
+    /* inputs needed: x[first + q0*D - (ntaps-1)  ..  first + (q0+255)*D] */
+    const long long x0 = first + q0 * D - (ntaps - 1);
+    for (int k = tid; k < ntp; k += 256)
+        sT[k] = k < ntaps ? taps[k] : 0.0f;
+    long long last_needed = first + (n_out - 1) * (long long)D;    /* last valid input index */
+    for (int i = tid; i < span; i += 256) {
+        const long long xi = x0 + i;
+        float2 v = make_float2(0.0f, 0.0f);
+        if (xi <= last_needed)
+            v = *reinterpret_cast<const float2 *>(in + 2 * xi);
+        const int o = i + (padshift >= 0 ? (i >> padshift) : 0);
+        sI[o] = v.x;
+        sQ[o] = v.y;
+    }
+    __syncthreads();
+    const long long q = q0 + tid;
+    if (q < n_out) {
+        /* output q uses local inputs i = tid*D + (ntaps-1) - k */
+        float ar0 = 0.0f, ai0 = 0.0f, ar1 = 0.0f, ai1 = 0.0f;
+        const int top = tid * D + (ntaps - 1);
+        int k = 0;
+        for (; k + 1 < ntaps; k += 2) {
+            const int i0 = top - k, i1 = top - k - 1;
+            const int o0 = i0 + (padshift >= 0 ? (i0 >> padshift) : 0);
+            const int o1 = i1 + (padshift >= 0 ? (i1 >> padshift) : 0);
+            const float h0 = sT[k], h1 = sT[k + 1];
+            ar0 = fmaf(h0, sI[o0], ar0);
+            ai0 = fmaf(h0, sQ[o0], ai0);
+            ar1 = fmaf(h1, sI[o1], ar1);
+            ai1 = fmaf(h1, sQ[o1], ai1);
+        }
+        if (k < ntaps) {
+            const int i0 = top - k;
+            const int o0 = i0 + (padshift >= 0 ? (i0 >> padshift) : 0);
+            ar0 = fmaf(sT[k], sI[o0], ar0);
+            ai0 = fmaf(sT[k], sQ[o0], ai0);
+        }
+        *reinterpret_cast<float2 *>(out + 2 * q) = make_float2(ar0 + ar1, ai0 + ai1);
+    }
+}
+
+hipError_t launch_fir_generic(const float *in, long long first, long long n_out, int D,
+                              const float *taps, int ntaps, float *out, hipStream_t s)
+{
+    if (n_out <= 0)
+        return hipSuccess;
+    const int span = 255 * D + ntaps;
+    /* pad one float every 2^padshift samples when D is even so the lane stride is odd */
+    int padshift = -1;
+    if ((D & 1) == 0) {
+        padshift = 0;
+        while ((1 << (padshift + 1)) <= D && (D % (1 << (padshift + 1))) == 0)
+            ++padshift;                       /* largest power of two dividing D */
+    }
+    const int plane = span + (padshift >= 0 ? (span >> padshift) : 0) + 4;
+    const int ntp = (ntaps + 3) & ~3;
+    const size_t lds = (size_t)(ntp + 2 * plane) * sizeof(float);
+    if (lds > 160 * 1024)
+        return hipErrorInvalidValue;
+    static int attr_lds = 0;
+    if ((int)lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_generic),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        attr_lds = (int)lds;
+    }
+    const dim3 grid((unsigned)((n_out + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(k_fir_generic, grid, blk, lds, s, in, first, n_out, D, taps, ntaps, out, span,
+                       padshift);
+    return hipGetLastError();
+}
+
+/* ======================================================================== */
+/* k_hist_update                                                            */
+/* ======================================================================== */
+__global__ __launch_bounds__(256) void k_hist_update(uint32_t *hist, int Hw, const uint32_t *batch,
+                                                      long long nw)
+{
+    /* words; new[i] = concat(hist, batch)[i + nw], i < Hw.  Single block:
+     * gather everything into registers before the first store.             */
+    constexpr int MAXPT = 16;
+    uint32_t v[MAXPT];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < MAXPT; ++k) {
+        const int i = tid + 256 * k;
+        if (i < Hw) {
+            const long long j = (long long)i + nw;
+            v[k] = j < Hw ? hist[j] : batch[j - Hw];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXPT; ++k) {
+        const int i = tid + 256 * k;
+        if (i < Hw)
+            hist[i] = v[k];
+    }
+}
+
+hipError_t launch_hist_update(void *hist, int H, const void *batch, long long n, int elem_bytes,
+                              hipStream_t s)
+{
+    if (H <= 0 || n <= 0)
+        return hipSuccess;
+    if ((elem_bytes * H) % 4 != 0 || ((long long)elem_bytes * n) % 4 != 0)
+        return hipErrorInvalidValue;
+    const int Hw = elem_bytes * H / 4;
+    if (Hw > 256 * 16)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_hist_update, dim3(1), dim3(256), 0, s, static_cast<uint32_t *>(hist), Hw,
+                       static_cast<const uint32_t *>(batch), (long long)elem_bytes * n / 4);
+    return hipGetLastError();
+}
+
+/* ======================================================================== */
+/* k_synth_lcg                                                              */
+/* ======================================================================== */
+__global__ __launch_bounds__(256) void k_synth_lcg(uint8_t *dst, unsigned long long nbytes, uint32_t seed,
+                                                    unsigned long long byte_offset)
+{
+    const unsigned long long nch = (nbytes + 15) >> 4;
+    for (unsigned long long c = (unsigned long long)blockIdx.x * 256 + threadIdx.x; c < nch;
+         c += (unsigned long long)gridDim.x * 256) {
+        /* state before byte (byte_offset + 16c): seed advanced that many steps */
+        unsigned long long steps = byte_offset + (c << 4);
+        uint32_t A = 1u, C = 0u;                  /* accumulated affine map  */
+        uint32_t a = 1664525u, cc = 1013904223u;  /* map for 2^b steps       */
+        while (steps) {
+            if (steps & 1ull) {
+                A = a * A;
+                C = a * C + cc;
+            }
+            cc = (a + 1u) * cc;
+            a = a * a;
+            steps >>= 1;
+        }
+        uint32_t st = A * seed + C;
+        uint32_t w[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                st = st * 1664525u + 1013904223u;
+                v |= (st >> 24) << (8 * b);
+            }
+            w[d] = v;
+        }
+        const unsigned long long o = c << 4;
+        if (o + 16 <= nbytes) {
+            *reinterpret_cast<uint4 *>(dst + o) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (int b = 0; b < 16 && o + b < nbytes; ++b)
+                dst[o + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+        }
+    }
+}
+
+hipError_t launch_synth_lcg(void *dst, size_t nbytes, uint32_t seed, uint64_t byte_offset, hipStream_t s)
+{
+    if (nbytes == 0)
+        return hipSuccess;
+    unsigned long long nch = ((unsigned long long)nbytes + 15) >> 4;
+    unsigned long long blocks = (nch + 255) / 256;
+    if (blocks > 256 * 32)
+        blocks = 256 * 32;
+    hipLaunchKernelGGL(k_synth_lcg, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint8_t *>(dst),
+                       (unsigned long long)nbytes, seed, (unsigned long long)byte_offset);
+    return hipGetLastError();
+}
+
+} // namespace pddc

@@ -1,0 +1,671 @@
+/*
+ * ddc_pipeline.cpp -- host side of the thin C ABI (include/perseus_ddc.h).
+ *
+ * Owns the per-stream state the reference never needed because its DDC lives
+ * in the FPGA (SURVEY.md 5 "checkpoint/resume"): FIR history per stage,
+ * decimation phase per stage, and the 64-bit sample counter that makes the
+ * NCO phase a pure function of the absolute sample index
+ * (phase(n) = n * freg mod 2^32, freg per perseus-sdr.c:584).
+ *
+ * There is no CPU implementation behind these entry points: if HIP reports no
+ * device they fail with PDDC_ENODEV.
+ */
+#include "../../include/perseus_ddc.h"
+#include "ddc_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace pddc;
+
+static thread_local char g_err[512] = "no error";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail(e__ == hipErrorOutOfMemory ? PDDC_ENOMEM                                   \
+                        : (e__ == hipErrorNoDevice || e__ == hipErrorInvalidDevice) ? PDDC_ENODEV  \
+                                                                                    : PDDC_EHIP,   \
+                        "%s: %s", #expr, hipGetErrorString(e__));                                  \
+    } while (0)
+
+/* ------------------------------------------------------------------------ */
+struct Stage {
+    int decim = 1;
+    int ntaps = 0;
+    std::vector<float> taps;      /* host copy (after optional fp16 rounding)  */
+    float *d_taps = nullptr;      /* h[k] linear                                */
+    float *d_taps_blk = nullptr;  /* [ntb][8] block-reversed (fused kernel)     */
+    int ntb = 0;                  /* tap blocks if fused-capable, else 0        */
+    int hist = 0;                 /* history length in samples (mult. of 8)     */
+    /* input buffer of stages >= 1 (or of stage 0 on the generic path):
+     * [hist | data], float2 */
+    float *d_buf = nullptr;
+    size_t buf_cap = 0;           /* data capacity in samples                   */
+    unsigned long long consumed = 0;   /* inputs consumed since reset           */
+};
+
+struct pddc_pipeline {
+    int device = 0;
+    uint32_t flags = 0;
+    int nstages = 0;
+    Stage st[PDDC_MAX_STAGES];
+    uint32_t freg = 0;
+    float lo_c[8], lo_s[8];
+    unsigned long long n0 = 0;    /* absolute sample counter (stage 0 input)    */
+    uint8_t *d_hist0 = nullptr;   /* packed history of stage 0 (fused path)     */
+    int R = 8;                    /* outputs per lane of the fused kernel       */
+    /* staging for push_host */
+    uint8_t *d_in = nullptr;
+    size_t d_in_cap = 0;
+    float *d_out = nullptr;
+    size_t d_out_cap = 0;
+    hipStream_t own_stream = nullptr;
+};
+
+static float round_to_half(float v)
+{
+    /* round-to-nearest-even to IEEE binary16, returned widened to float */
+    _Float16 h = (_Float16)v;
+    return (float)h;
+}
+
+static void compute_lo_steps(pddc_pipeline *p)
+{
+    const double k = 6.283185307179586476925286766559 / 4294967296.0;
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t ph = (uint32_t)((uint64_t)e * p->freg);
+        p->lo_c[e] = (float)std::cos(k * (double)ph);
+        p->lo_s[e] = (float)(-std::sin(k * (double)ph));
+    }
+}
+
+static bool stage_fused_capable(const Stage &s)
+{
+    if (s.decim != 8 || s.ntaps > PDDC_FAST_MAX_TAPS)
+        return false;
+    return true;
+}
+
+static int pick_ntb(int ntaps)
+{
+    const int need = (ntaps + 7) / 8;
+    const int opts[4] = { 4, 8, 16, 32 };
+    for (int o : opts)
+        if (need <= o)
+            return o;
+    return 0;
+}
+
+static int upload_taps(pddc_pipeline *p, int si)
+{
+    Stage &s = p->st[si];
+    if (s.d_taps) {
+        hipFree(s.d_taps);
+        s.d_taps = nullptr;
+    }
+    if (s.d_taps_blk) {
+        hipFree(s.d_taps_blk);
+        s.d_taps_blk = nullptr;
+    }
+    HIP_TRY(hipMalloc(&s.d_taps, sizeof(float) * (size_t)s.ntaps));
+    HIP_TRY(hipMemcpy(s.d_taps, s.taps.data(), sizeof(float) * (size_t)s.ntaps, hipMemcpyHostToDevice));
+    s.ntb = stage_fused_capable(s) ? pick_ntb(s.ntaps) : 0;
+    if (s.ntb) {
+        /* hb[j][e] = h[8j + 7 - e], zero beyond ntaps */
+        std::vector<float> blk((size_t)s.ntb * 8, 0.0f);
+        for (int j = 0; j < s.ntb; ++j)
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * j + 7 - e;
+                blk[(size_t)j * 8 + e] = k < s.ntaps ? s.taps[k] : 0.0f;
+            }
+        HIP_TRY(hipMalloc(&s.d_taps_blk, sizeof(float) * blk.size()));
+        HIP_TRY(hipMemcpy(s.d_taps_blk, blk.data(), sizeof(float) * blk.size(), hipMemcpyHostToDevice));
+    }
+    return PDDC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+extern "C" {
+
+int pddc_version(void) { return 100; }
+
+const char *pddc_last_error(void) { return g_err; }
+
+int pddc_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice)
+        return 0;
+    if (e != hipSuccess)
+        return fail(PDDC_EHIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+uint32_t pddc_nco_freg(double center_freq_hz, double adc_clk_hz)
+{
+    /* perseus-sdr.c:584 -- double arithmetic, truncation toward zero */
+    return (uint32_t)(center_freq_hz / adc_clk_hz * 4.294967296E9);
+}
+
+static int require_device(void)
+{
+    int n = pddc_device_count();
+    if (n < 0)
+        return n;
+    if (n == 0)
+        return fail(PDDC_ENODEV, "no HIP device visible (this library has no CPU fallback)");
+    return PDDC_OK;
+}
+
+int pddc_set_device(int device)
+{
+    int rc = require_device();
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(device));
+    return PDDC_OK;
+}
+
+int pddc_malloc(void **d_ptr, size_t nbytes)
+{
+    if (!d_ptr)
+        return fail(PDDC_EINVAL, "null pointer");
+    int rc = require_device();
+    if (rc)
+        return rc;
+    HIP_TRY(hipMalloc(d_ptr, nbytes ? nbytes : 16));
+    return PDDC_OK;
+}
+
+int pddc_free(void *d_ptr)
+{
+    if (d_ptr)
+        HIP_TRY(hipFree(d_ptr));
+    return PDDC_OK;
+}
+
+int pddc_memcpy_h2d(void *d_dst, const void *h_src, size_t nbytes, void *stream)
+{
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return PDDC_OK;
+}
+
+int pddc_memcpy_d2h(void *h_dst, const void *d_src, size_t nbytes, void *stream)
+{
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, nbytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return PDDC_OK;
+}
+
+int pddc_stream_sync(void *stream)
+{
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return PDDC_OK;
+}
+
+static int check_unpack_args(const void *d_in, const void *d_out, size_t ns)
+{
+    if (ns == 0)
+        return PDDC_OK;
+    if (!d_in || !d_out)
+        return fail(PDDC_EINVAL, "null device pointer");
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15))
+        return fail(PDDC_EINVAL, "device pointers must be 16-byte aligned");
+    return PDDC_OK;
+}
+
+int pddc_unpack24_f32(const void *d_packed, size_t nsamples, void *d_out, void *stream)
+{
+    int rc = require_device();
+    if (rc)
+        return rc;
+    if ((rc = check_unpack_args(d_packed, d_out, nsamples)))
+        return rc;
+    HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, d_out, false, false, 0, 0, nullptr, nullptr,
+                            (hipStream_t)stream));
+    return PDDC_OK;
+}
+
+int pddc_unpack24_i32(const void *d_packed, size_t nsamples, void *d_out, void *stream)
+{
+    int rc = require_device();
+    if (rc)
+        return rc;
+    if ((rc = check_unpack_args(d_packed, d_out, nsamples)))
+        return rc;
+    HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, d_out, true, false, 0, 0, nullptr, nullptr,
+                            (hipStream_t)stream));
+    return PDDC_OK;
+}
+
+int pddc_synth_lcg(void *d_dst, size_t nbytes, uint32_t seed, uint64_t byte_offset, void *stream)
+{
+    int rc = require_device();
+    if (rc)
+        return rc;
+    if (nbytes && (!d_dst || ((uintptr_t)d_dst & 15)))
+        return fail(PDDC_EINVAL, "destination must be a 16-byte aligned device pointer");
+    HIP_TRY(launch_synth_lcg(d_dst, nbytes, seed, byte_offset, (hipStream_t)stream));
+    return PDDC_OK;
+}
+
+/* ---------------------------------------------------------------- pipeline */
+int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc *stages, int nstages,
+                         uint32_t flags)
+{
+    if (!out)
+        return fail(PDDC_EINVAL, "null out pointer");
+    *out = nullptr;
+    if (!stages || nstages < 1 || nstages > PDDC_MAX_STAGES)
+        return fail(PDDC_EINVAL, "nstages must be 1..%d", PDDC_MAX_STAGES);
+    for (int i = 0; i < nstages; ++i) {
+        if (stages[i].decim < 1 || stages[i].decim > 4096)
+            return fail(PDDC_EINVAL, "stage %d: bad decimation %d", i, stages[i].decim);
+        if (stages[i].ntaps < 1 || stages[i].ntaps > PDDC_MAX_TAPS || !stages[i].taps)
+            return fail(PDDC_EINVAL, "stage %d: ntaps must be 1..%d", i, PDDC_MAX_TAPS);
+    }
+    int rc = require_device();
+    if (rc)
+        return rc;
+    int ndev = pddc_device_count();
+    if (device < 0 || device >= ndev)
+        return fail(PDDC_ENODEV, "device %d out of range (0..%d)", device, ndev - 1);
+    HIP_TRY(hipSetDevice(device));
+
+    pddc_pipeline *p = new (std::nothrow) pddc_pipeline();
+    if (!p)
+        return fail(PDDC_ENOMEM, "out of host memory");
+    p->device = device;
+    p->flags = flags;
+    p->nstages = nstages;
+    for (int i = 0; i < nstages; ++i) {
+        Stage &s = p->st[i];
+        s.decim = stages[i].decim;
+        s.ntaps = stages[i].ntaps;
+        s.taps.assign(stages[i].taps, stages[i].taps + s.ntaps);
+        if (flags & PDDC_F_TAPS_FP16)
+            for (float &v : s.taps)
+                v = round_to_half(v);
+        if ((rc = upload_taps(p, i))) {
+            pddc_pipeline_destroy(p);
+            return rc;
+        }
+        /* history: enough for ntaps-1, rounded to the 8-sample granule; the
+         * fused kernel wants exactly 8*ntb */
+        s.hist = s.ntb ? 8 * s.ntb : ((s.ntaps - 1 + 7) / 8) * 8;
+        if (s.hist == 0)
+            s.hist = 8;
+    }
+    compute_lo_steps(p);
+    hipError_t e = hipMalloc(&p->d_hist0, (size_t)p->st[0].hist * 6 + 64);
+    if (e != hipSuccess) {
+        pddc_pipeline_destroy(p);
+        return fail(PDDC_ENOMEM, "hipMalloc history: %s", hipGetErrorString(e));
+    }
+    e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        pddc_pipeline_destroy(p);
+        return fail(PDDC_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    if ((rc = pddc_pipeline_reset(p))) {
+        pddc_pipeline_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return PDDC_OK;
+}
+
+int pddc_pipeline_destroy(pddc_pipeline *p)
+{
+    if (!p)
+        return PDDC_OK;
+    hipSetDevice(p->device);
+    hipDeviceSynchronize();
+    for (int i = 0; i < PDDC_MAX_STAGES; ++i) {
+        if (p->st[i].d_taps)
+            hipFree(p->st[i].d_taps);
+        if (p->st[i].d_taps_blk)
+            hipFree(p->st[i].d_taps_blk);
+        if (p->st[i].d_buf)
+            hipFree(p->st[i].d_buf);
+    }
+    if (p->d_hist0)
+        hipFree(p->d_hist0);
+    if (p->d_in)
+        hipFree(p->d_in);
+    if (p->d_out)
+        hipFree(p->d_out);
+    if (p->own_stream)
+        hipStreamDestroy(p->own_stream);
+    delete p;
+    return PDDC_OK;
+}
+
+int pddc_pipeline_reset(pddc_pipeline *p)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    p->n0 = 0;
+    HIP_TRY(hipMemset(p->d_hist0, 0, (size_t)p->st[0].hist * 6 + 64));
+    for (int i = 0; i < p->nstages; ++i) {
+        p->st[i].consumed = 0;
+        if (p->st[i].d_buf)
+            HIP_TRY(hipMemset(p->st[i].d_buf, 0, sizeof(float) * 2 * (size_t)p->st[i].hist));
+    }
+    return PDDC_OK;
+}
+
+int pddc_pipeline_set_freg(pddc_pipeline *p, uint32_t freg)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    p->freg = freg;
+    compute_lo_steps(p);
+    return PDDC_OK;
+}
+
+int pddc_pipeline_set_center_freq(pddc_pipeline *p, double hz)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    /* same range check as perseus-sdr.c:575 */
+    if (hz < 0.0 || hz > PDDC_ADC_CLK_HZ / 2)
+        return fail(PDDC_EINVAL, "center frequency %.3f not in [0, %.0f]", hz, PDDC_ADC_CLK_HZ / 2);
+    return pddc_pipeline_set_freg(p, pddc_nco_freg(hz, PDDC_ADC_CLK_HZ));
+}
+
+uint32_t pddc_pipeline_get_freg(const pddc_pipeline *p) { return p ? p->freg : 0; }
+
+int pddc_pipeline_total_decim(const pddc_pipeline *p)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    long long d = 1;
+    for (int i = 0; i < p->nstages; ++i)
+        d *= p->st[i].decim;
+    return (int)d;
+}
+
+int pddc_pipeline_set_taps(pddc_pipeline *p, int stage, const float *taps, int ntaps)
+{
+    if (!p || !taps)
+        return fail(PDDC_EINVAL, "null argument");
+    if (stage < 0 || stage >= p->nstages)
+        return fail(PDDC_EINVAL, "stage %d out of range", stage);
+    Stage &s = p->st[stage];
+    /* the history length is fixed at create time; a new tap set must fit it */
+    if (ntaps < 1 || ntaps - 1 > s.hist || (s.ntb && ntaps > 8 * s.ntb))
+        return fail(PDDC_EINVAL, "ntaps %d does not fit the stage geometry (history %d)", ntaps, s.hist);
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int keep_ntb = s.ntb;
+    s.ntaps = ntaps;
+    s.taps.assign(taps, taps + ntaps);
+    if (p->flags & PDDC_F_TAPS_FP16)
+        for (float &v : s.taps)
+            v = round_to_half(v);
+    int rc = upload_taps(p, stage);
+    if (rc)
+        return rc;
+    if (keep_ntb && s.ntb != keep_ntb) {
+        /* keep the tile geometry (history length) chosen at create time */
+        s.ntb = keep_ntb;
+        std::vector<float> blk((size_t)s.ntb * 8, 0.0f);
+        for (int j = 0; j < s.ntb; ++j)
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * j + 7 - e;
+                blk[(size_t)j * 8 + e] = k < s.ntaps ? s.taps[k] : 0.0f;
+            }
+        hipFree(s.d_taps_blk);
+        s.d_taps_blk = nullptr;
+        HIP_TRY(hipMalloc(&s.d_taps_blk, sizeof(float) * blk.size()));
+        HIP_TRY(hipMemcpy(s.d_taps_blk, blk.data(), sizeof(float) * blk.size(), hipMemcpyHostToDevice));
+    }
+    return PDDC_OK;
+}
+
+/* outputs produced by a stage that has consumed `consumed` inputs and now
+ * receives n more: outputs m with consumed <= m*D < consumed+n              */
+static void stage_outputs(unsigned long long consumed, size_t n, int D, size_t *first_off, size_t *n_out)
+{
+    const unsigned long long m0 = (consumed + (unsigned long long)D - 1) / (unsigned long long)D;
+    const unsigned long long off = m0 * (unsigned long long)D - consumed;   /* 0..D-1 */
+    *first_off = (size_t)off;
+    *n_out = n > off ? (size_t)((n - off - 1) / (size_t)D + 1) : 0;
+}
+
+size_t pddc_pipeline_max_output(const pddc_pipeline *p, size_t n)
+{
+    if (!p)
+        return 0;
+    for (int i = 0; i < p->nstages; ++i)
+        n = (n + (size_t)p->st[i].decim - 1) / (size_t)p->st[i].decim;
+    return n;
+}
+
+static bool stage0_fused(const pddc_pipeline *p)
+{
+    return p->st[0].ntb != 0 && !(p->flags & PDDC_F_NO_FAST) && fir8_supported(p->st[0].ntb, p->R);
+}
+
+int pddc_pipeline_uses_fused(const pddc_pipeline *p) { return p && stage0_fused(p) ? 1 : 0; }
+
+static int ensure_buf(Stage &s, size_t need)
+{
+    if (s.d_buf && s.buf_cap >= need)
+        return PDDC_OK;
+    /* growing keeps the history: allocate, copy history, free.  Happens only
+     * when a batch is larger than any seen before (synchronising).           */
+    float *nb = nullptr;
+    const size_t cap = need + need / 4 + 64;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMalloc(&nb, sizeof(float) * 2 * ((size_t)s.hist + cap)));
+    if (s.d_buf) {
+        HIP_TRY(hipMemcpy(nb, s.d_buf, sizeof(float) * 2 * (size_t)s.hist, hipMemcpyDeviceToDevice));
+        HIP_TRY(hipFree(s.d_buf));
+    } else {
+        HIP_TRY(hipMemset(nb, 0, sizeof(float) * 2 * (size_t)s.hist));
+    }
+    s.d_buf = nb;
+    s.buf_cap = cap;
+    return PDDC_OK;
+}
+
+static void fill_fir8_args(const pddc_pipeline *p, Fir8Args &a)
+{
+    a.n0 = p->n0;
+    a.freg = p->freg;
+    for (int e = 0; e < 8; ++e) {
+        a.lo_c[e] = p->lo_c[e];
+        a.lo_s[e] = p->lo_s[e];
+    }
+}
+
+int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsamples, void *d_out,
+                          size_t out_capacity, size_t *n_out_ret, void *stream_v)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    if (n_out_ret)
+        *n_out_ret = 0;
+    if (nsamples == 0)
+        return PDDC_OK;
+    if (!d_packed || !d_out)
+        return fail(PDDC_EINVAL, "null device pointer");
+    if (nsamples % PDDC_INPUT_GRANULE)
+        return fail(PDDC_EINVAL, "nsamples (%zu) must be a multiple of %d", nsamples, PDDC_INPUT_GRANULE);
+    if (((uintptr_t)d_packed & 15) || ((uintptr_t)d_out & 15))
+        return fail(PDDC_EINVAL, "device pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream_v;
+    HIP_TRY(hipSetDevice(p->device));
+
+    /* plan: outputs per stage */
+    size_t n_in[PDDC_MAX_STAGES + 1], off[PDDC_MAX_STAGES];
+    n_in[0] = nsamples;
+    for (int i = 0; i < p->nstages; ++i)
+        stage_outputs(p->st[i].consumed, n_in[i], p->st[i].decim, &off[i], &n_in[i + 1]);
+    const size_t n_final = n_in[p->nstages];
+    if (n_final > out_capacity)
+        return fail(PDDC_ECAPACITY, "output capacity %zu < %zu", out_capacity, n_final);
+
+    const bool mix = (p->flags & PDDC_F_MIX) != 0;
+    int rc;
+    for (int i = 0; i < p->nstages; ++i) {
+        Stage &st = p->st[i];
+        /* destination of this stage: next stage's buffer (after its history) or the caller's */
+        float *dst;
+        if (i + 1 < p->nstages) {
+            if ((rc = ensure_buf(p->st[i + 1], n_in[i + 1] + 8)))
+                return rc;
+            dst = p->st[i + 1].d_buf + 2 * (size_t)p->st[i + 1].hist;
+        } else {
+            dst = static_cast<float *>(d_out);
+        }
+        if (i == 0) {
+            if (stage0_fused(p)) {
+                Fir8Args a;
+                a.in = d_packed;
+                a.hist = p->d_hist0;
+                a.out = dst;
+                a.taps_blk = st.d_taps_blk;
+                a.n_in = (long long)nsamples;
+                fill_fir8_args(p, a);
+                HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s));
+                HIP_TRY(launch_hist_update(p->d_hist0, st.hist, d_packed, (long long)nsamples, 6, s));
+            } else {
+                /* generic first stage: unpack(+mix) to float2 behind the history, then FIR */
+                if ((rc = ensure_buf(st, nsamples + 8)))
+                    return rc;
+                float *x = st.d_buf + 2 * (size_t)st.hist;
+                HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, x, false, mix, p->n0, p->freg,
+                                        p->lo_c, p->lo_s, s));
+                HIP_TRY(launch_fir_generic(x, (long long)off[0], (long long)n_in[1], st.decim, st.d_taps,
+                                           st.ntaps, dst, s));
+                HIP_TRY(launch_hist_update(st.d_buf, st.hist, x, (long long)nsamples, 8, s));
+            }
+        } else {
+            float *x = st.d_buf + 2 * (size_t)st.hist;
+            const bool fast = st.ntb != 0 && !(p->flags & PDDC_F_NO_FAST) && fir8_supported(st.ntb, p->R) &&
+                              (n_in[i] % 8 == 0) && off[i] == 0 && (st.consumed % 8 == 0) && n_in[i] > 0;
+            if (fast) {
+                Fir8Args a;
+                a.in = x;
+                a.hist = st.d_buf;            /* contiguous: hist == 8*ntb samples in front */
+                a.out = dst;
+                a.taps_blk = st.d_taps_blk;
+                a.n_in = (long long)n_in[i];
+                fill_fir8_args(p, a);
+                HIP_TRY(launch_fir8(st.ntb, p->R, IN_F32C, false, a, s));
+            } else if (n_in[i + 1] > 0) {
+                HIP_TRY(launch_fir_generic(x, (long long)off[i], (long long)n_in[i + 1], st.decim, st.d_taps,
+                                           st.ntaps, dst, s));
+            }
+            if (n_in[i] > 0)
+                HIP_TRY(launch_hist_update(st.d_buf, st.hist, x, (long long)n_in[i], 8, s));
+        }
+        st.consumed += n_in[i];
+    }
+    p->n0 += nsamples;
+    if (n_out_ret)
+        *n_out_ret = n_final;
+    return PDDC_OK;
+}
+
+int pddc_pipeline_push_host(pddc_pipeline *p, const void *h_packed, size_t nsamples, void *h_out,
+                            size_t out_capacity, size_t *n_out_ret)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    if (n_out_ret)
+        *n_out_ret = 0;
+    if (nsamples == 0)
+        return PDDC_OK;
+    if (!h_packed || !h_out)
+        return fail(PDDC_EINVAL, "null host pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t max_out = pddc_pipeline_max_output(p, nsamples) + 1;
+    if (p->d_in_cap < nsamples) {
+        if (p->d_in)
+            HIP_TRY(hipFree(p->d_in));
+        p->d_in = nullptr;
+        HIP_TRY(hipMalloc(&p->d_in, nsamples * 6 + 64));
+        p->d_in_cap = nsamples;
+    }
+    if (p->d_out_cap < max_out) {
+        if (p->d_out)
+            HIP_TRY(hipFree(p->d_out));
+        p->d_out = nullptr;
+        HIP_TRY(hipMalloc(&p->d_out, max_out * 8 + 64));
+        p->d_out_cap = max_out;
+    }
+    hipStream_t s = p->own_stream;
+    HIP_TRY(hipMemcpyAsync(p->d_in, h_packed, nsamples * 6, hipMemcpyHostToDevice, s));
+    size_t n_out = 0;
+    int rc = pddc_pipeline_process(p, p->d_in, nsamples, p->d_out, p->d_out_cap, &n_out, s);
+    if (rc)
+        return rc;
+    if (n_out > out_capacity) {
+        hipStreamSynchronize(s);
+        return fail(PDDC_ECAPACITY, "output capacity %zu < %zu", out_capacity, n_out);
+    }
+    if (n_out)
+        HIP_TRY(hipMemcpyAsync(h_out, p->d_out, n_out * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (n_out_ret)
+        *n_out_ret = n_out;
+    return PDDC_OK;
+}
+
+int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsamples, void *d_out,
+                              int iters, void *stream_v, float *avg_ms)
+{
+    if (!p || !avg_ms || iters < 1)
+        return fail(PDDC_EINVAL, "bad argument");
+    if (!stage0_fused(p))
+        return fail(PDDC_ESTATE, "stage 0 does not run the fused kernel");
+    if (nsamples % PDDC_INPUT_GRANULE || ((uintptr_t)d_packed & 15) || ((uintptr_t)d_out & 15))
+        return fail(PDDC_EINVAL, "bad size/alignment");
+    hipStream_t s = (hipStream_t)stream_v;
+    HIP_TRY(hipSetDevice(p->device));
+    Fir8Args a;
+    a.in = d_packed;
+    a.hist = p->d_hist0;
+    a.out = static_cast<float *>(d_out);
+    a.taps_blk = p->st[0].d_taps_blk;
+    a.n_in = (long long)nsamples;
+    fill_fir8_args(p, a);
+    const bool mix = (p->flags & PDDC_F_MIX) != 0;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        HIP_TRY(launch_fir8(p->st[0].ntb, p->R, IN_PACKED24, mix, a, s));
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *avg_ms = ms / (float)iters;
+    return PDDC_OK;
+}
+
+} /* extern "C" */

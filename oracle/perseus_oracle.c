@@ -1,0 +1,285 @@
+/*
+ * perseus_oracle.c -- see perseus_oracle.h.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Build: make -C oracle   (gcc -O3 -march=native -fopenmp, NO -ffast-math:
+ * the unpack divide must stay an IEEE divide; SURVEY.md 8c shows fast-math
+ * changes no bit, but the oracle should not depend on that.)
+ */
+#include "perseus_oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------ */
+uint32_t orc_lcg_fill(uint8_t *dst, size_t nbytes, uint32_t seed)
+{
+    uint32_t s = seed;
+    for (size_t i = 0; i < nbytes; i++) {
+        s = s * 1664525u + 1013904223u;
+        dst[i] = (uint8_t)(s >> 24);
+    }
+    return s;
+}
+
+/* ------------------------------------------------------------------------
+ * A1 (perseustest.c:411-426): the three wire bytes of a component occupy
+ * bytes 1..3 of a little-endian int32 whose byte 0 is zero, i.e. the value
+ * is the sign-extended 24-bit sample times 256.
+ */
+static inline int32_t msb_align24(const uint8_t *p)
+{
+    uint32_t u = ((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) |
+                 ((uint32_t)p[2] << 24);
+    return (int32_t)u;
+}
+
+/* A2 (perseustest.c:466-502): float = (float)int32 / (INT_MAX - 256); the
+ * int divisor is converted to float by the usual arithmetic conversions
+ * (2147483391 rounds to 2147483392.0f). */
+void orc_unpack24_f32(const uint8_t *in, size_t nbytes, float *out_iq)
+{
+    const size_t ns = nbytes / 6;
+    const float full_scale = (float)(INT_MAX - 256);
+    for (size_t k = 0; k < ns; k++) {
+        const uint8_t *p = in + 6 * k;
+        out_iq[2 * k + 0] = (float)msb_align24(p) / full_scale;
+        out_iq[2 * k + 1] = (float)msb_align24(p + 3) / full_scale;
+    }
+}
+
+/* A3 (perseustest.c:432-460): MSB-aligned int32 pairs. */
+void orc_unpack24_i32(const uint8_t *in, size_t nbytes, int32_t *out_iq)
+{
+    const size_t ns = nbytes / 6;
+    for (size_t k = 0; k < ns; k++) {
+        const uint8_t *p = in + 6 * k;
+        out_iq[2 * k + 0] = msb_align24(p);
+        out_iq[2 * k + 1] = msb_align24(p + 3);
+    }
+}
+
+void orc_unpack24_f32_callback_style(const uint8_t *in, size_t nbytes,
+                                     float *out_iq, size_t buf_bytes)
+{
+    size_t off = 0;
+    while (off < nbytes) {
+        size_t n = nbytes - off < buf_bytes ? nbytes - off : buf_bytes;
+        orc_unpack24_f32(in + off, n, out_iq + 2 * (off / 6));
+        off += n;
+    }
+}
+
+/* ------------------------------------------------------------------------
+ * A6 (perseus-sdr.c:584): FREG = (uint32)(f / fclk * 2^32), double
+ * arithmetic, truncation toward zero.
+ */
+uint32_t orc_nco_freg(double center_freq_hz, double adc_clk_hz)
+{
+    return (uint32_t)(center_freq_hz / adc_clk_hz * 4.294967296E9);
+}
+
+/* perseus-sdr.c:589-615 with the cut-off table of perseusfx2.h:70-93. */
+int orc_presel_id(double f, int enable_presel)
+{
+    static const double fc[10] = { 1.7e6, 2.1e6, 3.0e6, 4.2e6, 6.0e6,
+                                   8.4e6, 12.0e6, 17.0e6, 24.0e6, 32.0e6 };
+    if (!enable_presel)
+        return 10;
+    for (int i = 0; i < 10; i++)
+        if (f < fc[i])
+            return i;
+    return 10;
+}
+
+/* ------------------------------------------------------------------------
+ * A7 (perseus-sdr.c:776-811): walk the ascending table; a request above an
+ * entry moves on (or takes the last entry); otherwise compare with the
+ * midpoint to the previous entry, midpoint itself going to the LOWER rate.
+ */
+int orc_rate_index(int sps, const int *table, int n)
+{
+    int prev = 0;
+    for (int i = 0; i < n; i++) {
+        if (sps > table[i]) {
+            if (i < n - 1) {
+                prev = table[i];
+                continue;
+            }
+            return i;
+        }
+        int mid = (table[i] + prev) / 2;
+        if (sps <= mid)
+            return i == 0 ? 0 : i - 1;
+        return i;
+    }
+    return -1;
+}
+
+/* ------------------------------------------------------------------------
+ * A8 (authored).  Phase accumulator is exact integer arithmetic, so the LO
+ * at absolute sample n depends only on n and freg.
+ */
+void orc_nco_mix_f64(const float *x_iq, size_t ns, uint64_t n0, uint32_t freg,
+                     double *out_iq)
+{
+    const double two_pi_over_2p32 = 6.283185307179586476925286766559 / 4294967296.0;
+    for (size_t n = 0; n < ns; n++) {
+        uint32_t ph = (uint32_t)((n0 + n) * (uint64_t)freg);
+        double a = two_pi_over_2p32 * (double)ph;
+        double c = cos(a), s = -sin(a);   /* exp(-j a) = c + j s */
+        double xr = x_iq[2 * n], xi = x_iq[2 * n + 1];
+        out_iq[2 * n + 0] = xr * c - xi * s;
+        out_iq[2 * n + 1] = xr * s + xi * c;
+    }
+}
+
+size_t orc_fir_decim_f64(const double *x, size_t ns, const float *taps,
+                         int ntaps, int D, double *y)
+{
+    if (D <= 0 || ntaps <= 0)
+        return 0;
+    const size_t nout = (ns + (size_t)D - 1) / (size_t)D;
+#pragma omp parallel for schedule(static)
+    for (long long m = 0; m < (long long)nout; m++) {
+        const long long top = m * D;
+        double ar = 0.0, ai = 0.0;
+        int kmax = ntaps - 1;
+        if ((long long)kmax > top)
+            kmax = (int)top;
+        for (int k = 0; k <= kmax; k++) {
+            const double h = (double)taps[k];
+            ar += h * x[2 * (top - k)];
+            ai += h * x[2 * (top - k) + 1];
+        }
+        y[2 * m] = ar;
+        y[2 * m + 1] = ai;
+    }
+    return nout;
+}
+
+size_t orc_ddc_chain(const uint8_t *packed, size_t ns, uint32_t freg,
+                     int mix_enable, int nstages, const int *D,
+                     const int *ntaps, const float *const *taps,
+                     float *out_iq, size_t out_capacity)
+{
+    if (nstages < 0 || nstages > 8)
+        return (size_t)-1;
+    float *xf = (float *)malloc(sizeof(float) * 2 * (ns ? ns : 1));
+    double *cur = (double *)malloc(sizeof(double) * 2 * (ns ? ns : 1));
+    if (!xf || !cur) {
+        free(xf);
+        free(cur);
+        return (size_t)-1;
+    }
+    orc_unpack24_f32(packed, ns * 6, xf);
+    if (mix_enable) {
+        orc_nco_mix_f64(xf, ns, 0, freg, cur);
+    } else {
+        for (size_t i = 0; i < 2 * ns; i++)
+            cur[i] = (double)xf[i];
+    }
+    free(xf);
+    size_t n = ns;
+    for (int s = 0; s < nstages; s++) {
+        size_t nout = (n + (size_t)D[s] - 1) / (size_t)D[s];
+        double *nxt = (double *)malloc(sizeof(double) * 2 * (nout ? nout : 1));
+        if (!nxt) {
+            free(cur);
+            return (size_t)-1;
+        }
+        orc_fir_decim_f64(cur, n, taps[s], ntaps[s], D[s], nxt);
+        free(cur);
+        cur = nxt;
+        n = nout;
+    }
+    if (n > out_capacity) {
+        free(cur);
+        return (size_t)-1;
+    }
+    for (size_t i = 0; i < 2 * n; i++)
+        out_iq[i] = (float)cur[i];
+    free(cur);
+    return n;
+}
+
+/* ------------------------------------------------------------------------
+ * CPU baseline: unpack + one decimating FIR, float accumulate.  Chunks of
+ * outputs are independent (the input is read with its halo), so OpenMP
+ * splits the output range.  Each thread unpacks its input span into a
+ * private planar float buffer first (so the FIR inner loop vectorises).
+ */
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+size_t orc_stage1_f32(const uint8_t *packed, size_t ns, const float *taps,
+                      int ntaps, int D, float *out_iq, int threads)
+{
+    if (D <= 0 || ntaps <= 0)
+        return 0;
+    const size_t nout = (ns + (size_t)D - 1) / (size_t)D;
+    const size_t CH = 4096;              /* outputs per work item */
+    const size_t nchunks = (nout + CH - 1) / CH;
+#ifdef _OPENMP
+    if (threads > 0)
+        omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+    /* reversed taps so the inner loop walks the input forwards */
+    float *hr = (float *)malloc(sizeof(float) * (size_t)ntaps);
+    for (int k = 0; k < ntaps; k++)
+        hr[k] = taps[ntaps - 1 - k];
+#pragma omp parallel
+    {
+        const size_t span = CH * (size_t)D + (size_t)ntaps;
+        float *xi = (float *)malloc(sizeof(float) * span);
+        float *xq = (float *)malloc(sizeof(float) * span);
+        const float full_scale = (float)(INT_MAX - 256);
+#pragma omp for schedule(dynamic, 1)
+        for (long long c = 0; c < (long long)nchunks; c++) {
+            const size_t m0 = (size_t)c * CH;
+            const size_t m1 = m0 + CH < nout ? m0 + CH : nout;
+            /* inputs needed: [m0*D-(ntaps-1), (m1-1)*D] */
+            const long long first = (long long)(m0 * D) - (ntaps - 1);
+            const long long last = (long long)((m1 - 1) * D);
+            for (long long i = first; i <= last; i++) {
+                size_t j = (size_t)(i - first);
+                if (i < 0 || (size_t)i >= ns) {
+                    xi[j] = 0.0f;
+                    xq[j] = 0.0f;
+                } else {
+                    const uint8_t *p = packed + 6 * (size_t)i;
+                    xi[j] = (float)msb_align24(p) / full_scale;
+                    xq[j] = (float)msb_align24(p + 3) / full_scale;
+                }
+            }
+            for (size_t m = m0; m < m1; m++) {
+                const float *pi = xi + (m - m0) * (size_t)D;
+                const float *pq = xq + (m - m0) * (size_t)D;
+                float ar = 0.0f, ai = 0.0f;
+#pragma omp simd reduction(+ : ar, ai)
+                for (int k = 0; k < ntaps; k++) {
+                    ar += hr[k] * pi[k];
+                    ai += hr[k] * pq[k];
+                }
+                out_iq[2 * m] = ar;
+                out_iq[2 * m + 1] = ai;
+            }
+        }
+        free(xi);
+        free(xq);
+    }
+    free(hr);
+    return nout;
+}

@@ -1,0 +1,91 @@
+/*
+ * perseus_oracle.h -- CPU restatement of the libperseus-sdr I/Q ingest +
+ * decimation hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the timed CPU baseline.
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   - 24-bit unpack (orc_unpack24_f32 / orc_unpack24_i32): restates
+ *     examples/perseustest.c:411-502 of the reference.  The reference cannot
+ *     be compiled in this image (perseus-sdr.h:35 includes
+ *     <libusb-1.0/libusb.h>, which is absent, and stand-in headers are not
+ *     allowed), so oracle/_ref is not built.  The restatement is pinned
+ *     against the reference outputs recorded in SURVEY.md 8c (known-answer
+ *     table, exhaustive 2^24 SHA-256, LCG buffer SHA-256) -- see
+ *     tests/golden/unpack_golden.json.
+ *   - NCO tuning word / nearest-rate / preselector id: restate the one-line
+ *     formulas at perseus-sdr.c:584, :776-811, :589-615; pinned by the KATs
+ *     in SURVEY.md 4.
+ *   - NCO mix and FIR decimation: PARITY UNPINNED.  The reference holds no
+ *     software model of them (they live in opaque FPGA bitstreams), so these
+ *     functions are authored definitions: 32-bit phase accumulator
+ *     phase(n) = (n*freg) mod 2^32, LO = exp(-j*2*pi*phase/2^32), and
+ *     y[m] = sum_k h[k] * x[m*D - k] with zero history, all in double.
+ */
+#ifndef PERSEUS_ORACLE_H
+#define PERSEUS_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- synthetic input (LCG bytes) ---------------- */
+/* s = s*1664525 + 1013904223 (mod 2^32); byte = s >> 24; returns new state.
+ * The first byte produced comes from the state AFTER one step from `seed`. */
+uint32_t orc_lcg_fill(uint8_t *dst, size_t nbytes, uint32_t seed);
+
+/* ---- A1/A2/A3: 24-bit packed I/Q unpack (examples/perseustest.c) -------- */
+/* nbytes/6 samples are converted; trailing bytes ignored (perseustest.c:477) */
+void orc_unpack24_f32(const uint8_t *in, size_t nbytes, float *out_iq);
+void orc_unpack24_i32(const uint8_t *in, size_t nbytes, int32_t *out_iq);
+
+/* ---- A6: NCO tuning word (perseus-sdr.c:584) --------------------------- */
+uint32_t orc_nco_freg(double center_freq_hz, double adc_clk_hz);
+/* preselector filter id chosen by perseus-sdr.c:589-615 (10 = wide band) */
+int orc_presel_id(double center_freq_hz, int enable_presel);
+
+/* ---- A7: nearest sampling-rate selection (perseus-sdr.c:776-811) ------- */
+/* table must be sorted ascending; returns index or -1 */
+int orc_rate_index(int sps, const int *table, int n);
+
+/* ---- A8 (authored): NCO mix and polyphase FIR decimation --------------- */
+/* out[n] = x[n] * exp(-j*2*pi*((n0+n)*freg mod 2^32)/2^32), complex double */
+void orc_nco_mix_f64(const float *x_iq, size_t nsamples, uint64_t n0,
+                     uint32_t freg, double *out_iq);
+
+/* y[m] = sum_{k<ntaps} h[k]*x[m*D-k], x[i<0]=0, m = 0..ceil(n/D)-1.
+ * returns number of outputs written. */
+size_t orc_fir_decim_f64(const double *x_iq, size_t nsamples,
+                         const float *taps, int ntaps, int D, double *y_iq);
+
+/* whole chain: unpack -> (mix if mix_enable) -> nstages FIR decimators.
+ * All intermediates double; result cast to float.  Returns outputs written
+ * (capacity in complex samples), or (size_t)-1 on bad arguments. */
+size_t orc_ddc_chain(const uint8_t *packed, size_t nsamples,
+                     uint32_t freg, int mix_enable,
+                     int nstages, const int *D, const int *ntaps,
+                     const float *const *taps,
+                     float *out_iq, size_t out_capacity);
+
+/* ---- CPU baseline fast path (float accumulate, OpenMP over chunks) ------
+ * unpack + single-stage decimate-by-D, the work bench.py times beside the
+ * GPU kernel.  Same definition as the chain above with one stage and no mix,
+ * but accumulated in float.  threads<=0 -> omp default. Returns outputs. */
+size_t orc_stage1_f32(const uint8_t *packed, size_t nsamples,
+                      const float *taps, int ntaps, int D,
+                      float *out_iq, int threads);
+/* reference-style single-thread callback loop: 6144-byte buffers through
+ * orc_unpack24_f32 (perseustest.c:466-502 without the fwrite). */
+void orc_unpack24_f32_callback_style(const uint8_t *in, size_t nbytes,
+                                     float *out_iq, size_t buf_bytes);
+int orc_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

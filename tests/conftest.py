@@ -1,0 +1,47 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    p = importlib.import_module("libperseus-sdr_amd")
+    if not os.path.exists(p.DDC_LIB):
+        p.build()
+    return p
+
+
+@pytest.fixture(scope="session")
+def O():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+def load_taps(name):
+    return np.fromfile(os.path.join(GOLD, f"taps_{name}.f32"), dtype=np.float32)
+
+
+@pytest.fixture(scope="session")
+def taps():
+    return load_taps
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

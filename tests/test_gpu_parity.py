@@ -1,0 +1,295 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI
+(include/perseus_ddc.h), against the CPU oracle on the same inputs.
+
+Bars: unpack bit-exact; FIR / NCO stages max|y-ref|/max|ref| <= 1e-6
+(BASELINE.json north_star; metric defined in oracle.rel_err / DESIGN.md).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, load_taps
+
+pytestmark = pytest.mark.gpu
+FIR_TOL = 1e-6
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def to_dev(a, dev):
+    return _torch().from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ------------------------------------------------------------------ plumbing
+def test_native_library_loaded_and_device_visible(pkg, dev):
+    L = pkg.ddc_lib()
+    assert L.pddc_device_count() >= 1
+    with open("/proc/self/maps") as f:
+        assert "libperseus_ddc.so" in f.read()
+
+
+# -------------------------------------------------------------------- unpack
+def test_unpack_golden_kat(pkg, dev, O):
+    g = json.load(open(os.path.join(GOLD, "unpack_golden.json")))
+    codes = np.array([k["code24"] for k in g["kat"]], dtype=np.int64)
+    # pad to a multiple of 8 samples; Q carries the reversed list
+    packed = O.pack24(codes, codes[::-1])
+    f = pkg.unpack24_f32(to_dev(packed, dev)).cpu().numpy()
+    i = pkg.unpack24_i32(to_dev(packed, dev)).cpu().numpy()
+    for n, k in enumerate(g["kat"]):
+        assert f[n, 0].view(np.uint32) == k["float_bits"]
+        assert i[n, 0] == k["int32"]
+        assert f[len(codes) - 1 - n, 1].view(np.uint32) == k["float_bits"]
+
+
+def test_unpack_lcg_fixture(pkg, dev):
+    b = np.fromfile(os.path.join(GOLD, "lcg_6144.in"), dtype=np.uint8)
+    exp = np.fromfile(os.path.join(GOLD, "lcg_6144.f32.out"), dtype=np.float32)
+    got = pkg.unpack24_f32(to_dev(b, dev)).cpu().numpy().reshape(-1)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    sha = json.load(open(os.path.join(GOLD, "unpack_golden.json")))["sha256"]["lcg_6144_out_f32"]
+    assert hashlib.sha256(got.tobytes()).hexdigest() == sha
+
+
+def test_unpack_exhaustive_2p24_bit_exact(pkg, dev, O):
+    """Every 24-bit code in I, its complement in Q: the reference's own
+    exhaustive vector, hashes recorded from the reference."""
+    sha = json.load(open(os.path.join(GOLD, "unpack_golden.json")))["sha256"]
+    v = np.arange(1 << 24, dtype=np.int64)
+    packed = O.pack24(v, (~v) & 0xFFFFFF)
+    d = to_dev(packed, dev)
+    f = pkg.unpack24_f32(d).cpu().numpy()
+    assert hashlib.sha256(f.tobytes()).hexdigest() == sha["exhaustive_f32"]
+    i = pkg.unpack24_i32(d).cpu().numpy()
+    assert hashlib.sha256(i.tobytes()).hexdigest() == sha["exhaustive_i32"]
+    ref = O.unpack24_f32(packed)
+    assert np.array_equal(f.reshape(-1).view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("ns", [0, 1, 7, 8, 9, 1023, 1024, 4099])
+def test_unpack_ragged_sizes(pkg, dev, O, ns):
+    packed = O.lcg_bytes(6 * ns + 16, 99)[: 6 * ns]
+    buf = _torch().zeros(6 * ns + 64, dtype=_torch().uint8, device=dev)
+    buf[: 6 * ns] = to_dev(packed, dev) if ns else buf[:0]
+    got = pkg.unpack24_f32(buf[: 6 * ns]).cpu().numpy().reshape(-1)
+    ref = O.unpack24_f32(packed) if ns else np.zeros(0, np.float32)
+    assert got.size == 2 * ns
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_synth_lcg_matches_oracle(pkg, dev, O):
+    n = 6 * 8 * 1000 + 5
+    ref = O.lcg_bytes(n, 12345)
+    got = pkg.synth_lcg(n, 12345, 0, dev).cpu().numpy()
+    assert np.array_equal(got, ref)
+    off = 6 * 12345 + 3
+    got2 = pkg.synth_lcg(1000, 12345, off, dev).cpu().numpy()
+    assert np.array_equal(got2, ref[off:off + 1000])
+
+
+# ------------------------------------------------------------- fused /8 FIR
+@pytest.mark.parametrize("name", ["d8_127", "d8_255", "c320_s1_d8_32", "c320_s2_d8_64"])
+def test_fused_decimate8_vs_oracle(pkg, dev, O, name):
+    h = load_taps(name)
+    ns = 8 * 9000 + 8 * 3                      # several tiles + ragged tail
+    packed = O.lcg_bytes(6 * ns, 12345)
+    pipe = pkg.Pipeline([(8, h)])
+    assert pipe.fused
+    y = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+    ref = O.ddc_chain(packed, [(8, h)])
+    assert y.size == ref.size == 2 * (ns // 8)
+    assert O.rel_err(y, ref) <= FIR_TOL
+    pipe.close()
+
+
+@pytest.mark.parametrize("name", ["d8_127", "d8_255"])
+def test_fused_golden_fixture(pkg, dev, name):
+    meta = json.load(open(os.path.join(GOLD, "ddc_golden.json")))
+    from oracle import oracle as O
+    ns = meta["ddc_d8_lcg_samples"]
+    packed = O.lcg_bytes(6 * ns, meta["lcg_seed"])
+    exp = np.fromfile(os.path.join(GOLD, f"ddc_{name}_lcg.f32"), dtype=np.float32)
+    pipe = pkg.Pipeline([(8, load_taps(name))])
+    y = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+    assert y.size == exp.size
+    assert O.rel_err(y, exp) <= FIR_TOL
+    pipe.close()
+
+
+def test_stream_seams_match_single_shot(pkg, dev, O):
+    """FIR history + NCO counter carried across process() calls: pushing the
+    stream in uneven batches must equal one big batch (and the oracle)."""
+    h = load_taps("d8_127")
+    ns = 8 * 6000
+    packed = O.lcg_bytes(6 * ns, 777)
+    ref = O.ddc_chain(packed, [(8, h)], freg=381178347, mix=True)
+    pipe = pkg.Pipeline([(8, h)], mix=True)
+    pipe.set_center_freq(7.1e6)
+    assert pipe.freg == 381178347
+    cuts = [0, 8 * 16, 8 * 16 + 8 * 1024, 8 * 3000, 8 * 3001, ns]
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        parts.append(pipe.process(to_dev(packed[6 * a:6 * b], dev)).cpu().numpy().reshape(-1))
+    y = np.concatenate(parts)
+    assert y.size == ref.size
+    assert O.rel_err(y, ref) <= FIR_TOL
+    pipe.reset()
+    y1 = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+    assert O.rel_err(y1, ref) <= FIR_TOL
+    pipe.close()
+
+
+def test_generic_path_equals_oracle_and_fused(pkg, dev, O):
+    h = load_taps("d8_127")
+    ns = 8 * 2500
+    packed = O.lcg_bytes(6 * ns, 4242)
+    ref = O.ddc_chain(packed, [(8, h)])
+    slow = pkg.Pipeline([(8, h)], no_fast=True)
+    assert not slow.fused
+    y = slow.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+    assert O.rel_err(y, ref) <= FIR_TOL
+    slow.close()
+
+
+@pytest.mark.parametrize("D,nt", [(5, 161), (10, 77), (1, 9), (3, 1), (40, 401)])
+def test_generic_decimators(pkg, dev, O, D, nt):
+    rng = np.random.default_rng(D * 1000 + nt)
+    h = (rng.standard_normal(nt) / nt).astype(np.float32)
+    ns = 8 * 1300
+    packed = O.lcg_bytes(6 * ns, 31337)
+    ref = O.ddc_chain(packed, [(D, h)])
+    pipe = pkg.Pipeline([(D, h)])
+    # two uneven pushes exercise the decimation phase carry
+    a = 8 * 401
+    y = np.concatenate([pipe.process(to_dev(packed[:6 * a], dev)).cpu().numpy().reshape(-1),
+                        pipe.process(to_dev(packed[6 * a:], dev)).cpu().numpy().reshape(-1)])
+    assert y.size == ref.size
+    assert O.rel_err(y, ref) <= FIR_TOL
+    pipe.close()
+
+
+# ------------------------------------------------------- config 3: x320 + NCO
+def test_cascade_320_with_nco_fixture_and_oracle(pkg, dev, O):
+    meta = json.load(open(os.path.join(GOLD, "ddc_golden.json")))
+    tone = np.fromfile(os.path.join(GOLD, "tone_7101k.in"), dtype=np.uint8)
+    exp = np.fromfile(os.path.join(GOLD, "ddc_c320_tone.f32"), dtype=np.float32)
+    stages = [(d, load_taps(n)) for d, n in meta["c320_stages"]]
+    pipe = pkg.Pipeline(stages, mix=True)
+    pipe.set_freg(meta["freg"])
+    assert pipe.decim == 320
+    y = pipe.process(to_dev(tone, dev)).cpu().numpy().reshape(-1)
+    assert y.size == exp.size
+    assert O.rel_err(y, exp) <= FIR_TOL
+    # spectral sanity: a 7.101 MHz tone lands at ~1 kHz at 250 kS/s
+    z = y.reshape(-1, 2)[100:, 0] + 1j * y.reshape(-1, 2)[100:, 1]
+    f_est = np.mean(np.diff(np.unwrap(np.angle(z)))) * 250e3 / (2 * np.pi)
+    assert abs(f_est - 1000.0) < 1.0
+    # same stream in batches that are NOT multiples of 320
+    pipe.reset()
+    cuts = [0, 8 * 1000, 8 * 1000 + 8 * 77, tone.size // 6]
+    parts = [pipe.process(to_dev(tone[6 * a:6 * b], dev)).cpu().numpy().reshape(-1)
+             for a, b in zip(cuts[:-1], cuts[1:])]
+    y2 = np.concatenate(parts)
+    assert y2.size == exp.size
+    assert O.rel_err(y2, exp) <= FIR_TOL
+    pipe.close()
+
+
+def test_nco_mix_lcg_noise(pkg, dev, O):
+    """NCO on full-scale noise at an awkward tuning word, generic + fused."""
+    h = load_taps("c320_s1_d8_32")
+    ns = 8 * 4096
+    packed = O.lcg_bytes(6 * ns, 5)
+    for freg in (1, 0x80000000, 0xFFFFFFFF, 381178347, 123456789):
+        ref = O.ddc_chain(packed, [(8, h)], freg=freg, mix=True)
+        pipe = pkg.Pipeline([(8, h)], mix=True)
+        pipe.set_freg(freg)
+        y = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+        assert O.rel_err(y, ref) <= FIR_TOL, freg
+        pipe.close()
+
+
+def test_push_host_roundtrip(pkg, dev, O):
+    h = load_taps("d8_127")
+    ns = 8 * 1024 * 3
+    packed = O.lcg_bytes(6 * ns, 11)
+    ref = O.ddc_chain(packed, [(8, h)])
+    pipe = pkg.Pipeline([(8, h)])
+    y = np.concatenate([pipe.push_host(packed[: 6 * 8192]).reshape(-1),
+                        pipe.push_host(packed[6 * 8192:]).reshape(-1)])
+    assert O.rel_err(y, ref) <= FIR_TOL
+    pipe.close()
+
+
+# ------------------------------------------------------------ error behaviour
+def test_argument_errors(pkg, dev, O):
+    h = load_taps("d8_127")
+    pipe = pkg.Pipeline([(8, h)])
+    t = _torch()
+    buf = t.zeros(6 * 64 + 16, dtype=t.uint8, device=dev)
+    out = t.zeros(64, dtype=t.float32, device=dev)
+    with pytest.raises(pkg.PddcError) as e:          # not a multiple of 8 samples
+        pipe.process_ptr(buf.data_ptr(), 12, out.data_ptr(), 32)
+    assert e.value.code == pkg.PDDC_EINVAL
+    with pytest.raises(pkg.PddcError) as e:          # misaligned input
+        pipe.process_ptr(buf.data_ptr() + 2, 8, out.data_ptr(), 32)
+    assert e.value.code == pkg.PDDC_EINVAL
+    with pytest.raises(pkg.PddcError) as e:          # output too small
+        pipe.process_ptr(buf.data_ptr(), 64, out.data_ptr(), 4)
+    assert e.value.code == pkg.PDDC_ECAPACITY
+    with pytest.raises(pkg.PddcError):
+        pipe.set_center_freq(41e6)                   # perseus-sdr.c:575 range
+    assert pipe.process_ptr(buf.data_ptr(), 0, out.data_ptr(), 32) == 0
+    pipe.close()
+    with pytest.raises(pkg.PddcError):
+        pkg.Pipeline([(8, h)], device=99)
+
+
+# ------------------------------------------- full size, size-independent checks
+def test_full_size_properties(pkg, dev, O):
+    """BASELINE config 2 size (2^26 here to bound test time; bench runs 2^28):
+    (1) prefix equals the oracle, (2) linearity: DDC(a)+DDC(b) == DDC(a+b) for
+    24-bit inputs whose sum does not overflow, (3) DC gain = sum(h)."""
+    t = _torch()
+    h = load_taps("d8_127")
+    ns = 1 << 26
+    d_in = pkg.synth_lcg(6 * ns, 12345, 0, dev)
+    pipe = pkg.Pipeline([(8, h)])
+    y = pipe.process(d_in)
+    assert y.shape[0] == ns // 8
+    pre = 8 * 20000
+    ref = O.ddc_chain(O.lcg_bytes(6 * pre, 12345), [(8, h)])
+    assert O.rel_err(y[: pre // 8].cpu().numpy().reshape(-1), ref) <= FIR_TOL
+    # interior seam far from the start: compare a window against the oracle
+    s0 = (ns // 2 // 8192) * 8192 - 8 * 300
+    win = d_in[6 * (s0 - 8 * 64): 6 * (s0 + 8 * 700)].cpu().numpy()
+    refw = O.ddc_chain(win, [(8, h)])[2 * 64:]
+    got = y[s0 // 8: s0 // 8 + 700].cpu().numpy().reshape(-1)
+    assert O.rel_err(got, refw[: got.size]) <= FIR_TOL
+    del y, d_in
+    # DC gain
+    n2 = 8 * 8192 * 4
+    half = np.full(n2, 0x200000, dtype=np.int64)
+    packed = O.pack24(half, -half)
+    pipe.reset()
+    ydc = pipe.process(to_dev(packed, dev)).cpu().numpy()
+    g = float(np.sum(h.astype(np.float64)))
+    assert abs(ydc[-1, 0] - 0.25 * g * 8388608 / 8388607) < 1e-6
+    assert abs(ydc[-1, 1] + 0.25 * g * 8388608 / 8388607) < 1e-6
+    # linearity
+    rng = np.random.default_rng(1)
+    a = rng.integers(-(1 << 22), 1 << 22, size=(2, n2))
+    b = rng.integers(-(1 << 22), 1 << 22, size=(2, n2))
+    outs = []
+    for u in (a, b, a + b):
+        pipe.reset()
+        outs.append(pipe.process(to_dev(O.pack24(u[0], u[1]), dev)).cpu().numpy().astype(np.float64))
+    scale = np.max(np.abs(outs[2]))
+    assert np.max(np.abs(outs[0] + outs[1] - outs[2])) / scale <= 3e-6
+    pipe.close()
