@@ -67,20 +67,19 @@ def cpu_baseline(workload, seconds):
         h = load_taps("d8_255" if workload == "d8_255" else "d8_127")
         run = lambda b: O.stage1_f32(b, h, 8, threads)
         label = f"unpack + {h.size}-tap decimate-by-8, float accumulate, OpenMP"
-    n = 1 << 21
+    n = 1 << 25                                # 2^25 samples (192 MiB packed) per pass
     buf = O.lcg_bytes(6 * n, 12345)
     run(buf)                                   # warm (page-in, omp pool)
-    t0 = time.perf_counter()
-    run(buf)
-    rate = n / (time.perf_counter() - t0)
-    n_big = int(min(max(rate * seconds, n), 1 << 28)) // 8 * 8
-    if n_big > n:
-        buf = O.lcg_bytes(6 * n_big, 12345)
-    t0 = time.perf_counter()
-    run(buf)
-    dt = time.perf_counter() - t0
+    passes, t0 = 0, time.perf_counter()
+    while True:                                # repeat passes until ~`seconds` of CPU work
+        run(buf)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or passes >= 4096:
+            break
+    n_big = n * passes
     return {"value": round(n_big / dt / 1e6, 2), "unit": "MS/s", "cores": threads, "kind": "port",
-            "sample": f"{n_big} samples of the same LCG stream ({label}), {dt:.1f} s"}
+            "sample": f"{passes} passes over 2^25 samples of the same LCG stream ({label}), {dt:.1f} s"}
 
 
 def main():

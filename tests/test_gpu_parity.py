@@ -84,11 +84,11 @@ def test_unpack_ragged_sizes(pkg, dev, O, ns):
 
 
 def test_synth_lcg_matches_oracle(pkg, dev, O):
-    n = 6 * 8 * 1000 + 5
+    n = 6 * 8 * 2000 + 5
     ref = O.lcg_bytes(n, 12345)
     got = pkg.synth_lcg(n, 12345, 0, dev).cpu().numpy()
     assert np.array_equal(got, ref)
-    off = 6 * 12345 + 3
+    off = 6 * 1234 + 3
     got2 = pkg.synth_lcg(1000, 12345, off, dev).cpu().numpy()
     assert np.array_equal(got2, ref[off:off + 1000])
 
