@@ -30,6 +30,7 @@ struct Fir8Args {
 constexpr int fir8_tile_inputs(int R) { return 1024 * R; }
 size_t fir8_lds_bytes(int ntb, int R);
 bool   fir8_supported(int ntb, int R);
+void   fir8_set_grid_blocks(int nblocks);   /* persistent grid size (default 512) */
 
 /* returns hipSuccess or the launch error */
 hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s);

@@ -39,6 +39,9 @@ namespace pddc {
 
 static constexpr float kUnpackScale = 0x1.000002p-23f;   /* RN(1/8388607) */
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 /* ------------------------------------------------------------------------ */
 /* 12 dwords (48 bytes) = 8 packed samples -> sign-extended 24-bit integers  */
 __device__ __forceinline__ void unpack8_i24(const uint32_t (&w)[12], int32_t (&I)[8], int32_t (&Q)[8])
@@ -225,159 +228,232 @@ template <int NTB, int R>
 struct Fir8Geom {
     static constexpr int TI      = 1024 * R;            /* inputs per tile          */
     static constexpr int TO      = 128 * R;             /* outputs per tile         */
-    static constexpr int NG      = TI / 8 + NTB;        /* groups incl. history     */
+    static constexpr int GT      = TI / 8;              /* new groups per tile      */
+    static constexpr int GPT     = GT / 256;            /* groups per thread / tile */
+    static constexpr int NG      = GT + NTB;            /* groups incl. history     */
     static constexpr int PLANE   = 8 + 8 * NG + 4 * (NG / R) + 8;   /* floats      */
-    static constexpr int LDS_FLT = 2 * PLANE;
+    static constexpr int OT      = 2 * TO;              /* output staging, floats   */
+    static constexpr int LDS_FLT = 2 * PLANE + OT;
 };
 
 size_t fir8_lds_bytes(int ntb, int R)
 {
     const int NG = 1024 * R / 8 + ntb;
     const int plane = 8 + 8 * NG + 4 * (NG / R) + 8;
-    return (size_t)2 * plane * sizeof(float);
+    return (size_t)(2 * plane + 2 * 128 * R) * sizeof(float);
 }
 
+/* one 8-sample group: global words -> (mixed) planar floats */
+template <int INFMT, bool MIX, int NW>
+__device__ __forceinline__ void group_to_float(const uint4 (&raw)[NW], float (&xi)[8], float (&xq)[8],
+                                               unsigned long long nabs, const Fir8Args &p)
+{
+    if (INFMT == IN_PACKED24) {
+        const uint32_t w[12] = { raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y,
+                                 raw[1].z, raw[1].w, raw[2].x, raw[2].y, raw[2].z, raw[2].w };
+        int32_t I[8], Q[8];
+        unpack8_i24(w, I, Q);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xi[e] = (float)I[e] * kUnpackScale;
+            xq[e] = (float)Q[e] * kUnpackScale;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 f = raw[k < NW ? k : 0];
+            xi[2 * k]     = __uint_as_float(f.x);
+            xq[2 * k]     = __uint_as_float(f.y);
+            xi[2 * k + 1] = __uint_as_float(f.z);
+            xq[2 * k + 1] = __uint_as_float(f.w);
+        }
+    }
+    if (MIX)     /* zero-filled groups stay zero; the index wraps correctly for negative offsets */
+        mix8(xi, xq, nabs, p);
+}
+
+/* rotated LDS write of group v: e=0 -> slot 7 of group v-1 ; e=1..7 -> slots 0..6 of group v */
+template <int R>
+__device__ __forceinline__ void group_to_lds(float *sI, float *sQ, int v, const float (&xi)[8],
+                                             const float (&xq)[8])
+{
+    const int o_prev = (v == 0) ? 7 : goff<R>(v - 1) + 7;
+    const int o_cur  = goff<R>(v);
+    sI[o_prev] = xi[0];
+    sQ[o_prev] = xq[0];
+    *reinterpret_cast<float4 *>(sI + o_cur) = make_float4(xi[1], xi[2], xi[3], xi[4]);
+    *reinterpret_cast<float4 *>(sQ + o_cur) = make_float4(xq[1], xq[2], xq[3], xq[4]);
+    *reinterpret_cast<float2 *>(sI + o_cur + 4) = make_float2(xi[5], xi[6]);
+    *reinterpret_cast<float2 *>(sQ + o_cur + 4) = make_float2(xq[5], xq[6]);
+    sI[o_cur + 6] = xi[7];
+    sQ[o_cur + 6] = xq[7];
+}
+
+/* Persistent: block b owns the contiguous tile range [b*tpb, (b+1)*tpb).
+ * Per tile:  U  unpack the prefetched registers into the LDS planes
+ *            -- barrier A --
+ *            P  issue the NEXT tile's global loads (in flight during F)
+ *            F  FIR from LDS, results to the output staging area
+ *            -- barrier B --
+ *            S  coalesced stores; C  the last NTB groups become the next
+ *               tile's history (copied by the very threads that overwrite
+ *               them in the next U, so no third barrier is needed).       */
 template <int NTB, int R, int INFMT, bool MIX>
-__global__ __launch_bounds__(256) void k_fir8(Fir8Args p)
+__global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int tiles_per_block, int ntiles)
 {
     using G = Fir8Geom<NTB, R>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sI = smem;
     float *sQ = smem + G::PLANE;
+    float *ot = smem + 2 * G::PLANE;
+
+    constexpr int NW = (INFMT == IN_PACKED24) ? 3 : 4;             /* 16-byte words per group */
+    constexpr int ES = (INFMT == IN_PACKED24) ? 6 : 8;             /* bytes per sample        */
 
     const int tid = threadIdx.x;
-    const long long tile_in0 = (long long)blockIdx.x * G::TI;      /* first input of the tile */
+    const int t0  = blockIdx.x * tiles_per_block;
+    const int t1  = min(t0 + tiles_per_block, ntiles);
+    if (t0 >= t1)
+        return;
 
-    /* ---------------- load phase: groups v = 0 .. NG-1 -------------------- */
-    /* group v holds inputs i = 8v - 8*NTB + e (e=0..7) relative to the tile.
-     * All global loads of the thread are issued before the first unpack so
-     * that one HBM latency covers the whole tile (NITER groups in flight).   */
-    constexpr int NITER = (G::NG + 255) / 256;
-    constexpr int NW    = (INFMT == IN_PACKED24) ? 3 : 4;          /* 16-byte words per group */
-    uint4 raw[NITER][NW];
-#pragma unroll
-    for (int it = 0; it < NITER; ++it) {
-        const int v = tid + 256 * it;
-        const long long s_abs = tile_in0 + 8LL * v - 8 * NTB;      /* relative to batch start */
-        const bool have = (v < G::NG) && (s_abs < p.n_in);
-        constexpr int ES = (INFMT == IN_PACKED24) ? 6 : 8;         /* bytes per sample */
-        const uint8_t *src = (s_abs < 0)
-                                 ? static_cast<const uint8_t *>(p.hist) + (s_abs + 8 * NTB) * ES
-                                 : static_cast<const uint8_t *>(p.in) + s_abs * ES;
+    /* ---- history of the first tile: groups 0..NTB-1 ------------------------ */
+    if (tid < NTB) {
+        const long long s_abs = (long long)t0 * G::TI + 8LL * tid - 8 * NTB;
+        const uint8_t *src = (s_abs < 0) ? static_cast<const uint8_t *>(p.hist) + (s_abs + 8 * NTB) * ES
+                                         : static_cast<const uint8_t *>(p.in) + s_abs * ES;
+        uint4 hraw[NW];
 #pragma unroll
         for (int k = 0; k < NW; ++k)
-            raw[it][k] = have ? reinterpret_cast<const uint4 *>(src)[k] : make_uint4(0u, 0u, 0u, 0u);
+            hraw[k] = (s_abs < p.n_in) ? reinterpret_cast<const uint4 *>(src)[k] : make_uint4(0u, 0u, 0u, 0u);
+        float xi[8], xq[8];
+        group_to_float<INFMT, MIX, NW>(hraw, xi, xq, p.n0 + (unsigned long long)s_abs, p);
+        group_to_lds<R>(sI, sQ, tid, xi, xq);
     }
-#pragma unroll
-    for (int it = 0; it < NITER; ++it) {
-        const int v = tid + 256 * it;
-        if (v < G::NG) {
-            const long long s_abs = tile_in0 + 8LL * v - 8 * NTB;
-            float xi[8], xq[8];
-            if (INFMT == IN_PACKED24) {
-                const uint32_t w[12] = { raw[it][0].x, raw[it][0].y, raw[it][0].z, raw[it][0].w,
-                                         raw[it][1].x, raw[it][1].y, raw[it][1].z, raw[it][1].w,
-                                         raw[it][2].x, raw[it][2].y, raw[it][2].z, raw[it][2].w };
-                int32_t I[8], Q[8];
-                unpack8_i24(w, I, Q);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    xi[e] = (float)I[e] * kUnpackScale;
-                    xq[e] = (float)Q[e] * kUnpackScale;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint4 f = raw[it][k < NW ? k : 0];
-                    xi[2 * k]     = __uint_as_float(f.x);
-                    xq[2 * k]     = __uint_as_float(f.y);
-                    xi[2 * k + 1] = __uint_as_float(f.z);
-                    xq[2 * k + 1] = __uint_as_float(f.w);
-                }
-            }
-            if (MIX)     /* zero-filled groups stay zero; index wraps correctly for s_abs<0 */
-                mix8(xi, xq, p.n0 + (unsigned long long)s_abs, p);
-            /* rotated write: e=0 -> slot 7 of group v-1 ; e=1..7 -> slots 0..6 of group v */
-            const int o_prev = (v == 0) ? 7 : goff<R>(v - 1) + 7;
-            const int o_cur  = goff<R>(v);
-            sI[o_prev] = xi[0];
-            sQ[o_prev] = xq[0];
-            *reinterpret_cast<float4 *>(sI + o_cur) = make_float4(xi[1], xi[2], xi[3], xi[4]);
-            *reinterpret_cast<float4 *>(sQ + o_cur) = make_float4(xq[1], xq[2], xq[3], xq[4]);
-            *reinterpret_cast<float2 *>(sI + o_cur + 4) = make_float2(xi[5], xi[6]);
-            *reinterpret_cast<float2 *>(sQ + o_cur + 4) = make_float2(xq[5], xq[6]);
-            sI[o_cur + 6] = xi[7];
-            sQ[o_cur + 6] = xq[7];
-        }
-    }
-    __syncthreads();
 
-    /* ---------------- FIR phase ------------------------------------------ */
+    uint4 raw[G::GPT][NW];
+    auto prefetch = [&](int tile) {
+        const long long tin0 = (long long)tile * G::TI;
+        const uint4 *src0 = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(p.in) +
+                                                            (tin0 + 8LL * tid) * ES);
+        if (tin0 + G::TI <= p.n_in) {                  /* whole tile in range (wave-uniform) */
+#pragma unroll
+            for (int k = 0; k < G::GPT; ++k)
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                    raw[k][w] = src0[(256 * k * 8 * ES) / 16 + w];
+        } else {                                        /* ragged last tile */
+#pragma unroll
+            for (int k = 0; k < G::GPT; ++k) {
+                const bool have = tin0 + 8LL * (tid + 256 * k) < p.n_in;
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                    raw[k][w] = have ? src0[(256 * k * 8 * ES) / 16 + w] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+    prefetch(t0);
+
     const int wave  = tid >> 6;
     const int lane  = tid & 63;
     const int plane = wave & 1;
     const int L     = (wave >> 1) * 64 + lane;                     /* 0..127 */
     const float *base = (plane ? sQ : sI) + 8 + L * (8 * R + 4);   /* goff(R*L) */
     const float PDDC_CONSTANT *hb = (const float PDDC_CONSTANT *)p.taps_blk;
+    const long long n_out = p.n_in >> 3;
 
-    float accA[R], accB[R];
+    for (int t = t0; t < t1; ++t) {
+        /* ---- U: registers -> LDS planes (groups NTB ..) ------------------- */
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        accA[r] = 0.0f;
-        accB[r] = 0.0f;
-    }
+        for (int k = 0; k < G::GPT; ++k) {
+            const int v = NTB + tid + 256 * k;
+            float xi[8], xq[8];
+            group_to_float<INFMT, MIX, NW>(raw[k], xi, xq,
+                                           p.n0 + (unsigned long long)((long long)t * G::TI + 8LL * (tid + 256 * k)), p);
+            group_to_lds<R>(sI, sQ, v, xi, xq);
+        }
+        __syncthreads();                                           /* A */
+
+        /* ---- P: next tile's loads --------------------------------------- */
+        if (t + 1 < t1)
+            prefetch(t + 1);
+
+        /* ---- F: FIR ------------------------------------------------------ */
+        /* Packed fp32: every VALU op costs ~4 cycles per wave64 on gfx950, and
+         * v_pk_fma_f32 does two FMAs in that slot (measured 68 vs 33 TFMA/s,
+         * tools/ubench/fma_issue.hip).  The dot product of one output is split
+         * into its even and odd terms: acc.x += h[k]*x[i], acc.y += h[k-1]*x[i+1]
+         * -- both operands are natural adjacent pairs (SGPR pair of taps, VGPR
+         * pair of samples from one ds_read_b128), no broadcast, no shuffles.   */
+        asm volatile("" : "+s"(hb));      /* keep the tap s_loads inside the tile loop (no SGPR spills) */
+        f32x2 acc[R];
 #pragma unroll
-    for (int ub = 0; ub < R + NTB - 1; ++ub) {
-        const int go = 8 * ub + 4 * (ub / R);
-        const float4 d0 = *reinterpret_cast<const float4 *>(base + go);
-        const float4 d1 = *reinterpret_cast<const float4 *>(base + go + 4);
+        for (int r = 0; r < R; ++r)
+            acc[r] = f32x2{ 0.0f, 0.0f };
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int j = r + NTB - 1 - ub;
-            if (j >= 0 && j < NTB) {
-                const float PDDC_CONSTANT *h = hb + 8 * j;
-                float a = (j & 1) ? accB[r] : accA[r];
-                a = fmaf(h[0], d0.x, a);
-                a = fmaf(h[1], d0.y, a);
-                a = fmaf(h[2], d0.z, a);
-                a = fmaf(h[3], d0.w, a);
-                a = fmaf(h[4], d1.x, a);
-                a = fmaf(h[5], d1.y, a);
-                a = fmaf(h[6], d1.z, a);
-                a = fmaf(h[7], d1.w, a);
-                if (j & 1)
-                    accB[r] = a;
-                else
-                    accA[r] = a;
+        for (int ub = 0; ub < R + NTB - 1; ++ub) {
+            const int go = 8 * ub + 4 * (ub / R);
+            const f32x4 d0 = *reinterpret_cast<const f32x4 *>(base + go);
+            const f32x4 d1 = *reinterpret_cast<const f32x4 *>(base + go + 4);
+            const f32x2 x0 = { d0.x, d0.y }, x1 = { d0.z, d0.w }, x2 = { d1.x, d1.y }, x3 = { d1.z, d1.w };
+            const f32x2 xs[4] = { x0, x1, x2, x3 };
+            /* pair index outer, output inner: neighbouring instructions touch
+             * different accumulators (a dependent v_pk_fma pair costs an s_nop) */
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int j = r + NTB - 1 - ub;
+                    if (j >= 0 && j < NTB) {
+                        const f32x2 PDDC_CONSTANT *h = reinterpret_cast<const f32x2 PDDC_CONSTANT *>(hb + 8 * j);
+                        acc[r] = __builtin_elementwise_fma(h[i], xs[i], acc[r]);
+                    }
+                }
             }
         }
-    }
-    __syncthreads();          /* every wave is done reading the sample planes */
-
-    /* ---------------- store phase: transpose through LDS ------------------ */
-    float *ot = smem;         /* overlays sI */
+        /* results -> staging (XOR-swizzled 16-byte chunks, interleaved I/Q) */
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int f  = 2 * (R * L + r) + plane;
-        const int q  = f >> 2;
-        const int qs = q ^ ((q >> 3) & 7);
-        ot[4 * qs + (f & 3)] = accA[r] + accB[r];
-    }
-    __syncthreads();
-    const long long n_out    = p.n_in >> 3;
-    const long long tile_o0  = (long long)blockIdx.x * G::TO;
-    constexpr int NCH = G::TO / 2;                                  /* 16-byte chunks */
-#pragma unroll
-    for (int it = 0; it < (NCH + 255) / 256; ++it) {
-        const int q = tid + 256 * it;
-        if (q < NCH) {
+        for (int r = 0; r < R; ++r) {
+            const int f  = 2 * (R * L + r) + plane;
+            const int q  = f >> 2;
             const int qs = q ^ ((q >> 3) & 7);
-            const float4 v = *reinterpret_cast<const float4 *>(ot + 4 * qs);
-            const long long m = tile_o0 + 2LL * q;
-            if (m + 1 < n_out)
-                *reinterpret_cast<float4 *>(p.out + 2 * m) = v;
-            else if (m < n_out)
-                *reinterpret_cast<float2 *>(p.out + 2 * m) = make_float2(v.x, v.y);
+            ot[4 * qs + (f & 3)] = acc[r].x + acc[r].y;
+        }
+        __syncthreads();                                           /* B */
+
+        /* ---- S: coalesced stores ------------------------------------------ */
+        const long long tile_o0 = (long long)t * G::TO;
+        constexpr int NCH = G::TO / 2;                             /* 16-byte chunks */
+#pragma unroll
+        for (int it = 0; it < (NCH + 255) / 256; ++it) {
+            const int q = tid + 256 * it;
+            if (q < NCH) {
+                const int qs = q ^ ((q >> 3) & 7);
+                const float4 v = *reinterpret_cast<const float4 *>(ot + 4 * qs);
+                const long long m = tile_o0 + 2LL * q;
+                if (m + 1 < n_out)
+                    *reinterpret_cast<float4 *>(p.out + 2 * m) = v;
+                else if (m < n_out)
+                    *reinterpret_cast<float2 *>(p.out + 2 * m) = make_float2(v.x, v.y);
+            }
+        }
+        /* ---- C: tail groups -> history of the next tile -------------------- */
+        if (t + 1 < t1 && tid >= 256 - NTB) {
+            const int gd = tid - (256 - NTB);                      /* 0..NTB-1 */
+            const int os = goff<R>(G::GT + gd), od = goff<R>(gd);
+            const float4 i0 = *reinterpret_cast<const float4 *>(sI + os);
+            const float4 i1 = *reinterpret_cast<const float4 *>(sI + os + 4);
+            const float4 q0 = *reinterpret_cast<const float4 *>(sQ + os);
+            const float4 q1 = *reinterpret_cast<const float4 *>(sQ + os + 4);
+            *reinterpret_cast<float4 *>(sI + od) = i0;
+            *reinterpret_cast<float4 *>(sQ + od) = q0;
+            *reinterpret_cast<float2 *>(sI + od + 4) = make_float2(i1.x, i1.y);
+            *reinterpret_cast<float2 *>(sQ + od + 4) = make_float2(q1.x, q1.y);
+            sI[od + 6] = i1.z;
+            sQ[od + 6] = q1.z;
+            if (gd != NTB - 1) {          /* slot 7 of the last group belongs to the next tile's first sample */
+                sI[od + 7] = i1.w;
+                sQ[od + 7] = q1.w;
+            }
         }
     }
 }
@@ -387,15 +463,22 @@ bool fir8_supported(int ntb, int R)
     return (R == 4 || R == 8) && (ntb == 4 || ntb == 8 || ntb == 16 || ntb == 32);
 }
 
+static int g_fir8_blocks = 512;     /* persistent grid: 2 blocks per CU x 256 CUs */
+
 template <int NTB, int R>
 static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s)
 {
     using G = Fir8Geom<NTB, R>;
     const size_t lds = (size_t)G::LDS_FLT * sizeof(float);
-    const long long ntiles = (a.n_in + G::TI - 1) / G::TI;
-    if (ntiles <= 0)
+    const long long ntiles_ll = (a.n_in + G::TI - 1) / G::TI;
+    if (ntiles_ll <= 0)
         return hipSuccess;
-    const dim3 grid((unsigned)ntiles), blk(256);
+    if (ntiles_ll > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+    const int ntiles = (int)ntiles_ll;
+    const int tpb = (ntiles + g_fir8_blocks - 1) / g_fir8_blocks;
+    const int nblocks = (ntiles + tpb - 1) / tpb;
+    const dim3 grid((unsigned)nblocks), blk(256);
 #define PDDC_LAUNCH(FMT, MIXV)                                                                    \
     do {                                                                                          \
         static bool attr_done = false;                                                            \
@@ -407,7 +490,7 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
                 return e;                                                                         \
             attr_done = true;                                                                     \
         }                                                                                         \
-        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV>), grid, blk, lds, s, a);                    \
+        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV>), grid, blk, lds, s, a, tpb, ntiles);       \
     } while (0)
     if (fmt == IN_PACKED24) {
         if (mix)
@@ -420,6 +503,8 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
 #undef PDDC_LAUNCH
     return hipGetLastError();
 }
+
+void fir8_set_grid_blocks(int nblocks) { g_fir8_blocks = nblocks > 0 ? nblocks : 512; }
 
 hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s)
 {

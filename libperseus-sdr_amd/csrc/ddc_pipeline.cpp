@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -293,6 +294,12 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
     p->device = device;
     p->flags = flags;
     p->nstages = nstages;
+    /* tuning knobs (development): outputs per lane and persistent grid size */
+    if (const char *e = getenv("PDDC_FIR8_R"))
+        if (atoi(e) == 4 || atoi(e) == 8)
+            p->R = atoi(e);
+    if (const char *e = getenv("PDDC_FIR8_BLOCKS"))
+        fir8_set_grid_blocks(atoi(e));
     for (int i = 0; i < nstages; ++i) {
         Stage &s = p->st[i];
         s.decim = stages[i].decim;

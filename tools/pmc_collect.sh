@@ -1,0 +1,36 @@
+#!/bin/bash
+# Collect PMC counters for the bench in separate passes (gpurun refuses --pmc
+# together with trace domains other than kernel-trace).  Usage on the GPU box:
+#   tools/pmc_collect.sh <outdir> [bench args...]
+# Writes <outdir>/passN/... CSVs and a merged summary <outdir>/pmc_summary.txt
+set -u
+OUT=$1; shift
+export TMPDIR=/tmp
+mkdir -p "$OUT"
+PASSES=(
+ "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD"
+ "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR"
+ "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_INST_CYCLES_SMEM SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"
+ "FETCH_SIZE"
+ "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
+ "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum"
+)
+i=0
+for P in "${PASSES[@]}"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$OUT/pass$i" -- python3 bench.py --no-cpu "$@" > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed (see $OUT/pass$i.log)"
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"][:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(out + "/pmc_summary.txt", "w") as fo:
+    for k, d in acc.items():
+        fo.write(k + "\n")
+        for c, v in sorted(d.items()):
+            fo.write(f"   {c:34s} n={len(v):3d} mean={sum(v)/len(v):.6g}\n")
+print(open(out + "/pmc_summary.txt").read())
+PY
