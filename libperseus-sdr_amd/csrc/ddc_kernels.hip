@@ -37,22 +37,27 @@
 
 namespace pddc {
 
-static constexpr float kUnpackScale = 0x1.000002p-23f;   /* RN(1/8388607) */
+/* float = (float)(v24*256) * RN(1/2147483392): the int->float convert is exact
+ * (24 significant bits) and the product is bit-identical to the reference's
+ * (float)int32 / (float)(INT_MAX-256) for all 2^24 codes (tests). */
+static constexpr float kUnpackScale = 0x1.000002p-31f;   /* RN(1/8388607) / 256 */
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 /* ------------------------------------------------------------------------ */
-/* 12 dwords (48 bytes) = 8 packed samples -> sign-extended 24-bit integers  */
-__device__ __forceinline__ void unpack8_i24(const uint32_t (&w)[12], int32_t (&I)[8], int32_t (&Q)[8])
+/* 12 dwords (48 bytes) = 8 packed samples -> MSB-aligned int32 (value * 256),
+ * exactly the iq_sample union placement of examples/perseustest.c:411-426.
+ * One v_perm_b32 per component: bytes {b2,b1,b0,0x00}.                      */
+__device__ __forceinline__ void unpack8_msb(const uint32_t (&w)[12], int32_t (&I)[8], int32_t (&Q)[8])
 {
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const uint32_t a = w[3 * h], b = w[3 * h + 1], c = w[3 * h + 2];
-        I[2 * h]     = ((int32_t)(a << 8)) >> 8;                                        /* bytes 0..2  */
-        Q[2 * h]     = ((int32_t)(__builtin_amdgcn_alignbit(b, a, 24) << 8)) >> 8;      /* bytes 3..5  */
-        I[2 * h + 1] = ((int32_t)(__builtin_amdgcn_alignbit(c, b, 16) << 8)) >> 8;      /* bytes 6..8  */
-        Q[2 * h + 1] = ((int32_t)c) >> 8;                                               /* bytes 9..11 */
+        I[2 * h]     = (int32_t)__builtin_amdgcn_perm(a, a, 0x0201000cu);   /* bytes 0..2  */
+        Q[2 * h]     = (int32_t)__builtin_amdgcn_perm(b, a, 0x0504030cu);   /* bytes 3..5  */
+        I[2 * h + 1] = (int32_t)__builtin_amdgcn_perm(c, b, 0x0403020cu);   /* bytes 6..8  */
+        Q[2 * h + 1] = (int32_t)(c & 0xffffff00u);                          /* bytes 9..11 */
     }
 }
 
@@ -137,13 +142,13 @@ __global__ __launch_bounds__(256) void k_unpack24(UnpackArgs p)
             }
         }
         int32_t I[8], Q[8];
-        unpack8_i24(w, I, Q);
+        unpack8_msb(w, I, Q);
         uint32_t o[16];
         if (TO_I32) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                o[2 * e]     = (uint32_t)I[e] << 8;
-                o[2 * e + 1] = (uint32_t)Q[e] << 8;
+                o[2 * e]     = (uint32_t)I[e];
+                o[2 * e + 1] = (uint32_t)Q[e];
             }
         } else {
             float xi[8], xq[8];
@@ -212,16 +217,19 @@ hipError_t launch_unpack24(const void *d_in, long long ns, void *d_out, bool to_
 /* k_fir8 : fused unpack + mix + polyphase decimate-by-8                    */
 /* ======================================================================== */
 /* LDS plane layout: group G (8 samples) lives at float offset
- *   goff(G) = 8 + 8*G + 4*(G/R)      (G >= 0),   group -1 at offset 0.
+ *   goff(G) = 8 + 8*G + 4*(G/8)      (G >= 0),   group -1 at offset 0.
  * Sample position p = i + 8*NTB - 1 (i = input index relative to the tile),
  * group = p >> 3, slot = p & 7: the one-sample rotation puts the window
  * x[8m-7 .. 8m] of every output m into ONE aligned group.
- * The 4-float pad every R groups makes the lane stride of the FIR reads
- * 8R+4 floats = 4 (mod 8) banks-of-4: conflict-free ds_read_b128.            */
+ * A 4-float pad every 8 groups (64 samples) makes the lane stride of the FIR
+ * reads 68 floats = one 16-byte slot off the 256-byte bank row: conflict-free
+ * ds_read_b128.  R=8: a lane owns one 64-sample segment.  R=4: a lane owns a
+ * 32-sample half segment, and a wave takes the even (or the odd) halves so its
+ * lanes still sit 68 floats apart and see the pad at the same window offset. */
 template <int R>
 __device__ __forceinline__ int goff(int G)
 {
-    return 8 + 8 * G + 4 * (G / R);
+    return 8 + 8 * G + 4 * (G / 8);
 }
 
 template <int NTB, int R>
@@ -231,7 +239,7 @@ struct Fir8Geom {
     static constexpr int GT      = TI / 8;              /* new groups per tile      */
     static constexpr int GPT     = GT / 256;            /* groups per thread / tile */
     static constexpr int NG      = GT + NTB;            /* groups incl. history     */
-    static constexpr int PLANE   = 8 + 8 * NG + 4 * (NG / R) + 8;   /* floats      */
+    static constexpr int PLANE   = 8 + 8 * NG + 4 * (NG / 8) + 8;   /* floats      */
     static constexpr int OT      = 2 * TO;              /* output staging, floats   */
     static constexpr int LDS_FLT = 2 * PLANE + OT;
 };
@@ -239,7 +247,7 @@ struct Fir8Geom {
 size_t fir8_lds_bytes(int ntb, int R)
 {
     const int NG = 1024 * R / 8 + ntb;
-    const int plane = 8 + 8 * NG + 4 * (NG / R) + 8;
+    const int plane = 8 + 8 * NG + 4 * (NG / 8) + 8;
     return (size_t)(2 * plane + 2 * 128 * R) * sizeof(float);
 }
 
@@ -252,7 +260,7 @@ __device__ __forceinline__ void group_to_float(const uint4 (&raw)[NW], float (&x
         const uint32_t w[12] = { raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y,
                                  raw[1].z, raw[1].w, raw[2].x, raw[2].y, raw[2].z, raw[2].w };
         int32_t I[8], Q[8];
-        unpack8_i24(w, I, Q);
+        unpack8_msb(w, I, Q);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             xi[e] = (float)I[e] * kUnpackScale;
@@ -289,17 +297,46 @@ __device__ __forceinline__ void group_to_lds(float *sI, float *sQ, int v, const 
     sQ[o_cur + 6] = xq[7];
 }
 
+/* The register sliding window of one lane: R outputs over R+NTB-1 aligned
+ * 8-sample groups.  PAR (R=4 only) says whether the lane's half segment starts
+ * 4 groups into a padded 8-group row, which moves the pad inside the window.  */
+template <int NTB, int R, int PAR>
+__device__ __forceinline__ void fir_window(const float *base, const float PDDC_CONSTANT *hb, f32x2 (&acc)[R])
+{
+#pragma unroll
+    for (int ub = 0; ub < R + NTB - 1; ++ub) {
+        const int go = 8 * ub + 4 * ((ub + PAR * 4) >> 3);
+        const f32x4 d0 = *reinterpret_cast<const f32x4 *>(base + go);
+        const f32x4 d1 = *reinterpret_cast<const f32x4 *>(base + go + 4);
+        const f32x2 xs[4] = { { d0.x, d0.y }, { d0.z, d0.w }, { d1.x, d1.y }, { d1.z, d1.w } };
+        /* pair index outer, output inner: neighbouring instructions touch
+         * different accumulators (a dependent v_pk_fma pair costs an s_nop) */
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int j = r + NTB - 1 - ub;
+                if (j >= 0 && j < NTB) {
+                    const f32x2 PDDC_CONSTANT *h = reinterpret_cast<const f32x2 PDDC_CONSTANT *>(hb + 8 * j);
+                    acc[r] = __builtin_elementwise_fma(h[i], xs[i], acc[r]);
+                }
+            }
+        }
+    }
+}
+
 /* Persistent: block b owns the contiguous tile range [b*tpb, (b+1)*tpb).
- * Per tile:  U  unpack the prefetched registers into the LDS planes
- *            -- barrier A --
- *            P  issue the NEXT tile's global loads (in flight during F)
- *            F  FIR from LDS, results to the output staging area
- *            -- barrier B --
- *            S  coalesced stores; C  the last NTB groups become the next
- *               tile's history (copied by the very threads that overwrite
- *               them in the next U, so no third barrier is needed).       */
+ * Per tile t:  U  unpack the prefetched registers into the LDS planes
+ *              S  coalesced global stores of tile t-1 (staged by F of t-1)
+ *              -- barrier A --
+ *              P  issue tile t+1's global loads (in flight during F)
+ *              F  FIR from LDS, results to the output staging area
+ *              -- barrier B --
+ *              C  the last NTB groups become tile t+1's history (copied by
+ *                 the very threads that overwrite them in the next U, so no
+ *                 third barrier is needed).                                */
 template <int NTB, int R, int INFMT, bool MIX>
-__global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int tiles_per_block, int ntiles)
+__global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int tiles_per_block, int ntiles)
 {
     using G = Fir8Geom<NTB, R>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -311,6 +348,10 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int tiles_per_block
     constexpr int ES = (INFMT == IN_PACKED24) ? 6 : 8;             /* bytes per sample        */
 
     const int tid = threadIdx.x;
+    /* group handled by this thread in the load/unpack phases: lane bits 2 and 3
+     * swapped, so that the 8-lane groups of ds_write_b128/_b96 hit 8 distinct
+     * 4-bank sets (32-byte group stride + the 16-byte pad every R groups)      */
+    const int gtid = (tid & ~12) | ((tid & 4) << 1) | ((tid & 8) >> 1);
     const int t0  = blockIdx.x * tiles_per_block;
     const int t1  = min(t0 + tiles_per_block, ntiles);
     if (t0 >= t1)
@@ -334,8 +375,14 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int tiles_per_block
     auto prefetch = [&](int tile) {
         const long long tin0 = (long long)tile * G::TI;
         const uint4 *src0 = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(p.in) +
-                                                            (tin0 + 8LL * tid) * ES);
-        if (tin0 + G::TI <= p.n_in) {                  /* whole tile in range (wave-uniform) */
+                                                            (tin0 + 8LL * gtid) * ES);
+        if (p.ablate & 1) {
+#pragma unroll
+            for (int k = 0; k < G::GPT; ++k)
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                    raw[k][w] = make_uint4(tid + k, tid ^ w, tile, 0x01020304u);
+        } else if (tin0 + G::TI <= p.n_in) {                  /* whole tile in range (wave-uniform) */
 #pragma unroll
             for (int k = 0; k < G::GPT; ++k)
 #pragma unroll
@@ -344,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int tiles_per_block
         } else {                                        /* ragged last tile */
 #pragma unroll
             for (int k = 0; k < G::GPT; ++k) {
-                const bool have = tin0 + 8LL * (tid + 256 * k) < p.n_in;
+                const bool have = tin0 + 8LL * (gtid + 256 * k) < p.n_in;
 #pragma unroll
                 for (int w = 0; w < NW; ++w)
                     raw[k][w] = have ? src0[(256 * k * 8 * ES) / 16 + w] : make_uint4(0u, 0u, 0u, 0u);
@@ -356,21 +403,61 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int tiles_per_block
     const int wave  = tid >> 6;
     const int lane  = tid & 63;
     const int plane = wave & 1;
-    const int L     = (wave >> 1) * 64 + lane;                     /* 0..127 */
-    const float *base = (plane ? sQ : sI) + 8 + L * (8 * R + 4);   /* goff(R*L) */
+    /* segment (R outputs, 8R inputs) owned by this lane, 0..127 */
+    const int par   = (R == 4) ? (wave >> 1) : 0;                  /* R=4: even / odd half segments */
+    const int L     = (R == 4) ? (2 * lane + par) : ((wave >> 1) * 64 + lane);
+    const float *base = (plane ? sQ : sI) + 8 + 8 * R * L + 4 * ((R * L) >> 3);   /* goff(R*L) */
     const float PDDC_CONSTANT *hb = (const float PDDC_CONSTANT *)p.taps_blk;
     const long long n_out = p.n_in >> 3;
+
+    /* S: coalesced stores of one finished tile from the staging area */
+    auto store_tile = [&](int tile) {
+        const long long tile_o0 = (long long)tile * G::TO;
+        constexpr int NCH = G::TO / 2;                             /* 16-byte chunks */
+        if (p.ablate & 4)
+            return;
+        if (tile_o0 + G::TO <= n_out) {                            /* whole tile in range (uniform) */
+#pragma unroll
+            for (int it = 0; it < NCH / 256; ++it) {
+                const int q = tid + 256 * it;
+                const int qs = q ^ ((q >> 3) & 7);
+                /* streaming (nt) store: measured 0.349 vs 0.371 ms for this 6:1
+                 * read/write mix (tools/ubench/stream_mix.hip) */
+                __builtin_nontemporal_store(*reinterpret_cast<const f32x4 *>(ot + 4 * qs),
+                                            reinterpret_cast<f32x4 *>(p.out + 2 * (tile_o0 + 2LL * q)));
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NCH / 256; ++it) {
+                const int q = tid + 256 * it;
+                const int qs = q ^ ((q >> 3) & 7);
+                const float4 v = *reinterpret_cast<const float4 *>(ot + 4 * qs);
+                const long long m = tile_o0 + 2LL * q;
+                if (m + 1 < n_out)
+                    *reinterpret_cast<float4 *>(p.out + 2 * m) = v;
+                else if (m < n_out)
+                    *reinterpret_cast<float2 *>(p.out + 2 * m) = make_float2(v.x, v.y);
+            }
+        }
+    };
 
     for (int t = t0; t < t1; ++t) {
         /* ---- U: registers -> LDS planes (groups NTB ..) ------------------- */
 #pragma unroll
         for (int k = 0; k < G::GPT; ++k) {
-            const int v = NTB + tid + 256 * k;
+            const int v = NTB + gtid + 256 * k;
             float xi[8], xq[8];
             group_to_float<INFMT, MIX, NW>(raw[k], xi, xq,
-                                           p.n0 + (unsigned long long)((long long)t * G::TI + 8LL * (tid + 256 * k)), p);
+                                           p.n0 + (unsigned long long)((long long)t * G::TI + 8LL * (gtid + 256 * k)), p);
             group_to_lds<R>(sI, sQ, v, xi, xq);
         }
+        /* ---- S (deferred): the PREVIOUS tile's stores go out here, behind this
+         * tile's load wait.  gfx9 has one vmcnt for loads and stores and hipcc
+         * waits vmcnt(0) whenever both kinds are pending, so stores issued just
+         * before the wait for prefetched loads would stall every tile on the
+         * write acknowledgements (measured: +0.12 ms per 2^28 samples).        */
+        if (t > t0)
+            store_tile(t - 1);
         __syncthreads();                                           /* A */
 
         /* ---- P: next tile's loads --------------------------------------- */
@@ -389,26 +476,11 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int tiles_per_block
 #pragma unroll
         for (int r = 0; r < R; ++r)
             acc[r] = f32x2{ 0.0f, 0.0f };
-#pragma unroll
-        for (int ub = 0; ub < R + NTB - 1; ++ub) {
-            const int go = 8 * ub + 4 * (ub / R);
-            const f32x4 d0 = *reinterpret_cast<const f32x4 *>(base + go);
-            const f32x4 d1 = *reinterpret_cast<const f32x4 *>(base + go + 4);
-            const f32x2 x0 = { d0.x, d0.y }, x1 = { d0.z, d0.w }, x2 = { d1.x, d1.y }, x3 = { d1.z, d1.w };
-            const f32x2 xs[4] = { x0, x1, x2, x3 };
-            /* pair index outer, output inner: neighbouring instructions touch
-             * different accumulators (a dependent v_pk_fma pair costs an s_nop) */
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int j = r + NTB - 1 - ub;
-                    if (j >= 0 && j < NTB) {
-                        const f32x2 PDDC_CONSTANT *h = reinterpret_cast<const f32x2 PDDC_CONSTANT *>(hb + 8 * j);
-                        acc[r] = __builtin_elementwise_fma(h[i], xs[i], acc[r]);
-                    }
-                }
-            }
+        if (!(p.ablate & 2)) {
+            if (R == 4 && par)
+                fir_window<NTB, R, 1>(base, hb, acc);
+            else
+                fir_window<NTB, R, 0>(base, hb, acc);
         }
         /* results -> staging (XOR-swizzled 16-byte chunks, interleaved I/Q) */
 #pragma unroll
@@ -420,25 +492,9 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int tiles_per_block
         }
         __syncthreads();                                           /* B */
 
-        /* ---- S: coalesced stores ------------------------------------------ */
-        const long long tile_o0 = (long long)t * G::TO;
-        constexpr int NCH = G::TO / 2;                             /* 16-byte chunks */
-#pragma unroll
-        for (int it = 0; it < (NCH + 255) / 256; ++it) {
-            const int q = tid + 256 * it;
-            if (q < NCH) {
-                const int qs = q ^ ((q >> 3) & 7);
-                const float4 v = *reinterpret_cast<const float4 *>(ot + 4 * qs);
-                const long long m = tile_o0 + 2LL * q;
-                if (m + 1 < n_out)
-                    *reinterpret_cast<float4 *>(p.out + 2 * m) = v;
-                else if (m < n_out)
-                    *reinterpret_cast<float2 *>(p.out + 2 * m) = make_float2(v.x, v.y);
-            }
-        }
         /* ---- C: tail groups -> history of the next tile -------------------- */
-        if (t + 1 < t1 && tid >= 256 - NTB) {
-            const int gd = tid - (256 - NTB);                      /* 0..NTB-1 */
+        if (t + 1 < t1 && gtid >= 256 - NTB) {
+            const int gd = gtid - (256 - NTB);                      /* 0..NTB-1 */
             const int os = goff<R>(G::GT + gd), od = goff<R>(gd);
             const float4 i0 = *reinterpret_cast<const float4 *>(sI + os);
             const float4 i1 = *reinterpret_cast<const float4 *>(sI + os + 4);
@@ -456,6 +512,7 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int tiles_per_block
             }
         }
     }
+    store_tile(t1 - 1);
 }
 
 bool fir8_supported(int ntb, int R)
@@ -463,7 +520,7 @@ bool fir8_supported(int ntb, int R)
     return (R == 4 || R == 8) && (ntb == 4 || ntb == 8 || ntb == 16 || ntb == 32);
 }
 
-static int g_fir8_blocks = 512;     /* persistent grid: 2 blocks per CU x 256 CUs */
+static int g_fir8_blocks = 0;       /* persistent grid override (0 = resident blocks per CU x 256 CUs) */
 
 template <int NTB, int R>
 static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s)
@@ -476,7 +533,8 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
     if (ntiles_ll > 0x7fffffffLL)
         return hipErrorInvalidValue;
     const int ntiles = (int)ntiles_ll;
-    const int tpb = (ntiles + g_fir8_blocks - 1) / g_fir8_blocks;
+    const int want = g_fir8_blocks > 0 ? g_fir8_blocks : 256 * (R == 4 ? 4 : 2);
+    const int tpb = (ntiles + want - 1) / want;
     const int nblocks = (ntiles + tpb - 1) / tpb;
     const dim3 grid((unsigned)nblocks), blk(256);
 #define PDDC_LAUNCH(FMT, MIXV)                                                                    \
@@ -504,7 +562,7 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
     return hipGetLastError();
 }
 
-void fir8_set_grid_blocks(int nblocks) { g_fir8_blocks = nblocks > 0 ? nblocks : 512; }
+void fir8_set_grid_blocks(int nblocks) { g_fir8_blocks = nblocks > 0 ? nblocks : 0; }
 
 hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s)
 {
