@@ -17,6 +17,8 @@ enum InFmt { IN_PACKED24 = 0, IN_F32C = 1 };
 struct Fir8Args {
     const void *in;          /* batch start: packed bytes or float2            */
     const void *hist;        /* 8*ntb samples that precede the batch           */
+    void       *hist_out;    /* receives the batch's last 8*ntb samples (or NULL;
+                                must not alias `hist`; needs n_in >= 8*ntb)     */
     float      *out;         /* float2 outputs                                 */
     const float *taps_blk;   /* [ntb][8] block-reversed taps (device)          */
     long long   n_in;        /* samples in the batch, multiple of 8            */
@@ -41,14 +43,14 @@ hipError_t launch_unpack24(const void *d_in, long long nsamples, void *d_out, bo
                            const float *lo_c, const float *lo_s, hipStream_t s);
 
 /* generic decimating FIR on float2: out[q] = sum_k h[k]*x[first + q*D - k],
- * x indexed relative to `in`, valid down to in[-(ntaps-1)] (history is
- * contiguous in front of the batch). */
-hipError_t launch_fir_generic(const float *in, long long first, long long n_out, int D,
-                              const float *taps, int ntaps, float *out, hipStream_t s);
+ * x indexed relative to `in`; x[-H..-1] come from `hist` (H >= ntaps-1). */
+hipError_t launch_fir_generic(const float *in, const float *hist, int H, long long first, long long n_out,
+                              int D, const float *taps, int ntaps, float *out, hipStream_t s);
 
-/* new_hist = last H elements of [hist(H) | batch(n)], elem_bytes each (H*elem_bytes <= 16 KiB) */
-hipError_t launch_hist_update(void *hist, int H, const void *batch, long long n, int elem_bytes,
-                              hipStream_t s);
+/* dst = last H elements of [hist(H) | batch(n)], elem_bytes each (H*elem_bytes <= 16 KiB);
+ * dst may alias hist */
+hipError_t launch_hist_update(void *dst, const void *hist, int H, const void *batch, long long n,
+                              int elem_bytes, hipStream_t s);
 
 hipError_t launch_synth_lcg(void *dst, size_t nbytes, uint32_t seed, uint64_t byte_offset,
                             hipStream_t s);

@@ -513,6 +513,17 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         }
     }
     store_tile(t1 - 1);
+
+    /* the block that owns the last tile leaves the batch's last 8*NTB input
+     * samples as the next call's history (the host alternates two buffers, so
+     * block 0 of THIS launch never sees them)                                 */
+    if (p.hist_out != nullptr && t1 == ntiles && p.n_in >= 8 * NTB) {
+        constexpr int HCH = 8 * NTB * ES / 16;                     /* 16-byte chunks */
+        const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(p.in) +
+                                                           (p.n_in - 8 * NTB) * ES);
+        for (int c = tid; c < HCH; c += 256)
+            static_cast<uint4 *>(p.hist_out)[c] = src[c];
+    }
 }
 
 bool fir8_supported(int ntb, int R)
@@ -590,9 +601,10 @@ hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, h
  * (255*D + ntaps samples) is staged planar in LDS with a pad that makes the
  * lane stride odd, the taps sit in LDS and are read as broadcasts.  This is
  * the low-rate path (stages 2.. of a cascade, and odd first stages).        */
-__global__ __launch_bounds__(256) void k_fir_generic(const float *__restrict__ in, long long first,
-                                                      long long n_out, int D, const float *__restrict__ taps,
-                                                      int ntaps, float *__restrict__ out, int span, int padshift)
+__global__ __launch_bounds__(256) void k_fir_generic(const float *__restrict__ in, const float *__restrict__ hist,
+                                                      int H, long long first, long long n_out, int D,
+                                                      const float *__restrict__ taps, int ntaps,
+                                                      float *__restrict__ out, int span, int padshift)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     /* layout: taps[ntaps_pad] | I plane | Q plane */
@@ -611,8 +623,12 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float *__restrict__ i
     for (int i = tid; i < span; i += 256) {
         const long long xi = x0 + i;
         float2 v = make_float2(0.0f, 0.0f);
-        if (xi <= last_needed)
+        if (xi < 0) {
+            if (xi >= -(long long)H)          /* history: the H samples that precede the batch */
+                v = *reinterpret_cast<const float2 *>(hist + 2 * (xi + H));
+        } else if (xi <= last_needed) {
             v = *reinterpret_cast<const float2 *>(in + 2 * xi);
+        }
         const int o = i + (padshift >= 0 ? (i >> padshift) : 0);
         sI[o] = v.x;
         sQ[o] = v.y;
@@ -644,8 +660,8 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float *__restrict__ i
     }
 }
 
-hipError_t launch_fir_generic(const float *in, long long first, long long n_out, int D,
-                              const float *taps, int ntaps, float *out, hipStream_t s)
+hipError_t launch_fir_generic(const float *in, const float *hist, int H, long long first, long long n_out,
+                              int D, const float *taps, int ntaps, float *out, hipStream_t s)
 {
     if (n_out <= 0)
         return hipSuccess;
@@ -671,7 +687,7 @@ hipError_t launch_fir_generic(const float *in, long long first, long long n_out,
         attr_lds = (int)lds;
     }
     const dim3 grid((unsigned)((n_out + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(k_fir_generic, grid, blk, lds, s, in, first, n_out, D, taps, ntaps, out, span,
+    hipLaunchKernelGGL(k_fir_generic, grid, blk, lds, s, in, hist, H, first, n_out, D, taps, ntaps, out, span,
                        padshift);
     return hipGetLastError();
 }
@@ -679,8 +695,8 @@ hipError_t launch_fir_generic(const float *in, long long first, long long n_out,
 /* ======================================================================== */
 /* k_hist_update                                                            */
 /* ======================================================================== */
-__global__ __launch_bounds__(256) void k_hist_update(uint32_t *hist, int Hw, const uint32_t *batch,
-                                                      long long nw)
+__global__ __launch_bounds__(256) void k_hist_update(uint32_t *dst, const uint32_t *hist, int Hw,
+                                                      const uint32_t *batch, long long nw)
 {
     /* words; new[i] = concat(hist, batch)[i + nw], i < Hw.  Single block:
      * gather everything into registers before the first store.             */
@@ -700,12 +716,12 @@ __global__ __launch_bounds__(256) void k_hist_update(uint32_t *hist, int Hw, con
     for (int k = 0; k < MAXPT; ++k) {
         const int i = tid + 256 * k;
         if (i < Hw)
-            hist[i] = v[k];
+            dst[i] = v[k];
     }
 }
 
-hipError_t launch_hist_update(void *hist, int H, const void *batch, long long n, int elem_bytes,
-                              hipStream_t s)
+hipError_t launch_hist_update(void *dst, const void *hist, int H, const void *batch, long long n,
+                              int elem_bytes, hipStream_t s)
 {
     if (H <= 0 || n <= 0)
         return hipSuccess;
@@ -714,8 +730,9 @@ hipError_t launch_hist_update(void *hist, int H, const void *batch, long long n,
     const int Hw = elem_bytes * H / 4;
     if (Hw > 256 * 16)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_hist_update, dim3(1), dim3(256), 0, s, static_cast<uint32_t *>(hist), Hw,
-                       static_cast<const uint32_t *>(batch), (long long)elem_bytes * n / 4);
+    hipLaunchKernelGGL(k_hist_update, dim3(1), dim3(256), 0, s, static_cast<uint32_t *>(dst),
+                       static_cast<const uint32_t *>(hist), Hw, static_cast<const uint32_t *>(batch),
+                       (long long)elem_bytes * n / 4);
     return hipGetLastError();
 }
 

@@ -53,10 +53,16 @@ struct Stage {
     float *d_taps_blk = nullptr;  /* [ntb][8] block-reversed (fused kernel)     */
     int ntb = 0;                  /* tap blocks if fused-capable, else 0        */
     int hist = 0;                 /* history length in samples (mult. of 8)     */
-    /* input buffer of stages >= 1 (or of stage 0 on the generic path):
-     * [hist | data], float2 */
+    int hist_elem = 8;            /* bytes per history sample: 6 packed, 8 float2 */
+    /* the `hist` input samples that precede the next batch.  Two buffers,
+     * alternated every call: a launch reads d_hist[cur] and leaves the new
+     * history in d_hist[cur^1], so no block can see a half-updated history
+     * and no separate update kernel sits between two launches.               */
+    void *d_hist[2] = { nullptr, nullptr };
+    int cur = 0;
+    /* input data of stages >= 1 (and the unpacked floats of a generic stage 0) */
     float *d_buf = nullptr;
-    size_t buf_cap = 0;           /* data capacity in samples                   */
+    size_t buf_cap = 0;           /* capacity in samples                        */
     unsigned long long consumed = 0;   /* inputs consumed since reset           */
 };
 
@@ -68,8 +74,7 @@ struct pddc_pipeline {
     uint32_t freg = 0;
     float lo_c[8], lo_s[8];
     unsigned long long n0 = 0;    /* absolute sample counter (stage 0 input)    */
-    uint8_t *d_hist0 = nullptr;   /* packed history of stage 0 (fused path)     */
-    int R = 8;                    /* outputs per lane of the fused kernel       */
+    int R = 4;                    /* outputs per lane of the fused kernel (4: 16 waves/CU) */
     /* staging for push_host */
     uint8_t *d_in = nullptr;
     size_t d_in_cap = 0;
@@ -77,6 +82,8 @@ struct pddc_pipeline {
     size_t d_out_cap = 0;
     hipStream_t own_stream = nullptr;
 };
+
+static bool stage0_fused(const pddc_pipeline *p);
 
 static float round_to_half(float v)
 {
@@ -319,7 +326,13 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
             s.hist = 8;
     }
     compute_lo_steps(p);
-    hipError_t e = hipMalloc(&p->d_hist0, (size_t)p->st[0].hist * 6 + 64);
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < nstages && e == hipSuccess; ++i) {
+        Stage &s = p->st[i];
+        s.hist_elem = (i == 0 && stage0_fused(p)) ? PDDC_PACKED_BYTES : 8;
+        for (int b = 0; b < 2 && e == hipSuccess; ++b)
+            e = hipMalloc(&s.d_hist[b], (size_t)s.hist * (size_t)s.hist_elem + 64);
+    }
     if (e != hipSuccess) {
         pddc_pipeline_destroy(p);
         return fail(PDDC_ENOMEM, "hipMalloc history: %s", hipGetErrorString(e));
@@ -350,9 +363,10 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
             hipFree(p->st[i].d_taps_blk);
         if (p->st[i].d_buf)
             hipFree(p->st[i].d_buf);
+        for (int b = 0; b < 2; ++b)
+            if (p->st[i].d_hist[b])
+                hipFree(p->st[i].d_hist[b]);
     }
-    if (p->d_hist0)
-        hipFree(p->d_hist0);
     if (p->d_in)
         hipFree(p->d_in);
     if (p->d_out)
@@ -370,11 +384,12 @@ int pddc_pipeline_reset(pddc_pipeline *p)
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipDeviceSynchronize());
     p->n0 = 0;
-    HIP_TRY(hipMemset(p->d_hist0, 0, (size_t)p->st[0].hist * 6 + 64));
     for (int i = 0; i < p->nstages; ++i) {
-        p->st[i].consumed = 0;
-        if (p->st[i].d_buf)
-            HIP_TRY(hipMemset(p->st[i].d_buf, 0, sizeof(float) * 2 * (size_t)p->st[i].hist));
+        Stage &s = p->st[i];
+        s.consumed = 0;
+        s.cur = 0;
+        for (int b = 0; b < 2; ++b)
+            HIP_TRY(hipMemset(s.d_hist[b], 0, (size_t)s.hist * (size_t)s.hist_elem + 64));
     }
     return PDDC_OK;
 }
@@ -478,19 +493,14 @@ static int ensure_buf(Stage &s, size_t need)
 {
     if (s.d_buf && s.buf_cap >= need)
         return PDDC_OK;
-    /* growing keeps the history: allocate, copy history, free.  Happens only
-     * when a batch is larger than any seen before (synchronising).           */
-    float *nb = nullptr;
+    /* happens only when a batch is larger than any seen before (synchronising) */
     const size_t cap = need + need / 4 + 64;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMalloc(&nb, sizeof(float) * 2 * ((size_t)s.hist + cap)));
-    if (s.d_buf) {
-        HIP_TRY(hipMemcpy(nb, s.d_buf, sizeof(float) * 2 * (size_t)s.hist, hipMemcpyDeviceToDevice));
+    if (s.d_buf)
         HIP_TRY(hipFree(s.d_buf));
-    } else {
-        HIP_TRY(hipMemset(nb, 0, sizeof(float) * 2 * (size_t)s.hist));
-    }
-    s.d_buf = nb;
+    s.d_buf = nullptr;
+    s.buf_cap = 0;
+    HIP_TRY(hipMalloc(&s.d_buf, sizeof(float) * 2 * cap));
     s.buf_cap = cap;
     return PDDC_OK;
 }
@@ -537,56 +547,62 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
     int rc;
     for (int i = 0; i < p->nstages; ++i) {
         Stage &st = p->st[i];
-        /* destination of this stage: next stage's buffer (after its history) or the caller's */
+        /* destination of this stage: next stage's input buffer or the caller's */
         float *dst;
         if (i + 1 < p->nstages) {
             if ((rc = ensure_buf(p->st[i + 1], n_in[i + 1] + 8)))
                 return rc;
-            dst = p->st[i + 1].d_buf + 2 * (size_t)p->st[i + 1].hist;
+            dst = p->st[i + 1].d_buf;
         } else {
             dst = static_cast<float *>(d_out);
         }
-        if (i == 0) {
-            if (stage0_fused(p)) {
-                Fir8Args a;
-                a.in = d_packed;
-                a.hist = p->d_hist0;
-                a.out = dst;
-                a.taps_blk = st.d_taps_blk;
-                a.n_in = (long long)nsamples;
-                fill_fir8_args(p, a);
-                HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s));
-                HIP_TRY(launch_hist_update(p->d_hist0, st.hist, d_packed, (long long)nsamples, 6, s));
-            } else {
-                /* generic first stage: unpack(+mix) to float2 behind the history, then FIR */
+        void *h_in = st.d_hist[st.cur], *h_out = st.d_hist[st.cur ^ 1];
+        const void *x = d_packed;                       /* this stage's input batch */
+        bool hist_done = false;
+        if (i == 0 && stage0_fused(p)) {
+            Fir8Args a;
+            a.in = d_packed;
+            a.hist = h_in;
+            a.hist_out = nsamples >= (size_t)st.hist ? h_out : nullptr;
+            a.out = dst;
+            a.taps_blk = st.d_taps_blk;
+            a.n_in = (long long)nsamples;
+            fill_fir8_args(p, a);
+            HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s));
+            hist_done = a.hist_out != nullptr;
+        } else {
+            if (i == 0) {
+                /* generic first stage: unpack(+mix) to float2, then the generic FIR */
                 if ((rc = ensure_buf(st, nsamples + 8)))
                     return rc;
-                float *x = st.d_buf + 2 * (size_t)st.hist;
-                HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, x, false, mix, p->n0, p->freg,
+                HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, st.d_buf, false, mix, p->n0, p->freg,
                                         p->lo_c, p->lo_s, s));
-                HIP_TRY(launch_fir_generic(x, (long long)off[0], (long long)n_in[1], st.decim, st.d_taps,
-                                           st.ntaps, dst, s));
-                HIP_TRY(launch_hist_update(st.d_buf, st.hist, x, (long long)nsamples, 8, s));
             }
-        } else {
-            float *x = st.d_buf + 2 * (size_t)st.hist;
-            const bool fast = st.ntb != 0 && !(p->flags & PDDC_F_NO_FAST) && fir8_supported(st.ntb, p->R) &&
-                              (n_in[i] % 8 == 0) && off[i] == 0 && (st.consumed % 8 == 0) && n_in[i] > 0;
+            x = st.d_buf;
+            const bool fast = i > 0 && st.ntb != 0 && !(p->flags & PDDC_F_NO_FAST) &&
+                              fir8_supported(st.ntb, p->R) && (n_in[i] % 8 == 0) && off[i] == 0 &&
+                              (st.consumed % 8 == 0) && n_in[i] > 0;
             if (fast) {
                 Fir8Args a;
                 a.in = x;
-                a.hist = st.d_buf;            /* contiguous: hist == 8*ntb samples in front */
+                a.hist = h_in;
+                a.hist_out = n_in[i] >= (size_t)st.hist ? h_out : nullptr;
                 a.out = dst;
                 a.taps_blk = st.d_taps_blk;
                 a.n_in = (long long)n_in[i];
                 fill_fir8_args(p, a);
                 HIP_TRY(launch_fir8(st.ntb, p->R, IN_F32C, false, a, s));
+                hist_done = a.hist_out != nullptr;
             } else if (n_in[i + 1] > 0) {
-                HIP_TRY(launch_fir_generic(x, (long long)off[i], (long long)n_in[i + 1], st.decim, st.d_taps,
-                                           st.ntaps, dst, s));
+                HIP_TRY(launch_fir_generic(static_cast<const float *>(x), static_cast<const float *>(h_in),
+                                           st.hist, (long long)off[i], (long long)n_in[i + 1], st.decim,
+                                           st.d_taps, st.ntaps, dst, s));
             }
-            if (n_in[i] > 0)
-                HIP_TRY(launch_hist_update(st.d_buf, st.hist, x, (long long)n_in[i], 8, s));
+        }
+        if (n_in[i] > 0) {
+            if (!hist_done)
+                HIP_TRY(launch_hist_update(h_out, h_in, st.hist, x, (long long)n_in[i], st.hist_elem, s));
+            st.cur ^= 1;
         }
         st.consumed += n_in[i];
     }
@@ -654,7 +670,8 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     HIP_TRY(hipSetDevice(p->device));
     Fir8Args a;
     a.in = d_packed;
-    a.hist = p->d_hist0;
+    a.hist = p->st[0].d_hist[p->st[0].cur];
+    a.hist_out = nullptr;                  /* state is not advanced */
     a.out = static_cast<float *>(d_out);
     a.taps_blk = p->st[0].d_taps_blk;
     a.n_in = (long long)nsamples;
