@@ -88,6 +88,7 @@ def main():
     import torch
     import torch.distributed as dist
     pkg = importlib.import_module("libperseus-sdr_amd")
+    shard = importlib.import_module("libperseus-sdr_amd.shard")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -117,12 +118,17 @@ def main():
         stages, mix, bytes_per_sample, decim = [(8, h)], False, 7.0, 8
         wl = f"80 MS/s synthetic 24-bit I/Q, unpack + {h.size}-tap polyphase decimate-by-8"
 
-    d_in = pkg.synth_lcg(6 * ns, 12345 + rank, 0, dev)         # device resident before timing
+    # configuration (taps, NCO word, plan) comes from rank 0 over RCCL: a few KB, once
+    if stages is not None:
+        cfg = shard.broadcast_config({"freg": pkg.ddc_lib().pddc_nco_freg(7.1e6, 80e6) if mix else 0,
+                                      "stages": stages} if rank == 0 else None, dev)
+        stages = cfg["stages"]
+    d_in = pkg.synth_lcg(6 * ns, shard.stream_seed(rank), 0, dev)   # device resident before timing
     stream = torch.cuda.current_stream(dev).cuda_stream
     if stages is not None:
         pipe = pkg.Pipeline(stages, device=local, mix=mix, taps_fp16=a.taps_fp16)
         if mix:
-            pipe.set_center_freq(7.1e6)
+            pipe.set_freg(cfg["freg"])
         out = torch.empty((pipe.max_output(ns) + 8, 2), dtype=torch.float32, device=dev)
 
         def step():
@@ -134,9 +140,7 @@ def main():
             pkg.check(pkg.ddc_lib().pddc_unpack24_f32(d_in.data_ptr(), ns, out.data_ptr(), stream))
             return ns
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = shard.barrier
 
     for _ in range(a.warmup):
         step()
@@ -154,10 +158,7 @@ def main():
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)                       # HIP events on the launch stream
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
+    dt_max = shard.max_over_ranks(dt, dev)
 
     # dominant-kernel duration: stage-0 kernel alone, HIP events on the same stream
     kern_ms = None
@@ -172,18 +173,16 @@ def main():
         mine = out[:n_out].contiguous()
         bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
         for _ in range(2):
-            dist.gather(mine, bufs, dst=0)
+            shard.gather_to_root(mine, bufs)
         torch.cuda.synchronize(dev)
         barrier()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step()
-            dist.gather(mine, bufs, dst=0)
+            shard.gather_to_root(mine, bufs)
         torch.cuda.synchronize(dev)
         barrier()
-        tg = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        tgv = float(tg.item())
+        tgv = shard.max_over_ranks(time.perf_counter() - t0, dev)
         gather = {"value": round(world * ns * a.steps / tgv / 1e6, 1), "unit": "MS/s",
                   "note": "hot path + RCCL gather of the /%d float32 output to rank 0 each step" % decim,
                   "out_bytes_per_rank_per_step": int(n_out * 8),

@@ -1,0 +1,81 @@
+/*
+ * perseus-amd-ext.h -- what this build adds to the reference API.
+ *
+ * The reference talks to a USB receiver whose FPGA does the DSP.  Here the
+ * USB side is a *source* (synthetic or file) and the FPGA's work runs on the
+ * GPU, so two things need configuring that the reference API has no call for:
+ * where samples come from, and what the callback buffers carry.
+ *
+ * Everything can also be set through environment variables read by
+ * perseus_init(), so an unmodified reference client can be pointed at a source:
+ *   PERSEUS_AMD_DEVICES   number of virtual receivers, 1..8 (default 1; the
+ *                         reference's PERSEUS_MAX_DESCR is 8, perseus-sdr.c:43)
+ *   PERSEUS_AMD_MODE      "wire" (default) | "ddc"
+ *   PERSEUS_AMD_SOURCE    "lcg[:seed]" (default lcg:12345) | "zero" | "file:<path>"
+ *   PERSEUS_AMD_PACE      1 = pace the source at the nominal rate (default), 0 = free-running
+ *   PERSEUS_AMD_BATCH     ddc mode: ADC-rate samples per GPU batch (default 2^22)
+ *   PERSEUS_AMD_DROP      fault injection: every k-th transfer completes short
+ *                         and is dropped like perseus-in.c:209-216 (default 0 = never)
+ */
+#ifndef PERSEUS_AMD_EXT_H
+#define PERSEUS_AMD_EXT_H
+
+#include "perseus-sdr.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* What the callback `buf` carries.
+ *  WIRE: the source plays the receiver: 24-bit packed I/Q, 6 bytes/sample, at
+ *        the rate chosen with perseus_set_sampling_rate(); the library does no
+ *        arithmetic, the client unpacks (examples/perseustest.c:466-502).  No GPU
+ *        needed.  This is what every reference client expects.
+ *  DDC:  the source delivers the 80 MS/s ADC-rate 24-bit I/Q stream; the GPU
+ *        pipeline mixes it with the NCO set by perseus_set_ddc_center_freq()
+ *        and decimates to the selected rate; callbacks carry interleaved
+ *        float32 I/Q (8 bytes/sample) in buffers of `buffersize` bytes.  Needs a
+ *        GPU: perseus_start_async_input() fails (no CPU fallback) without one. */
+#define PERSEUS_AMD_MODE_WIRE 0
+#define PERSEUS_AMD_MODE_DDC  1
+
+#define PERSEUS_AMD_SRC_LCG   0
+#define PERSEUS_AMD_SRC_ZERO  1
+#define PERSEUS_AMD_SRC_FILE  2
+
+typedef struct {
+    int         mode;         /* PERSEUS_AMD_MODE_*                              */
+    int         source;       /* PERSEUS_AMD_SRC_*                               */
+    uint32_t    lcg_seed;     /* LCG: s=s*1664525+1013904223, byte=s>>24          */
+    const char *file_path;    /* FILE: raw 24-bit packed capture, no header       */
+    int         pace;         /* 1: real-time pacing at the nominal sample rate   */
+    int         gpu_device;   /* DDC: HIP device index (-1: descriptor index % n) */
+    uint32_t    batch_samples;/* DDC: ADC-rate samples per GPU batch (mult. of 8) */
+    int         drop_every;   /* fault injection, 0 = off                         */
+    uint64_t    max_buffers;  /* stop the source after this many callbacks (0 = unbounded;
+                                 a FILE source also stops at end of file)          */
+} perseus_amd_config;
+
+/* valid between perseus_open() and perseus_start_async_input() */
+int perseus_amd_get_config(perseus_descr *descr, perseus_amd_config *cfg);
+int perseus_amd_set_config(perseus_descr *descr, const perseus_amd_config *cfg);
+
+/* state introspection (for tests and tools) */
+uint32_t perseus_amd_get_freg(perseus_descr *descr);          /* NCO word, perseus-sdr.c:584 */
+int      perseus_amd_get_sampling_rate(perseus_descr *descr); /* selected rate in S/s, 0 if none */
+int      perseus_amd_get_frontendctl(perseus_descr *descr);   /* atten_id<<4 | presel_id   */
+int      perseus_amd_get_sioctl(perseus_descr *descr);        /* FIFOEN|DITHER|GAINHIGH bits */
+uint64_t perseus_amd_buffers_delivered(perseus_descr *descr);
+uint64_t perseus_amd_buffers_dropped(perseus_descr *descr);
+/* 1 while the source still has data (a bounded source ends by itself) */
+int      perseus_amd_source_running(perseus_descr *descr);
+
+/* DDC mode: the decimation plan chosen for the selected rate.  Returns the
+ * number of stages (0 if the rate has no integer plan), fills decim[]/ntaps[]
+ * (up to 4) and, if taps[i] is non-NULL, copies stage i's taps (ntaps[i] floats). */
+int perseus_amd_get_plan(perseus_descr *descr, int decim[4], int ntaps[4], float *taps[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

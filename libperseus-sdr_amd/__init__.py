@@ -219,3 +219,74 @@ def synth_lcg(nbytes: int, seed: int = 12345, byte_offset: int = 0, device="cuda
     st = stream if stream is not None else torch.cuda.current_stream(out.device).cuda_stream
     check(ddc_lib().pddc_synth_lcg(out.data_ptr(), nbytes, seed & 0xFFFFFFFF, byte_offset, st))
     return out
+
+
+# --------------------------------------------------------------------------
+# drop-in perseus_* API (include/perseus-sdr.h, include/perseus-amd-ext.h)
+# --------------------------------------------------------------------------
+PERSEUS_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+
+
+class EepromProdId(C.Structure):
+    _pack_ = 1
+    _fields_ = [("sn", C.c_uint16), ("prodcode", C.c_uint16), ("hwrel", C.c_uint8),
+                ("hwver", C.c_uint8), ("signature", C.c_uint8 * 6)]
+
+
+class AmdConfig(C.Structure):
+    _fields_ = [("mode", C.c_int), ("source", C.c_int), ("lcg_seed", C.c_uint32),
+                ("file_path", C.c_char_p), ("pace", C.c_int), ("gpu_device", C.c_int),
+                ("batch_samples", C.c_uint32), ("drop_every", C.c_int), ("max_buffers", C.c_uint64)]
+
+
+_sdr = None
+
+
+def sdr_lib() -> C.CDLL:
+    """Load libperseus-sdr.so (the perseus_* API); raises if not built."""
+    global _sdr
+    if _sdr is not None:
+        return _sdr
+    if not os.path.exists(SDR_LIB):
+        raise FileNotFoundError(f"{SDR_LIB} is missing: run __graft_entry__.build()")
+    ddc_lib()                      # same HIP runtime ordering as above
+    L = C.CDLL(SDR_LIB)
+    vp = C.c_void_p
+    L.perseus_set_debug.argtypes = [C.c_int]
+    L.perseus_set_debug.restype = None
+    L.perseus_init.restype = C.c_int
+    L.perseus_exit.restype = C.c_int
+    L.perseus_open.argtypes = [C.c_int]
+    L.perseus_open.restype = vp
+    L.perseus_close.argtypes = [vp]
+    L.perseus_firmware_download.argtypes = [vp, C.c_char_p]
+    L.perseus_get_product_id.argtypes = [vp, C.POINTER(EepromProdId)]
+    L.perseus_set_attenuator.argtypes = [vp, C.c_uint8]
+    L.perseus_set_attenuator_in_db.argtypes = [vp, C.c_int]
+    L.perseus_get_attenuator_values.argtypes = [vp, C.POINTER(C.c_int), C.c_uint]
+    L.perseus_set_attenuator_n.argtypes = [vp, C.c_int]
+    L.perseus_set_adc.argtypes = [vp, C.c_int, C.c_int]
+    L.perseus_set_ddc_center_freq.argtypes = [vp, C.c_double, C.c_int]
+    L.perseus_start_async_input.argtypes = [vp, C.c_uint32, PERSEUS_CALLBACK, vp]
+    L.perseus_stop_async_input.argtypes = [vp]
+    L.perseus_set_sampling_rate.argtypes = [vp, C.c_int]
+    L.perseus_set_sampling_rate_n.argtypes = [vp, C.c_uint]
+    L.perseus_get_sampling_rates.argtypes = [vp, C.POINTER(C.c_int), C.c_uint]
+    L.perseus_is_preserie.argtypes = [vp, C.POINTER(C.c_int)]
+    L.perseus_errorstr.restype = C.c_char_p
+    L.perseus_amd_get_config.argtypes = [vp, C.POINTER(AmdConfig)]
+    L.perseus_amd_set_config.argtypes = [vp, C.POINTER(AmdConfig)]
+    L.perseus_amd_get_freg.argtypes = [vp]
+    L.perseus_amd_get_freg.restype = C.c_uint32
+    L.perseus_amd_get_sampling_rate.argtypes = [vp]
+    L.perseus_amd_get_frontendctl.argtypes = [vp]
+    L.perseus_amd_get_sioctl.argtypes = [vp]
+    L.perseus_amd_buffers_delivered.argtypes = [vp]
+    L.perseus_amd_buffers_delivered.restype = C.c_uint64
+    L.perseus_amd_buffers_dropped.argtypes = [vp]
+    L.perseus_amd_buffers_dropped.restype = C.c_uint64
+    L.perseus_amd_source_running.argtypes = [vp]
+    L.perseus_amd_get_plan.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                       C.POINTER(C.POINTER(C.c_float))]
+    _sdr = L
+    return L

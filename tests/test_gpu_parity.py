@@ -293,3 +293,44 @@ def test_full_size_properties(pkg, dev, O):
     scale = np.max(np.abs(outs[2]))
     assert np.max(np.abs(outs[0] + outs[1] - outs[2])) / scale <= 3e-6
     pipe.close()
+
+
+# ----------------------------------- drop-in API, DDC mode (GPU behind callbacks)
+def test_perseus_api_ddc_mode_vs_oracle(pkg, dev, O, monkeypatch):
+    """perseus_* callback API with the GPU doing the FPGA's job: 80 MS/s LCG
+    source -> NCO at 7.1 MHz -> plan for 250 kS/s (8*8*5) -> float32 callbacks."""
+    import ctypes as C
+    import time
+    monkeypatch.setenv("PERSEUS_AMD_PACE", "0")
+    monkeypatch.delenv("PERSEUS_AMD_DEVICES", raising=False)
+    L = pkg.sdr_lib()
+    L.perseus_set_debug(0)
+    assert L.perseus_init() == 1
+    d = L.perseus_open(0)
+    assert L.perseus_firmware_download(d, None) == 0
+    assert L.perseus_set_sampling_rate(d, 250000) == 0
+    assert L.perseus_set_ddc_center_freq(d, C.c_double(7.1e6), 1) == 0
+    cfg = pkg.AmdConfig()
+    L.perseus_amd_get_config(d, C.byref(cfg))
+    cfg.mode, cfg.pace, cfg.batch_samples, cfg.max_buffers = 1, 0, 8 * 40000, 3
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    dec, nt = (C.c_int * 4)(), (C.c_int * 4)()
+    n = L.perseus_amd_get_plan(d, dec, nt, None)
+    taps = [np.zeros(nt[i], np.float32) for i in range(n)]
+    arr = (C.POINTER(C.c_float) * 4)(*[t.ctypes.data_as(C.POINTER(C.c_float)) for t in taps], None)
+    L.perseus_amd_get_plan(d, dec, nt, arr)
+    got = []
+    cb = pkg.PERSEUS_CALLBACK(lambda b, nbytes, x: got.append(C.string_at(b, nbytes)) or 0)
+    assert L.perseus_start_async_input(d, 6144, cb, None) == 0, L.perseus_errorstr()
+    t0 = time.time()
+    while L.perseus_amd_source_running(d) and time.time() - t0 < 60:
+        time.sleep(0.005)
+    assert L.perseus_stop_async_input(d) == 0
+    L.perseus_exit()
+    assert len(got) == 3
+    y = np.frombuffer(b"".join(got), dtype=np.float32)
+    nout = y.size // 2                                       # 3 * 768 complex samples
+    need = nout * 320
+    packed = O.lcg_bytes(6 * need, 12345)
+    ref = O.ddc_chain(packed, [(dec[i], taps[i]) for i in range(n)], freg=381178347, mix=True)
+    assert O.rel_err(y, ref[: y.size]) <= FIR_TOL

@@ -1,0 +1,132 @@
+"""CPU tests: the oracle against the reference outputs recorded in
+tests/golden and against its own second (numpy) restatement."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, load_taps
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return json.load(open(os.path.join(GOLD, "unpack_golden.json")))
+
+
+def test_unpack_kat_reference_table(O, gold):
+    for k in gold["kat"]:
+        p = O.pack24(np.array([k["code24"]]), np.array([k["code24"]]))
+        for fn in (O.unpack24_f32, O.unpack24_f32_numpy):
+            f = fn(p)
+            assert f.view(np.uint32)[0] == k["float_bits"] and f.view(np.uint32)[1] == k["float_bits"]
+        for fn in (O.unpack24_i32, O.unpack24_i32_numpy):
+            assert fn(p)[0] == k["int32"] and fn(p)[1] == k["int32"]
+
+
+def test_unpack_range_and_extremes(O):
+    p = O.pack24(np.array([0x7FFFFF, 0x800000]), np.array([0x800000, 0x7FFFFF]))
+    f = O.unpack24_f32(p)
+    assert f[0] == 1.0 and f[3] == 1.0
+    assert f[1].view(np.uint32) == 0xBF800001      # -1.00000012, reference range note
+    assert O.unpack24_f32(np.zeros(5, np.uint8)).size == 0   # buf_size/6 samples, tail ignored
+    assert O.unpack24_f32(p[:11]).size == 2
+
+
+def test_unpack_exhaustive_sha256_matches_reference(O, gold):
+    v = np.arange(1 << 24, dtype=np.int64)
+    packed = O.pack24(v, (~v) & 0xFFFFFF)
+    f = O.unpack24_f32(packed)
+    assert hashlib.sha256(f.tobytes()).hexdigest() == gold["sha256"]["exhaustive_f32"]
+    i = O.unpack24_i32(packed)
+    assert hashlib.sha256(i.tobytes()).hexdigest() == gold["sha256"]["exhaustive_i32"]
+    # second restatement (numpy divide) agrees bit for bit on a slice of it
+    sl = packed[: 6 * 300000]
+    assert np.array_equal(O.unpack24_f32_numpy(sl).view(np.uint32), f[:600000].view(np.uint32))
+
+
+def test_lcg_buffer_fixture(O, gold):
+    b = O.lcg_bytes(6144, 12345)
+    assert b[:12].tobytes().hex() == gold["sha256"]["lcg_6144_in_first12"]
+    assert hashlib.sha256(b.tobytes()).hexdigest().startswith(gold["sha256"]["lcg_6144_in_prefix"])
+    assert np.array_equal(b, np.fromfile(os.path.join(GOLD, "lcg_6144.in"), dtype=np.uint8))
+    out = O.unpack24_f32(b)
+    assert hashlib.sha256(out.tobytes()).hexdigest() == gold["sha256"]["lcg_6144_out_f32"]
+    assert np.array_equal(out, np.fromfile(os.path.join(GOLD, "lcg_6144.f32.out"), dtype=np.float32))
+    assert np.array_equal(O.lcg_bytes_numpy(50000, 777), O.lcg_bytes(50000, 777))
+
+
+def test_nco_word_kats(O, gold):
+    for hz, w in gold["nco_freg_kat"].items():
+        assert O.nco_freg(float(hz)) == w
+    assert O.nco_freg(7.1e6) == 0x16B851EB
+
+
+def test_rate_selection_semantics(O):
+    R = O.REFERENCE_RATES
+    for i, r in enumerate(R):
+        assert O.rate_index(r) == i
+    assert O.rate_index(1) == 0 and O.rate_index(10 ** 9) == len(R) - 1
+    # midpoint goes to the LOWER rate (perseus-sdr.c:799-807)
+    assert O.rate_index((48000 + 95000) // 2) == 0
+    assert O.rate_index((48000 + 95000) // 2 + 1) == 1
+    assert O.rate_index(1800000) == 8 and O.rate_index(1800001) == 9
+
+
+def test_preselector_choice(O):
+    assert O.presel_id(7.1e6) == 5          # FLT_6
+    assert O.presel_id(1.0e6) == 0 and O.presel_id(1.7e6) == 1
+    assert O.presel_id(32e6) == 10 and O.presel_id(5e6, False) == 10
+
+
+def test_fir_two_restatements_agree(O):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(2 * 5000)
+    for D, nt in ((8, 127), (5, 161), (1, 4), (3, 50)):
+        h = rng.standard_normal(nt).astype(np.float32)
+        a = O.fir_decim(x, h, D)
+        b = O.fir_decim_numpy(x, h, D)
+        assert a.size == b.size
+        assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b))
+
+
+def test_nco_mix_properties(O):
+    x = np.zeros(2 * 64, np.float32)
+    x[0::2] = 1.0
+    assert np.allclose(O.nco_mix(x, 0), x.astype(np.float64))
+    y = O.nco_mix(x, 1 << 30).reshape(-1, 2)            # fs/4: 1, -j, -1, j
+    assert np.allclose(y[:4], [[1, 0], [0, -1], [-1, 0], [0, 1]], atol=1e-12)
+    # phase is a pure function of the absolute index
+    a = O.nco_mix(x, 381178347, n0=0).reshape(-1, 2)
+    b = O.nco_mix(x[: 2 * 32], 381178347, n0=32).reshape(-1, 2)
+    assert np.allclose(a[32:], b, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["d8_127", "d8_255"])
+def test_ddc_golden_fixture_regression(O, name):
+    meta = json.load(open(os.path.join(GOLD, "ddc_golden.json")))
+    packed = O.lcg_bytes(6 * meta["ddc_d8_lcg_samples"], meta["lcg_seed"])
+    y = O.ddc_chain(packed, [(8, load_taps(name))])
+    exp = np.fromfile(os.path.join(GOLD, f"ddc_{name}_lcg.f32"), dtype=np.float32)
+    assert np.array_equal(y, exp)
+    # the float baseline path stays within the FIR tolerance of the double oracle
+    yf = O.stage1_f32(packed, load_taps(name), 8, 2)
+    assert O.rel_err(yf, exp) <= 1e-6
+
+
+def test_cascade_fixture_regression(O):
+    meta = json.load(open(os.path.join(GOLD, "ddc_golden.json")))
+    tone = np.fromfile(os.path.join(GOLD, "tone_7101k.in"), dtype=np.uint8)
+    st = [(d, load_taps(n)) for d, n in meta["c320_stages"]]
+    y = O.ddc_chain(tone, st, freg=meta["freg"], mix=True)
+    exp = np.fromfile(os.path.join(GOLD, "ddc_c320_tone.f32"), dtype=np.float32)
+    assert np.array_equal(y, exp)
+
+
+def test_taps_manifest(O):
+    man = json.load(open(os.path.join(GOLD, "taps_manifest.json")))
+    for name, m in man.items():
+        h = load_taps(name)
+        assert h.size == m["ntaps"] and abs(float(h.astype(np.float64).sum()) - 1.0) < 1e-6
+        assert m["stop_atten_db"] >= 85

