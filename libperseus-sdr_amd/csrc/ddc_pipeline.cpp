@@ -673,6 +673,12 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     a.hist = p->st[0].d_hist[p->st[0].cur];
     a.hist_out = nullptr;                  /* state is not advanced */
     a.out = static_cast<float *>(d_out);
+    if (p->nstages > 1) {                  /* stage 0 of a cascade writes the next stage's input buffer */
+        int rc = ensure_buf(p->st[1], nsamples / (size_t)p->st[0].decim + 8);
+        if (rc)
+            return rc;
+        a.out = p->st[1].d_buf;
+    }
     a.taps_blk = p->st[0].d_taps_blk;
     a.n_in = (long long)nsamples;
     fill_fir8_args(p, a);
