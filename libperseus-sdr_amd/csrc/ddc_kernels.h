@@ -33,7 +33,8 @@ struct Fir8Args {
 constexpr int fir8_tile_inputs(int R) { return 1024 * R; }
 size_t fir8_lds_bytes(int ntb, int R);
 bool   fir8_supported(int ntb, int R);
-void   fir8_set_grid_blocks(int nblocks);   /* persistent grid size (default 512) */
+void   fir8_set_grid_blocks(int nblocks);   /* persistent grid override (0 = resident blocks x CUs) */
+void   fir8_set_prefetch_depth(int d);      /* 1 or 2 tiles of loads in flight per block */
 
 /* returns hipSuccess or the launch error */
 hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s);

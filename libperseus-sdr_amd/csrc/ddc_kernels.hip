@@ -44,6 +44,7 @@ static constexpr float kUnpackScale = 0x1.000002p-31f;   /* RN(1/8388607) / 256 
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 /* ------------------------------------------------------------------------ */
 /* 12 dwords (48 bytes) = 8 packed samples -> MSB-aligned int32 (value * 256),
@@ -118,12 +119,19 @@ struct UnpackArgs {
 template <bool TO_I32, bool MIX>
 __global__ __launch_bounds__(256) void k_unpack24(UnpackArgs p)
 {
-    const long long ngroups = (p.ns + 7) >> 3;
+    __shared__ __attribute__((aligned(16))) uint32_t slabs[4][1024];
+    const int lane = threadIdx.x & 63;
+    uint32_t *slab = slabs[threadIdx.x >> 6];
+    const long long ngroups = (((p.ns + 7) >> 3) + 63) & ~63LL;   /* whole waves iterate together */
     for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < ngroups;
          g += (long long)gridDim.x * 256) {
         const long long s0 = g << 3;
         uint32_t w[12];
-        if (s0 + 8 <= p.ns) {
+        if (s0 >= p.ns) {
+#pragma unroll
+            for (int d = 0; d < 12; ++d)
+                w[d] = 0;
+        } else if (s0 + 8 <= p.ns) {
             const uint4 *src = reinterpret_cast<const uint4 *>(p.in + s0 * 6);
             const uint4 a = src[0], b = src[1], c = src[2];
             w[0] = a.x; w[1] = a.y; w[2] = a.z;  w[3] = a.w;
@@ -166,12 +174,34 @@ __global__ __launch_bounds__(256) void k_unpack24(UnpackArgs p)
             }
         }
         uint32_t *dst = reinterpret_cast<uint32_t *>(p.out) + s0 * 2;
-        if (s0 + 8 <= p.ns) {
+        /* A lane holds 64 contiguous output bytes; storing them directly would
+         * make every store instruction touch 64 separate 64-byte segments.  The
+         * wave transposes its 4 KiB through a private LDS slab (XOR-swizzled
+         * 16-byte chunks, conflict-free both ways, no block barrier) so that each
+         * global_store_dwordx4 writes 1 KiB contiguous, with the nt hint.        */
+        const long long wave_g0 = g - lane;                      /* first group of this wave */
+        const bool wave_full = (wave_g0 + 64) * 8 <= p.ns;       /* wave-uniform */
+        if (wave_full) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * lane + j;
+                *reinterpret_cast<uint4 *>(slab + 4 * (c ^ ((c >> 3) & 7))) =
+                    make_uint4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+            }
+            /* same wave wrote and reads: program order + lgkmcnt is enough */
+            u32x4 *wdst = reinterpret_cast<u32x4 *>(reinterpret_cast<uint32_t *>(p.out) + wave_g0 * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = 64 * j + lane;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(slab + 4 * (q ^ ((q >> 3) & 7)));
+                __builtin_nontemporal_store(v, wdst + q);
+            }
+        } else if (s0 + 8 <= p.ns) {
             uint4 *d4 = reinterpret_cast<uint4 *>(dst);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 d4[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-        } else {
+        } else if (s0 < p.ns) {
             const int rem = (int)(p.ns - s0);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -335,7 +365,7 @@ __device__ __forceinline__ void fir_window(const float *base, const float PDDC_C
  *              C  the last NTB groups become tile t+1's history (copied by
  *                 the very threads that overwrite them in the next U, so no
  *                 third barrier is needed).                                */
-template <int NTB, int R, int INFMT, bool MIX>
+template <int NTB, int R, int INFMT, bool MIX, int PFD>
 __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int tiles_per_block, int ntiles)
 {
     using G = Fir8Geom<NTB, R>;
@@ -371,8 +401,10 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         group_to_lds<R>(sI, sQ, tid, xi, xq);
     }
 
-    uint4 raw[G::GPT][NW];
-    auto prefetch = [&](int tile) {
+    /* PFD register sets of prefetched input: tile t+PFD is requested while tile t
+     * is filtered (PFD=2 keeps two tiles of loads in flight per block)          */
+    uint4 rawA[G::GPT][NW], rawB[PFD > 1 ? G::GPT : 1][NW];
+    auto prefetch = [&](int tile, uint4 (&raw)[G::GPT][NW]) {
         const long long tin0 = (long long)tile * G::TI;
         const uint4 *src0 = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(p.in) +
                                                             (tin0 + 8LL * gtid) * ES);
@@ -398,7 +430,9 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
             }
         }
     };
-    prefetch(t0);
+    prefetch(t0, rawA);
+    if (PFD > 1 && t0 + 1 < t1)
+        prefetch(t0 + 1, reinterpret_cast<uint4 (&)[G::GPT][NW]>(rawB));
 
     const int wave  = tid >> 6;
     const int lane  = tid & 63;
@@ -441,7 +475,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         }
     };
 
-    for (int t = t0; t < t1; ++t) {
+    auto tile_body = [&](int t, uint4 (&raw)[G::GPT][NW]) {
         /* ---- U: registers -> LDS planes (groups NTB ..) ------------------- */
 #pragma unroll
         for (int k = 0; k < G::GPT; ++k) {
@@ -461,8 +495,8 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         __syncthreads();                                           /* A */
 
         /* ---- P: next tile's loads --------------------------------------- */
-        if (t + 1 < t1)
-            prefetch(t + 1);
+        if (t + PFD < t1)
+            prefetch(t + PFD, raw);
 
         /* ---- F: FIR ------------------------------------------------------ */
         /* Packed fp32: every VALU op costs ~4 cycles per wave64 on gfx950, and
@@ -511,6 +545,17 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
                 sQ[od + 7] = q1.w;
             }
         }
+    };
+
+    if (PFD == 1) {
+        for (int t = t0; t < t1; ++t)
+            tile_body(t, rawA);
+    } else {
+        for (int t = t0; t < t1; t += 2) {
+            tile_body(t, rawA);
+            if (t + 1 < t1)
+                tile_body(t + 1, reinterpret_cast<uint4 (&)[G::GPT][NW]>(rawB));
+        }
     }
     store_tile(t1 - 1);
 
@@ -531,6 +576,7 @@ bool fir8_supported(int ntb, int R)
     return (R == 4 || R == 8) && (ntb == 4 || ntb == 8 || ntb == 16 || ntb == 32);
 }
 
+static int g_fir8_pfd = 1;          /* prefetch depth in tiles (1 or 2); 2 measured no faster */
 static int g_fir8_blocks = 0;       /* persistent grid override (0 = resident blocks per CU x 256 CUs) */
 
 template <int NTB, int R>
@@ -548,32 +594,35 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
     const int tpb = (ntiles + want - 1) / want;
     const int nblocks = (ntiles + tpb - 1) / tpb;
     const dim3 grid((unsigned)nblocks), blk(256);
-#define PDDC_LAUNCH(FMT, MIXV)                                                                    \
+#define PDDC_LAUNCH(FMT, MIXV, PF)                                                                \
     do {                                                                                          \
         static bool attr_done = false;                                                            \
         if (!attr_done) {                                                                         \
             hipError_t e = hipFuncSetAttribute(                                                   \
-                reinterpret_cast<const void *>(&k_fir8<NTB, R, FMT, MIXV>),                       \
+                reinterpret_cast<const void *>(&k_fir8<NTB, R, FMT, MIXV, PF>),                   \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
             if (e != hipSuccess)                                                                  \
                 return e;                                                                         \
             attr_done = true;                                                                     \
         }                                                                                         \
-        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV>), grid, blk, lds, s, a, tpb, ntiles);       \
+        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV, PF>), grid, blk, lds, s, a, tpb, ntiles);   \
     } while (0)
+    const bool pf2 = g_fir8_pfd > 1;
     if (fmt == IN_PACKED24) {
-        if (mix)
-            PDDC_LAUNCH(IN_PACKED24, true);
-        else
-            PDDC_LAUNCH(IN_PACKED24, false);
+        if (mix) {
+            if (pf2) PDDC_LAUNCH(IN_PACKED24, true, 2); else PDDC_LAUNCH(IN_PACKED24, true, 1);
+        } else {
+            if (pf2) PDDC_LAUNCH(IN_PACKED24, false, 2); else PDDC_LAUNCH(IN_PACKED24, false, 1);
+        }
     } else {
-        PDDC_LAUNCH(IN_F32C, false);
+        PDDC_LAUNCH(IN_F32C, false, 1);
     }
 #undef PDDC_LAUNCH
     return hipGetLastError();
 }
 
 void fir8_set_grid_blocks(int nblocks) { g_fir8_blocks = nblocks > 0 ? nblocks : 0; }
+void fir8_set_prefetch_depth(int d) { g_fir8_pfd = d >= 2 ? 2 : 1; }
 
 hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s)
 {
