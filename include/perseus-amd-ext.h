@@ -10,7 +10,7 @@
  * perseus_init(), so an unmodified reference client can be pointed at a source:
  *   PERSEUS_AMD_DEVICES   number of virtual receivers, 1..8 (default 1; the
  *                         reference's PERSEUS_MAX_DESCR is 8, perseus-sdr.c:43)
- *   PERSEUS_AMD_MODE      "wire" (default) | "ddc"
+ *   PERSEUS_AMD_MODE      "wire" (default) | "ddc" | "ddc-wire"
  *   PERSEUS_AMD_SOURCE    "lcg[:seed]" (default lcg:12345) | "zero" | "file:<path>"
  *   PERSEUS_AMD_PACE      1 = pace the source at the nominal rate (default), 0 = free-running
  *   PERSEUS_AMD_BATCH     ddc mode: ADC-rate samples per GPU batch (default 2^22)
@@ -38,6 +38,11 @@ extern "C" {
  *        GPU: perseus_start_async_input() fails (no CPU fallback) without one. */
 #define PERSEUS_AMD_MODE_WIRE 0
 #define PERSEUS_AMD_MODE_DDC  1
+/*  DDC_WIRE: as DDC, but the GPU re-quantises its output to the 24-bit wire
+ *        format (pddc_pack24_f32), so callbacks look exactly like the hardware's:
+ *        6 bytes/sample at the selected rate ("FPGA emulation").
+ *        An unmodified reference client runs on the GPU path this way.            */
+#define PERSEUS_AMD_MODE_DDC_WIRE 2
 
 #define PERSEUS_AMD_SRC_LCG   0
 #define PERSEUS_AMD_SRC_ZERO  1

@@ -7,6 +7,9 @@
  *   pddc_unpack24_f32      examples/perseustest.c:466-502  user_data_callback_c_f
  *   pddc_unpack24_i32      examples/perseustest.c:432-460  user_data_callback_c_u
  *                          (dup. examples/simple.c:33-61)
+ *   pddc_pack24_f32        (none) inverse of the above: what the FPGA emits on USB endpoint
+ *                          0x82 -- 24-bit packed samples at the selected rate -- so that an
+ *                          unmodified client sees the wire format it expects (perseustest.c:434)
  *   pddc_nco_freg          perseus-sdr.c:584   tuning word written to the FPGA
  *   pddc_pipeline_*        the FPGA DDC itself (NCO mix + decimating FIR chain)
  *                          that perseus_set_sampling_rate() selects by bitstream
@@ -61,6 +64,8 @@ extern "C" {
 #define PDDC_F_MIX         0x1u   /* NCO complex mix before stage 0            */
 #define PDDC_F_TAPS_FP16   0x2u   /* round taps to fp16 storage (config 5)     */
 #define PDDC_F_NO_FAST     0x4u   /* force the generic kernels (testing)       */
+#define PDDC_F_OUT_PACKED24 0x8u  /* process()/push_host() emit 24-bit packed (6 B/sample)
+                                     instead of float32: "FPGA emulation"      */
 
 typedef struct pddc_pipeline pddc_pipeline;
 
@@ -82,6 +87,8 @@ uint32_t    pddc_nco_freg(double center_freq_hz, double adc_clk_hz);
 /* d_packed must be 16-byte aligned; nsamples may be any value >= 0.          */
 int pddc_unpack24_f32(const void *d_packed, size_t nsamples, void *d_out_f32, void *stream);
 int pddc_unpack24_i32(const void *d_packed, size_t nsamples, void *d_out_i32, void *stream);
+/* float32 I/Q -> 24-bit packed: code = clamp(rint(x*8388607), -2^23, 2^23-1).  */
+int pddc_pack24_f32(const void *d_in_f32, size_t nsamples, void *d_out_packed, void *stream);
 /* synthetic source of BASELINE.md section 3: byte k of the LCG stream
  * s=s*1664525+1013904223, byte=s>>24, starting `byte_offset` bytes in.        */
 int pddc_synth_lcg(void *d_dst, size_t nbytes, uint32_t seed, uint64_t byte_offset, void *stream);
@@ -111,7 +118,8 @@ size_t pddc_pipeline_max_output(const pddc_pipeline *p, size_t nsamples_in);
 int pddc_pipeline_uses_fused(const pddc_pipeline *p);
 
 /* Device-resident batch: d_packed (16-byte aligned, nsamples % 8 == 0) ->
- * d_out_f32 (16-byte aligned, capacity in complex samples).  Asynchronous on
+ * d_out_f32 (16-byte aligned, capacity in complex samples; with
+ * PDDC_F_OUT_PACKED24 it receives 6 bytes per sample instead of 8).  Asynchronous on
  * `stream`; *n_out (host) is written before return (it depends only on sizes).
  * Stream state (FIR history, phase, NCO counter) advances by nsamples.        */
 int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsamples,

@@ -29,7 +29,7 @@ DDC_LIB = os.path.join(_HERE, "libperseus_ddc.so")
 SDR_LIB = os.path.join(_HERE, "libperseus-sdr.so")
 
 PDDC_OK, PDDC_EINVAL, PDDC_ENODEV, PDDC_EHIP, PDDC_ENOMEM, PDDC_ECAPACITY, PDDC_ESTATE = 0, -1, -2, -3, -4, -5, -6
-PDDC_F_MIX, PDDC_F_TAPS_FP16, PDDC_F_NO_FAST = 1, 2, 4
+PDDC_F_MIX, PDDC_F_TAPS_FP16, PDDC_F_NO_FAST, PDDC_F_OUT_PACKED24 = 1, 2, 4, 8
 
 
 class PddcError(RuntimeError):
@@ -76,6 +76,7 @@ def ddc_lib() -> C.CDLL:
     L.pddc_nco_freg.restype = C.c_uint32
     L.pddc_unpack24_f32.argtypes = [vp, sz, vp, vp]
     L.pddc_unpack24_i32.argtypes = [vp, sz, vp, vp]
+    L.pddc_pack24_f32.argtypes = [vp, sz, vp, vp]
     L.pddc_synth_lcg.argtypes = [vp, sz, C.c_uint32, C.c_uint64, vp]
     L.pddc_set_device.argtypes = [C.c_int]
     L.pddc_malloc.argtypes = [C.POINTER(vp), sz]
@@ -98,7 +99,7 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_process.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp]
     L.pddc_pipeline_push_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     L.pddc_pipeline_time_stage0.argtypes = [vp, vp, sz, vp, C.c_int, vp, C.POINTER(C.c_float)]
-    for name in ("pddc_unpack24_f32", "pddc_unpack24_i32", "pddc_synth_lcg", "pddc_set_device",
+    for name in ("pddc_unpack24_f32", "pddc_unpack24_i32", "pddc_pack24_f32", "pddc_synth_lcg", "pddc_set_device",
                  "pddc_malloc", "pddc_free", "pddc_memcpy_h2d", "pddc_memcpy_d2h", "pddc_stream_sync",
                  "pddc_pipeline_create", "pddc_pipeline_destroy", "pddc_pipeline_reset",
                  "pddc_pipeline_set_freg", "pddc_pipeline_set_center_freq", "pddc_pipeline_set_taps",
@@ -119,7 +120,7 @@ class Pipeline:
     """Thin handle over pddc_pipeline_* (include/perseus_ddc.h)."""
 
     def __init__(self, stages, device: int = 0, mix: bool = False, taps_fp16: bool = False,
-                 no_fast: bool = False):
+                 no_fast: bool = False, out_packed: bool = False):
         import numpy as np
         L = ddc_lib()
         self._taps = [np.ascontiguousarray(h, dtype=np.float32) for _, h in stages]
@@ -129,7 +130,8 @@ class Pipeline:
             arr[i].ntaps = int(self._taps[i].size)
             arr[i].taps = self._taps[i].ctypes.data_as(C.POINTER(C.c_float))
         flags = (PDDC_F_MIX if mix else 0) | (PDDC_F_TAPS_FP16 if taps_fp16 else 0) | \
-                (PDDC_F_NO_FAST if no_fast else 0)
+                (PDDC_F_NO_FAST if no_fast else 0) | (PDDC_F_OUT_PACKED24 if out_packed else 0)
+        self.out_packed = out_packed
         h = C.c_void_p()
         check(L.pddc_pipeline_create(C.byref(h), device, arr, len(stages), flags))
         self._h = h
@@ -172,9 +174,13 @@ class Pipeline:
         import torch
         ns = packed_u8.numel() // 6
         cap = self.max_output(ns) + 1
+        st = stream if stream is not None else torch.cuda.current_stream(packed_u8.device).cuda_stream
+        if self.out_packed:                       # 6 bytes per output sample
+            out_u8 = torch.empty(6 * cap + 16, dtype=torch.uint8, device=packed_u8.device)
+            n = self.process_ptr(packed_u8.data_ptr(), ns, out_u8.data_ptr(), cap, st)
+            return out_u8[:6 * n]
         if out_f32 is None:
             out_f32 = torch.empty((cap, 2), dtype=torch.float32, device=packed_u8.device)
-        st = stream if stream is not None else torch.cuda.current_stream(packed_u8.device).cuda_stream
         n = self.process_ptr(packed_u8.data_ptr(), ns, out_f32.data_ptr(), out_f32.numel() // 2, st)
         return out_f32[:n]
 
@@ -211,6 +217,16 @@ def unpack24_i32(packed_u8, stream=None):
     st = stream if stream is not None else torch.cuda.current_stream(packed_u8.device).cuda_stream
     check(ddc_lib().pddc_unpack24_i32(packed_u8.data_ptr(), ns, out.data_ptr(), st))
     return out
+
+
+def pack24_f32(x_f32, stream=None):
+    """torch float32 CUDA tensor [ns, 2] -> uint8 wire bytes [6*ns] via the HIP kernel."""
+    import torch
+    ns = x_f32.numel() // 2
+    out = torch.empty(6 * ns + 16, dtype=torch.uint8, device=x_f32.device)
+    st = stream if stream is not None else torch.cuda.current_stream(x_f32.device).cuda_stream
+    check(ddc_lib().pddc_pack24_f32(x_f32.data_ptr(), ns, out.data_ptr(), st))
+    return out[:6 * ns]
 
 
 def synth_lcg(nbytes: int, seed: int = 12345, byte_offset: int = 0, device="cuda:0", stream=None):

@@ -53,6 +53,9 @@ hipError_t launch_fir_generic(const float *in, const float *hist, int H, long lo
 hipError_t launch_hist_update(void *dst, const void *hist, int H, const void *batch, long long n,
                               int elem_bytes, hipStream_t s);
 
+/* float32 I/Q -> 24-bit packed (6 B/sample); in and out 16-byte aligned */
+hipError_t launch_pack24(const float *in, long long nsamples, void *out, hipStream_t s);
+
 hipError_t launch_synth_lcg(void *dst, size_t nbytes, uint32_t seed, uint64_t byte_offset,
                             hipStream_t s);
 

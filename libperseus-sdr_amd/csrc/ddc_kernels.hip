@@ -742,6 +742,70 @@ hipError_t launch_fir_generic(const float *in, const float *hist, int H, long lo
 }
 
 /* ======================================================================== */
+/* k_pack24 : float32 I/Q -> 24-bit packed wire format (the inverse of A2)  */
+/* ======================================================================== */
+/* code = clamp(rint(x * 8388607), -2^23, 2^23-1), ties to even, NaN -> -2^23;
+ * pack(unpack(c)) == c for all 2^24 codes.  Runs at the decimated rate, so a
+ * plain 8-samples-per-thread layout is enough.                                 */
+__device__ __forceinline__ uint32_t quant24(float x)
+{
+    float v = __builtin_rintf(x * 8388607.0f);
+    v = fminf(fmaxf(v, -8388608.0f), 8388607.0f);       /* fmaxf(NaN, lo) = lo */
+    return (uint32_t)(int32_t)v & 0xffffffu;
+}
+
+__global__ __launch_bounds__(256) void k_pack24(const float *__restrict__ in, uint8_t *__restrict__ out, long long ns)
+{
+    const long long ngroups = (ns + 7) >> 3;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (long long)gridDim.x * 256) {
+        const long long s0 = g << 3;
+        uint32_t c[16];
+        if (s0 + 8 <= ns) {
+            const float4 *src = reinterpret_cast<const float4 *>(in + 2 * s0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 f = src[k];
+                c[4 * k] = quant24(f.x); c[4 * k + 1] = quant24(f.y);
+                c[4 * k + 2] = quant24(f.z); c[4 * k + 3] = quant24(f.w);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                c[e] = (s0 + e / 2 < ns) ? quant24(in[2 * s0 + e]) : 0u;
+        }
+        uint32_t w[12];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {       /* 4 codes (I0 Q0 I1 Q1) -> 3 dwords */
+            const uint32_t a = c[4 * h], b = c[4 * h + 1], d = c[4 * h + 2], e = c[4 * h + 3];
+            w[3 * h]     = a | (b << 24);
+            w[3 * h + 1] = (b >> 8) | (d << 16);
+            w[3 * h + 2] = (d >> 16) | (e << 8);
+        }
+        if (s0 + 8 <= ns) {
+            uint4 *dst = reinterpret_cast<uint4 *>(out + s0 * 6);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+        } else {
+            const long long nb = (ns - s0) * 6;
+            for (int b = 0; b < 48 && b < nb; ++b)
+                out[s0 * 6 + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+        }
+    }
+}
+
+hipError_t launch_pack24(const float *in, long long ns, void *out, hipStream_t s)
+{
+    if (ns <= 0)
+        return hipSuccess;
+    long long blocks = (((ns + 7) >> 3) + 255) / 256;
+    if (blocks > 4096)
+        blocks = 4096;
+    hipLaunchKernelGGL(k_pack24, dim3((unsigned)blocks), dim3(256), 0, s, in, static_cast<uint8_t *>(out), ns);
+    return hipGetLastError();
+}
+
+/* ======================================================================== */
 /* k_hist_update                                                            */
 /* ======================================================================== */
 __global__ __launch_bounds__(256) void k_hist_update(uint32_t *dst, const uint32_t *hist, int Hw,

@@ -80,6 +80,8 @@ struct pddc_pipeline {
     size_t d_in_cap = 0;
     float *d_out = nullptr;
     size_t d_out_cap = 0;
+    float *d_fout = nullptr;      /* float output of the last stage when the caller wants packed */
+    size_t d_fout_cap = 0;
     hipStream_t own_stream = nullptr;
 };
 
@@ -261,6 +263,17 @@ int pddc_unpack24_i32(const void *d_packed, size_t nsamples, void *d_out, void *
     return PDDC_OK;
 }
 
+int pddc_pack24_f32(const void *d_in, size_t nsamples, void *d_out, void *stream)
+{
+    int rc = require_device();
+    if (rc)
+        return rc;
+    if ((rc = check_unpack_args(d_in, d_out, nsamples)))
+        return rc;
+    HIP_TRY(launch_pack24(static_cast<const float *>(d_in), (long long)nsamples, d_out, (hipStream_t)stream));
+    return PDDC_OK;
+}
+
 int pddc_synth_lcg(void *d_dst, size_t nbytes, uint32_t seed, uint64_t byte_offset, void *stream)
 {
     int rc = require_device();
@@ -373,6 +386,8 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
         hipFree(p->d_in);
     if (p->d_out)
         hipFree(p->d_out);
+    if (p->d_fout)
+        hipFree(p->d_fout);
     if (p->own_stream)
         hipStreamDestroy(p->own_stream);
     delete p;
@@ -555,6 +570,17 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             if ((rc = ensure_buf(p->st[i + 1], n_in[i + 1] + 8)))
                 return rc;
             dst = p->st[i + 1].d_buf;
+        } else if (p->flags & PDDC_F_OUT_PACKED24) {
+            if (p->d_fout_cap < n_final + 8) {
+                HIP_TRY(hipDeviceSynchronize());
+                if (p->d_fout)
+                    HIP_TRY(hipFree(p->d_fout));
+                p->d_fout = nullptr;
+                p->d_fout_cap = 0;
+                HIP_TRY(hipMalloc(&p->d_fout, (n_final + n_final / 4 + 64) * 8));
+                p->d_fout_cap = n_final + n_final / 4 + 64;
+            }
+            dst = p->d_fout;
         } else {
             dst = static_cast<float *>(d_out);
         }
@@ -608,6 +634,8 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         }
         st.consumed += n_in[i];
     }
+    if (p->flags & PDDC_F_OUT_PACKED24)
+        HIP_TRY(launch_pack24(p->d_fout, (long long)n_final, d_out, s));
     p->n0 += nsamples;
     if (n_out_ret)
         *n_out_ret = n_final;
@@ -652,7 +680,8 @@ int pddc_pipeline_push_host(pddc_pipeline *p, const void *h_packed, size_t nsamp
         return fail(PDDC_ECAPACITY, "output capacity %zu < %zu", out_capacity, n_out);
     }
     if (n_out)
-        HIP_TRY(hipMemcpyAsync(h_out, p->d_out, n_out * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h_out, p->d_out, n_out * ((p->flags & PDDC_F_OUT_PACKED24) ? 6 : 8),
+                               hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (n_out_ret)
         *n_out_ret = n_out;

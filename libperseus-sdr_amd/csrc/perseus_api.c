@@ -338,7 +338,7 @@ static void pump_ddc(perseus_descr *d)
         return;
     }
     d->adc_samples += ns;
-    const size_t nb = n_out * 8;
+    const size_t nb = n_out * (d->cfg.mode == PERSEUS_AMD_MODE_DDC_WIRE ? 6 : 8);
     if (d->fifo_len + nb > d->fifo_cap) {
         size_t cap = (d->fifo_len + nb) * 2;
         uint8_t *nf = (uint8_t *)realloc(d->fifo, cap);
@@ -366,13 +366,13 @@ static void *worker_fn(void *arg)
                 continue;
             if (d->cfg.max_buffers && d->delivered + d->dropped >= d->cfg.max_buffers)
                 d->source_done = 1;
-            if (d->source_done && !(d->cfg.mode == PERSEUS_AMD_MODE_DDC && d->fifo_len >= d->buffersize &&
+            if (d->source_done && !(d->cfg.mode != PERSEUS_AMD_MODE_WIRE && d->fifo_len >= d->buffersize &&
                                     !(d->cfg.max_buffers && d->delivered + d->dropped >= d->cfg.max_buffers)))
                 continue;
             busy = 1;
             pthread_mutex_lock(&d->pump_lock);
             if (d->streaming && !d->cancelling) {
-                if (d->cfg.mode == PERSEUS_AMD_MODE_DDC)
+                if (d->cfg.mode != PERSEUS_AMD_MODE_WIRE)
                     pump_ddc(d);
                 else
                     pump_wire(d);
@@ -398,8 +398,12 @@ static void default_config(perseus_descr *d)
     d->cfg.pace = 1;
     d->cfg.gpu_device = -1;
     d->cfg.batch_samples = 1u << 22;
-    if ((e = getenv("PERSEUS_AMD_MODE")) && strcmp(e, "ddc") == 0)
-        d->cfg.mode = PERSEUS_AMD_MODE_DDC;
+    if ((e = getenv("PERSEUS_AMD_MODE"))) {
+        if (strcmp(e, "ddc") == 0)
+            d->cfg.mode = PERSEUS_AMD_MODE_DDC;
+        else if (strcmp(e, "ddc-wire") == 0)
+            d->cfg.mode = PERSEUS_AMD_MODE_DDC_WIRE;
+    }
     if ((e = getenv("PERSEUS_AMD_SOURCE"))) {
         if (strncmp(e, "lcg", 3) == 0) {
             d->cfg.source = PERSEUS_AMD_SRC_LCG;
@@ -748,7 +752,7 @@ int perseus_start_async_input(perseus_descr *d, uint32_t buffersize, perseus_inp
                             d->cfg.file_path ? d->cfg.file_path : "(null)");
         }
     }
-    if (d->cfg.mode == PERSEUS_AMD_MODE_DDC) {
+    if (d->cfg.mode != PERSEUS_AMD_MODE_WIRE) {
         if (d->plan.nstages == 0) {
             free_stream(d);
             return errorset(PERSEUS_FPGANOTCFGD,
@@ -768,7 +772,8 @@ int perseus_start_async_input(perseus_descr *d, uint32_t buffersize, perseus_inp
                             pddc_last_error());
         }
         int dev = d->cfg.gpu_device >= 0 ? d->cfg.gpu_device : d->index % ndev;
-        int rc = pddc_pipeline_create(&d->pipe, dev, sd, d->plan.nstages, PDDC_F_MIX);
+        int rc = pddc_pipeline_create(&d->pipe, dev, sd, d->plan.nstages,
+                                      PDDC_F_MIX | (d->cfg.mode == PERSEUS_AMD_MODE_DDC_WIRE ? PDDC_F_OUT_PACKED24 : 0));
         if (rc != PDDC_OK) {
             free_stream(d);
             return errorset(PERSEUS_DEVCONF, "GPU pipeline creation failed (%d): %s", rc, pddc_last_error());
@@ -845,7 +850,7 @@ int perseus_amd_set_config(perseus_descr *d, const perseus_amd_config *cfg)
         return errorset(PERSEUS_NULLDESCR, "null descriptor");
     if (d->streaming)
         return errorset(PERSEUS_ASYNCSTARTED, "cannot reconfigure while streaming");
-    if (cfg->mode != PERSEUS_AMD_MODE_WIRE && cfg->mode != PERSEUS_AMD_MODE_DDC)
+    if (cfg->mode < PERSEUS_AMD_MODE_WIRE || cfg->mode > PERSEUS_AMD_MODE_DDC_WIRE)
         return errorset(PERSEUS_ERRPARAM, "bad mode %d", cfg->mode);
     if (cfg->source < PERSEUS_AMD_SRC_LCG || cfg->source > PERSEUS_AMD_SRC_FILE)
         return errorset(PERSEUS_ERRPARAM, "bad source %d", cfg->source);
@@ -872,7 +877,7 @@ int perseus_amd_source_running(perseus_descr *d)
         return 0;
     if (!d->source_done)
         return 1;
-    return d->cfg.mode == PERSEUS_AMD_MODE_DDC && d->fifo_len >= d->buffersize &&
+    return d->cfg.mode != PERSEUS_AMD_MODE_WIRE && d->fifo_len >= d->buffersize &&
            !(d->cfg.max_buffers && d->delivered + d->dropped >= d->cfg.max_buffers);
 }
 

@@ -51,6 +51,8 @@ def lib() -> C.CDLL:
         L.orc_unpack24_i32.restype = None
         L.orc_unpack24_f32_callback_style.argtypes = [u8p, C.c_size_t, f32p, C.c_size_t]
         L.orc_unpack24_f32_callback_style.restype = None
+        L.orc_pack24_f32.argtypes = [f32p, C.c_size_t, u8p]
+        L.orc_pack24_f32.restype = None
         L.orc_nco_freg.argtypes = [C.c_double, C.c_double]
         L.orc_nco_freg.restype = C.c_uint32
         L.orc_presel_id.argtypes = [C.c_double, C.c_int]
@@ -143,6 +145,14 @@ def unpack24_i32(packed: np.ndarray) -> np.ndarray:
     b = np.ascontiguousarray(packed, dtype=np.uint8)
     out = np.empty(2 * (b.size // 6), dtype=np.int32)
     lib().orc_unpack24_i32(_p(b, C.c_uint8), b.size, _p(out, C.c_int32))
+    return out
+
+
+def pack24_f32(x_iq: np.ndarray) -> np.ndarray:
+    """N1 (authored): float32 I/Q -> wire bytes, inverse of unpack24_f32."""
+    x = np.ascontiguousarray(x_iq, dtype=np.float32).reshape(-1)
+    out = np.empty(3 * x.size, dtype=np.uint8)
+    lib().orc_pack24_f32(_p(x, C.c_float), x.size // 2, _p(out, C.c_uint8))
     return out
 
 

@@ -74,6 +74,29 @@ void orc_unpack24_f32_callback_style(const uint8_t *in, size_t nbytes,
     }
 }
 
+/* N1 (authored): inverse of A2.  x*8388607 is evaluated in float (one
+ * rounding), then rounded to the nearest integer, ties to even (rintf in the
+ * default rounding mode), then saturated to the 24-bit range. */
+static inline int32_t quant24(float x)
+{
+    float v = rintf(x * 8388607.0f);
+    if (!(v >= -8388608.0f))
+        v = -8388608.0f;          /* also catches NaN */
+    if (v > 8388607.0f)
+        v = 8388607.0f;
+    return (int32_t)v;
+}
+
+void orc_pack24_f32(const float *in_iq, size_t ns, uint8_t *out)
+{
+    for (size_t k = 0; k < ns; k++) {
+        const uint32_t i = (uint32_t)quant24(in_iq[2 * k]), q = (uint32_t)quant24(in_iq[2 * k + 1]);
+        uint8_t *p = out + 6 * k;
+        p[0] = (uint8_t)i; p[1] = (uint8_t)(i >> 8); p[2] = (uint8_t)(i >> 16);
+        p[3] = (uint8_t)q; p[4] = (uint8_t)(q >> 8); p[5] = (uint8_t)(q >> 16);
+    }
+}
+
 /* ------------------------------------------------------------------------
  * A6 (perseus-sdr.c:584): FREG = (uint32)(f / fclk * 2^32), double
  * arithmetic, truncation toward zero.

@@ -44,6 +44,11 @@ uint32_t orc_lcg_fill(uint8_t *dst, size_t nbytes, uint32_t seed);
 void orc_unpack24_f32(const uint8_t *in, size_t nbytes, float *out_iq);
 void orc_unpack24_i32(const uint8_t *in, size_t nbytes, int32_t *out_iq);
 
+/* ---- N1 (authored): float -> 24-bit packed, the inverse of A2 --------------
+ * code = clamp(rint(x * 8388607), -8388608, 8388607), round half to even;
+ * pack(unpack(c)) == c for every 24-bit code c (tested exhaustively).         */
+void orc_pack24_f32(const float *in_iq, size_t nsamples, uint8_t *out);
+
 /* ---- A6: NCO tuning word (perseus-sdr.c:584) --------------------------- */
 uint32_t orc_nco_freg(double center_freq_hz, double adc_clk_hz);
 /* preselector filter id chosen by perseus-sdr.c:589-615 (10 = wide band) */

@@ -334,3 +334,76 @@ def test_perseus_api_ddc_mode_vs_oracle(pkg, dev, O, monkeypatch):
     packed = O.lcg_bytes(6 * need, 12345)
     ref = O.ddc_chain(packed, [(dec[i], taps[i]) for i in range(n)], freg=381178347, mix=True)
     assert O.rel_err(y, ref[: y.size]) <= FIR_TOL
+
+
+# ------------------------------------------------ N1: float -> 24-bit repack
+def test_pack24_roundtrip_exhaustive_and_edges(pkg, dev, O):
+    t = _torch()
+    v = np.arange(1 << 24, dtype=np.int64)
+    packed = O.pack24(v, (~v) & 0xFFFFFF)
+    d = to_dev(packed, dev)
+    f = pkg.unpack24_f32(d)
+    back = pkg.pack24_f32(f).cpu().numpy()
+    assert np.array_equal(back, packed)                       # pack(unpack(c)) == c for all 2^24 codes
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal(2 * 100003) * 0.7).astype(np.float32)   # odd count: ragged tail, saturation
+    x[:8] = [2.0, -2.0, np.nan, 0.5, 1e-9, -1e-9, 1.0, -1.00000012]
+    got = pkg.pack24_f32(to_dev(x, dev)).cpu().numpy()
+    assert np.array_equal(got, O.pack24_f32(x))
+
+
+def test_pipeline_packed_output(pkg, dev, O):
+    h = load_taps("d8_127")
+    ns = 8 * 5000
+    packed = O.lcg_bytes(6 * ns, 21)
+    pf = pkg.Pipeline([(8, h)])
+    pp = pkg.Pipeline([(8, h)], out_packed=True)
+    yf = pf.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+    yp = pp.process(to_dev(packed, dev)).cpu().numpy()
+    assert yp.size == 6 * (ns // 8)
+    assert np.array_equal(yp, O.pack24_f32(yf))               # same floats, oracle quantiser
+    ref = O.ddc_chain(packed, [(8, h)])
+    assert O.rel_err(O.unpack24_f32(yp), ref) <= FIR_TOL + 1.0 / 8388607 / np.max(np.abs(ref))
+    pf.close()
+    pp.close()
+
+
+def test_perseus_api_fpga_emulation_mode(pkg, dev, O, monkeypatch):
+    """DDC_WIRE: an unmodified reference-style client (24-bit packed callbacks,
+    client-side unpack) running on the GPU path at 2 MS/s (80 MS/s / 40)."""
+    import ctypes as C
+    import time
+    monkeypatch.setenv("PERSEUS_AMD_PACE", "0")
+    monkeypatch.delenv("PERSEUS_AMD_DEVICES", raising=False)
+    L = pkg.sdr_lib()
+    L.perseus_set_debug(0)
+    assert L.perseus_init() == 1
+    d = L.perseus_open(0)
+    L.perseus_firmware_download(d, None)
+    assert L.perseus_set_sampling_rate(d, 2000000) == 0
+    assert L.perseus_set_ddc_center_freq(d, C.c_double(7.05e6), 1) == 0
+    cfg = pkg.AmdConfig()
+    L.perseus_amd_get_config(d, C.byref(cfg))
+    cfg.mode, cfg.pace, cfg.batch_samples, cfg.max_buffers = 2, 0, 8 * 20000, 4
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    dec, nt = (C.c_int * 4)(), (C.c_int * 4)()
+    n = L.perseus_amd_get_plan(d, dec, nt, None)
+    assert list(dec)[:n] == [8, 5]
+    taps = [np.zeros(nt[i], np.float32) for i in range(n)]
+    arr = (C.POINTER(C.c_float) * 4)(*[t.ctypes.data_as(C.POINTER(C.c_float)) for t in taps], None, None)
+    L.perseus_amd_get_plan(d, dec, nt, arr)
+    got = []
+    cb = pkg.PERSEUS_CALLBACK(lambda b, nbytes, x: got.append(C.string_at(b, nbytes)) or 0)
+    assert L.perseus_start_async_input(d, 6144, cb, None) == 0, L.perseus_errorstr()
+    t0 = time.time()
+    while L.perseus_amd_source_running(d) and time.time() - t0 < 60:
+        time.sleep(0.005)
+    assert L.perseus_stop_async_input(d) == 0
+    L.perseus_exit()
+    assert len(got) == 4 and all(len(g) == 6144 for g in got)
+    wire = np.frombuffer(b"".join(got), dtype=np.uint8)
+    y = O.unpack24_f32(wire)                                   # what the client's callback would compute
+    nout = y.size // 2
+    ref = O.ddc_chain(O.lcg_bytes(6 * nout * 40, 12345), [(dec[i], taps[i]) for i in range(n)],
+                      freg=O.nco_freg(7.05e6), mix=True)
+    assert O.rel_err(y, ref[: y.size]) <= FIR_TOL + 1.0 / 8388607 / np.max(np.abs(ref))
