@@ -76,9 +76,12 @@ uint64_t perseus_amd_buffers_dropped(perseus_descr *descr);
 int      perseus_amd_source_running(perseus_descr *descr);
 
 /* DDC mode: the decimation plan chosen for the selected rate.  Returns the
- * number of stages (0 if the rate has no integer plan), fills decim[]/ntaps[]
+ * number of stages, fills decim[]/ntaps[]
  * (up to 4) and, if taps[i] is non-NULL, copies stage i's taps (ntaps[i] floats). */
 int perseus_amd_get_plan(perseus_descr *descr, int decim[4], int ntaps[4], float *taps[4]);
+/* interpolation factor L of each stage (1 = plain decimator; >1 = rational L/decim
+ * resampler, used by the 48k/95k/96k/192k plans) */
+int perseus_amd_get_plan_interp(perseus_descr *descr, int interp[4]);
 
 #ifdef __cplusplus
 }

@@ -55,7 +55,7 @@ extern "C" {
 
 #define PDDC_ADC_CLK_HZ        80000000.0   /* perseus-sdr.h:44 */
 #define PDDC_MAX_STAGES        4
-#define PDDC_MAX_TAPS          1024
+#define PDDC_MAX_TAPS          4096
 #define PDDC_FAST_MAX_TAPS     256          /* fused decimate-by-8 kernel      */
 #define PDDC_PACKED_BYTES      6
 #define PDDC_INPUT_GRANULE     8            /* process(): nsamples % 8 == 0    */
@@ -70,9 +70,13 @@ extern "C" {
 typedef struct pddc_pipeline pddc_pipeline;
 
 typedef struct {
-    int          decim;    /* decimation factor D >= 1                         */
+    int          decim;    /* decimation factor D (M of a rational L/M stage), >= 1 */
     int          ntaps;    /* 1 .. PDDC_MAX_TAPS                               */
     const float *taps;     /* h[0..ntaps-1], host memory, copied               */
+    int          interp;   /* 0 or 1: plain decimator.  L > 1: rational resampler
+                              y[m] = sum_j h[j*L + (m*D mod L)] * x[floor(m*D/L) - j]
+                              (upsample by L, filter, keep every D-th); used for the
+                              reference's non-integer rates  */
 } pddc_stage_desc;
 
 /* ---- library ------------------------------------------------------------ */

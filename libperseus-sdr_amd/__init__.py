@@ -47,7 +47,8 @@ def build(verbose: bool = False) -> None:
 
 
 class StageDesc(C.Structure):
-    _fields_ = [("decim", C.c_int), ("ntaps", C.c_int), ("taps", C.POINTER(C.c_float))]
+    _fields_ = [("decim", C.c_int), ("ntaps", C.c_int), ("taps", C.POINTER(C.c_float)),
+                ("interp", C.c_int)]
 
 
 _ddc = None
@@ -123,10 +124,11 @@ class Pipeline:
                  no_fast: bool = False, out_packed: bool = False):
         import numpy as np
         L = ddc_lib()
-        self._taps = [np.ascontiguousarray(h, dtype=np.float32) for _, h in stages]
+        self._taps = [np.ascontiguousarray(st[1], dtype=np.float32) for st in stages]
         arr = (StageDesc * len(stages))()
-        for i, (d, _) in enumerate(stages):
-            arr[i].decim = int(d)
+        for i, st in enumerate(stages):
+            arr[i].decim = int(st[0])
+            arr[i].interp = int(st[2]) if len(st) > 2 and st[2] else 0
             arr[i].ntaps = int(self._taps[i].size)
             arr[i].taps = self._taps[i].ctypes.data_as(C.POINTER(C.c_float))
         flags = (PDDC_F_MIX if mix else 0) | (PDDC_F_TAPS_FP16 if taps_fp16 else 0) | \
@@ -304,5 +306,6 @@ def sdr_lib() -> C.CDLL:
     L.perseus_amd_source_running.argtypes = [vp]
     L.perseus_amd_get_plan.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                        C.POINTER(C.POINTER(C.c_float))]
+    L.perseus_amd_get_plan_interp.argtypes = [vp, C.POINTER(C.c_int)]
     _sdr = L
     return L

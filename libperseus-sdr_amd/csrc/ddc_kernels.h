@@ -53,6 +53,12 @@ hipError_t launch_fir_generic(const float *in, const float *hist, int H, long lo
 hipError_t launch_hist_update(void *dst, const void *hist, int H, const void *batch, long long n,
                               int elem_bytes, hipStream_t s);
 
+/* rational resampler: outputs m0..m0+n_out-1 of y[m] = sum_j g[jL+ph] x[floor(mM/L)-j];
+ * `consumed` = absolute index of in[0]; x[-H..-1] from hist */
+hipError_t launch_resample(const float *in, const float *hist, int H, unsigned long long consumed,
+                           unsigned long long m0, long long n_out, int L, int M, const float *taps, int ntaps,
+                           float *out, hipStream_t s);
+
 /* float32 I/Q -> 24-bit packed (6 B/sample); in and out 16-byte aligned */
 hipError_t launch_pack24(const float *in, long long nsamples, void *out, hipStream_t s);
 

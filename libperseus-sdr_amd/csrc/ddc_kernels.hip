@@ -742,6 +742,56 @@ hipError_t launch_fir_generic(const float *in, const float *hist, int H, long lo
 }
 
 /* ======================================================================== */
+/* k_resample : rational L/M polyphase resampler on float2 (low rate)       */
+/* ======================================================================== */
+/* y[m] = sum_j g[j*L + ph] * x[n - j],  n = floor(m*M/L), ph = (m*M) mod L:
+ * upsample by L, filter with g (ntaps = K*L), keep every M-th sample.  Used
+ * for the reference's non-integer rates (48k/95k/96k/192k from 1-2 MS/s), so
+ * one output per thread with taps and samples straight from L2 is enough.    */
+__global__ __launch_bounds__(256) void k_resample(const float *__restrict__ in, const float *__restrict__ hist,
+                                                   int H, unsigned long long consumed, unsigned long long m0,
+                                                   long long n_out, int L, int M, const float *__restrict__ taps,
+                                                   int ntaps, float *__restrict__ out)
+{
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_out)
+        return;
+    const unsigned long long t = (m0 + (unsigned long long)q) * (unsigned long long)M;
+    const long long n = (long long)(t / (unsigned long long)L) - (long long)consumed;   /* index into the batch */
+    const int ph = (int)(t % (unsigned long long)L);
+    float ar0 = 0.0f, ai0 = 0.0f, ar1 = 0.0f, ai1 = 0.0f;
+    int j = 0;
+    for (int k = ph; k < ntaps; k += L, ++j) {
+        const long long xi = n - j;
+        float2 v = make_float2(0.0f, 0.0f);
+        if (xi >= 0)
+            v = *reinterpret_cast<const float2 *>(in + 2 * xi);
+        else if (xi >= -(long long)H)
+            v = *reinterpret_cast<const float2 *>(hist + 2 * (xi + H));
+        const float h = taps[k];
+        if (j & 1) {
+            ar1 = fmaf(h, v.x, ar1);
+            ai1 = fmaf(h, v.y, ai1);
+        } else {
+            ar0 = fmaf(h, v.x, ar0);
+            ai0 = fmaf(h, v.y, ai0);
+        }
+    }
+    *reinterpret_cast<float2 *>(out + 2 * q) = make_float2(ar0 + ar1, ai0 + ai1);
+}
+
+hipError_t launch_resample(const float *in, const float *hist, int H, unsigned long long consumed,
+                           unsigned long long m0, long long n_out, int L, int M, const float *taps, int ntaps,
+                           float *out, hipStream_t s)
+{
+    if (n_out <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_resample, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, in, hist, H, consumed,
+                       m0, n_out, L, M, taps, ntaps, out);
+    return hipGetLastError();
+}
+
+/* ======================================================================== */
 /* k_pack24 : float32 I/Q -> 24-bit packed wire format (the inverse of A2)  */
 /* ======================================================================== */
 /* code = clamp(rint(x * 8388607), -2^23, 2^23-1), ties to even, NaN -> -2^23;

@@ -47,6 +47,7 @@ static int fail(int code, const char *fmt, ...)
 /* ------------------------------------------------------------------------ */
 struct Stage {
     int decim = 1;
+    int interp = 1;               /* L of a rational L/decim stage (1 = plain decimator) */
     int ntaps = 0;
     std::vector<float> taps;      /* host copy (after optional fp16 rounding)  */
     float *d_taps = nullptr;      /* h[k] linear                                */
@@ -106,7 +107,7 @@ static void compute_lo_steps(pddc_pipeline *p)
 
 static bool stage_fused_capable(const Stage &s)
 {
-    if (s.decim != 8 || s.ntaps > PDDC_FAST_MAX_TAPS)
+    if (s.decim != 8 || s.interp != 1 || s.ntaps > PDDC_FAST_MAX_TAPS)
         return false;
     return true;
 }
@@ -297,6 +298,8 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
     for (int i = 0; i < nstages; ++i) {
         if (stages[i].decim < 1 || stages[i].decim > 4096)
             return fail(PDDC_EINVAL, "stage %d: bad decimation %d", i, stages[i].decim);
+        if (stages[i].interp < 0 || stages[i].interp > 256)
+            return fail(PDDC_EINVAL, "stage %d: bad interpolation %d", i, stages[i].interp);
         if (stages[i].ntaps < 1 || stages[i].ntaps > PDDC_MAX_TAPS || !stages[i].taps)
             return fail(PDDC_EINVAL, "stage %d: ntaps must be 1..%d", i, PDDC_MAX_TAPS);
     }
@@ -325,6 +328,7 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
     for (int i = 0; i < nstages; ++i) {
         Stage &s = p->st[i];
         s.decim = stages[i].decim;
+        s.interp = stages[i].interp > 1 ? stages[i].interp : 1;
         s.ntaps = stages[i].ntaps;
         s.taps.assign(stages[i].taps, stages[i].taps + s.ntaps);
         if (flags & PDDC_F_TAPS_FP16)
@@ -337,6 +341,8 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
         /* history: enough for ntaps-1, rounded to the 8-sample granule; the
          * fused kernel wants exactly 8*ntb */
         s.hist = s.ntb ? 8 * s.ntb : ((s.ntaps - 1 + 7) / 8) * 8;
+        if (s.interp > 1)           /* at most ceil(ntaps/L) inputs per output */
+            s.hist = (((s.ntaps + s.interp - 1) / s.interp) + 7) / 8 * 8;
         if (s.hist == 0)
             s.hist = 8;
     }
@@ -436,10 +442,11 @@ int pddc_pipeline_total_decim(const pddc_pipeline *p)
 {
     if (!p)
         return fail(PDDC_EINVAL, "null pipeline");
-    long long d = 1;
+    /* rounded overall rate ratio in/out (exact for integer plans) */
+    double d = 1.0;
     for (int i = 0; i < p->nstages; ++i)
-        d *= p->st[i].decim;
-    return (int)d;
+        d *= (double)p->st[i].decim / (double)p->st[i].interp;
+    return (int)(d + 0.5);
 }
 
 int pddc_pipeline_set_taps(pddc_pipeline *p, int stage, const float *taps, int ntaps)
@@ -450,7 +457,8 @@ int pddc_pipeline_set_taps(pddc_pipeline *p, int stage, const float *taps, int n
         return fail(PDDC_EINVAL, "stage %d out of range", stage);
     Stage &s = p->st[stage];
     /* the history length is fixed at create time; a new tap set must fit it */
-    if (ntaps < 1 || ntaps - 1 > s.hist || (s.ntb && ntaps > 8 * s.ntb))
+    const int need_hist = s.interp > 1 ? (ntaps + s.interp - 1) / s.interp : ntaps - 1;
+    if (ntaps < 1 || need_hist > s.hist || (s.ntb && ntaps > 8 * s.ntb))
         return fail(PDDC_EINVAL, "ntaps %d does not fit the stage geometry (history %d)", ntaps, s.hist);
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipDeviceSynchronize());
@@ -482,11 +490,22 @@ int pddc_pipeline_set_taps(pddc_pipeline *p, int stage, const float *taps, int n
 
 /* outputs produced by a stage that has consumed `consumed` inputs and now
  * receives n more: outputs m with consumed <= m*D < consumed+n              */
-static void stage_outputs(unsigned long long consumed, size_t n, int D, size_t *first_off, size_t *n_out)
+static void stage_outputs(unsigned long long consumed, size_t n, int D, int L, size_t *first_off,
+                          unsigned long long *m0, size_t *n_out)
 {
-    const unsigned long long m0 = (consumed + (unsigned long long)D - 1) / (unsigned long long)D;
-    const unsigned long long off = m0 * (unsigned long long)D - consumed;   /* 0..D-1 */
+    if (L > 1) {
+        /* rational: output m needs input floor(m*D/L); outputs with consumed <= that < consumed+n */
+        const unsigned long long a = (consumed * (unsigned long long)L + (unsigned long long)D - 1) / (unsigned long long)D;
+        const unsigned long long b = ((consumed + n) * (unsigned long long)L + (unsigned long long)D - 1) / (unsigned long long)D;
+        *first_off = 0;
+        *m0 = a;
+        *n_out = (size_t)(b - a);
+        return;
+    }
+    const unsigned long long mm = (consumed + (unsigned long long)D - 1) / (unsigned long long)D;
+    const unsigned long long off = mm * (unsigned long long)D - consumed;   /* 0..D-1 */
     *first_off = (size_t)off;
+    *m0 = mm;
     *n_out = n > off ? (size_t)((n - off - 1) / (size_t)D + 1) : 0;
 }
 
@@ -495,7 +514,7 @@ size_t pddc_pipeline_max_output(const pddc_pipeline *p, size_t n)
     if (!p)
         return 0;
     for (int i = 0; i < p->nstages; ++i)
-        n = (n + (size_t)p->st[i].decim - 1) / (size_t)p->st[i].decim;
+        n = (n * (size_t)p->st[i].interp + (size_t)p->st[i].decim - 1) / (size_t)p->st[i].decim + (p->st[i].interp > 1 ? 1 : 0);
     return n;
 }
 
@@ -553,9 +572,10 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
 
     /* plan: outputs per stage */
     size_t n_in[PDDC_MAX_STAGES + 1], off[PDDC_MAX_STAGES];
+    unsigned long long m0[PDDC_MAX_STAGES];
     n_in[0] = nsamples;
     for (int i = 0; i < p->nstages; ++i)
-        stage_outputs(p->st[i].consumed, n_in[i], p->st[i].decim, &off[i], &n_in[i + 1]);
+        stage_outputs(p->st[i].consumed, n_in[i], p->st[i].decim, p->st[i].interp, &off[i], &m0[i], &n_in[i + 1]);
     const size_t n_final = n_in[p->nstages];
     if (n_final > out_capacity)
         return fail(PDDC_ECAPACITY, "output capacity %zu < %zu", out_capacity, n_final);
@@ -621,6 +641,11 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                 fill_fir8_args(p, a);
                 HIP_TRY(launch_fir8(st.ntb, p->R, IN_F32C, false, a, s));
                 hist_done = a.hist_out != nullptr;
+            } else if (st.interp > 1) {
+                if (n_in[i + 1] > 0)
+                    HIP_TRY(launch_resample(static_cast<const float *>(x), static_cast<const float *>(h_in), st.hist,
+                                            st.consumed, m0[i], (long long)n_in[i + 1], st.interp, st.decim,
+                                            st.d_taps, st.ntaps, dst, s));
             } else if (n_in[i + 1] > 0) {
                 HIP_TRY(launch_fir_generic(static_cast<const float *>(x), static_cast<const float *>(h_in),
                                            st.hist, (long long)off[i], (long long)n_in[i + 1], st.decim,

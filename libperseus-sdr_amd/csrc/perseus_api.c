@@ -58,6 +58,7 @@ static const int k_rates[] = { 48000, 95000, 96000, 125000, 192000, 250000,
 
 typedef struct {
     int   nstages;
+    int   interp[4];            /* L of a rational L/decim stage, 1 otherwise */
     int   decim[4];
     int   ntaps[4];
     float *taps[4];
@@ -185,44 +186,58 @@ static void plan_free(ddc_plan *p)
     p->nstages = 0;
 }
 
-/* integer plans from the 80 MS/s ADC rate; 0 stages = no plan (non-integer ratio) */
+/* Plans from the 80 MS/s ADC rate to the ten rates of the reference's FPGA
+ * images.  Integer ratios are decimator cascades; the four non-integer rates
+ * end in a rational L/M polyphase resampler fed at 200/400 kS/s. */
 static int plan_build(ddc_plan *p, int rate)
 {
-    static const struct { int rate, n, d[3]; } tab[] = {
-        { 2000000, 2, { 8, 5, 0 } },  { 1600000, 2, { 10, 5, 0 } }, { 1000000, 2, { 8, 10, 0 } },
-        { 500000, 3, { 8, 4, 5 } },   { 250000, 3, { 8, 8, 5 } },   { 125000, 3, { 8, 8, 10 } },
+    static const struct { int rate, n, d[4], l[4]; } tab[] = {
+        { 2000000, 2, { 8, 5, 0, 0 },   { 1, 1, 0, 0 } },  { 1600000, 2, { 10, 5, 0, 0 },  { 1, 1, 0, 0 } },
+        { 1000000, 2, { 8, 10, 0, 0 },  { 1, 1, 0, 0 } },  { 500000, 3, { 8, 4, 5, 0 },    { 1, 1, 1, 0 } },
+        { 250000, 3, { 8, 8, 5, 0 },    { 1, 1, 1, 0 } },  { 125000, 3, { 8, 8, 10, 0 },   { 1, 1, 1, 0 } },
+        { 192000, 4, { 8, 5, 5, 25 },   { 1, 1, 1, 12 } }, { 96000, 4, { 8, 10, 5, 25 },   { 1, 1, 1, 12 } },
+        { 48000, 4, { 8, 10, 5, 25 },   { 1, 1, 1, 6 } },  { 95000, 4, { 8, 10, 5, 40 },   { 1, 1, 1, 19 } },
     };
     plan_free(p);
     for (size_t t = 0; t < sizeof(tab) / sizeof(tab[0]); t++) {
         if (tab[t].rate != rate)
             continue;
         double fs = PERSEUS_ADC_CLK_FREQ;
-        const double fpass = 0.4 * rate, atten = 90.0;
+        const double fpass = 0.4 * rate;
         for (int i = 0; i < tab[t].n; i++) {
-            const int D = tab[t].d[i];
-            const double fs_out = fs / D;
+            const int D = tab[t].d[i], L = tab[t].l[i];
+            const double fs_out = fs * L / D;
+            const double fproto = fs * L;              /* rate the prototype filter runs at */
+            const int last = (i == tab[t].n - 1);
+            const double atten = L > 1 ? 80.0 : 90.0;
             /* protect +-fpass of the FINAL band: stop-band starts where aliases
-             * would fold onto it; the last stage uses the output Nyquist */
-            double fstop = (i == tab[t].n - 1) ? 0.5 * fs_out : fs_out - fpass;
-            double dw = 2.0 * M_PI * (fstop - fpass) / fs;
+             * would fold onto it; the last stage may alias into its own transition band */
+            double fstop = last ? 0.6 * rate : fs_out - fpass;
+            double dw = 2.0 * M_PI * (fstop - fpass) / fproto;
             int n = (int)ceil((atten - 8.0) / (2.285 * dw)) + 1;
             if (n < 8)
                 n = 8;
-            if (i == 0 && D == 8) {             /* fused kernel: whole tap blocks of 8 */
+            if (L > 1)
+                n = (n + L - 1) / L * L;            /* whole polyphase branches */
+            if (i == 0 && D == 8 && L == 1) {       /* fused kernel: whole tap blocks of 8 */
                 n = (n + 7) / 8 * 8;
                 if (n > PDDC_FAST_MAX_TAPS)
                     n = PDDC_FAST_MAX_TAPS;
             }
             if (n > PDDC_MAX_TAPS)
-                n = PDDC_MAX_TAPS;
+                n = PDDC_MAX_TAPS / L * L;
             p->decim[i] = D;
+            p->interp[i] = L;
             p->ntaps[i] = n;
             p->taps[i] = (float *)malloc(sizeof(float) * (size_t)n);
             if (!p->taps[i]) {
                 plan_free(p);
                 return 0;
             }
-            kaiser_lowpass(p->taps[i], n, 0.5 * (fpass + fstop) / fs, atten);
+            kaiser_lowpass(p->taps[i], n, 0.5 * (fpass + fstop) / fproto, atten);
+            if (L > 1)                               /* zero stuffing divides the gain by L */
+                for (int k = 0; k < n; k++)
+                    p->taps[i][k] *= (float)L;
             fs = fs_out;
         }
         p->nstages = tab[t].n;
@@ -756,7 +771,7 @@ int perseus_start_async_input(perseus_descr *d, uint32_t buffersize, perseus_inp
         if (d->plan.nstages == 0) {
             free_stream(d);
             return errorset(PERSEUS_FPGANOTCFGD,
-                            "no integer decimation plan from 80 MS/s to %d S/s (rational resampler not built)",
+                            "no decimation plan from 80 MS/s to %d S/s",
                             d->sample_rate);
         }
         pddc_stage_desc sd[4];
@@ -764,6 +779,7 @@ int perseus_start_async_input(perseus_descr *d, uint32_t buffersize, perseus_inp
             sd[i].decim = d->plan.decim[i];
             sd[i].ntaps = d->plan.ntaps[i];
             sd[i].taps = d->plan.taps[i];
+            sd[i].interp = d->plan.interp[i];
         }
         int ndev = pddc_device_count();
         if (ndev <= 0) {
@@ -879,6 +895,15 @@ int perseus_amd_source_running(perseus_descr *d)
         return 1;
     return d->cfg.mode != PERSEUS_AMD_MODE_WIRE && d->fifo_len >= d->buffersize &&
            !(d->cfg.max_buffers && d->delivered + d->dropped >= d->cfg.max_buffers);
+}
+
+int perseus_amd_get_plan_interp(perseus_descr *d, int interp[4])
+{
+    if (d == NULL || interp == NULL)
+        return errorset(PERSEUS_NULLDESCR, "null descriptor");
+    for (int i = 0; i < d->plan.nstages; i++)
+        interp[i] = d->plan.interp[i];
+    return errornone(d->plan.nstages);
 }
 
 int perseus_amd_get_plan(perseus_descr *d, int decim[4], int ntaps[4], float *taps[4])

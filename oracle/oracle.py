@@ -65,7 +65,9 @@ def lib() -> C.CDLL:
         L.orc_fir_decim_f64.restype = C.c_size_t
         L.orc_ddc_chain.argtypes = [u8p, C.c_size_t, C.c_uint32, C.c_int, C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(C.c_int),
-                                    C.POINTER(f32p), f32p, C.c_size_t]
+                                    C.POINTER(f32p), C.POINTER(C.c_int), f32p, C.c_size_t]
+        L.orc_resample_f64.argtypes = [f64p, C.c_size_t, f32p, C.c_int, C.c_int, C.c_int, f64p]
+        L.orc_resample_f64.restype = C.c_size_t
         L.orc_ddc_chain.restype = C.c_size_t
         L.orc_stage1_f32.argtypes = [u8p, C.c_size_t, f32p, C.c_int, C.c_int, f32p, C.c_int]
         L.orc_stage1_f32.restype = C.c_size_t
@@ -188,23 +190,36 @@ def fir_decim(x_iq: np.ndarray, taps: np.ndarray, D: int) -> np.ndarray:
 
 
 def ddc_chain(packed: np.ndarray, stages, freg: int = 0, mix: bool = False) -> np.ndarray:
-    """stages: sequence of (D, taps float32 array). Returns float32 I/Q."""
+    """stages: sequence of (D, taps) or (D, taps, L) -- L > 1 makes the stage a
+    rational L/D resampler.  Returns float32 I/Q."""
     b = np.ascontiguousarray(packed, dtype=np.uint8)
     ns = b.size // 6
-    ds = [int(d) for d, _ in stages]
-    hs = [np.ascontiguousarray(h, dtype=np.float32) for _, h in stages]
+    ds = [int(st[0]) for st in stages]
+    ls = [int(st[2]) if len(st) > 2 and st[2] and st[2] > 1 else 1 for st in stages]
+    hs = [np.ascontiguousarray(st[1], dtype=np.float32) for st in stages]
     n = ns
-    for d in ds:
-        n = (n + d - 1) // d
+    for d, l in zip(ds, ls):
+        n = (n * l + d - 1) // d
     out = np.empty(2 * max(n, 1), dtype=np.float32)
-    Darr = (C.c_int * max(len(ds), 1))(*ds)
-    Narr = (C.c_int * max(len(ds), 1))(*[h.size for h in hs])
-    Tarr = (C.POINTER(C.c_float) * max(len(ds), 1))(*[_p(h, C.c_float) for h in hs])
+    k = max(len(ds), 1)
+    Darr = (C.c_int * k)(*ds)
+    Larr = (C.c_int * k)(*ls)
+    Narr = (C.c_int * k)(*[h.size for h in hs])
+    Tarr = (C.POINTER(C.c_float) * k)(*[_p(h, C.c_float) for h in hs])
     r = lib().orc_ddc_chain(_p(b, C.c_uint8), ns, freg & 0xFFFFFFFF, int(bool(mix)),
-                            len(ds), Darr, Narr, Tarr, _p(out, C.c_float), max(n, 1))
+                            len(ds), Darr, Narr, Tarr, Larr, _p(out, C.c_float), max(n, 1))
     if r == C.c_size_t(-1).value:
         raise RuntimeError("orc_ddc_chain failed")
     return out[:2 * r]
+
+
+def resample(x_iq: np.ndarray, taps: np.ndarray, L: int, M: int) -> np.ndarray:
+    x = np.ascontiguousarray(x_iq, dtype=np.float64)
+    h = np.ascontiguousarray(taps, dtype=np.float32)
+    ns = x.size // 2
+    out = np.empty(2 * ((ns * L + M - 1) // M), dtype=np.float64)
+    n = lib().orc_resample_f64(_p(x, C.c_double), ns, _p(h, C.c_float), h.size, L, M, _p(out, C.c_double))
+    return out[:2 * n]
 
 
 def fir_decim_numpy(x_iq: np.ndarray, taps: np.ndarray, D: int) -> np.ndarray:

@@ -185,9 +185,32 @@ size_t orc_fir_decim_f64(const double *x, size_t ns, const float *taps,
     return nout;
 }
 
+size_t orc_resample_f64(const double *x, size_t ns, const float *taps, int ntaps, int L, int M, double *y)
+{
+    if (L <= 0 || M <= 0 || ntaps <= 0)
+        return 0;
+    const size_t nout = (ns * (size_t)L + (size_t)M - 1) / (size_t)M;
+#pragma omp parallel for schedule(static)
+    for (long long m = 0; m < (long long)nout; m++) {
+        const unsigned long long t = (unsigned long long)m * (unsigned long long)M;
+        const long long n = (long long)(t / (unsigned long long)L);
+        const int ph = (int)(t % (unsigned long long)L);
+        double ar = 0.0, ai = 0.0;
+        long long j = 0;
+        for (int k = ph; k < ntaps && n - j >= 0; k += L, j++) {
+            const double h = (double)taps[k];
+            ar += h * x[2 * (n - j)];
+            ai += h * x[2 * (n - j) + 1];
+        }
+        y[2 * m] = ar;
+        y[2 * m + 1] = ai;
+    }
+    return nout;
+}
+
 size_t orc_ddc_chain(const uint8_t *packed, size_t ns, uint32_t freg,
                      int mix_enable, int nstages, const int *D,
-                     const int *ntaps, const float *const *taps,
+                     const int *ntaps, const float *const *taps, const int *interp,
                      float *out_iq, size_t out_capacity)
 {
     if (nstages < 0 || nstages > 8)
@@ -209,13 +232,17 @@ size_t orc_ddc_chain(const uint8_t *packed, size_t ns, uint32_t freg,
     free(xf);
     size_t n = ns;
     for (int s = 0; s < nstages; s++) {
-        size_t nout = (n + (size_t)D[s] - 1) / (size_t)D[s];
+        const int L = (interp && interp[s] > 1) ? interp[s] : 1;
+        size_t nout = (n * (size_t)L + (size_t)D[s] - 1) / (size_t)D[s];
         double *nxt = (double *)malloc(sizeof(double) * 2 * (nout ? nout : 1));
         if (!nxt) {
             free(cur);
             return (size_t)-1;
         }
-        orc_fir_decim_f64(cur, n, taps[s], ntaps[s], D[s], nxt);
+        if (L > 1)
+            orc_resample_f64(cur, n, taps[s], ntaps[s], L, D[s], nxt);
+        else
+            orc_fir_decim_f64(cur, n, taps[s], ntaps[s], D[s], nxt);
         free(cur);
         cur = nxt;
         n = nout;

@@ -68,13 +68,21 @@ void orc_nco_mix_f64(const float *x_iq, size_t nsamples, uint64_t n0,
 size_t orc_fir_decim_f64(const double *x_iq, size_t nsamples,
                          const float *taps, int ntaps, int D, double *y_iq);
 
+/* rational L/M resampler (authored): upsample by L (zero
+ * stuffing), filter with h, keep every M-th sample:
+ *   y[m] = sum_j h[j*L + (m*M mod L)] * x[floor(m*M/L) - j],  m = 0..ceil(n*L/M)-1 */
+size_t orc_resample_f64(const double *x_iq, size_t nsamples, const float *taps, int ntaps,
+                        int L, int M, double *y_iq);
+
 /* whole chain: unpack -> (mix if mix_enable) -> nstages FIR decimators.
+ * interp may be NULL (all plain decimators); interp[s] > 1 makes stage s a
+ * rational interp[s]/D[s] resampler.
  * All intermediates double; result cast to float.  Returns outputs written
  * (capacity in complex samples), or (size_t)-1 on bad arguments. */
 size_t orc_ddc_chain(const uint8_t *packed, size_t nsamples,
                      uint32_t freg, int mix_enable,
                      int nstages, const int *D, const int *ntaps,
-                     const float *const *taps,
+                     const float *const *taps, const int *interp,
                      float *out_iq, size_t out_capacity);
 
 /* ---- CPU baseline fast path (float accumulate, OpenMP over chunks) ------

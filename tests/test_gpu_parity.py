@@ -407,3 +407,62 @@ def test_perseus_api_fpga_emulation_mode(pkg, dev, O, monkeypatch):
     ref = O.ddc_chain(O.lcg_bytes(6 * nout * 40, 12345), [(dec[i], taps[i]) for i in range(n)],
                       freg=O.nco_freg(7.05e6), mix=True)
     assert O.rel_err(y, ref[: y.size]) <= FIR_TOL + 1.0 / 8388607 / np.max(np.abs(ref))
+
+
+# ------------------------------------- N3: rational resampler / non-integer rates
+@pytest.mark.parametrize("L,M,K", [(12, 25, 40), (19, 40, 30), (6, 25, 33), (3, 2, 16)])
+def test_rational_resampler_stage_vs_oracle(pkg, dev, O, L, M, K):
+    rng = np.random.default_rng(L * 100 + M)
+    h1 = load_taps("c320_s1_d8_32")
+    g = (rng.standard_normal(K * L) / K).astype(np.float32)
+    ns = 8 * 2600
+    packed = O.lcg_bytes(6 * ns, 606)
+    stages = [(8, h1), (M, g, L)]
+    ref = O.ddc_chain(packed, stages)
+    pipe = pkg.Pipeline(stages)
+    cuts = [0, 8 * 700, 8 * 701, 8 * 1900, ns]                  # uneven pushes: phase carry
+    y = np.concatenate([pipe.process(to_dev(packed[6 * a:6 * b], dev)).cpu().numpy().reshape(-1)
+                        for a, b in zip(cuts[:-1], cuts[1:])])
+    assert y.size == ref.size
+    assert O.rel_err(y, ref) <= FIR_TOL
+    pipe.close()
+
+
+@pytest.mark.parametrize("rate", [96000, 95000])
+def test_perseus_api_non_integer_rate(pkg, dev, O, monkeypatch, rate):
+    import ctypes as C
+    import time
+    monkeypatch.setenv("PERSEUS_AMD_PACE", "0")
+    monkeypatch.delenv("PERSEUS_AMD_DEVICES", raising=False)
+    L = pkg.sdr_lib()
+    L.perseus_set_debug(0)
+    assert L.perseus_init() == 1
+    d = L.perseus_open(0)
+    L.perseus_firmware_download(d, None)
+    assert L.perseus_set_sampling_rate(d, rate) == 0
+    assert L.perseus_set_ddc_center_freq(d, C.c_double(7.0e6), 1) == 0
+    cfg = pkg.AmdConfig()
+    L.perseus_amd_get_config(d, C.byref(cfg))
+    cfg.mode, cfg.pace, cfg.batch_samples, cfg.max_buffers = 1, 0, 8 * 100000, 1
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    dec, nt, it = (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)()
+    n = L.perseus_amd_get_plan(d, dec, nt, None)
+    L.perseus_amd_get_plan_interp(d, it)
+    taps = [np.zeros(nt[i], np.float32) for i in range(n)]
+    arr = (C.POINTER(C.c_float) * 4)(*([t.ctypes.data_as(C.POINTER(C.c_float)) for t in taps] + [None] * (4 - n)))
+    L.perseus_amd_get_plan(d, dec, nt, arr)
+    got = []
+    cb = pkg.PERSEUS_CALLBACK(lambda b, nbytes, x: got.append(C.string_at(b, nbytes)) or 0)
+    assert L.perseus_start_async_input(d, 6144, cb, None) == 0, L.perseus_errorstr()
+    t0 = time.time()
+    while L.perseus_amd_source_running(d) and time.time() - t0 < 60:
+        time.sleep(0.005)
+    assert L.perseus_stop_async_input(d) == 0
+    L.perseus_exit()
+    assert len(got) == 1
+    y = np.frombuffer(got[0], dtype=np.float32)                 # 768 complex outputs
+    need = int(np.ceil(768 * 80e6 / rate)) + 8
+    need += (-need) % 8
+    stages = [(dec[i], taps[i], it[i]) for i in range(n)]
+    ref = O.ddc_chain(O.lcg_bytes(6 * need, 12345), stages, freg=O.nco_freg(7.0e6), mix=True)
+    assert O.rel_err(y, ref[: y.size]) <= FIR_TOL

@@ -265,9 +265,6 @@ def test_ddc_mode_without_gpu_fails_loudly(L, pkg):
     cb = pkg.PERSEUS_CALLBACK(lambda b, n, x: 0)
     assert L.perseus_start_async_input(d, 6144, cb, None) == -10   # PERSEUS_DEVNOTFOUND
     assert b"no CPU fallback" in L.perseus_errorstr()
-    # non-integer rate: no plan
-    L.perseus_set_sampling_rate(d, 96000)
-    assert L.perseus_start_async_input(d, 6144, cb, None) == E["FPGANOTCFGD"]
 
 
 def test_plan_export(L, pkg):
@@ -282,6 +279,25 @@ def test_plan_export(L, pkg):
     for b in bufs:
         assert abs(float(b.astype(np.float64).sum()) - 1.0) < 1e-5   # unity DC gain
         assert np.allclose(b, b[::-1], atol=1e-9)                     # linear phase
+
+
+def test_every_reference_rate_has_an_exact_plan(L, O):
+    """All ten rates of the reference's FPGA images: integer
+    cascades, and rational L/M tails for 48k/95k/96k/192k."""
+    d = bring_up(L)
+    for rate in O.REFERENCE_RATES:
+        assert L.perseus_set_sampling_rate(d, rate) == 0
+        dec, nt, it = (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)()
+        n = L.perseus_amd_get_plan(d, dec, nt, None)
+        assert 2 <= n <= 4 and L.perseus_amd_get_plan_interp(d, it) == n
+        num, den = 80000000, 1
+        for i in range(n):
+            num *= max(it[i], 1)
+            den *= dec[i]
+        assert num % den == 0 and num // den == rate
+        assert all(0 < nt[i] <= 4096 for i in range(n))
+        if rate in (48000, 95000, 96000, 192000):
+            assert it[n - 1] > 1 and nt[n - 1] % it[n - 1] == 0
 
 
 def test_plumbing_client_binary(pkg, tmp_path):
