@@ -15,11 +15,19 @@
  *   -f hz     tuning frequency (7000000)               -a           no attenuator/ADC test calls
  *   -t sec    run time (10)                            -m count     stop after count buffers
  *   -o file   output ("perseusdata", "-" = stdout)     -p           float32 output (default int32)
- *   -d level  debug level (3)
+ *   -d level  debug level (3)                          -F fifo      control FIFO (see below)
+ *
+ * -F creates a named pipe and a control thread, as the reference example's fifo.c
+ * does: each line is "<MHz as float>", "<Hz as integer>", "att <0..3>" or "quit";
+ * tuning and attenuator calls are made WHILE streaming (examples/fifo.c:23-60) and
+ * in DDC mode a retune takes effect at the next GPU batch boundary.
  */
 #include "../../include/perseus-amd-ext.h"
 
+#include <fcntl.h>
+#include <pthread.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 typedef struct {
@@ -76,14 +84,44 @@ static int on_buffer_float(void *buf, int buf_size, void *extra)
     return 0;
 }
 
+static perseus_descr *g_descr;
+static volatile int g_quit;
+
+static void *fifo_thread(void *arg)
+{
+    const char *path = (const char *)arg;
+    char line[128];
+    while (!g_quit) {
+        FILE *f = fopen(path, "r");              /* blocks until a writer shows up */
+        if (!f)
+            break;
+        while (!g_quit && fgets(line, sizeof(line), f)) {
+            int n;
+            if (strncmp(line, "quit", 4) == 0) {
+                g_quit = 1;
+            } else if (sscanf(line, "att %d", &n) == 1) {
+                perseus_set_attenuator_n(g_descr, n);
+            } else if (strchr(line, '.')) {
+                perseus_set_ddc_center_freq(g_descr, atof(line) * 1e6, 1);
+            } else if (atol(line) > 0) {
+                perseus_set_ddc_center_freq(g_descr, (double)atol(line), 1);
+            }
+        }
+        fclose(f);
+    }
+    return NULL;
+}
+
 int main(int argc, char **argv)
 {
     int rate = 95000, nb = 6, bs = 1024, dbg = 3, seconds = 10, as_float = 0, test_fe = 1;
     long max_buffers = 0;
     double freq = 7000000.0;
     const char *outname = "perseusdata";
+    const char *fifo = NULL;
+    pthread_t fifo_tid;
     int c;
-    while ((c = getopt(argc, argv, "s:n:b:d:t:o:f:m:pah")) != -1) {
+    while ((c = getopt(argc, argv, "s:n:b:d:t:o:f:m:F:pah")) != -1) {
         switch (c) {
         case 's': rate = atoi(optarg); break;
         case 'n': nb = atoi(optarg); break;
@@ -93,6 +131,7 @@ int main(int argc, char **argv)
         case 'o': outname = optarg; break;
         case 'f': freq = atof(optarg); break;
         case 'm': max_buffers = atol(optarg); break;
+        case 'F': fifo = optarg; break;
         case 'p': as_float = 1; break;
         case 'a': test_fe = 0; break;
         default:
@@ -166,14 +205,28 @@ int main(int argc, char **argv)
         perseus_exit();
         return 1;
     }
+    g_descr = d;
+    if (fifo) {
+        mkfifo(fifo, 0600);
+        pthread_create(&fifo_tid, NULL, fifo_thread, (void *)fifo);
+    }
     fprintf(stderr, "Collecting input samples... \n");
     for (int t = 0; t < seconds * 100; t++) {
-        if (!perseus_amd_source_running(d))
+        if (!perseus_amd_source_running(d) || g_quit)
             break;
         usleep(10000);
     }
     fprintf(stderr, "done\n");
     perseus_stop_async_input(d);
+    if (fifo) {
+        g_quit = 1;
+        int k = open(fifo, O_WRONLY | O_NONBLOCK);  /* unblock a reader waiting in fopen() */
+        if (k >= 0)
+            close(k);
+        pthread_join(fifo_tid, NULL);
+        unlink(fifo);
+    }
+    fprintf(stderr, "final NCO word: %u\n", perseus_amd_get_freg(d));
     if (s.out && s.out != stdout)
         fclose(s.out);
     fprintf(stderr, "%llu buffers, %llu samples\n", s.buffers, s.samples);

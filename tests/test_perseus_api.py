@@ -313,3 +313,26 @@ def test_plumbing_client_binary(pkg, tmp_path):
     f = np.fromfile(out, dtype=np.float32)
     exp = np.fromfile(os.path.join(GOLD, "lcg_6144.f32.out"), dtype=np.float32)
     assert f.size == 5 * 2048 and np.array_equal(f[:2048].view(np.uint32), exp.view(np.uint32))
+
+
+def test_fifo_control_thread_retunes_while_streaming(pkg, tmp_path):
+    """examples/fifo.c behaviour: tuning commands arrive on a named pipe while
+    the stream runs; the last word wins and 'quit' ends the run."""
+    exe = os.path.join(os.path.dirname(pkg.SDR_LIB), "perseus_plumbing")
+    fifo = str(tmp_path / "ctl")
+    env = dict(os.environ, PERSEUS_AMD_PACE="1")
+    p = subprocess.Popen([exe, "-s", "250000", "-o", "none", "-t", "20", "-d", "0", "-F", fifo, "-a"],
+                         env=env, stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while not os.path.exists(fifo) and time.time() - t0 < 10:
+        time.sleep(0.01)
+    with open(fifo, "w") as f:
+        f.write("7.05\n")
+        f.write("att 2\n")
+        f.write("7100000\n")
+        f.flush()
+        time.sleep(0.2)
+        f.write("quit\n")
+    _, err = p.communicate(timeout=30)
+    assert p.returncode == 0, err
+    assert "final NCO word: 381178347" in err          # 7.1 MHz, perseus-sdr.c:584
