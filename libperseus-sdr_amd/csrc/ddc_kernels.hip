@@ -457,8 +457,15 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
                 const int qs = q ^ ((q >> 3) & 7);
                 /* streaming (nt) store: measured 0.349 vs 0.371 ms for this 6:1
                  * read/write mix (tools/ubench/stream_mix.hip) */
-                __builtin_nontemporal_store(*reinterpret_cast<const f32x4 *>(ot + 4 * qs),
-                                            reinterpret_cast<f32x4 *>(p.out + 2 * (tile_o0 + 2LL * q)));
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(ot + 4 * qs);
+                float *dstp = p.out + 2 * (tile_o0 + 2LL * q);
+                /* Issued from inline asm on purpose: hipcc then does not count the store
+                 * in its vmcnt bookkeeping, so the waits it places for the prefetched
+                 * loads stay COUNTED (vmcnt(N)) instead of collapsing to vmcnt(0) as they
+                 * do whenever loads and stores are both pending.  Memory operations
+                 * retire in issue order on gfx9, so a counted wait computed without
+                 * these stores is only ever stronger than needed, never weaker.        */
+                asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dstp), "v"(v) : "memory");
             }
         } else {
 #pragma unroll
