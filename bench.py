@@ -37,10 +37,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--settle-ms", type=float, default=40.0,
-                    help="untimed pre-conditioning before the W warmup steps: the chip's power\n"
-                         "management overshoots for the first ~15 launches after idle (kernel trace in\n"
-                         "profiles/), which is a transient, not the path's throughput")
+    ap.add_argument("--settle-ms", type=float, default=250.0,
+                    help="untimed back-to-back launches before the W warmup steps: after idle the\n"
+                         "chip's power management first boosts, then overshoots downwards for some tens\n"
+                         "of ms (kernel trace in profiles/) before it settles; the timed region should see\n"
+                         "the settled, sustained-load clocks")
     ap.add_argument("--log2n", type=int, default=28, help="log2 complex samples per GPU per step")
     ap.add_argument("--workload", default="d8_127",
                     choices=["d8_127", "d8_255", "c320", "unpack"],

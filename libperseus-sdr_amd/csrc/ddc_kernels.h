@@ -26,7 +26,6 @@ struct Fir8Args {
     uint32_t    freg;        /* NCO tuning word                                */
     float       lo_c[8];     /* cos/sin of step e*freg, e=0..7 (host, double)  */
     float       lo_s[8];
-    int         ablate;      /* development only: 1 skip global loads, 2 skip FIR, 4 skip stores */
 };
 
 /* tile geometry of k_fir8<NTB,R>: inputs per block tile */

@@ -283,7 +283,7 @@ size_t fir8_lds_bytes(int ntb, int R)
 
 /* one 8-sample group: global words -> (mixed) planar floats */
 template <int INFMT, bool MIX, int NW>
-__device__ __forceinline__ void group_to_float(const uint4 (&raw)[NW], float (&xi)[8], float (&xq)[8],
+__device__ __forceinline__ void group_to_float(const u32x4 (&raw)[NW], float (&xi)[8], float (&xq)[8],
                                                unsigned long long nabs, const Fir8Args &p)
 {
     if (INFMT == IN_PACKED24) {
@@ -299,7 +299,7 @@ __device__ __forceinline__ void group_to_float(const uint4 (&raw)[NW], float (&x
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint4 f = raw[k < NW ? k : 0];
+            const u32x4 f = raw[k < NW ? k : 0];
             xi[2 * k]     = __uint_as_float(f.x);
             xq[2 * k]     = __uint_as_float(f.y);
             xi[2 * k + 1] = __uint_as_float(f.z);
@@ -392,28 +392,42 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         const long long s_abs = (long long)t0 * G::TI + 8LL * tid - 8 * NTB;
         const uint8_t *src = (s_abs < 0) ? static_cast<const uint8_t *>(p.hist) + (s_abs + 8 * NTB) * ES
                                          : static_cast<const uint8_t *>(p.in) + s_abs * ES;
-        uint4 hraw[NW];
+        u32x4 hraw[NW];
 #pragma unroll
         for (int k = 0; k < NW; ++k)
-            hraw[k] = (s_abs < p.n_in) ? reinterpret_cast<const uint4 *>(src)[k] : make_uint4(0u, 0u, 0u, 0u);
+            hraw[k] = (s_abs < p.n_in) ? reinterpret_cast<const u32x4 *>(src)[k] : u32x4{ 0u, 0u, 0u, 0u };
         float xi[8], xq[8];
         group_to_float<INFMT, MIX, NW>(hraw, xi, xq, p.n0 + (unsigned long long)s_abs, p);
         group_to_lds<R>(sI, sQ, tid, xi, xq);
     }
 
     /* PFD register sets of prefetched input: tile t+PFD is requested while tile t
-     * is filtered (PFD=2 keeps two tiles of loads in flight per block)          */
-    uint4 rawA[G::GPT][NW], rawB[PFD > 1 ? G::GPT : 1][NW];
-    auto prefetch = [&](int tile, uint4 (&raw)[G::GPT][NW]) {
+     * is filtered.  With PFD=2 the loads are issued from inline asm and waited for
+     * with hand-counted s_waitcnt vmcnt(N): hipcc's own bookkeeping collapses to
+     * vmcnt(0) for loads carried around the loop, which would wait for the
+     * YOUNGER tile too and turn depth 2 back into depth 1.                       */
+    constexpr bool ASML = (PFD == 2) && (INFMT == IN_PACKED24);
+    using RawSet = u32x4[G::GPT][NW];
+    u32x4 rawA[G::GPT][NW], rawB[PFD > 1 ? G::GPT : 1][NW];
+    auto prefetch = [&](int tile, RawSet &raw) {
         const long long tin0 = (long long)tile * G::TI;
-        const uint4 *src0 = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(p.in) +
+        const u32x4 *src0 = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(p.in) +
                                                             (tin0 + 8LL * gtid) * ES);
-        if (p.ablate & 1) {
+        if (ASML) {
+            /* asm loads, full and ragged tiles alike (a ragged tile clamps the
+             * pointer of its out-of-range groups to the tile's first group and
+             * zeroes them after the wait): no compiler-tracked load may be pending
+             * on these registers, or hipcc adds its own vmcnt(0) in front of ours  */
+            const bool full = tin0 + G::TI <= p.n_in;
 #pragma unroll
-            for (int k = 0; k < G::GPT; ++k)
-#pragma unroll
-                for (int w = 0; w < NW; ++w)
-                    raw[k][w] = make_uint4(tid + k, tid ^ w, tile, 0x01020304u);
+            for (int k = 0; k < G::GPT; ++k) {
+                const u32x4 *sk = src0 + (256 * k * 8 * ES) / 16;
+                if (!full && !(tin0 + 8LL * (gtid + 256 * k) < p.n_in))
+                    sk = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(p.in) + tin0 * ES);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[k][0]) : "v"(sk) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(raw[k][1]) : "v"(sk) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(raw[k][2]) : "v"(sk) : "memory");
+            }
         } else if (tin0 + G::TI <= p.n_in) {                  /* whole tile in range (wave-uniform) */
 #pragma unroll
             for (int k = 0; k < G::GPT; ++k)
@@ -426,13 +440,28 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
                 const bool have = tin0 + 8LL * (gtid + 256 * k) < p.n_in;
 #pragma unroll
                 for (int w = 0; w < NW; ++w)
-                    raw[k][w] = have ? src0[(256 * k * 8 * ES) / 16 + w] : make_uint4(0u, 0u, 0u, 0u);
+                    raw[k][w] = have ? src0[(256 * k * 8 * ES) / 16 + w] : u32x4{ 0u, 0u, 0u, 0u };
             }
         }
     };
+    /* hand-counted wait for an asm-loaded register set: at most `younger` newer
+     * vector-memory operations may stay outstanding (they retire in issue order).
+     * The empty asm statements make every later use of the registers depend on
+     * the wait.                                                                  */
+    auto wait_set = [&](RawSet &raw, bool younger_tile_in_flight) {
+        if (younger_tile_in_flight)
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::GPT * NW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#pragma unroll
+        for (int k = 0; k < G::GPT; ++k)
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                asm volatile("" : "+v"(raw[k][w]));
+    };
     prefetch(t0, rawA);
     if (PFD > 1 && t0 + 1 < t1)
-        prefetch(t0 + 1, reinterpret_cast<uint4 (&)[G::GPT][NW]>(rawB));
+        prefetch(t0 + 1, reinterpret_cast<RawSet &>(rawB));
 
     const int wave  = tid >> 6;
     const int lane  = tid & 63;
@@ -448,8 +477,6 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
     auto store_tile = [&](int tile) {
         const long long tile_o0 = (long long)tile * G::TO;
         constexpr int NCH = G::TO / 2;                             /* 16-byte chunks */
-        if (p.ablate & 4)
-            return;
         if (tile_o0 + G::TO <= n_out) {                            /* whole tile in range (uniform) */
 #pragma unroll
             for (int it = 0; it < NCH / 256; ++it) {
@@ -482,8 +509,20 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         }
     };
 
-    auto tile_body = [&](int t, uint4 (&raw)[G::GPT][NW]) {
+    auto tile_body = [&](int t, RawSet &raw) {
         /* ---- U: registers -> LDS planes (groups NTB ..) ------------------- */
+        if (ASML) {
+            wait_set(raw, t + 1 < t1);
+            const long long tin0 = (long long)t * G::TI;
+            if (tin0 + G::TI > p.n_in) {                /* ragged tile: drop the clamped groups */
+#pragma unroll
+                for (int k = 0; k < G::GPT; ++k)
+                    if (!(tin0 + 8LL * (gtid + 256 * k) < p.n_in))
+#pragma unroll
+                        for (int w = 0; w < NW; ++w)
+                            raw[k][w] = u32x4{ 0u, 0u, 0u, 0u };
+            }
+        }
 #pragma unroll
         for (int k = 0; k < G::GPT; ++k) {
             const int v = NTB + gtid + 256 * k;
@@ -517,12 +556,10 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
 #pragma unroll
         for (int r = 0; r < R; ++r)
             acc[r] = f32x2{ 0.0f, 0.0f };
-        if (!(p.ablate & 2)) {
-            if (R == 4 && par)
-                fir_window<NTB, R, 1>(base, hb, acc);
-            else
-                fir_window<NTB, R, 0>(base, hb, acc);
-        }
+        if (R == 4 && par)
+            fir_window<NTB, R, 1>(base, hb, acc);
+        else
+            fir_window<NTB, R, 0>(base, hb, acc);
         /* results -> staging (XOR-swizzled 16-byte chunks, interleaved I/Q) */
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -561,7 +598,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         for (int t = t0; t < t1; t += 2) {
             tile_body(t, rawA);
             if (t + 1 < t1)
-                tile_body(t + 1, reinterpret_cast<uint4 (&)[G::GPT][NW]>(rawB));
+                tile_body(t + 1, reinterpret_cast<RawSet &>(rawB));
         }
     }
     store_tile(t1 - 1);

@@ -545,7 +545,6 @@ static void fill_fir8_args(const pddc_pipeline *p, Fir8Args &a)
 {
     a.n0 = p->n0;
     a.freg = p->freg;
-    a.ablate = getenv("PDDC_ABLATE") ? atoi(getenv("PDDC_ABLATE")) : 0;   /* development only */
     for (int e = 0; e < 8; ++e) {
         a.lo_c[e] = p->lo_c[e];
         a.lo_s[e] = p->lo_s[e];
