@@ -491,8 +491,11 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
                  * loads stay COUNTED (vmcnt(N)) instead of collapsing to vmcnt(0) as they
                  * do whenever loads and stores are both pending.  Memory operations
                  * retire in issue order on gfx9, so a counted wait computed without
-                 * these stores is only ever stronger than needed, never weaker.        */
-                asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dstp), "v"(v) : "memory");
+                 * these stores is only ever stronger than needed, never weaker.  The
+                 * trailing s_nop 1 is the wait state a 128-bit store needs before the next
+                 * instruction may overwrite its data registers (hipcc pads nothing inside
+                 * or after an asm string).                                             */
+                asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dstp), "v"(v) : "memory");
             }
         } else {
 #pragma unroll
@@ -640,14 +643,16 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
     const dim3 grid((unsigned)nblocks), blk(256);
 #define PDDC_LAUNCH(FMT, MIXV, PF)                                                                \
     do {                                                                                          \
-        static bool attr_done = false;                                                            \
-        if (!attr_done) {                                                                         \
+        static unsigned long long attr_done = 0;   /* one bit per device: the attribute is per device */ \
+        int dev__ = 0;                                                                            \
+        (void)hipGetDevice(&dev__);                                                               \
+        if (!(attr_done >> (dev__ & 63) & 1ull)) {                                                \
             hipError_t e = hipFuncSetAttribute(                                                   \
                 reinterpret_cast<const void *>(&k_fir8<NTB, R, FMT, MIXV, PF>),                   \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
             if (e != hipSuccess)                                                                  \
                 return e;                                                                         \
-            attr_done = true;                                                                     \
+            attr_done |= 1ull << (dev__ & 63);                                                    \
         }                                                                                         \
         hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV, PF>), grid, blk, lds, s, a, tpb, ntiles);   \
     } while (0)
@@ -771,13 +776,15 @@ hipError_t launch_fir_generic(const float *in, const float *hist, int H, long lo
     const size_t lds = (size_t)(ntp + 2 * plane) * sizeof(float);
     if (lds > 160 * 1024)
         return hipErrorInvalidValue;
-    static int attr_lds = 0;
-    if ((int)lds > attr_lds) {
+    static int attr_lds[64] = { 0 };            /* per device */
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if ((int)lds > attr_lds[dev & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_generic),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
-        attr_lds = (int)lds;
+        attr_lds[dev & 63] = (int)lds;
     }
     const dim3 grid((unsigned)((n_out + 255) / 256)), blk(256);
     hipLaunchKernelGGL(k_fir_generic, grid, blk, lds, s, in, hist, H, first, n_out, D, taps, ntaps, out, span,

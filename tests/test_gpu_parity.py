@@ -466,3 +466,99 @@ def test_perseus_api_non_integer_rate(pkg, dev, O, monkeypatch, rate):
     stages = [(dec[i], taps[i], it[i]) for i in range(n)]
     ref = O.ddc_chain(O.lcg_bytes(6 * need, 12345), stages, freg=O.nco_freg(7.0e6), mix=True)
     assert O.rel_err(y, ref[: y.size]) <= FIR_TOL
+
+
+# ----------------------------------------------- persistence / state edge cases
+def test_long_tile_runs_per_block_all_variants(pkg, dev, O, monkeypatch):
+    """Few persistent blocks => many consecutive tiles per block: exercises the
+    LDS-carried history of every kernel variant (packed, packed+NCO, float2
+    second stage) and the ragged last tile."""
+    monkeypatch.setenv("PDDC_FIR8_BLOCKS", "3")
+    ns = 8 * (4096 * 5 + 333)                                  # 40+ tiles over 3 blocks, ragged tail
+    packed = O.lcg_bytes(6 * ns, 2024)
+    h1, h2, h255 = load_taps("c320_s1_d8_32"), load_taps("c320_s2_d8_64"), load_taps("d8_255")
+    for stages, mix in (([(8, load_taps("d8_127"))], False), ([(8, h255)], True), ([(8, h1), (8, h2)], True)):
+        for R in ("4", "8"):
+            monkeypatch.setenv("PDDC_FIR8_R", R)
+            ref = O.ddc_chain(packed, stages, freg=123456789, mix=mix)
+            pipe = pkg.Pipeline(stages, mix=mix)
+            pipe.set_freg(123456789)
+            y = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+            assert y.size == ref.size
+            assert O.rel_err(y, ref) <= FIR_TOL, (len(stages), mix, R)
+            pipe.close()
+
+
+def test_prefetch_depth_two_is_bit_identical(pkg, dev, O, monkeypatch):
+    """The asm-load / hand-counted-vmcnt variant must reproduce the default build
+    bit for bit on a buffer large enough that a stale register would show."""
+    t = _torch()
+    h = load_taps("d8_127")
+    ns = 1 << 24
+    d_in = pkg.synth_lcg(6 * ns, 99, 0, dev)
+    outs = []
+    for pfd in ("1", "2"):
+        monkeypatch.setenv("PDDC_FIR8_PFD", pfd)
+        pipe = pkg.Pipeline([(8, h)])
+        outs.append(pipe.process(d_in).clone())
+        pipe.close()
+    assert t.equal(outs[0], outs[1])
+    monkeypatch.setenv("PDDC_FIR8_PFD", "1")
+    pkg.Pipeline([(8, h)]).close()                             # restore the process-wide default
+
+
+def test_set_taps_reset_and_tiny_batches(pkg, dev, O):
+    h = load_taps("d8_127")
+    g = (np.arange(100, dtype=np.float32) - 50) / 5000
+    ns = 8 * 700
+    packed = O.lcg_bytes(6 * ns, 8)
+    pipe = pkg.Pipeline([(8, h)])
+    # batches of 8 samples (far below the history length) take the generic history path
+    y = np.concatenate([pipe.process(to_dev(packed[6 * a: 6 * (a + 8)], dev)).cpu().numpy().reshape(-1)
+                        for a in range(0, 8 * 40, 8)] +
+                       [pipe.process(to_dev(packed[6 * 8 * 40:], dev)).cpu().numpy().reshape(-1)])
+    assert O.rel_err(y, O.ddc_chain(packed, [(8, h)])) <= FIR_TOL
+    import ctypes as C
+    pkg.check(pkg.ddc_lib().pddc_pipeline_set_taps(pipe._h, 0, g.ctypes.data_as(C.POINTER(C.c_float)), g.size))
+    pipe.reset()
+    y2 = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+    assert O.rel_err(y2, O.ddc_chain(packed, [(8, g)])) <= FIR_TOL
+    with pytest.raises(pkg.PddcError):                          # does not fit the geometry fixed at create time
+        big = np.ones(400, np.float32)
+        pkg.check(pkg.ddc_lib().pddc_pipeline_set_taps(pipe._h, 0, big.ctypes.data_as(C.POINTER(C.c_float)), 400))
+    pipe.close()
+
+
+def test_fp16_tap_storage_rounding(pkg, dev, O):
+    h = load_taps("d8_255")
+    h16 = h.astype(np.float16).astype(np.float32)
+    ns = 8 * 3000
+    packed = O.lcg_bytes(6 * ns, 55)
+    pipe = pkg.Pipeline([(8, h)], taps_fp16=True)
+    y = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+    assert O.rel_err(y, O.ddc_chain(packed, [(8, h16)])) <= FIR_TOL      # oracle with the same rounded taps
+    assert O.rel_err(y, O.ddc_chain(packed, [(8, h)])) > FIR_TOL          # and visibly not the fp32 taps
+    pipe.close()
+
+
+@pytest.mark.parametrize("R", ["4", "8"])
+def test_whole_buffer_fused_vs_generic_path(pkg, dev, O, monkeypatch, R):
+    """Every output of a 2^22-sample batch: the fused kernel (asm stores, LDS
+    carry, persistent tiles) against the independent generic kernels."""
+    t = _torch()
+    monkeypatch.setenv("PDDC_FIR8_R", R)
+    h = load_taps("d8_127")
+    ns = (1 << 22) + 8 * 77
+    d_in = pkg.synth_lcg(6 * ns, 4711, 0, dev)
+    fast = pkg.Pipeline([(8, h)])
+    slow = pkg.Pipeline([(8, h)], no_fast=True)
+    a, b = fast.process(d_in), slow.process(d_in)
+    assert a.shape == b.shape
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) / scale <= 1e-6
+    # and twice in a row on the same state-advancing pipelines (history hand-over between launches)
+    a2, b2 = fast.process(d_in), slow.process(d_in)
+    assert float((a2 - b2).abs().max()) / scale <= 1e-6
+    assert not t.equal(a[:64], a2[:64])              # the second call really saw the first call's history
+    fast.close()
+    slow.close()
