@@ -104,9 +104,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = os.environ.get("PDDC_BENCH_FORCE_DIST") == "1"     # 1-rank RCCL group (testing)
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ns = 1 << a.log2n
     # ---- workload ---------------------------------------------------------
@@ -178,7 +180,7 @@ def main():
         kern_ms = ev_ms / a.steps
 
     gather = None
-    if a.gather and world > 1 and stages is not None:
+    if a.gather and shard.is_dist() and stages is not None:
         n_out = pipe.max_output(ns)
         mine = out[:n_out].contiguous()
         bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
@@ -204,7 +206,7 @@ def main():
         achieved = bytes_per_sample * ns / (kern_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and a.log2n == 28 and not a.taps_fp16:   # measured for this exact launch shape
             try:
                 traffic = json.load(open(pmc)).get(a.workload)
             except Exception:
@@ -234,9 +236,13 @@ def main():
             res["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_seconds)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res), flush=True)
-    if world > 1:
+    else:
+        res = None
+    if shard.is_dist():
         dist.destroy_process_group()
+    if res is not None:                     # the JSON line is the last thing this process prints
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

@@ -22,7 +22,9 @@ def env_rank_world():
 
 
 def is_dist() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True once a process group exists (also for a 1-rank group, which the
+    bench can force to exercise the RCCL calls on a single GPU)."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def stream_seed(rank: int, base: int = 12345) -> int:
