@@ -120,6 +120,10 @@ int pddc_pipeline_total_decim(const pddc_pipeline *p);
 size_t pddc_pipeline_max_output(const pddc_pipeline *p, size_t nsamples_in);
 /* 1 if stage 0 runs the fused unpack+mix+polyphase kernel for this geometry   */
 int pddc_pipeline_uses_fused(const pddc_pipeline *p);
+/* 1 if a process() of nsamples would run stages 0 AND 1 as one kernel (both
+ * decimate-by-8, stage 1 <= 64 taps, nsamples a multiple of the kernel's tile):
+ * the stage-0 output then never reaches HBM                                    */
+int pddc_pipeline_uses_fused_pair(const pddc_pipeline *p, size_t nsamples);
 
 /* Device-resident batch: d_packed (16-byte aligned, nsamples % 8 == 0) ->
  * d_out_f32 (16-byte aligned, capacity in complex samples; with

@@ -97,6 +97,8 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_max_output.argtypes = [vp, sz]
     L.pddc_pipeline_max_output.restype = sz
     L.pddc_pipeline_uses_fused.argtypes = [vp]
+    L.pddc_pipeline_uses_fused_pair.argtypes = [vp, sz]
+    L.pddc_pipeline_uses_fused_pair.restype = C.c_int
     L.pddc_pipeline_process.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp]
     L.pddc_pipeline_push_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     L.pddc_pipeline_time_stage0.argtypes = [vp, vp, sz, vp, C.c_int, vp, C.POINTER(C.c_float)]
@@ -162,6 +164,9 @@ class Pipeline:
     @property
     def fused(self) -> bool:
         return bool(ddc_lib().pddc_pipeline_uses_fused(self._h))
+
+    def fused_pair(self, nsamples: int) -> bool:
+        return bool(ddc_lib().pddc_pipeline_uses_fused_pair(self._h, nsamples))
 
     def max_output(self, n: int) -> int:
         return int(ddc_lib().pddc_pipeline_max_output(self._h, n))

@@ -21,6 +21,11 @@ struct Fir8Args {
                                 must not alias `hist`; needs n_in >= 8*ntb)     */
     float      *out;         /* float2 outputs                                 */
     const float *taps_blk;   /* [ntb][8] block-reversed taps (device)          */
+    /* fused second decimate-by-8 stage (launch_fir8_fused2 only) */
+    const float *taps2_blk = nullptr;  /* [8][8] block-reversed taps of the second stage  */
+    const void  *hist2 = nullptr;      /* its history: the 64 stage-1 outputs (float2) that
+                                precede this batch                               */
+    void        *hist2_out = nullptr;  /* receives the batch's last 64 stage-1 outputs    */
     long long   n_in;        /* samples in the batch, multiple of 8            */
     unsigned long long n0;   /* absolute index of batch sample 0 (NCO phase)   */
     uint32_t    freg;        /* NCO tuning word                                */
@@ -34,6 +39,11 @@ size_t fir8_lds_bytes(int ntb, int R);
 bool   fir8_supported(int ntb, int R);
 void   fir8_set_grid_blocks(int nblocks);   /* persistent grid override (0 = resident blocks x CUs) */
 void   fir8_set_prefetch_depth(int d);      /* 1 or 2 tiles of loads in flight per block */
+
+/* packed -> [mix] -> /8 -> /8 in one kernel: `out` receives the SECOND stage's
+ * outputs (n_in/64); n_in must be a multiple of the tile (1024*R samples) */
+bool fir8_fused2_supported(int ntb, int ntb2, int R);
+hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipStream_t s);
 
 /* returns hipSuccess or the launch error */
 hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s);

@@ -274,6 +274,20 @@ struct Fir8Geom {
     static constexpr int LDS_FLT = 2 * PLANE + OT;
 };
 
+/* second (fused) decimate-by-8 stage: its input is the tile's TO stage-1
+ * outputs, kept in LDS in the same rotated / padded plane layout */
+template <int NTB2, int R>
+struct Fir8Geom2 {
+    static constexpr int TO2   = 16 * R;                 /* stage-2 outputs per tile (TO/8)   */
+    static constexpr int R2    = TO2 / 64;               /* per lane of waves 0 (I) and 1 (Q) */
+    static constexpr int GT2   = 16 * R;                 /* new input groups per tile (TO/8)  */
+    static constexpr int NG2   = GT2 + NTB2;
+    /* plain layout (offset 8 + position): the second stage is ~3 % of the work, a
+     * 2-way bank conflict on its reads is cheaper than the LDS a pad would cost  */
+    static constexpr int PLANE = NTB2 > 0 ? 8 + 8 * NG2 + 8 : 0;
+    static constexpr int LDS_FLT = NTB2 > 0 ? 2 * PLANE + 2 * TO2 : 0;
+};
+
 size_t fir8_lds_bytes(int ntb, int R)
 {
     const int NG = 1024 * R / 8 + ntb;
@@ -330,12 +344,12 @@ __device__ __forceinline__ void group_to_lds(float *sI, float *sQ, int v, const 
 /* The register sliding window of one lane: R outputs over R+NTB-1 aligned
  * 8-sample groups.  PAR (R=4 only) says whether the lane's half segment starts
  * 4 groups into a padded 8-group row, which moves the pad inside the window.  */
-template <int NTB, int R, int PAR>
+template <int NTB, int R, int PAR, bool PADDED = true>
 __device__ __forceinline__ void fir_window(const float *base, const float PDDC_CONSTANT *hb, f32x2 (&acc)[R])
 {
 #pragma unroll
     for (int ub = 0; ub < R + NTB - 1; ++ub) {
-        const int go = 8 * ub + 4 * ((ub + PAR * 4) >> 3);
+        const int go = 8 * ub + (PADDED ? 4 * ((ub + PAR * 4) >> 3) : 0);
         const f32x4 d0 = *reinterpret_cast<const f32x4 *>(base + go);
         const f32x4 d1 = *reinterpret_cast<const f32x4 *>(base + go + 4);
         const f32x2 xs[4] = { { d0.x, d0.y }, { d0.z, d0.w }, { d1.x, d1.y }, { d1.z, d1.w } };
@@ -365,14 +379,19 @@ __device__ __forceinline__ void fir_window(const float *base, const float PDDC_C
  *              C  the last NTB groups become tile t+1's history (copied by
  *                 the very threads that overwrite them in the next U, so no
  *                 third barrier is needed).                                */
-template <int NTB, int R, int INFMT, bool MIX, int PFD>
+template <int NTB, int R, int INFMT, bool MIX, int PFD, int NTB2>
 __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int tiles_per_block, int ntiles)
 {
     using G = Fir8Geom<NTB, R>;
+    using G2 = Fir8Geom2<NTB2, R>;
+    constexpr bool FUSE2 = NTB2 > 0;     /* a second decimate-by-8 stage runs on the tile's outputs in LDS */
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sI = smem;
     float *sQ = smem + G::PLANE;
-    float *ot = smem + 2 * G::PLANE;
+    float *ot = smem + 2 * G::PLANE;     /* stage-1 output staging (unfused) ...                            */
+    float *sI2 = ot;                     /* ... or the second stage's input planes + its staging (fused)    */
+    float *sQ2 = ot + G2::PLANE;
+    float *ot2 = ot + 2 * G2::PLANE;
 
     constexpr int NW = (INFMT == IN_PACKED24) ? 3 : 4;             /* 16-byte words per group */
     constexpr int ES = (INFMT == IN_PACKED24) ? 6 : 8;             /* bytes per sample        */
@@ -382,10 +401,25 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
      * swapped, so that the 8-lane groups of ds_write_b128/_b96 hit 8 distinct
      * 4-bank sets (32-byte group stride + the 16-byte pad every R groups)      */
     const int gtid = (tid & ~12) | ((tid & 4) << 1) | ((tid & 8) >> 1);
-    const int t0  = blockIdx.x * tiles_per_block;
-    const int t1  = min(t0 + tiles_per_block, ntiles);
-    if (t0 >= t1)
+    const int t_own = blockIdx.x * tiles_per_block;      /* first tile whose outputs this block writes */
+    const int t1  = min(t_own + tiles_per_block, ntiles);
+    if (t_own >= t1)
         return;
+    /* fused second stage: its history is 8*NTB2 stage-1 outputs, i.e. the tile
+     * in front of the block's range is recomputed as a warm-up (no output) --
+     * except for block 0, whose stage-2 history comes from the previous call   */
+    const int t0 = (FUSE2 && t_own > 0) ? t_own - 1 : t_own;
+    if (FUSE2 && t_own == 0 && tid < NTB2) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(static_cast<const float *>(p.hist2) + 16 * tid);
+        const u32x4 h2raw[4] = { src[0], src[1], src[2], src[3] };
+        float xi[8], xq[8];
+        group_to_float<IN_F32C, false, 4>(h2raw, xi, xq, 0ull, p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {            /* position p2 = 8*tid + e - 1, offset 8 + p2 */
+            sI2[7 + 8 * tid + e] = xi[e];
+            sQ2[7 + 8 * tid + e] = xq[e];
+        }
+    }
 
     /* ---- history of the first tile: groups 0..NTB-1 ------------------------ */
     if (tid < NTB) {
@@ -463,7 +497,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
     if (PFD > 1 && t0 + 1 < t1)
         prefetch(t0 + 1, reinterpret_cast<RawSet &>(rawB));
 
-    const int wave  = tid >> 6;
+    const int wave  = __builtin_amdgcn_readfirstlane(tid >> 6);   /* provably wave-uniform */
     const int lane  = tid & 63;
     const int plane = wave & 1;
     /* segment (R outputs, 8R inputs) owned by this lane, 0..127 */
@@ -472,6 +506,18 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
     const float *base = (plane ? sQ : sI) + 8 + 8 * R * L + 4 * ((R * L) >> 3);   /* goff(R*L) */
     const float PDDC_CONSTANT *hb = (const float PDDC_CONSTANT *)p.taps_blk;
     const long long n_out = p.n_in >> 3;
+
+    /* S (fused): the tile's TO2 second-stage outputs, 16 bytes per thread */
+    auto store_tile2 = [&](int tile) {
+        constexpr int NCH2 = G2::TO2 / 2;
+        if (tid < NCH2) {
+            const long long m = (long long)tile * G2::TO2 + 2LL * tid;     /* no ragged tiles when fused */
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(ot2 + 4 * tid);
+            float *dstp = p.out + 2 * m;
+            asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dstp), "v"(v) : "memory");
+        }
+    };
+    const float PDDC_CONSTANT *hb2 = (const float PDDC_CONSTANT *)p.taps2_blk;
 
     /* S: coalesced stores of one finished tile from the staging area */
     auto store_tile = [&](int tile) {
@@ -539,9 +585,11 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
          * waits vmcnt(0) whenever both kinds are pending, so stores issued just
          * before the wait for prefetched loads would stall every tile on the
          * write acknowledgements (measured: +0.12 ms per 2^28 samples).        */
-        if (t > t0)
+        if (!FUSE2 && t > t0)
             store_tile(t - 1);
         __syncthreads();                                           /* A */
+        if (FUSE2 && t > t_own)        /* written by waves 0/1 after the previous barrier B */
+            store_tile2(t - 1);
 
         /* ---- P: next tile's loads --------------------------------------- */
         if (t + PFD < t1)
@@ -555,6 +603,8 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
          * -- both operands are natural adjacent pairs (SGPR pair of taps, VGPR
          * pair of samples from one ds_read_b128), no broadcast, no shuffles.   */
         asm volatile("" : "+s"(hb));      /* keep the tap s_loads inside the tile loop (no SGPR spills) */
+        if (FUSE2)
+            asm volatile("" : "+s"(hb2));
         f32x2 acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -563,13 +613,24 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
             fir_window<NTB, R, 1>(base, hb, acc);
         else
             fir_window<NTB, R, 0>(base, hb, acc);
-        /* results -> staging (XOR-swizzled 16-byte chunks, interleaved I/Q) */
+        if (FUSE2) {
+            /* results -> the second stage's input plane, rotated like the first:
+             * position p2 = m + 8*NTB2 - 1 for tile-relative output m = R*L + r,
+             * float offset 8 + p2                                                  */
+            float *pl2 = plane ? sQ2 : sI2;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int f  = 2 * (R * L + r) + plane;
-            const int q  = f >> 2;
-            const int qs = q ^ ((q >> 3) & 7);
-            ot[4 * qs + (f & 3)] = acc[r].x + acc[r].y;
+            for (int r = 0; r < R; ++r) {
+                pl2[8 + (R * L + r + 8 * NTB2 - 1)] = acc[r].x + acc[r].y;
+            }
+        } else {
+            /* results -> staging (XOR-swizzled 16-byte chunks, interleaved I/Q) */
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int f  = 2 * (R * L + r) + plane;
+                const int q  = f >> 2;
+                const int qs = q ^ ((q >> 3) & 7);
+                ot[4 * qs + (f & 3)] = acc[r].x + acc[r].y;
+            }
         }
         __syncthreads();                                           /* B */
 
@@ -592,6 +653,35 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
                 sQ[od + 7] = q1.w;
             }
         }
+        /* ---- F2 / C2 (fused): waves 0 (I) and 1 (Q) run the second decimator on
+         * the TO stage-1 outputs now in LDS, then carry its history.  Ordering
+         * needs no extra barrier: the inputs were written before B, the outputs
+         * (ot2) are read after the next A, and the next writes into these planes
+         * come after the next A as well.                                        */
+        if (FUSE2 && wave < 2) {
+            float *pl2 = wave ? sQ2 : sI2;
+            if (t >= t_own) {
+                constexpr int R2 = G2::R2 > 0 ? G2::R2 : 1;
+                f32x2 acc2[R2];
+#pragma unroll
+                for (int r = 0; r < R2; ++r)
+                    acc2[r] = f32x2{ 0.0f, 0.0f };
+                fir_window<(NTB2 > 0 ? NTB2 : 1), R2, 0, false>(pl2 + 8 + 8 * R2 * lane, hb2, acc2);
+#pragma unroll
+                for (int r = 0; r < R2; ++r)
+                    ot2[2 * (R2 * lane + r) + wave] = acc2[r].x + acc2[r].y;
+            }
+            if (t + 1 < t1 && lane < NTB2) {
+                const int os = 8 + 8 * (G2::GT2 + lane), od = 8 + 8 * lane;
+                const float4 a0 = *reinterpret_cast<const float4 *>(pl2 + os);
+                const float4 a1 = *reinterpret_cast<const float4 *>(pl2 + os + 4);
+                *reinterpret_cast<float4 *>(pl2 + od) = a0;
+                *reinterpret_cast<float2 *>(pl2 + od + 4) = make_float2(a1.x, a1.y);
+                pl2[od + 6] = a1.z;
+                if (lane != NTB2 - 1)
+                    pl2[od + 7] = a1.w;
+            }
+        }
     };
 
     if (PFD == 1) {
@@ -604,7 +694,17 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
                 tile_body(t + 1, reinterpret_cast<RawSet &>(rawB));
         }
     }
-    store_tile(t1 - 1);
+    if (FUSE2) {
+        __syncthreads();                 /* ot2 and the stage-2 planes of the last tile are complete */
+        store_tile2(t1 - 1);
+        /* the last 8*NTB2 stage-1 outputs are the second stage's next history */
+        if (p.hist2_out != nullptr && t1 == ntiles && tid < 8 * NTB2) {
+            const int o = 8 + (G::TO + tid - 1);       /* position of stage-1 output TO - 8*NTB2 + tid */
+            static_cast<float2 *>(p.hist2_out)[tid] = make_float2(sI2[o], sQ2[o]);
+        }
+    } else {
+        store_tile(t1 - 1);
+    }
 
     /* the block that owns the last tile leaves the batch's last 8*NTB input
      * samples as the next call's history (the host alternates two buffers, so
@@ -648,13 +748,13 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
         (void)hipGetDevice(&dev__);                                                               \
         if (!(attr_done >> (dev__ & 63) & 1ull)) {                                                \
             hipError_t e = hipFuncSetAttribute(                                                   \
-                reinterpret_cast<const void *>(&k_fir8<NTB, R, FMT, MIXV, PF>),                   \
+                reinterpret_cast<const void *>(&k_fir8<NTB, R, FMT, MIXV, PF, 0>),                \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
             if (e != hipSuccess)                                                                  \
                 return e;                                                                         \
             attr_done |= 1ull << (dev__ & 63);                                                    \
         }                                                                                         \
-        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV, PF>), grid, blk, lds, s, a, tpb, ntiles);   \
+        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV, PF, 0>), grid, blk, lds, s, a, tpb, ntiles); \
     } while (0)
     const bool pf2 = g_fir8_pfd > 1;
     if (fmt == IN_PACKED24) {
@@ -668,6 +768,61 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
     }
 #undef PDDC_LAUNCH
     return hipGetLastError();
+}
+
+/* fused pair: packed input -> [mix] -> /8 (NTB blocks) -> /8 (<= 64 taps) */
+template <int NTB, int R>
+static hipError_t launch_fir8_fused2_t(bool mix, const Fir8Args &a, hipStream_t s)
+{
+    using G = Fir8Geom<NTB, R>;
+    using G2 = Fir8Geom2<8, R>;
+    const size_t lds = (size_t)(2 * G::PLANE + G2::LDS_FLT) * sizeof(float);
+    if (a.n_in <= 0 || a.n_in % G::TI)
+        return hipErrorInvalidValue;             /* whole tiles only */
+    const long long ntiles_ll = a.n_in / G::TI;
+    if (ntiles_ll > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+    const int ntiles = (int)ntiles_ll;
+    const int want = g_fir8_blocks > 0 ? g_fir8_blocks : 256 * (R == 4 ? 4 : 2);
+    const int tpb = (ntiles + want - 1) / want;
+    const int nblocks = (ntiles + tpb - 1) / tpb;
+    const dim3 grid((unsigned)nblocks), blk(256);
+#define PDDC_LAUNCH2(MIXV)                                                                        \
+    do {                                                                                          \
+        static unsigned long long attr_done = 0;                                                  \
+        int dev__ = 0;                                                                            \
+        (void)hipGetDevice(&dev__);                                                               \
+        if (!(attr_done >> (dev__ & 63) & 1ull)) {                                                \
+            hipError_t e = hipFuncSetAttribute(                                                   \
+                reinterpret_cast<const void *>(&k_fir8<NTB, R, IN_PACKED24, MIXV, 1, 8>),         \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+            if (e != hipSuccess)                                                                  \
+                return e;                                                                         \
+            attr_done |= 1ull << (dev__ & 63);                                                    \
+        }                                                                                         \
+        hipLaunchKernelGGL((k_fir8<NTB, R, IN_PACKED24, MIXV, 1, 8>), grid, blk, lds, s, a, tpb,  \
+                           ntiles);                                                               \
+    } while (0)
+    if (mix)
+        PDDC_LAUNCH2(true);
+    else
+        PDDC_LAUNCH2(false);
+#undef PDDC_LAUNCH2
+    return hipGetLastError();
+}
+
+bool fir8_fused2_supported(int ntb, int ntb2, int R)
+{
+    return (R == 4 || R == 8) && (ntb == 4 || ntb == 8) && ntb2 > 0 && ntb2 <= 8;
+}
+
+hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipStream_t s)
+{
+    if (ntb == 4 && R == 4) return launch_fir8_fused2_t<4, 4>(mix, a, s);
+    if (ntb == 8 && R == 4) return launch_fir8_fused2_t<8, 4>(mix, a, s);
+    if (ntb == 4 && R == 8) return launch_fir8_fused2_t<4, 8>(mix, a, s);
+    if (ntb == 8 && R == 8) return launch_fir8_fused2_t<8, 8>(mix, a, s);
+    return hipErrorInvalidValue;
 }
 
 void fir8_set_grid_blocks(int nblocks) { g_fir8_blocks = nblocks > 0 ? nblocks : 0; }

@@ -136,6 +136,10 @@ static int upload_taps(pddc_pipeline *p, int si)
     HIP_TRY(hipMalloc(&s.d_taps, sizeof(float) * (size_t)s.ntaps));
     HIP_TRY(hipMemcpy(s.d_taps, s.taps.data(), sizeof(float) * (size_t)s.ntaps, hipMemcpyHostToDevice));
     s.ntb = stage_fused_capable(s) ? pick_ntb(s.ntaps) : 0;
+    /* a second stage that can be fused behind stage 0 always uses 8 tap blocks
+     * (64-sample history), fused or not, so both paths share one state format */
+    if (si == 1 && s.ntb != 0 && s.ntaps <= 64)
+        s.ntb = 8;
     if (s.ntb) {
         /* hb[j][e] = h[8j + 7 - e], zero beyond ntaps */
         std::vector<float> blk((size_t)s.ntb * 8, 0.0f);
@@ -525,6 +529,27 @@ static bool stage0_fused(const pddc_pipeline *p)
 
 int pddc_pipeline_uses_fused(const pddc_pipeline *p) { return p && stage0_fused(p) ? 1 : 0; }
 
+/* stages 0+1 run as one kernel when: stage 0 is the fused decimate-by-8, stage 1
+ * is a plain decimate-by-8 with <= 64 taps, the batch is whole tiles, and both
+ * stages sit on an 8-sample phase boundary */
+static bool stages01_fusable(const pddc_pipeline *p, size_t nsamples)
+{
+    if (p->nstages < 2 || !stage0_fused(p) || getenv("PDDC_NO_FUSE2"))
+        return false;
+    const Stage &s0 = p->st[0], &s1 = p->st[1];
+    if (s1.decim != 8 || s1.interp != 1 || s1.ntb != 8 || s1.hist != 64)
+        return false;
+    if (!fir8_fused2_supported(s0.ntb, s1.ntb, p->R))
+        return false;
+    return nsamples > 0 && nsamples % (size_t)fir8_tile_inputs(p->R) == 0 && s0.consumed % 8 == 0 &&
+           s1.consumed % 8 == 0;
+}
+
+extern "C" int pddc_pipeline_uses_fused_pair(const pddc_pipeline *p, size_t nsamples)
+{
+    return p && stages01_fusable(p, nsamples) ? 1 : 0;
+}
+
 static int ensure_buf(Stage &s, size_t need)
 {
     if (s.d_buf && s.buf_cap >= need)
@@ -581,14 +606,13 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
 
     const bool mix = (p->flags & PDDC_F_MIX) != 0;
     int rc;
-    for (int i = 0; i < p->nstages; ++i) {
-        Stage &st = p->st[i];
-        /* destination of this stage: next stage's input buffer or the caller's */
-        float *dst;
+    /* destination of stage i: the next stage's input buffer, or the caller's */
+    auto stage_dst = [&](int i, float **dst) -> int {
         if (i + 1 < p->nstages) {
-            if ((rc = ensure_buf(p->st[i + 1], n_in[i + 1] + 8)))
-                return rc;
-            dst = p->st[i + 1].d_buf;
+            int r = ensure_buf(p->st[i + 1], n_in[i + 1] + 8);
+            if (r)
+                return r;
+            *dst = p->st[i + 1].d_buf;
         } else if (p->flags & PDDC_F_OUT_PACKED24) {
             if (p->d_fout_cap < n_final + 8) {
                 HIP_TRY(hipDeviceSynchronize());
@@ -599,10 +623,44 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                 HIP_TRY(hipMalloc(&p->d_fout, (n_final + n_final / 4 + 64) * 8));
                 p->d_fout_cap = n_final + n_final / 4 + 64;
             }
-            dst = p->d_fout;
+            *dst = p->d_fout;
         } else {
-            dst = static_cast<float *>(d_out);
+            *dst = static_cast<float *>(d_out);
         }
+        return PDDC_OK;
+    };
+
+    int first = 0;
+    if (stages01_fusable(p, nsamples)) {
+        /* stages 0 and 1 in ONE kernel: the 8 B/sample-at-1/8-rate intermediate
+         * (1 B written + 1 B read per input sample) never touches HBM */
+        Stage &s0 = p->st[0], &s1 = p->st[1];
+        float *dst;
+        if ((rc = stage_dst(1, &dst)))
+            return rc;
+        Fir8Args a;
+        a.in = d_packed;
+        a.hist = s0.d_hist[s0.cur];
+        a.hist_out = s0.d_hist[s0.cur ^ 1];
+        a.out = dst;
+        a.taps_blk = s0.d_taps_blk;
+        a.taps2_blk = s1.d_taps_blk;
+        a.hist2 = s1.d_hist[s1.cur];
+        a.hist2_out = s1.d_hist[s1.cur ^ 1];
+        a.n_in = (long long)nsamples;
+        fill_fir8_args(p, a);
+        HIP_TRY(launch_fir8_fused2(s0.ntb, p->R, mix, a, s));
+        s0.cur ^= 1;
+        s1.cur ^= 1;
+        s0.consumed += n_in[0];
+        s1.consumed += n_in[1];
+        first = 2;
+    }
+    for (int i = first; i < p->nstages; ++i) {
+        Stage &st = p->st[i];
+        float *dst;
+        if ((rc = stage_dst(i, &dst)))
+            return rc;
         void *h_in = st.d_hist[st.cur], *h_out = st.d_hist[st.cur ^ 1];
         const void *x = d_packed;                       /* this stage's input batch */
         bool hist_done = false;
@@ -728,11 +786,17 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     a.hist = p->st[0].d_hist[p->st[0].cur];
     a.hist_out = nullptr;                  /* state is not advanced */
     a.out = static_cast<float *>(d_out);
-    if (p->nstages > 1) {                  /* stage 0 of a cascade writes the next stage's input buffer */
+    const bool fuse2 = stages01_fusable(p, nsamples);
+    if (p->nstages > 1) {                  /* stage 0 (or the fused pair) of a cascade writes an internal buffer */
         int rc = ensure_buf(p->st[1], nsamples / (size_t)p->st[0].decim + 8);
         if (rc)
             return rc;
         a.out = p->st[1].d_buf;
+    }
+    if (fuse2) {
+        a.taps2_blk = p->st[1].d_taps_blk;
+        a.hist2 = p->st[1].d_hist[p->st[1].cur];
+        a.hist2_out = nullptr;
     }
     a.taps_blk = p->st[0].d_taps_blk;
     a.n_in = (long long)nsamples;
@@ -742,8 +806,12 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i)
-        HIP_TRY(launch_fir8(p->st[0].ntb, p->R, IN_PACKED24, mix, a, s));
+    for (int i = 0; i < iters; ++i) {
+        if (fuse2)
+            HIP_TRY(launch_fir8_fused2(p->st[0].ntb, p->R, mix, a, s));
+        else
+            HIP_TRY(launch_fir8(p->st[0].ntb, p->R, IN_PACKED24, mix, a, s));
+    }
     HIP_TRY(hipEventRecord(e1, s));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.0f;

@@ -562,3 +562,56 @@ def test_whole_buffer_fused_vs_generic_path(pkg, dev, O, monkeypatch, R):
     assert not t.equal(a[:64], a2[:64])              # the second call really saw the first call's history
     fast.close()
     slow.close()
+
+
+# ------------------------------------------- stages 0+1 fused into one kernel
+@pytest.mark.parametrize("R", ["4", "8"])
+@pytest.mark.parametrize("mix", [False, True])
+def test_fused_stage_pair_vs_oracle(pkg, dev, O, monkeypatch, R, mix):
+    """/8 -> /8 (-> /5) with the first intermediate kept in LDS: warm-up tiles at
+    block-range starts (few blocks), history hand-over between calls, and the
+    switch to and from the unfused path when a batch is not whole tiles."""
+    monkeypatch.setenv("PDDC_FIR8_R", R)
+    monkeypatch.setenv("PDDC_FIR8_BLOCKS", "3")
+    tile = 1024 * int(R)
+    h1, h2, h3 = load_taps("c320_s1_d8_32"), load_taps("c320_s2_d8_64"), load_taps("c320_s3_d5_161")
+    for stages in ([(8, h1), (8, h2)], [(8, h1), (8, h2), (5, h3)]):
+        cuts = [0, 7 * tile, 7 * tile + 8 * 64, 7 * tile + 8 * 64 + 5 * tile, 30 * tile + 8 * 64]
+        ns = cuts[-1]
+        packed = O.lcg_bytes(6 * ns, 17)
+        ref = O.ddc_chain(packed, stages, freg=381178347, mix=mix)
+        pipe = pkg.Pipeline(stages, mix=mix)
+        pipe.set_freg(381178347)
+        assert pipe.fused_pair(7 * tile) and not pipe.fused_pair(8 * 64)
+        parts, used = [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            used.append(pipe.fused_pair(b - a))
+            parts.append(pipe.process(to_dev(packed[6 * a:6 * b], dev)).cpu().numpy().reshape(-1))
+        assert used == [True, False, True, True]
+        y = np.concatenate(parts)
+        assert y.size == ref.size
+        assert O.rel_err(y, ref) <= FIR_TOL, (len(stages), R, mix)
+        pipe.close()
+
+
+def test_fused_stage_pair_equals_unfused_whole_buffer(pkg, dev, O, monkeypatch):
+    t = _torch()
+    h1, h2 = load_taps("c320_s1_d8_32"), load_taps("c320_s2_d8_64")
+    ns = 1 << 22
+    d_in = pkg.synth_lcg(6 * ns, 5150, 0, dev)
+    fused = pkg.Pipeline([(8, h1), (8, h2)], mix=True)
+    fused.set_center_freq(7.1e6)
+    assert fused.fused_pair(ns)
+    a = fused.process(d_in).clone()
+    a2 = fused.process(d_in).clone()
+    monkeypatch.setenv("PDDC_NO_FUSE2", "1")
+    plain = pkg.Pipeline([(8, h1), (8, h2)], mix=True)
+    plain.set_center_freq(7.1e6)
+    assert not plain.fused_pair(ns)
+    b = plain.process(d_in).clone()
+    b2 = plain.process(d_in).clone()
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) / scale <= 1e-6
+    assert float((a2 - b2).abs().max()) / scale <= 1e-6
+    fused.close()
+    plain.close()
