@@ -18,7 +18,8 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def pkg():
     p = importlib.import_module("libperseus-sdr_amd")
-    if not os.path.exists(p.DDC_LIB):
+    plumbing = os.path.join(os.path.dirname(p.SDR_LIB), "perseus_plumbing")
+    if not all(os.path.exists(f) for f in (p.DDC_LIB, p.SDR_LIB, plumbing)):
         p.build()
     return p
 

@@ -615,3 +615,28 @@ def test_fused_stage_pair_equals_unfused_whole_buffer(pkg, dev, O, monkeypatch):
     assert float((a2 - b2).abs().max()) / scale <= 1e-6
     fused.close()
     plain.close()
+
+
+# --------------------------------------------- randomized chunking (state machine)
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_chunking_is_equivalent_to_one_batch(pkg, dev, O, seed):
+    """Property: any split of the stream into batches (multiples of 8 samples)
+    gives the single-batch result, for integer, fused-pair and rational plans."""
+    rng = np.random.default_rng(seed)
+    h1, h2, h3 = load_taps("c320_s1_d8_32"), load_taps("c320_s2_d8_64"), load_taps("c320_s3_d5_161")
+    g = (rng.standard_normal(12 * 20) / 20).astype(np.float32)
+    plans = [[(8, load_taps("d8_127"))], [(8, h1), (8, h2), (5, h3)], [(8, h1), (5, h3[:41]), (25, g, 12)],
+             [(10, h3[:77])]]
+    ns = 8 * 4096 * 3 + 8 * int(rng.integers(1, 500))
+    packed = O.lcg_bytes(6 * ns, 1000 + seed)
+    for stages in plans:
+        ref = O.ddc_chain(packed, stages, freg=987654321, mix=True)
+        cuts = sorted(set([0, ns] + [8 * int(c) for c in rng.integers(1, ns // 8, size=6)] +
+                          [4096 * int(c) for c in rng.integers(1, ns // 4096, size=3)]))
+        pipe = pkg.Pipeline(stages, mix=True)
+        pipe.set_freg(987654321)
+        y = np.concatenate([pipe.process(to_dev(packed[6 * a:6 * b], dev)).cpu().numpy().reshape(-1)
+                            for a, b in zip(cuts[:-1], cuts[1:])])
+        assert y.size == ref.size, (seed, len(stages))
+        assert O.rel_err(y, ref) <= FIR_TOL, (seed, len(stages), cuts)
+        pipe.close()
