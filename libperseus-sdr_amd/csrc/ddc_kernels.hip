@@ -12,24 +12,35 @@
  *                The 8 B/sample float intermediate never touches HBM:
  *                algorithmic traffic 6 B in + 1 B out per input sample.
  *   k_fir_generic  any-D decimating FIR on float2 (later cascade stages).
- *   k_hist_update  carries the FIR history between batches.
+ *   k_resample     rational L/M polyphase resampler (non-integer rates).
+ *   k_pack24       float32 -> 24-bit packed (inverse of the unpack).
+ *   k_hist_update  carries the FIR history between batches (generic path).
  *   k_synth_lcg    device-side synthetic source.
  *
  * k_fir8 design (DESIGN.md "Kernels"):
- *   - block = 256 threads = 4 waves; tile = 1024*R input samples (+8*NTB halo)
+ *   - persistent grid (4 blocks per CU at R=4); a block = 256 threads = 4 waves
+ *     owns a contiguous run of tiles; tile = 1024*R input samples
  *   - load phase: every thread pulls whole 48-byte groups (8 samples) with
- *     3x global_load_dwordx4, unpacks in registers (v_bfe_i32 / v_alignbit),
+ *     3x global_load_dwordx4 one tile ahead (registers), unpacks with
+ *     v_perm_b32 / v_cvt_f32_i32 / one multiply (bit-exact with the reference),
  *     optionally mixes with the NCO, and writes PLANAR I / Q floats to LDS,
- *     rotated by one sample so that FIR windows are 16-byte aligned
+ *     rotated by one sample so that FIR windows are 16-byte aligned; the
+ *     last NTB groups of a tile stay in LDS as the next tile's history
  *   - FIR phase: waves 0,2 filter the I plane, waves 1,3 the Q plane; each
  *     lane owns R consecutive outputs (a register sliding window over
  *     R+NTB-1 aligned 8-sample LDS groups, 2x ds_read_b128 each, conflict
- *     free through a 4-float pad per lane segment); taps are wave-uniform and
- *     come through the scalar cache into SGPRs (s_load), so an FMA costs one
- *     VALU slot and no VGPR/LDS traffic for the coefficient
+ *     free through a 4-float pad every 8 groups); taps are wave-uniform and
+ *     come through the scalar cache into SGPR pairs (s_load), so a tap costs
+ *     no VGPR and no LDS traffic; the FMAs are PACKED (v_pk_fma_f32: every
+ *     VALU op costs ~4 clocks per wave64 on this chip and the packed form does
+ *     two FMAs in that slot), each output's dot product split into its even
+ *     and odd terms so both operands are natural adjacent pairs
  *   - store phase: results are transposed through LDS (XOR-swizzled 16-byte
- *     chunks) into interleaved float2 and leave as coalesced dwordx4 stores
- *   No MFMA: 9 flop/B, a memory-bound stream (BASELINE.json north_star).
+ *     chunks) into interleaved float2 and leave as coalesced nontemporal
+ *     dwordx4 stores, one tile late so they sit behind the next load wait
+ *   - optional fused second decimate-by-8 stage on the tile's outputs (NTB2)
+ *   No MFMA: 9 flop/B, a banded single-filter FIR would waste 2/3 of a matrix
+ *   op, and the stream is memory-bound (BASELINE.json north_star).
  */
 #include "ddc_kernels.h"
 

@@ -640,3 +640,42 @@ def test_random_chunking_is_equivalent_to_one_batch(pkg, dev, O, seed):
         assert y.size == ref.size, (seed, len(stages))
         assert O.rel_err(y, ref) <= FIR_TOL, (seed, len(stages), cuts)
         pipe.close()
+
+
+def test_perseus_api_ddc_mode_uses_fused_pair_with_default_style_batches(pkg, dev, O, monkeypatch):
+    """125 kS/s plan (8*8*10) with power-of-two batches: stages 0+1 run fused."""
+    import ctypes as C
+    import time
+    monkeypatch.setenv("PERSEUS_AMD_PACE", "0")
+    monkeypatch.delenv("PERSEUS_AMD_DEVICES", raising=False)
+    L = pkg.sdr_lib()
+    L.perseus_set_debug(0)
+    assert L.perseus_init() == 1
+    d = L.perseus_open(0)
+    L.perseus_firmware_download(d, None)
+    assert L.perseus_set_sampling_rate(d, 125000) == 0
+    assert L.perseus_set_ddc_center_freq(d, C.c_double(14.2e6), 1) == 0
+    cfg = pkg.AmdConfig()
+    L.perseus_amd_get_config(d, C.byref(cfg))
+    cfg.mode, cfg.pace, cfg.batch_samples, cfg.max_buffers = 1, 0, 1 << 18, 2
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    dec, nt = (C.c_int * 4)(), (C.c_int * 4)()
+    n = L.perseus_amd_get_plan(d, dec, nt, None)
+    assert list(dec)[:n] == [8, 8, 10] and nt[1] <= 64
+    taps = [np.zeros(nt[i], np.float32) for i in range(n)]
+    arr = (C.POINTER(C.c_float) * 4)(*([t.ctypes.data_as(C.POINTER(C.c_float)) for t in taps] + [None]))
+    L.perseus_amd_get_plan(d, dec, nt, arr)
+    got = []
+    cb = pkg.PERSEUS_CALLBACK(lambda b, nbytes, x: got.append(C.string_at(b, nbytes)) or 0)
+    assert L.perseus_start_async_input(d, 6144, cb, None) == 0, L.perseus_errorstr()
+    t0 = time.time()
+    while L.perseus_amd_source_running(d) and time.time() - t0 < 60:
+        time.sleep(0.005)
+    assert L.perseus_stop_async_input(d) == 0
+    L.perseus_exit()
+    y = np.frombuffer(b"".join(got), dtype=np.float32)
+    assert y.size == 2 * 2 * 768
+    need = (y.size // 2) * 640
+    ref = O.ddc_chain(O.lcg_bytes(6 * need, 12345), [(dec[i], taps[i]) for i in range(n)],
+                      freg=O.nco_freg(14.2e6), mix=True)
+    assert O.rel_err(y, ref[: y.size]) <= FIR_TOL
