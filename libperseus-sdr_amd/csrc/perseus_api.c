@@ -28,6 +28,7 @@
 #include <errno.h>
 #include <math.h>
 #include <pthread.h>
+#include <stdatomic.h>
 #include <string.h>
 #include <sys/time.h>
 #include <unistd.h>
@@ -75,23 +76,26 @@ struct perseus_descr_ds {
     uint8_t frontendctl;        /* atten_id<<4 | presel_id                       */
     uint8_t presel_flt_id;
     uint8_t sio_ctl;
-    uint32_t freg;
+    atomic_uint freg;           /* written by client threads, read by the delivery thread */
     double adc_clk_freq;
     int sample_rate;            /* selected table entry, 0 = none                */
     perseus_amd_config cfg;
     char file_path[1024];
     /* streaming state */
-    volatile int streaming;     /* transfer queue exists                         */
-    volatile int cancelling;
-    volatile int in_callback;
-    volatile int source_done;
+    /* flags shared between client threads and the delivery thread are atomics;
+     * everything else below is touched either before `streaming` is published
+     * or under pump_lock (ThreadSanitizer-clean, unlike the reference's
+     * volatile flags)                                              */
+    atomic_int streaming;       /* transfer queue exists                         */
+    atomic_int cancelling;
+    atomic_int source_done;
     perseus_input_callback cb;
     void *cb_extra;
     uint32_t buffersize;
     uint8_t *ring;              /* QUEUE_SIZE * buffersize                       */
     int idx;                    /* next ring slot                                */
     uint64_t seq;               /* transfers completed by the source             */
-    uint64_t delivered, dropped;
+    atomic_ullong delivered, dropped;
     unsigned long bytes_received;
     struct timeval t_start, t_stop;
     uint32_t lcg_state;
@@ -112,7 +116,7 @@ static perseus_descr g_list[MAX_DESCR];
 static int g_entries = 0;
 static pthread_t g_thread;
 static int g_thread_on = 0;
-static volatile int g_thread_stop = 0;
+static atomic_int g_thread_stop;
 
 /* ------------------------------------------------------------------------- */
 static double now_s(void)
@@ -296,9 +300,7 @@ static void deliver(perseus_descr *d, int full)
         d->bytes_received += d->buffersize;
         perseus_input_callback cb = d->cb;
         if (cb && !d->cancelling) {
-            d->in_callback = 1;
             cb(slot, (int)d->buffersize, d->cb_extra);
-            d->in_callback = 0;
             d->delivered++;
         }
     } else {
@@ -740,6 +742,8 @@ static void free_stream(perseus_descr *d)
     }
 }
 
+static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_callback cb, void *extra);
+
 int perseus_start_async_input(perseus_descr *d, uint32_t buffersize, perseus_input_callback cb, void *extra)
 {
     dbgprintf(3, "perseus_start_async_input(%p,%u,...)", (void *)d, buffersize);
@@ -754,6 +758,14 @@ int perseus_start_async_input(perseus_descr *d, uint32_t buffersize, perseus_inp
         return errorset(PERSEUS_BUFFERSIZE,
                         "buffer size should be an integer multiple of 6144 bytes (1024 I/Q samples)");
 
+    pthread_mutex_lock(&d->pump_lock);      /* the delivery thread reads these fields under the same lock */
+    const int rc_start = start_locked(d, buffersize, cb, extra);
+    pthread_mutex_unlock(&d->pump_lock);
+    return rc_start;
+}
+
+static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_callback cb, void *extra)
+{
     d->ring = (uint8_t *)malloc((size_t)QUEUE_SIZE * buffersize);
     if (!d->ring)
         return errorset(PERSEUS_NOMEM, "can't allocate the transfer buffers");
@@ -817,7 +829,6 @@ int perseus_start_async_input(perseus_descr *d, uint32_t buffersize, perseus_inp
     d->cancelling = 0;
     gettimeofday(&d->t_start, NULL);
     d->sio_ctl |= SIO_FIFOEN;
-    __sync_synchronize();
     d->streaming = 1;
     return errornone(0);
 }
@@ -830,15 +841,14 @@ int perseus_stop_async_input(perseus_descr *d)
     if (!d->streaming)
         return errorset(PERSEUS_ASYNCSTARTED, "async input not started");
     d->cancelling = 1;
-    d->cb = NULL;
     gettimeofday(&d->t_stop, NULL);
-    __sync_synchronize();
     /* the delivery thread holds pump_lock while it fills a buffer or runs this
      * descriptor's callback: once we own it no callback is in flight, and with
      * `cancelling` set none can start (reference perseus-sdr.c:709-716) */
     const int on_worker = g_thread_on && pthread_equal(pthread_self(), g_thread);
     if (!on_worker)
         pthread_mutex_lock(&d->pump_lock);
+    d->cb = NULL;
     d->streaming = 0;
     const double elapsed = 1e-6 * (d->t_stop.tv_usec - d->t_start.tv_usec) + (d->t_stop.tv_sec - d->t_start.tv_sec);
     dbgprintf(3, "Elapsed time: %f s - kSamples read: %ld - Rate: %.1f kS/s\n", elapsed,

@@ -26,6 +26,7 @@
 
 #include <fcntl.h>
 #include <pthread.h>
+#include <stdatomic.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -85,7 +86,7 @@ static int on_buffer_float(void *buf, int buf_size, void *extra)
 }
 
 static perseus_descr *g_descr;
-static volatile int g_quit;
+static atomic_int g_quit;
 
 static void *fifo_thread(void *arg)
 {
