@@ -55,7 +55,8 @@ extern "C" {
 
 #define PDDC_ADC_CLK_HZ        80000000.0   /* perseus-sdr.h:44 */
 #define PDDC_MAX_STAGES        4
-#define PDDC_MAX_TAPS          4096
+#define PDDC_MAX_TAPS          4096         /* rational (interp > 1) stages       */
+#define PDDC_MAX_TAPS_DECIM    1024         /* plain decimators                   */
 #define PDDC_FAST_MAX_TAPS     256          /* fused decimate-by-8 kernel      */
 #define PDDC_PACKED_BYTES      6
 #define PDDC_INPUT_GRANULE     8            /* process(): nsamples % 8 == 0    */
@@ -71,7 +72,7 @@ typedef struct pddc_pipeline pddc_pipeline;
 
 typedef struct {
     int          decim;    /* decimation factor D (M of a rational L/M stage), >= 1 */
-    int          ntaps;    /* 1 .. PDDC_MAX_TAPS                               */
+    int          ntaps;    /* 1 .. PDDC_MAX_TAPS_DECIM (PDDC_MAX_TAPS if interp > 1) */
     const float *taps;     /* h[0..ntaps-1], host memory, copied               */
     int          interp;   /* 0 or 1: plain decimator.  L > 1: rational resampler
                               y[m] = sum_j h[j*L + (m*D mod L)] * x[floor(m*D/L) - j]
@@ -129,7 +130,10 @@ int pddc_pipeline_uses_fused_pair(const pddc_pipeline *p, size_t nsamples);
  * d_out_f32 (16-byte aligned, capacity in complex samples; with
  * PDDC_F_OUT_PACKED24 it receives 6 bytes per sample instead of 8).  Asynchronous on
  * `stream`; *n_out (host) is written before return (it depends only on sizes).
- * Stream state (FIR history, phase, NCO counter) advances by nsamples.        */
+ * Stream state (FIR history, phase, NCO counter) advances by nsamples.  The state
+ * lives in device memory ordered by `stream`: use ONE stream per pipeline, and do
+ * not mix process() and push_host() (which runs on the pipeline's own stream)
+ * without a synchronisation in between.                                        */
 int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsamples,
                           void *d_out_f32, size_t out_capacity, size_t *n_out, void *stream);
 /* Host batch: H2D copy, process, D2H copy, synchronous.                        */

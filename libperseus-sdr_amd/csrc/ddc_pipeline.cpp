@@ -304,8 +304,9 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
             return fail(PDDC_EINVAL, "stage %d: bad decimation %d", i, stages[i].decim);
         if (stages[i].interp < 0 || stages[i].interp > 256)
             return fail(PDDC_EINVAL, "stage %d: bad interpolation %d", i, stages[i].interp);
-        if (stages[i].ntaps < 1 || stages[i].ntaps > PDDC_MAX_TAPS || !stages[i].taps)
-            return fail(PDDC_EINVAL, "stage %d: ntaps must be 1..%d", i, PDDC_MAX_TAPS);
+        const int max_taps = stages[i].interp > 1 ? PDDC_MAX_TAPS : PDDC_MAX_TAPS_DECIM;
+        if (stages[i].ntaps < 1 || stages[i].ntaps > max_taps || !stages[i].taps)
+            return fail(PDDC_EINVAL, "stage %d: ntaps must be 1..%d", i, max_taps);
     }
     int rc = require_device();
     if (rc)

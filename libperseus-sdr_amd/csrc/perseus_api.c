@@ -228,8 +228,8 @@ static int plan_build(ddc_plan *p, int rate)
                 if (n > PDDC_FAST_MAX_TAPS)
                     n = PDDC_FAST_MAX_TAPS;
             }
-            if (n > PDDC_MAX_TAPS)
-                n = PDDC_MAX_TAPS / L * L;
+            if (n > (L > 1 ? PDDC_MAX_TAPS : PDDC_MAX_TAPS_DECIM))
+                n = (L > 1 ? PDDC_MAX_TAPS : PDDC_MAX_TAPS_DECIM) / L * L;
             p->decim[i] = D;
             p->interp[i] = L;
             p->ntaps[i] = n;
