@@ -851,8 +851,11 @@ int perseus_stop_async_input(perseus_descr *d)
     d->cb = NULL;
     d->streaming = 0;
     const double elapsed = 1e-6 * (d->t_stop.tv_usec - d->t_start.tv_usec) + (d->t_stop.tv_sec - d->t_start.tv_sec);
+    /* same line as the reference (perseus-sdr.c:719-722); a sample is 6 bytes on
+     * the wire, 8 bytes in float32 DDC mode */
+    const double per_ksample = (d->cfg.mode == PERSEUS_AMD_MODE_DDC ? 8.0 : 6.0) * 1000.0;
     dbgprintf(3, "Elapsed time: %f s - kSamples read: %ld - Rate: %.1f kS/s\n", elapsed,
-              (long)(d->bytes_received / 6000), elapsed > 0 ? 1.0 * d->bytes_received / elapsed / 6000 : 0.0);
+              (long)(d->bytes_received / per_ksample), elapsed > 0 ? d->bytes_received / elapsed / per_ksample : 0.0);
     free_stream(d);
     d->sio_ctl &= (uint8_t)~SIO_FIFOEN;
     d->cancelling = 0;
