@@ -38,7 +38,6 @@ constexpr int fir8_tile_inputs(int R) { return 1024 * R; }
 size_t fir8_lds_bytes(int ntb, int R);
 bool   fir8_supported(int ntb, int R);
 void   fir8_set_grid_blocks(int nblocks);   /* persistent grid override (0 = resident blocks x CUs) */
-void   fir8_set_prefetch_depth(int d);      /* 1 or 2 tiles of loads in flight per block */
 
 /* packed -> [mix] -> /8 -> /8 in one kernel: `out` receives the SECOND stage's
  * outputs (n_in/64); n_in must be a multiple of the tile (1024*R samples) */

@@ -390,7 +390,7 @@ __device__ __forceinline__ void fir_window(const float *base, const float PDDC_C
  *              C  the last NTB groups become tile t+1's history (copied by
  *                 the very threads that overwrite them in the next U, so no
  *                 third barrier is needed).                                */
-template <int NTB, int R, int INFMT, bool MIX, int PFD, int NTB2>
+template <int NTB, int R, int INFMT, bool MIX, int NTB2>
 __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int tiles_per_block, int ntiles)
 {
     using G = Fir8Geom<NTB, R>;
@@ -446,34 +446,17 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         group_to_lds<R>(sI, sQ, tid, xi, xq);
     }
 
-    /* PFD register sets of prefetched input: tile t+PFD is requested while tile t
-     * is filtered.  With PFD=2 the loads are issued from inline asm and waited for
-     * with hand-counted s_waitcnt vmcnt(N): hipcc's own bookkeeping collapses to
-     * vmcnt(0) for loads carried around the loop, which would wait for the
-     * YOUNGER tile too and turn depth 2 back into depth 1.                       */
-    constexpr bool ASML = (PFD == 2) && (INFMT == IN_PACKED24);
+    /* one tile of prefetched input in registers: tile t+1 is requested while tile t
+     * is filtered.  (A second tile in flight was measured no faster; it needs asm
+     * loads with hand-counted vmcnt because hipcc waits vmcnt(0) for loop-carried
+     * loads, and that form is fragile under register pressure -- DESIGN.md 5.)   */
     using RawSet = u32x4[G::GPT][NW];
-    u32x4 rawA[G::GPT][NW], rawB[PFD > 1 ? G::GPT : 1][NW];
+    u32x4 rawA[G::GPT][NW];
     auto prefetch = [&](int tile, RawSet &raw) {
         const long long tin0 = (long long)tile * G::TI;
         const u32x4 *src0 = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(p.in) +
                                                             (tin0 + 8LL * gtid) * ES);
-        if (ASML) {
-            /* asm loads, full and ragged tiles alike (a ragged tile clamps the
-             * pointer of its out-of-range groups to the tile's first group and
-             * zeroes them after the wait): no compiler-tracked load may be pending
-             * on these registers, or hipcc adds its own vmcnt(0) in front of ours  */
-            const bool full = tin0 + G::TI <= p.n_in;
-#pragma unroll
-            for (int k = 0; k < G::GPT; ++k) {
-                const u32x4 *sk = src0 + (256 * k * 8 * ES) / 16;
-                if (!full && !(tin0 + 8LL * (gtid + 256 * k) < p.n_in))
-                    sk = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(p.in) + tin0 * ES);
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[k][0]) : "v"(sk) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(raw[k][1]) : "v"(sk) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(raw[k][2]) : "v"(sk) : "memory");
-            }
-        } else if (tin0 + G::TI <= p.n_in) {                  /* whole tile in range (wave-uniform) */
+        if (tin0 + G::TI <= p.n_in) {                         /* whole tile in range (wave-uniform) */
 #pragma unroll
             for (int k = 0; k < G::GPT; ++k)
 #pragma unroll
@@ -489,24 +472,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
             }
         }
     };
-    /* hand-counted wait for an asm-loaded register set: at most `younger` newer
-     * vector-memory operations may stay outstanding (they retire in issue order).
-     * The empty asm statements make every later use of the registers depend on
-     * the wait.                                                                  */
-    auto wait_set = [&](RawSet &raw, bool younger_tile_in_flight) {
-        if (younger_tile_in_flight)
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G::GPT * NW) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-#pragma unroll
-        for (int k = 0; k < G::GPT; ++k)
-#pragma unroll
-            for (int w = 0; w < NW; ++w)
-                asm volatile("" : "+v"(raw[k][w]));
-    };
     prefetch(t0, rawA);
-    if (PFD > 1 && t0 + 1 < t1)
-        prefetch(t0 + 1, reinterpret_cast<RawSet &>(rawB));
 
     const int wave  = __builtin_amdgcn_readfirstlane(tid >> 6);   /* provably wave-uniform */
     const int lane  = tid & 63;
@@ -571,18 +537,6 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
 
     auto tile_body = [&](int t, RawSet &raw) {
         /* ---- U: registers -> LDS planes (groups NTB ..) ------------------- */
-        if (ASML) {
-            wait_set(raw, t + 1 < t1);
-            const long long tin0 = (long long)t * G::TI;
-            if (tin0 + G::TI > p.n_in) {                /* ragged tile: drop the clamped groups */
-#pragma unroll
-                for (int k = 0; k < G::GPT; ++k)
-                    if (!(tin0 + 8LL * (gtid + 256 * k) < p.n_in))
-#pragma unroll
-                        for (int w = 0; w < NW; ++w)
-                            raw[k][w] = u32x4{ 0u, 0u, 0u, 0u };
-            }
-        }
 #pragma unroll
         for (int k = 0; k < G::GPT; ++k) {
             const int v = NTB + gtid + 256 * k;
@@ -603,8 +557,8 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
             store_tile2(t - 1);
 
         /* ---- P: next tile's loads --------------------------------------- */
-        if (t + PFD < t1)
-            prefetch(t + PFD, raw);
+        if (t + 1 < t1)
+            prefetch(t + 1, raw);
 
         /* ---- F: FIR ------------------------------------------------------ */
         /* Packed fp32: every VALU op costs ~4 cycles per wave64 on gfx950, and
@@ -695,16 +649,8 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         }
     };
 
-    if (PFD == 1) {
-        for (int t = t0; t < t1; ++t)
-            tile_body(t, rawA);
-    } else {
-        for (int t = t0; t < t1; t += 2) {
-            tile_body(t, rawA);
-            if (t + 1 < t1)
-                tile_body(t + 1, reinterpret_cast<RawSet &>(rawB));
-        }
-    }
+    for (int t = t0; t < t1; ++t)
+        tile_body(t, rawA);
     if (FUSE2) {
         __syncthreads();                 /* ot2 and the stage-2 planes of the last tile are complete */
         store_tile2(t1 - 1);
@@ -734,7 +680,6 @@ bool fir8_supported(int ntb, int R)
     return (R == 4 || R == 8) && (ntb == 4 || ntb == 8 || ntb == 16 || ntb == 32);
 }
 
-static int g_fir8_pfd = 1;          /* prefetch depth in tiles (1 or 2); 2 measured no faster */
 static int g_fir8_blocks = 0;       /* persistent grid override (0 = resident blocks per CU x 256 CUs) */
 
 template <int NTB, int R>
@@ -752,30 +697,28 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
     const int tpb = (ntiles + want - 1) / want;
     const int nblocks = (ntiles + tpb - 1) / tpb;
     const dim3 grid((unsigned)nblocks), blk(256);
-#define PDDC_LAUNCH(FMT, MIXV, PF)                                                                \
+#define PDDC_LAUNCH(FMT, MIXV)                                                                    \
     do {                                                                                          \
         static unsigned long long attr_done = 0;   /* one bit per device: the attribute is per device */ \
         int dev__ = 0;                                                                            \
         (void)hipGetDevice(&dev__);                                                               \
         if (!(attr_done >> (dev__ & 63) & 1ull)) {                                                \
             hipError_t e = hipFuncSetAttribute(                                                   \
-                reinterpret_cast<const void *>(&k_fir8<NTB, R, FMT, MIXV, PF, 0>),                \
+                reinterpret_cast<const void *>(&k_fir8<NTB, R, FMT, MIXV, 0>),                    \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
             if (e != hipSuccess)                                                                  \
                 return e;                                                                         \
             attr_done |= 1ull << (dev__ & 63);                                                    \
         }                                                                                         \
-        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV, PF, 0>), grid, blk, lds, s, a, tpb, ntiles); \
+        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV, 0>), grid, blk, lds, s, a, tpb, ntiles);    \
     } while (0)
-    const bool pf2 = g_fir8_pfd > 1;
     if (fmt == IN_PACKED24) {
-        if (mix) {
-            if (pf2) PDDC_LAUNCH(IN_PACKED24, true, 2); else PDDC_LAUNCH(IN_PACKED24, true, 1);
-        } else {
-            if (pf2) PDDC_LAUNCH(IN_PACKED24, false, 2); else PDDC_LAUNCH(IN_PACKED24, false, 1);
-        }
+        if (mix)
+            PDDC_LAUNCH(IN_PACKED24, true);
+        else
+            PDDC_LAUNCH(IN_PACKED24, false);
     } else {
-        PDDC_LAUNCH(IN_F32C, false, 1);
+        PDDC_LAUNCH(IN_F32C, false);
     }
 #undef PDDC_LAUNCH
     return hipGetLastError();
@@ -805,13 +748,13 @@ static hipError_t launch_fir8_fused2_t(bool mix, const Fir8Args &a, hipStream_t 
         (void)hipGetDevice(&dev__);                                                               \
         if (!(attr_done >> (dev__ & 63) & 1ull)) {                                                \
             hipError_t e = hipFuncSetAttribute(                                                   \
-                reinterpret_cast<const void *>(&k_fir8<NTB, R, IN_PACKED24, MIXV, 1, 8>),         \
+                reinterpret_cast<const void *>(&k_fir8<NTB, R, IN_PACKED24, MIXV, 8>),            \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
             if (e != hipSuccess)                                                                  \
                 return e;                                                                         \
             attr_done |= 1ull << (dev__ & 63);                                                    \
         }                                                                                         \
-        hipLaunchKernelGGL((k_fir8<NTB, R, IN_PACKED24, MIXV, 1, 8>), grid, blk, lds, s, a, tpb,  \
+        hipLaunchKernelGGL((k_fir8<NTB, R, IN_PACKED24, MIXV, 8>), grid, blk, lds, s, a, tpb,     \
                            ntiles);                                                               \
     } while (0)
     if (mix)
@@ -837,7 +780,6 @@ hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipSt
 }
 
 void fir8_set_grid_blocks(int nblocks) { g_fir8_blocks = nblocks > 0 ? nblocks : 0; }
-void fir8_set_prefetch_depth(int d) { g_fir8_pfd = d >= 2 ? 2 : 1; }
 
 hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s)
 {

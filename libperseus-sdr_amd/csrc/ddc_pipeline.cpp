@@ -328,8 +328,6 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
             p->R = atoi(e);
     if (const char *e = getenv("PDDC_FIR8_BLOCKS"))
         fir8_set_grid_blocks(atoi(e));
-    if (const char *e = getenv("PDDC_FIR8_PFD"))
-        fir8_set_prefetch_depth(atoi(e));
     for (int i = 0; i < nstages; ++i) {
         Stage &s = p->st[i];
         s.decim = stages[i].decim;

@@ -489,24 +489,6 @@ def test_long_tile_runs_per_block_all_variants(pkg, dev, O, monkeypatch):
             pipe.close()
 
 
-def test_prefetch_depth_two_is_bit_identical(pkg, dev, O, monkeypatch):
-    """The asm-load / hand-counted-vmcnt variant must reproduce the default build
-    bit for bit on a buffer large enough that a stale register would show."""
-    t = _torch()
-    h = load_taps("d8_127")
-    ns = 1 << 24
-    d_in = pkg.synth_lcg(6 * ns, 99, 0, dev)
-    outs = []
-    for pfd in ("1", "2"):
-        monkeypatch.setenv("PDDC_FIR8_PFD", pfd)
-        pipe = pkg.Pipeline([(8, h)])
-        outs.append(pipe.process(d_in).clone())
-        pipe.close()
-    assert t.equal(outs[0], outs[1])
-    monkeypatch.setenv("PDDC_FIR8_PFD", "1")
-    pkg.Pipeline([(8, h)]).close()                             # restore the process-wide default
-
-
 def test_set_taps_reset_and_tiny_batches(pkg, dev, O):
     h = load_taps("d8_127")
     g = (np.arange(100, dtype=np.float32) - 50) / 5000
