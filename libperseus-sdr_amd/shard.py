@@ -70,6 +70,17 @@ def barrier():
         dist.barrier()
 
 
+def gather_to_root_async(mine: torch.Tensor, bufs=None, dst: int = 0):
+    """Start the gather and return a work handle (None without a process group):
+    the transfer of batch k then overlaps the kernels of batch k+1, which write a
+    different output buffer.  Call .wait() before `mine` is overwritten."""
+    if not is_dist():
+        return None
+    if dist.get_rank() == dst:
+        return dist.gather(mine, bufs, dst=dst, async_op=True)
+    return dist.gather(mine, None, dst=dst, async_op=True)
+
+
 def gather_to_root(mine: torch.Tensor, bufs=None, dst: int = 0):
     """Gather each rank's decimated output on rank `dst` (direct peer->root
     transfers: all 7 xGMI links of the root are used).  Returns the
