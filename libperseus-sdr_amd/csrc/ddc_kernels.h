@@ -44,9 +44,6 @@ void   fir8_set_grid_blocks(int nblocks);   /* persistent grid override (0 = res
 bool fir8_fused2_supported(int ntb, int ntb2, int R);
 hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipStream_t s);
 
-/* producer/consumer-wave variant of the packed decimate-by-8 kernel (R = 4) */
-hipError_t launch_fir8s(int ntb, bool mix, const Fir8Args &a, hipStream_t s);
-
 /* returns hipSuccess or the launch error */
 hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s);
 

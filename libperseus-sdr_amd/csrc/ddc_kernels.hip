@@ -786,216 +786,6 @@ hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipSt
     return hipErrorInvalidValue;
 }
 
-/* ======================================================================== */
-/* k_fir8s : the same tile pipeline with producer / consumer waves          */
-/* ======================================================================== */
-/* 512 threads: waves 0-3 load + unpack tile t+1 into one LDS plane set while
- * waves 4-7 filter tile t out of the other; one barrier per tile.  The load
- * stream no longer waits for the FIR of the same waves.  R = 4 geometry.     */
-template <int NTB, bool MIX>
-__global__ __launch_bounds__(512, 2) void k_fir8s(Fir8Args p, int tiles_per_block, int ntiles)
-{
-    constexpr int R = 4;
-    using G = Fir8Geom<NTB, R>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int SET = 2 * G::PLANE;                 /* floats per plane set (I + Q)      */
-    float *ots = smem + 2 * SET;                      /* two staging areas of OT floats    */
-    constexpr int NW = 3, ES = 6;
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wave < 4;
-    const int t0 = blockIdx.x * tiles_per_block;
-    const int t1 = min(t0 + tiles_per_block, ntiles);
-    if (t0 >= t1)
-        return;
-    const long long n_out = p.n_in >> 3;
-
-    /* ---------------- producer state ---------------- */
-    const int ptid = tid & 255;
-    const int gtid = (ptid & ~12) | ((ptid & 4) << 1) | ((ptid & 8) >> 1);
-    using RawSet = u32x4[G::GPT][NW];
-    u32x4 raw[G::GPT][NW];
-    auto prefetch = [&](int tile) {
-        const long long tin0 = (long long)tile * G::TI;
-        const u32x4 *src0 = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(p.in) +
-                                                            (tin0 + 8LL * gtid) * ES);
-        if (tin0 + G::TI <= p.n_in) {
-#pragma unroll
-            for (int k = 0; k < G::GPT; ++k)
-#pragma unroll
-                for (int w = 0; w < NW; ++w)
-                    raw[k][w] = src0[(256 * k * 8 * ES) / 16 + w];
-        } else {
-#pragma unroll
-            for (int k = 0; k < G::GPT; ++k) {
-                const bool have = tin0 + 8LL * (gtid + 256 * k) < p.n_in;
-#pragma unroll
-                for (int w = 0; w < NW; ++w)
-                    raw[k][w] = have ? src0[(256 * k * 8 * ES) / 16 + w] : u32x4{ 0u, 0u, 0u, 0u };
-            }
-        }
-    };
-    auto unpack_tile = [&](int tile, float *sI, float *sQ) {
-#pragma unroll
-        for (int k = 0; k < G::GPT; ++k) {
-            float xi[8], xq[8];
-            group_to_float<IN_PACKED24, MIX, NW>(raw[k], xi, xq,
-                                                 p.n0 + (unsigned long long)((long long)tile * G::TI + 8LL * (gtid + 256 * k)), p);
-            group_to_lds<R>(sI, sQ, NTB + gtid + 256 * k, xi, xq);
-        }
-    };
-
-    /* ---------------- consumer state ---------------- */
-    const int cw = wave & 3, lane = tid & 63;
-    const int plane = cw & 1, par = cw >> 1;
-    const int L = 2 * lane + par;
-    const int boff = (plane ? G::PLANE : 0) + 8 + 8 * R * L + 4 * ((R * L) >> 3);
-    const float PDDC_CONSTANT *hb = (const float PDDC_CONSTANT *)p.taps_blk;
-    auto store_tile = [&](int tile, const float *ot) {           /* consumers: 256 chunks, one each */
-        const long long tile_o0 = (long long)tile * G::TO;
-        const int q = tid & 255;
-        const int qs = q ^ ((q >> 3) & 7);
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(ot + 4 * qs);
-        const long long m = tile_o0 + 2LL * q;
-        float *dstp = p.out + 2 * m;
-        if (m + 1 < n_out)
-            asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dstp), "v"(v) : "memory");
-        else if (m < n_out)
-            *reinterpret_cast<float2 *>(dstp) = make_float2(v.x, v.y);
-    };
-
-    /* ---------------- prologue: tile t0 into set 0 ---------------- */
-    if (producer) {
-        if (ptid < NTB) {
-            const long long s_abs = (long long)t0 * G::TI + 8LL * ptid - 8 * NTB;
-            const uint8_t *src = (s_abs < 0) ? static_cast<const uint8_t *>(p.hist) + (s_abs + 8 * NTB) * ES
-                                             : static_cast<const uint8_t *>(p.in) + s_abs * ES;
-            u32x4 hraw[NW];
-#pragma unroll
-            for (int k = 0; k < NW; ++k)
-                hraw[k] = (s_abs < p.n_in) ? reinterpret_cast<const u32x4 *>(src)[k] : u32x4{ 0u, 0u, 0u, 0u };
-            float xi[8], xq[8];
-            group_to_float<IN_PACKED24, MIX, NW>(hraw, xi, xq, p.n0 + (unsigned long long)s_abs, p);
-            group_to_lds<R>(smem, smem + G::PLANE, ptid, xi, xq);
-        }
-        prefetch(t0);
-        unpack_tile(t0, smem, smem + G::PLANE);
-        if (t0 + 1 < t1)
-            prefetch(t0 + 1);
-    }
-    __syncthreads();
-
-    for (int t = t0; t < t1; ++t) {
-        const int cur = (t - t0) & 1;
-        float *cI = smem + cur * SET, *cQ = cI + G::PLANE;
-        float *nI = smem + (cur ^ 1) * SET, *nQ = nI + G::PLANE;
-        if (producer) {
-            if (t + 1 < t1) {
-                /* history of tile t+1 = the last NTB groups of tile t (written one
-                 * iteration ago by these same waves), then the prefetched groups */
-                if (gtid >= 256 - NTB) {
-                    const int gd = gtid - (256 - NTB);
-                    const int os = goff<R>(G::GT + gd), od = goff<R>(gd);
-                    const float4 i0 = *reinterpret_cast<const float4 *>(cI + os);
-                    const float4 i1 = *reinterpret_cast<const float4 *>(cI + os + 4);
-                    const float4 q0 = *reinterpret_cast<const float4 *>(cQ + os);
-                    const float4 q1 = *reinterpret_cast<const float4 *>(cQ + os + 4);
-                    *reinterpret_cast<float4 *>(nI + od) = i0;
-                    *reinterpret_cast<float4 *>(nQ + od) = q0;
-                    *reinterpret_cast<float2 *>(nI + od + 4) = make_float2(i1.x, i1.y);
-                    *reinterpret_cast<float2 *>(nQ + od + 4) = make_float2(q1.x, q1.y);
-                    nI[od + 6] = i1.z;
-                    nQ[od + 6] = q1.z;
-                    if (gd != NTB - 1) {
-                        nI[od + 7] = i1.w;
-                        nQ[od + 7] = q1.w;
-                    }
-                }
-                unpack_tile(t + 1, nI, nQ);
-                if (t + 2 < t1)
-                    prefetch(t + 2);
-            }
-        } else {
-            if (t > t0)
-                store_tile(t - 1, ots + ((cur ^ 1) ? G::OT : 0));
-            asm volatile("" : "+s"(hb));
-            f32x2 acc[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                acc[r] = f32x2{ 0.0f, 0.0f };
-            if (par)
-                fir_window<NTB, R, 1>(cI + boff, hb, acc);
-            else
-                fir_window<NTB, R, 0>(cI + boff, hb, acc);
-            float *ot = ots + (cur ? G::OT : 0);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int f = 2 * (R * L + r) + plane;
-                const int q = f >> 2;
-                const int qs = q ^ ((q >> 3) & 7);
-                ot[4 * qs + (f & 3)] = acc[r].x + acc[r].y;
-            }
-        }
-        __syncthreads();
-    }
-    if (!producer)
-        store_tile(t1 - 1, ots + (((t1 - 1 - t0) & 1) ? G::OT : 0));
-    if (producer && p.hist_out != nullptr && t1 == ntiles && p.n_in >= 8 * NTB) {
-        constexpr int HCH = 8 * NTB * ES / 16;
-        const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(p.in) +
-                                                           (p.n_in - 8 * NTB) * ES);
-        for (int c = ptid; c < HCH; c += 256)
-            static_cast<uint4 *>(p.hist_out)[c] = src[c];
-    }
-}
-
-template <int NTB>
-static hipError_t launch_fir8s_t(bool mix, const Fir8Args &a, hipStream_t s)
-{
-    using G = Fir8Geom<NTB, 4>;
-    const size_t lds = (size_t)(4 * G::PLANE + 2 * G::OT) * sizeof(float);
-    const long long ntiles_ll = (a.n_in + G::TI - 1) / G::TI;
-    if (ntiles_ll <= 0)
-        return hipSuccess;
-    if (ntiles_ll > 0x7fffffffLL)
-        return hipErrorInvalidValue;
-    const int ntiles = (int)ntiles_ll;
-    const int want = g_fir8_blocks > 0 ? g_fir8_blocks : kFir8DefaultBlocks;
-    const int tpb = (ntiles + want - 1) / want;
-    const int nblocks = (ntiles + tpb - 1) / tpb;
-    const dim3 grid((unsigned)nblocks), blk(512);
-#define PDDC_LAUNCHS(MIXV)                                                                        \
-    do {                                                                                          \
-        static unsigned long long attr_done = 0;                                                  \
-        int dev__ = 0;                                                                            \
-        (void)hipGetDevice(&dev__);                                                               \
-        if (!(attr_done >> (dev__ & 63) & 1ull)) {                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir8s<NTB, MIXV>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess)                                                                  \
-                return e;                                                                         \
-            attr_done |= 1ull << (dev__ & 63);                                                    \
-        }                                                                                         \
-        hipLaunchKernelGGL((k_fir8s<NTB, MIXV>), grid, blk, lds, s, a, tpb, ntiles);              \
-    } while (0)
-    if (mix)
-        PDDC_LAUNCHS(true);
-    else
-        PDDC_LAUNCHS(false);
-#undef PDDC_LAUNCHS
-    return hipGetLastError();
-}
-
-hipError_t launch_fir8s(int ntb, bool mix, const Fir8Args &a, hipStream_t s)
-{
-    if (ntb == 4) return launch_fir8s_t<4>(mix, a, s);
-    if (ntb == 8) return launch_fir8s_t<8>(mix, a, s);
-    if (ntb == 16) return launch_fir8s_t<16>(mix, a, s);
-    if (ntb == 32) return launch_fir8s_t<32>(mix, a, s);
-    return hipErrorInvalidValue;
-}
-
 void fir8_set_grid_blocks(int nblocks) { g_fir8_blocks = nblocks > 0 ? nblocks : 0; }
 
 hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s)

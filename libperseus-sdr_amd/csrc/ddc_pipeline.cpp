@@ -672,10 +672,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             a.taps_blk = st.d_taps_blk;
             a.n_in = (long long)nsamples;
             fill_fir8_args(p, a);
-            if (getenv("PDDC_FIR8_SPEC"))
-                HIP_TRY(launch_fir8s(st.ntb, mix, a, s));
-            else
-                HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s));
+            HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s));
             hist_done = a.hist_out != nullptr;
         } else {
             if (i == 0) {
@@ -811,8 +808,6 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     for (int i = 0; i < iters; ++i) {
         if (fuse2)
             HIP_TRY(launch_fir8_fused2(p->st[0].ntb, p->R, mix, a, s));
-        else if (getenv("PDDC_FIR8_SPEC"))
-            HIP_TRY(launch_fir8s(p->st[0].ntb, mix, a, s));
         else
             HIP_TRY(launch_fir8(p->st[0].ntb, p->R, IN_PACKED24, mix, a, s));
     }
