@@ -16,6 +16,7 @@
  *   PERSEUS_AMD_BATCH     ddc mode: ADC-rate samples per GPU batch (default 2^22)
  *   PERSEUS_AMD_DROP      fault injection: every k-th transfer completes short
  *                         and is dropped like perseus-in.c:209-216 (default 0 = never)
+ *   PERSEUS_AMD_MAX_BUFFERS  the source ends after this many transfers (default 0 = unbounded)
  */
 #ifndef PERSEUS_AMD_EXT_H
 #define PERSEUS_AMD_EXT_H

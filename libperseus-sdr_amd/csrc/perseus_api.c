@@ -440,6 +440,8 @@ static void default_config(perseus_descr *d)
         d->cfg.batch_samples = (uint32_t)(atol(e) / 8 * 8);
     if ((e = getenv("PERSEUS_AMD_DROP")))
         d->cfg.drop_every = atoi(e);
+    if ((e = getenv("PERSEUS_AMD_MAX_BUFFERS")))
+        d->cfg.max_buffers = strtoull(e, NULL, 0);
 }
 
 int perseus_init(void)

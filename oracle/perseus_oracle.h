@@ -8,13 +8,18 @@
  *
  * Parity status (see DESIGN.md "Oracle"):
  *   - 24-bit unpack (orc_unpack24_f32 / orc_unpack24_i32): restates
- *     examples/perseustest.c:411-502 of the reference.  The reference cannot
- *     be compiled in this image (perseus-sdr.h:35 includes
- *     <libusb-1.0/libusb.h>, which is absent, and stand-in headers are not
- *     allowed), so oracle/_ref is not built.  The restatement is pinned
- *     against the reference outputs recorded in SURVEY.md 8c (known-answer
- *     table, exhaustive 2^24 SHA-256, LCG buffer SHA-256) -- see
- *     tests/golden/unpack_golden.json.
+ *     examples/perseustest.c:411-502 of the reference.  PINNED against the
+ *     reference itself run on this machine: oracle/_ref/perseustest_ref is the
+ *     reference's example client compiled from /root/reference/examples as it
+ *     lies (oracle/Makefile, target `ref`) against this repository's drop-in
+ *     header and library -- the reference's libusb dependency is exactly what
+ *     that library replaces, so no stand-in header or library is involved.
+ *     tests/test_reference_client.py runs it: the bytes its callbacks write
+ *     (float and int32) equal this oracle's for the LCG stream and for the
+ *     exhaustive 2^24 vector (SHA-256 7e5c094b...2884, also the value SURVEY.md
+ *     8c recorded).  The library core itself (perseus-sdr.c etc.) still cannot
+ *     be built here (needs <libusb-1.0/libusb.h>), which is fine: it holds no
+ *     sample arithmetic.
  *   - NCO tuning word / nearest-rate / preselector id: restate the one-line
  *     formulas at perseus-sdr.c:584, :776-811, :589-615; pinned by the KATs
  *     in SURVEY.md 4.
