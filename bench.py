@@ -64,6 +64,21 @@ def cpu_baseline(workload, seconds):
     from oracle import oracle as O
     O.build()
     threads = O.max_threads()
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "perseustest_ref")
+    if workload == "unpack" and os.path.exists(ref_bin):
+        # the reference's own client (compiled from its sources, oracle/Makefile `ref`):
+        # user_data_callback_c_f with its per-sample fwrite, fed unpaced by the drop-in library
+        import re
+        import subprocess
+        env = dict(os.environ, PERSEUS_AMD_PACE="0", PERSEUS_AMD_SOURCE="zero", PERSEUS_AMD_MODE="wire")
+        t = max(1, int(round(min(seconds, 5.0))))
+        p = subprocess.run([ref_bin, "-a", "-t", str(t), "-p", "-s", "2000000", "-d", "3", "-o", "/dev/null"],
+                           env=env, capture_output=True, text=True, timeout=120)
+        m = re.search(r"Rate: ([0-9.]+) kS/s", p.stderr)
+        if m:
+            return {"value": round(float(m.group(1)) / 1e3, 2), "unit": "MS/s", "cores": 1, "kind": "reference",
+                    "sample": f"examples/perseustest.c user_data_callback_c_f (6144-byte buffers, per-sample fwrite to "
+                              f"/dev/null) driven unpaced by libperseus-sdr.so for {t} s"}
     if workload == "unpack":
         run = lambda b: O.unpack24_f32(b)
         label = "24-bit unpack only, 1 thread (reference callback style)"
