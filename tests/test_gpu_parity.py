@@ -688,3 +688,42 @@ def test_spectral_sanity_two_tone(pkg, dev, O):
     peak = lambda f: S[np.argmin(np.abs(fo - f))]
     assert abs(20 * np.log10(peak(f_pass) / 0.4)) < 0.05                 # unity pass-band gain
     assert 20 * np.log10(peak(f_alias) / 0.4) < -80.0                    # alias of the stop-band tone
+
+
+# --------------------- the unmodified reference client on the GPU path (full circle)
+def test_reference_client_on_gpu_path_fpga_emulation(pkg, dev, O, tmp_path, monkeypatch):
+    """oracle/_ref/perseustest_ref (the reference's examples/perseustest.c, compiled
+    unmodified) with PERSEUS_AMD_MODE=ddc-wire: the GPU does NCO + /320, re-quantises
+    to the 24-bit wire format, and the REFERENCE's own callback unpacks it."""
+    import ctypes as C
+    import subprocess
+    ref_bin = os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "perseustest_ref")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref not built")
+    out = tmp_path / "gpu_ref.bin"
+    env = dict(os.environ, PERSEUS_AMD_PACE="0", PERSEUS_AMD_MODE="ddc-wire", PERSEUS_AMD_SOURCE="lcg:12345",
+               PERSEUS_AMD_MAX_BUFFERS="3", PERSEUS_AMD_BATCH=str(1 << 18))
+    env.pop("PERSEUS_AMD_DEVICES", None)
+    p = subprocess.run([ref_bin, "-a", "-t", "2", "-p", "-s", "250000", "-f", "7100000", "-d", "3", "-o", str(out)],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert "Elapsed time:" in p.stderr, p.stderr[-500:]
+    y = np.fromfile(out, dtype=np.float32)
+    assert y.size == 3 * 2048                                  # 3 transfers of 1024 samples
+    # the plan the library used for 250 kS/s (deterministic), through the in-process API
+    monkeypatch.setenv("PERSEUS_AMD_PACE", "0")
+    L = pkg.sdr_lib()
+    L.perseus_set_debug(0)
+    assert L.perseus_init() == 1
+    d = L.perseus_open(0)
+    L.perseus_firmware_download(d, None)
+    L.perseus_set_sampling_rate(d, 250000)
+    dec, nt = (C.c_int * 4)(), (C.c_int * 4)()
+    n = L.perseus_amd_get_plan(d, dec, nt, None)
+    taps = [np.zeros(nt[i], np.float32) for i in range(n)]
+    arr = (C.POINTER(C.c_float) * 4)(*([t.ctypes.data_as(C.POINTER(C.c_float)) for t in taps] + [None]))
+    L.perseus_amd_get_plan(d, dec, nt, arr)
+    L.perseus_exit()
+    ref = O.ddc_chain(O.lcg_bytes(6 * (y.size // 2) * 320, 12345), [(dec[i], taps[i]) for i in range(n)],
+                      freg=O.nco_freg(7.1e6), mix=True)
+    # float path tolerance + one 24-bit quantisation step of the wire format
+    assert O.rel_err(y, ref[: y.size]) <= FIR_TOL + 1.0 / 8388607 / np.max(np.abs(ref))
