@@ -26,6 +26,9 @@ struct Fir8Args {
     const void  *hist2 = nullptr;      /* its history: the 64 stage-1 outputs (float2) that
                                 precede this batch                               */
     void        *hist2_out = nullptr;  /* receives the batch's last 64 stage-1 outputs    */
+    unsigned    *sched = nullptr;      /* 2 zero-initialised words of device memory: the tile
+                                scheduler's chunk counter and exit counter (the kernel
+                                leaves them zero again); one pair per stream      */
     long long   n_in;        /* samples in the batch, multiple of 8            */
     unsigned long long n0;   /* absolute index of batch sample 0 (NCO phase)   */
     uint32_t    freg;        /* NCO tuning word                                */
@@ -72,6 +75,10 @@ hipError_t launch_pack24(const float *in, long long nsamples, void *out, hipStre
 
 hipError_t launch_synth_lcg(void *dst, size_t nbytes, uint32_t seed, uint64_t byte_offset,
                             hipStream_t s);
+
+#ifdef PDDC_CLOCK_PROBE
+void fir8_probe_dump();
+#endif
 
 } // namespace pddc
 #endif

@@ -44,6 +44,7 @@
  */
 #include "ddc_kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 #define PDDC_CONSTANT __attribute__((address_space(4)))
@@ -383,19 +384,89 @@ __device__ __forceinline__ void fir_window(const float *base, const float PDDC_C
     }
 }
 
-/* Persistent: block b owns the contiguous tile range [b*tpb, (b+1)*tpb).
+#ifdef PDDC_CLOCK_PROBE
+/* development: per-block 100 MHz wall-clock (s_memrealtime) and shader-clock (s_memtime)
+ * stamps plus the hardware placement, to see the engine clock the kernel ran at and how
+ * evenly the persistent blocks finish (make HIPFLAGS+=-DPDDC_CLOCK_PROBE; the report is
+ * printed by pddc_pipeline_time_stage0, PDDC_PROBE_VERBOSE=1 lists every block)          */
+struct ProbeRec { unsigned long long w0, w1, c0, c1; unsigned hw, xcc; };
+__device__ ProbeRec g_probe[4096];
+void fir8_probe_dump()
+{
+    static ProbeRec h[4096];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe), sizeof(h)) != hipSuccess)
+        return;
+    int nb = 0;
+    while (nb < 4096 && h[nb].w1 != 0)
+        ++nb;
+    if (nb == 0)
+        return;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int b = 0; b < nb; ++b) {
+        if (h[b].w0 < t0) t0 = h[b].w0;
+        if (h[b].w1 > t1) t1 = h[b].w1;
+    }
+    static double dur[4096], st[4096], en[4096];
+    for (int b = 0; b < nb; ++b) {
+        st[b] = (h[b].w0 - t0) / 100.0;
+        en[b] = (h[b].w1 - t0) / 100.0;
+        dur[b] = en[b] - st[b];
+    }
+    if (getenv("PDDC_PROBE_VERBOSE"))
+        for (int b = 0; b < nb; ++b)
+            fprintf(stderr, "[blk] %d xcc %u se %u sh %u cu %u simd %u wave %u  start %.1f end %.1f\n", b, h[b].xcc & 15,
+                    (h[b].hw >> 13) & 7, (h[b].hw >> 12) & 1, (h[b].hw >> 8) & 15, (h[b].hw >> 4) & 3, h[b].hw & 15,
+                    st[b], en[b]);
+    auto srt = [&](double *v) { for (int i = 1; i < nb; ++i) { double x = v[i]; int j = i - 1; while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; } v[j + 1] = x; } };
+    const double mhz = (double)(h[0].c1 - h[0].c0) / ((double)(h[0].w1 - h[0].w0) / 100.0);
+    srt(st); srt(en); srt(dur);
+    fprintf(stderr, "[probe] %d blocks, span %.1f us, block 0 at %.0f MHz\n", nb, (t1 - t0) / 100.0, mhz);
+    fprintf(stderr, "[probe] start  min %.1f  p50 %.1f  p90 %.1f  max %.1f us\n", st[0], st[nb / 2], st[nb * 9 / 10], st[nb - 1]);
+    fprintf(stderr, "[probe] end    min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f us\n", en[0], en[nb / 10], en[nb / 2], en[nb * 9 / 10], en[nb - 1]);
+    for (int b = 0; b < nb; ++b)
+        h[b] = ProbeRec{};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe), h, sizeof(h));
+}
+#endif
+
+/* Persistent grid with a two-level tile schedule.  Tiles are grouped into
+ * CHUNKS of consecutive tiles; inside a chunk the FIR history is carried in LDS.
+ *   static part : block b first owns the S tiles [b*S, (b+1)*S)
+ *   dynamic part: the remaining tiles [nblk*S, ntiles) are cut into chunks of K
+ *                 tiles that the blocks take from an atomic counter (p.sched[0])
+ *                 as they run dry.  The two blocks resident on a CU do not run at
+ *                 the same speed (the older wave wins the issue arbitration: with
+ *                 equal static shares one block finished 15-25 % before its
+ *                 neighbour, which then ran alone and badly overlapped); the
+ *                 dynamic tail lets them finish together.
+ * The first tile of a chunk takes its history from global memory (the previous
+ * 8*NTB input samples, or p.hist for tile 0), prefetched with the tile itself.
+ * The counter is taken one tile ahead (thread 0, published through LDS) so its
+ * latency is never waited for, and the last block to leave resets it.
+ *
  * Per tile t:  U  unpack the prefetched registers into the LDS planes
- *              S  coalesced global stores of tile t-1 (staged by F of t-1)
+ *              S  coalesced global stores of the previous tile (staged by its F)
  *              -- barrier A --
- *              P  issue tile t+1's global loads (in flight during F)
+ *              P  issue the next tile's global loads (in flight during F)
  *              F  FIR from LDS, results to the output staging area
  *              -- barrier B --
- *              C  the last NTB groups become tile t+1's history (copied by
+ *              C  the last NTB groups become the next tile's history (copied by
  *                 the very threads that overwrite them in the next U, so no
  *                 third barrier is needed).                                */
 template <int NTB, int R, int INFMT, bool MIX, int NTB2>
-__global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int tiles_per_block, int ntiles)
+__global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int ntiles, int S, int K)
 {
+#ifdef PDDC_CLOCK_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_probe[blockIdx.x].c0 = clock64();
+        g_probe[blockIdx.x].w0 = wall_clock64();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_probe[blockIdx.x].hw = hw;
+        g_probe[blockIdx.x].xcc = xcc;
+    }
+#endif
     using G = Fir8Geom<NTB, R>;
     using G2 = Fir8Geom2<NTB2, R>;
     constexpr bool FUSE2 = NTB2 > 0;     /* a second decimate-by-8 stage runs on the tile's outputs in LDS */
@@ -406,6 +477,9 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
     float *sI2 = ot;                     /* ... or the second stage's input planes + its staging (fused)    */
     float *sQ2 = ot + G2::PLANE;
     float *ot2 = ot + 2 * G2::PLANE;
+    /* plane offsets 0..6 (slots 0..6 of "group -1") never hold a sample: offset 0 of the
+     * I plane carries the next chunk index from thread 0 to the block                   */
+    volatile int *s_next = reinterpret_cast<volatile int *>(smem);
 
     constexpr int NW = (INFMT == IN_PACKED24) ? 3 : 4;             /* 16-byte words per group */
     constexpr int ES = (INFMT == IN_PACKED24) ? 6 : 8;             /* bytes per sample        */
@@ -415,15 +489,46 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
      * swapped, so that the 8-lane groups of ds_write_b128/_b96 hit 8 distinct
      * 4-bank sets (32-byte group stride + the 16-byte pad every R groups)      */
     const int gtid = (tid & ~12) | ((tid & 4) << 1) | ((tid & 8) >> 1);
-    const int t_own = blockIdx.x * tiles_per_block;      /* first tile whose outputs this block writes */
-    const int t1  = min(t_own + tiles_per_block, ntiles);
-    if (t_own >= t1)
-        return;
+    const int nblk = (int)gridDim.x;
+    const int dyn0 = nblk * S;                           /* first tile of the dynamic part */
+    const int ND   = (ntiles - dyn0 + K - 1) / K;        /* number of dynamic chunks       */
+
+    /* leaving: the last block out resets the schedule for the next launch */
+    auto leave = [&]() {
+        if (tid == 0 && atomicAdd(p.sched + 1, 1u) == (unsigned)(nblk - 1)) {
+            atomicExch(p.sched, 0u);
+            atomicExch(p.sched + 1, 0u);
+        }
+#ifdef PDDC_CLOCK_PROBE
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {
+            g_probe[blockIdx.x].c1 = clock64();
+            g_probe[blockIdx.x].w1 = wall_clock64();
+        }
+#endif
+    };
+
+    /* ---- first chunk: [c_lo, c_hi) are the tiles whose outputs the block writes ---- */
+    int c_lo, c_hi;
+    if (S > 0) {
+        c_lo = (int)blockIdx.x * S;
+        c_hi = c_lo + S;
+    } else {
+        if (tid == 0)
+            *s_next = (int)atomicAdd(p.sched, 1u);
+        __syncthreads();
+        const int j = __builtin_amdgcn_readfirstlane(*s_next);
+        __syncthreads();
+        if (j >= ND) {
+            leave();
+            return;
+        }
+        c_lo = dyn0 + j * K;
+        c_hi = min(c_lo + K, ntiles);
+    }
     /* fused second stage: its history is 8*NTB2 stage-1 outputs, i.e. the tile
-     * in front of the block's range is recomputed as a warm-up (no output) --
-     * except for block 0, whose stage-2 history comes from the previous call   */
-    const int t0 = (FUSE2 && t_own > 0) ? t_own - 1 : t_own;
-    if (FUSE2 && t_own == 0 && tid < NTB2) {
+     * in front of a chunk is recomputed as a warm-up (no output) -- except for
+     * tile 0, whose stage-2 history comes from the previous call               */
+    if (FUSE2 && c_lo == 0 && tid < NTB2) {
         const u32x4 *src = reinterpret_cast<const u32x4 *>(static_cast<const float *>(p.hist2) + 16 * tid);
         const u32x4 h2raw[4] = { src[0], src[1], src[2], src[3] };
         float xi[8], xq[8];
@@ -435,27 +540,14 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         }
     }
 
-    /* ---- history of the first tile: groups 0..NTB-1 ------------------------ */
-    if (tid < NTB) {
-        const long long s_abs = (long long)t0 * G::TI + 8LL * tid - 8 * NTB;
-        const uint8_t *src = (s_abs < 0) ? static_cast<const uint8_t *>(p.hist) + (s_abs + 8 * NTB) * ES
-                                         : static_cast<const uint8_t *>(p.in) + s_abs * ES;
-        u32x4 hraw[NW];
-#pragma unroll
-        for (int k = 0; k < NW; ++k)
-            hraw[k] = (s_abs < p.n_in) ? reinterpret_cast<const u32x4 *>(src)[k] : u32x4{ 0u, 0u, 0u, 0u };
-        float xi[8], xq[8];
-        group_to_float<INFMT, MIX, NW>(hraw, xi, xq, p.n0 + (unsigned long long)s_abs, p);
-        group_to_lds<R>(sI, sQ, tid, xi, xq);
-    }
-
-    /* one tile of prefetched input in registers: tile t+1 is requested while tile t
-     * is filtered.  (A second tile in flight was measured no faster; it needs asm
-     * loads with hand-counted vmcnt because hipcc waits vmcnt(0) for loop-carried
-     * loads, and that form is fragile under register pressure -- DESIGN.md 5.)   */
-    using RawSet = u32x4[G::GPT][NW];
+    /* one tile of prefetched input in registers: the next tile is requested while
+     * this one is filtered.  (A second tile in flight was measured no faster; it
+     * needs asm loads with hand-counted vmcnt because hipcc waits vmcnt(0) for
+     * loop-carried loads, and that form is fragile under register pressure --
+     * DESIGN.md 5.)  rawH: the NTB history groups of a chunk's first tile.       */
     u32x4 rawA[G::GPT][NW];
-    auto prefetch = [&](int tile, RawSet &raw) {
+    u32x4 rawH[NW];
+    auto prefetch = [&](int tile, bool with_hist) {
         const long long tin0 = (long long)tile * G::TI;
         const u32x4 *src0 = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(p.in) +
                                                             (tin0 + 8LL * gtid) * ES);
@@ -464,18 +556,29 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
             for (int k = 0; k < G::GPT; ++k)
 #pragma unroll
                 for (int w = 0; w < NW; ++w)
-                    raw[k][w] = src0[(256 * k * 8 * ES) / 16 + w];
+#ifdef PDDC_ABLATE_LOADS
+                    rawA[k][w] = u32x4{ (unsigned)tile * 2654435761u + tid, (unsigned)(k + w) << 20, (unsigned)tile << 9, 77u * tid };
+#else
+                    rawA[k][w] = src0[(256 * k * 8 * ES) / 16 + w];
+#endif
         } else {                                        /* ragged last tile */
 #pragma unroll
             for (int k = 0; k < G::GPT; ++k) {
                 const bool have = tin0 + 8LL * (gtid + 256 * k) < p.n_in;
 #pragma unroll
                 for (int w = 0; w < NW; ++w)
-                    raw[k][w] = have ? src0[(256 * k * 8 * ES) / 16 + w] : u32x4{ 0u, 0u, 0u, 0u };
+                    rawA[k][w] = have ? src0[(256 * k * 8 * ES) / 16 + w] : u32x4{ 0u, 0u, 0u, 0u };
             }
         }
+        if (with_hist && tid < NTB) {                   /* groups 0..NTB-1: the 8*NTB samples before the tile */
+            const long long s_abs = tin0 + 8LL * tid - 8 * NTB;
+            const uint8_t *src = (s_abs < 0) ? static_cast<const uint8_t *>(p.hist) + (s_abs + 8 * NTB) * ES
+                                             : static_cast<const uint8_t *>(p.in) + s_abs * ES;
+#pragma unroll
+            for (int k = 0; k < NW; ++k)
+                rawH[k] = (s_abs < p.n_in) ? reinterpret_cast<const u32x4 *>(src)[k] : u32x4{ 0u, 0u, 0u, 0u };
+        }
     };
-    prefetch(t0, rawA);
 
     const int wave  = __builtin_amdgcn_readfirstlane(tid >> 6);   /* provably wave-uniform */
     const int lane  = tid & 63;
@@ -521,6 +624,9 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
                  * trailing s_nop 1 is the wait state a 128-bit store needs before the next
                  * instruction may overwrite its data registers (hipcc pads nothing inside
                  * or after an asm string).                                             */
+#ifdef PDDC_ABLATE_STORES
+                if (v.x == 1.2345e-30f)
+#endif
                 asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dstp), "v"(v) : "memory");
             }
         } else {
@@ -538,14 +644,33 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         }
     };
 
-    auto tile_body = [&](int t, RawSet &raw) {
-        /* ---- U: registers -> LDS planes (groups NTB ..) ------------------- */
+    int  t = (FUSE2 && c_lo > 0) ? c_lo - 1 : c_lo;   /* tile in work (a fused chunk starts one tile early) */
+    bool first = true;                                /* t opens a chunk: history comes from rawH            */
+    int  tprev = -1;                                  /* tile whose outputs are staged, not yet stored        */
+    bool prev_out2 = false;                           /* ... and (fused) whether it produced stage-2 outputs  */
+    unsigned grabv = 0;                               /* thread 0: the chunk taken for after this one         */
+    prefetch(t, true);
+    if (t + 1 == c_hi && tid == 0)
+        grabv = atomicAdd(p.sched, 1u);
+
+    for (;;) {
+        const bool last = (t + 1 == c_hi);            /* last tile of its chunk */
+        /* ---- U: registers -> LDS planes (groups NTB ..; a chunk's first tile also 0..NTB-1) ---- */
+        if (first && tid < NTB) {
+            float xi[8], xq[8];
+            group_to_float<INFMT, MIX, NW>(rawH, xi, xq,
+                                           p.n0 + (unsigned long long)((long long)t * G::TI + 8LL * tid - 8 * NTB), p);
+            group_to_lds<R>(sI, sQ, tid, xi, xq);
+        }
 #pragma unroll
         for (int k = 0; k < G::GPT; ++k) {
             const int v = NTB + gtid + 256 * k;
             float xi[8], xq[8];
-            group_to_float<INFMT, MIX, NW>(raw[k], xi, xq,
+            group_to_float<INFMT, MIX, NW>(rawA[k], xi, xq,
                                            p.n0 + (unsigned long long)((long long)t * G::TI + 8LL * (gtid + 256 * k)), p);
+#ifdef PDDC_ABLATE_LDSW
+            if (xi[0] + xi[1] + xi[2] + xi[3] + xi[4] + xi[5] + xi[6] + xi[7] + xq[0] + xq[1] + xq[2] + xq[3] + xq[4] + xq[5] + xq[6] + xq[7] == 1.2345e-30f)
+#endif
             group_to_lds<R>(sI, sQ, v, xi, xq);
         }
         /* ---- S (deferred): the PREVIOUS tile's stores go out here, behind this
@@ -553,15 +678,38 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
          * waits vmcnt(0) whenever both kinds are pending, so stores issued just
          * before the wait for prefetched loads would stall every tile on the
          * write acknowledgements (measured: +0.12 ms per 2^28 samples).        */
-        if (!FUSE2 && t > t0)
-            store_tile(t - 1);
+        /* publish the next chunk BEFORE the stores are issued: reading grabv waits
+         * for everything outstanding (vmcnt(0)), which here is nothing new -- after the
+         * stores it would wait for their acknowledgements                             */
+        if (last && tid == 0)
+            *s_next = (int)grabv;
+        if (!FUSE2 && tprev >= 0)
+            store_tile(tprev);
+#ifndef PDDC_ABLATE_BARRIERS
         __syncthreads();                                           /* A */
-        if (FUSE2 && t > t_own)        /* written by waves 0/1 after the previous barrier B */
-            store_tile2(t - 1);
+#endif
+        if (FUSE2 && prev_out2)        /* written by waves 0/1 after the previous barrier B */
+            store_tile2(tprev);
 
-        /* ---- P: next tile's loads --------------------------------------- */
-        if (t + 1 < t1)
-            prefetch(t + 1, raw);
+        /* ---- P: next tile's loads (and, one tile before a chunk ends, the next chunk) ---- */
+        int tn = t + 1, n_lo = c_lo, n_hi = c_hi;
+        if (last) {
+            const int j = __builtin_amdgcn_readfirstlane(*s_next);
+            if (j < ND) {
+                n_lo = dyn0 + j * K;
+                n_hi = min(n_lo + K, ntiles);
+                tn = FUSE2 ? n_lo - 1 : n_lo;                        /* dynamic chunks never start at tile 0... */
+                if (FUSE2 && n_lo == 0)
+                    tn = 0;                                          /* ... unless S == 0                      */
+            } else {
+                tn = -1;
+            }
+        }
+        if (tn >= 0) {
+            prefetch(tn, last);
+            if (tn + 1 == n_hi && tid == 0)
+                grabv = atomicAdd(p.sched, 1u);
+        }
 
         /* ---- F: FIR ------------------------------------------------------ */
         /* Packed fp32: every VALU op costs ~4 cycles per wave64 on gfx950, and
@@ -577,10 +725,16 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
 #pragma unroll
         for (int r = 0; r < R; ++r)
             acc[r] = f32x2{ 0.0f, 0.0f };
+#ifdef PDDC_ABLATE_FIR
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            acc[r] = *reinterpret_cast<const f32x2 *>(base + 8 * r);
+#else
         if (R == 4 && par)
             fir_window<NTB, R, 1>(base, hb, acc);
         else
             fir_window<NTB, R, 0>(base, hb, acc);
+#endif
         if (FUSE2) {
             /* results -> the second stage's input plane, rotated like the first:
              * position p2 = m + 8*NTB2 - 1 for tile-relative output m = R*L + r,
@@ -600,10 +754,12 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
                 ot[4 * qs + (f & 3)] = acc[r].x + acc[r].y;
             }
         }
+#ifndef PDDC_ABLATE_BARRIERS
         __syncthreads();                                           /* B */
+#endif
 
-        /* ---- C: tail groups -> history of the next tile -------------------- */
-        if (t + 1 < t1 && gtid >= 256 - NTB) {
+        /* ---- C: tail groups -> history of the next tile of the chunk -------- */
+        if (!last && gtid >= 256 - NTB) {
             const int gd = gtid - (256 - NTB);                      /* 0..NTB-1 */
             const int os = goff<R>(G::GT + gd), od = goff<R>(gd);
             const float4 i0 = *reinterpret_cast<const float4 *>(sI + os);
@@ -628,7 +784,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
          * come after the next A as well.                                        */
         if (FUSE2 && wave < 2) {
             float *pl2 = wave ? sQ2 : sI2;
-            if (t >= t_own) {
+            if (t >= c_lo) {
                 constexpr int R2 = G2::R2 > 0 ? G2::R2 : 1;
                 f32x2 acc2[R2];
 #pragma unroll
@@ -639,7 +795,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
                 for (int r = 0; r < R2; ++r)
                     ot2[2 * (R2 * lane + r) + wave] = acc2[r].x + acc2[r].y;
             }
-            if (t + 1 < t1 && lane < NTB2) {
+            if (!last && lane < NTB2) {
                 const int os = 8 + 8 * (G2::GT2 + lane), od = 8 + 8 * lane;
                 const float4 a0 = *reinterpret_cast<const float4 *>(pl2 + os);
                 const float4 a1 = *reinterpret_cast<const float4 *>(pl2 + os + 4);
@@ -650,32 +806,40 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
                     pl2[od + 7] = a1.w;
             }
         }
-    };
+        tprev = t;
+        prev_out2 = FUSE2 && t >= c_lo;
+        if (tn < 0)
+            break;
+        first = last;
+        t = tn;
+        c_lo = n_lo;
+        c_hi = n_hi;
+    }
 
-    for (int t = t0; t < t1; ++t)
-        tile_body(t, rawA);
     if (FUSE2) {
         __syncthreads();                 /* ot2 and the stage-2 planes of the last tile are complete */
-        store_tile2(t1 - 1);
+        if (prev_out2)
+            store_tile2(tprev);
         /* the last 8*NTB2 stage-1 outputs are the second stage's next history */
-        if (p.hist2_out != nullptr && t1 == ntiles && tid < 8 * NTB2) {
+        if (p.hist2_out != nullptr && tprev == ntiles - 1 && tid < 8 * NTB2) {
             const int o = 8 + (G::TO + tid - 1);       /* position of stage-1 output TO - 8*NTB2 + tid */
             static_cast<float2 *>(p.hist2_out)[tid] = make_float2(sI2[o], sQ2[o]);
         }
     } else {
-        store_tile(t1 - 1);
+        store_tile(tprev);
     }
 
-    /* the block that owns the last tile leaves the batch's last 8*NTB input
+    /* the block that ran the last tile leaves the batch's last 8*NTB input
      * samples as the next call's history (the host alternates two buffers, so
-     * block 0 of THIS launch never sees them)                                 */
-    if (p.hist_out != nullptr && t1 == ntiles && p.n_in >= 8 * NTB) {
+     * tile 0 of THIS launch never sees them)                                  */
+    if (p.hist_out != nullptr && tprev == ntiles - 1 && p.n_in >= 8 * NTB) {
         constexpr int HCH = 8 * NTB * ES / 16;                     /* 16-byte chunks */
         const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(p.in) +
                                                            (p.n_in - 8 * NTB) * ES);
         for (int c = tid; c < HCH; c += 256)
             static_cast<uint4 *>(p.hist_out)[c] = src[c];
     }
+    leave();
 }
 
 bool fir8_supported(int ntb, int R)
@@ -689,6 +853,35 @@ bool fir8_supported(int ntb, int R)
 static constexpr int kFir8DefaultBlocks = 512;
 static int g_fir8_blocks = 0;       /* override (development) */
 
+/* two-level tile schedule of k_fir8: S static tiles per block, the rest in dynamic
+ * chunks of K tiles.  Measured (profiles/r01/v7_schedule_sweep.txt): 127 taps R=4
+ * 0.398 -> 0.385 ms with 15-25 % dynamic in 4-tile chunks, 255 taps R=8 0.538 ->
+ * 0.511 ms with 25 % in 2-tile chunks; single-tile chunks lose (one atomic per
+ * tile on one address).  The fused pair pays a warm-up tile per chunk and gains
+ * nothing, so only its remainder (< one tile per block) is dynamic.
+ * Development overrides: PDDC_FIR8_DYN_PCT (share of the tiles handed out
+ * dynamically), PDDC_FIR8_CHUNK (K).                                              */
+struct Fir8Sched {
+    int nblocks, S, K;
+};
+static Fir8Sched fir8_schedule(int ntiles, int R, bool fused)
+{
+    /* read per launch (two getenv calls against a launch of several microseconds), so a
+     * test can switch schedules inside one process */
+    const char *e = getenv("PDDC_FIR8_DYN_PCT");
+    const int v = e ? atoi(e) : -1;
+    const int dyn_pct = v < 0 ? -1 : (v > 100 ? 100 : v);
+    e = getenv("PDDC_FIR8_CHUNK");
+    const int chunk = e ? atoi(e) : 0;
+    Fir8Sched sc;
+    const int want = g_fir8_blocks > 0 ? g_fir8_blocks : kFir8DefaultBlocks;
+    sc.nblocks = ntiles < want ? ntiles : want;
+    sc.K = chunk > 0 ? chunk : (fused ? 8 : (R == 4 ? 4 : 2));
+    const int pct = dyn_pct >= 0 ? dyn_pct : (fused ? 0 : 20);
+    sc.S = (int)((long long)ntiles * (100 - pct) / 100 / sc.nblocks);
+    return sc;
+}
+
 template <int NTB, int R>
 static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s)
 {
@@ -700,10 +893,10 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
     if (ntiles_ll > 0x7fffffffLL)
         return hipErrorInvalidValue;
     const int ntiles = (int)ntiles_ll;
-    const int want = g_fir8_blocks > 0 ? g_fir8_blocks : kFir8DefaultBlocks;
-    const int tpb = (ntiles + want - 1) / want;
-    const int nblocks = (ntiles + tpb - 1) / tpb;
-    const dim3 grid((unsigned)nblocks), blk(256);
+    if (a.sched == nullptr)
+        return hipErrorInvalidValue;
+    const Fir8Sched sc = fir8_schedule(ntiles, R, false);
+    const dim3 grid((unsigned)sc.nblocks), blk(256);
 #define PDDC_LAUNCH(FMT, MIXV)                                                                    \
     do {                                                                                          \
         static unsigned long long attr_done = 0;   /* one bit per device: the attribute is per device */ \
@@ -717,7 +910,7 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
                 return e;                                                                         \
             attr_done |= 1ull << (dev__ & 63);                                                    \
         }                                                                                         \
-        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV, 0>), grid, blk, lds, s, a, tpb, ntiles);    \
+        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV, 0>), grid, blk, lds, s, a, ntiles, sc.S, sc.K); \
     } while (0)
     if (fmt == IN_PACKED24) {
         if (mix)
@@ -744,10 +937,10 @@ static hipError_t launch_fir8_fused2_t(bool mix, const Fir8Args &a, hipStream_t 
     if (ntiles_ll > 0x7fffffffLL)
         return hipErrorInvalidValue;
     const int ntiles = (int)ntiles_ll;
-    const int want = g_fir8_blocks > 0 ? g_fir8_blocks : kFir8DefaultBlocks;
-    const int tpb = (ntiles + want - 1) / want;
-    const int nblocks = (ntiles + tpb - 1) / tpb;
-    const dim3 grid((unsigned)nblocks), blk(256);
+    if (a.sched == nullptr)
+        return hipErrorInvalidValue;
+    const Fir8Sched sc = fir8_schedule(ntiles, R, true);
+    const dim3 grid((unsigned)sc.nblocks), blk(256);
 #define PDDC_LAUNCH2(MIXV)                                                                        \
     do {                                                                                          \
         static unsigned long long attr_done = 0;                                                  \
@@ -761,8 +954,8 @@ static hipError_t launch_fir8_fused2_t(bool mix, const Fir8Args &a, hipStream_t 
                 return e;                                                                         \
             attr_done |= 1ull << (dev__ & 63);                                                    \
         }                                                                                         \
-        hipLaunchKernelGGL((k_fir8<NTB, R, IN_PACKED24, MIXV, 8>), grid, blk, lds, s, a, tpb,     \
-                           ntiles);                                                               \
+        hipLaunchKernelGGL((k_fir8<NTB, R, IN_PACKED24, MIXV, 8>), grid, blk, lds, s, a, ntiles,  \
+                           sc.S, sc.K);                                                           \
     } while (0)
     if (mix)
         PDDC_LAUNCH2(true);

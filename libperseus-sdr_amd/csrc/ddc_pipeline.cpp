@@ -84,6 +84,7 @@ struct pddc_pipeline {
     float *d_fout = nullptr;      /* float output of the last stage when the caller wants packed */
     size_t d_fout_cap = 0;
     hipStream_t own_stream = nullptr;
+    unsigned *d_sched = nullptr;  /* k_fir8's tile scheduler words (zero between launches) */
 };
 
 static bool stage0_fused(const pddc_pipeline *p);
@@ -365,6 +366,11 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
         pddc_pipeline_destroy(p);
         return fail(PDDC_ENOMEM, "hipMalloc history: %s", hipGetErrorString(e));
     }
+    e = hipMalloc((void **)&p->d_sched, 64);
+    if (e != hipSuccess) {
+        pddc_pipeline_destroy(p);
+        return fail(PDDC_ENOMEM, "hipMalloc scheduler words: %s", hipGetErrorString(e));
+    }
     e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         pddc_pipeline_destroy(p);
@@ -401,6 +407,8 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
         hipFree(p->d_out);
     if (p->d_fout)
         hipFree(p->d_fout);
+    if (p->d_sched)
+        hipFree(p->d_sched);
     if (p->own_stream)
         hipStreamDestroy(p->own_stream);
     delete p;
@@ -414,6 +422,7 @@ int pddc_pipeline_reset(pddc_pipeline *p)
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipDeviceSynchronize());
     p->n0 = 0;
+    HIP_TRY(hipMemset(p->d_sched, 0, 64));
     for (int i = 0; i < p->nstages; ++i) {
         Stage &s = p->st[i];
         s.consumed = 0;
@@ -573,6 +582,7 @@ static void fill_fir8_args(const pddc_pipeline *p, Fir8Args &a)
 {
     a.n0 = p->n0;
     a.freg = p->freg;
+    a.sched = p->d_sched;
     for (int e = 0; e < 8; ++e) {
         a.lo_c[e] = p->lo_c[e];
         a.lo_s[e] = p->lo_s[e];
@@ -822,6 +832,9 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     *avg_ms = ms / (float)iters;
+#ifdef PDDC_CLOCK_PROBE
+    fir8_probe_dump();
+#endif
     return PDDC_OK;
 }
 

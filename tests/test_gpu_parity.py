@@ -489,6 +489,33 @@ def test_long_tile_runs_per_block_all_variants(pkg, dev, O, monkeypatch):
             pipe.close()
 
 
+@pytest.mark.parametrize("dyn,chunk", [("100", "1"), ("100", "3"), ("60", "2"), ("0", "5"), ("100", "64")])
+def test_tile_scheduler_variants(pkg, dev, O, monkeypatch, dyn, chunk):
+    """k_fir8 hands part of the tiles out dynamically (atomic chunk counter, the
+    history of a chunk's first tile re-read from global memory, a warm-up tile for
+    the fused pair).  Every schedule must give the same stream: all-dynamic with
+    single-tile chunks, odd chunk sizes, mostly static, one chunk larger than the
+    batch; several launches in a row check that the counters are left at zero."""
+    monkeypatch.setenv("PDDC_FIR8_DYN_PCT", dyn)
+    monkeypatch.setenv("PDDC_FIR8_CHUNK", chunk)
+    monkeypatch.setenv("PDDC_FIR8_BLOCKS", "5")
+    h1, h2 = load_taps("c320_s1_d8_32"), load_taps("c320_s2_d8_64")
+    for stages, mix, R in (([(8, load_taps("d8_127"))], False, "4"), ([(8, load_taps("d8_255"))], True, "8"),
+                           ([(8, h1), (8, h2)], True, "4"), ([(8, h1), (8, h2)], False, "8")):
+        monkeypatch.setenv("PDDC_FIR8_R", R)
+        tile = 1024 * int(R)
+        cuts = [0, 23 * tile, 23 * tile + 2 * tile, 60 * tile + (0 if len(stages) == 2 else 8 * 41)]
+        packed = O.lcg_bytes(6 * cuts[-1], 99)
+        ref = O.ddc_chain(packed, stages, freg=987654321, mix=mix)
+        pipe = pkg.Pipeline(stages, mix=mix)
+        pipe.set_freg(987654321)
+        y = np.concatenate([pipe.process(to_dev(packed[6 * a:6 * b], dev)).cpu().numpy().reshape(-1)
+                            for a, b in zip(cuts[:-1], cuts[1:])])
+        assert y.size == ref.size
+        assert O.rel_err(y, ref) <= FIR_TOL, (len(stages), mix, R, dyn, chunk)
+        pipe.close()
+
+
 def test_set_taps_reset_and_tiny_batches(pkg, dev, O):
     h = load_taps("d8_127")
     g = (np.arange(100, dtype=np.float32) - 50) / 5000
