@@ -55,9 +55,12 @@ hipError_t launch_unpack24(const void *d_in, long long nsamples, void *d_out, bo
                            const float *lo_c, const float *lo_s, hipStream_t s);
 
 /* generic decimating FIR on float2: out[q] = sum_k h[k]*x[first + q*D - k],
- * x indexed relative to `in`; x[-H..-1] come from `hist` (H >= ntaps-1). */
+ * x indexed relative to `in`; x[-H..-1] come from `hist` (H >= ntaps-1).
+ * `taps` must be readable, as zeros, over [-3*D - 8, ntaps + 3*D + 8).  hist_out (or
+ * NULL) receives the last H samples of [hist | in(n_batch)]; must not alias hist. */
 hipError_t launch_fir_generic(const float *in, const float *hist, int H, long long first, long long n_out,
-                              int D, const float *taps, int ntaps, float *out, hipStream_t s);
+                              int D, const float *taps, int ntaps, float *out, float *hist_out,
+                              long long n_batch, hipStream_t s);
 
 /* dst = last H elements of [hist(H) | batch(n)], elem_bytes each (H*elem_bytes <= 16 KiB);
  * dst may alias hist */

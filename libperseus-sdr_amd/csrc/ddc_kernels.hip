@@ -478,8 +478,9 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
     float *sQ2 = ot + G2::PLANE;
     float *ot2 = ot + 2 * G2::PLANE;
     /* plane offsets 0..6 (slots 0..6 of "group -1") never hold a sample: offset 0 of the
-     * I plane carries the next chunk index from thread 0 to the block                   */
-    volatile int *s_next = reinterpret_cast<volatile int *>(smem);
+     * I plane (smem[0], as raw bits) carries the next chunk index from thread 0 to the
+     * block.  Accessed as smem[0] so it stays an LDS access (a cast pointer becomes a
+     * flat load whose vmcnt(0) wait would also wait for the tile's stores).             */
 
     constexpr int NW = (INFMT == IN_PACKED24) ? 3 : 4;             /* 16-byte words per group */
     constexpr int ES = (INFMT == IN_PACKED24) ? 6 : 8;             /* bytes per sample        */
@@ -514,9 +515,9 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         c_hi = c_lo + S;
     } else {
         if (tid == 0)
-            *s_next = (int)atomicAdd(p.sched, 1u);
+            smem[0] = __int_as_float((int)atomicAdd(p.sched, 1u));
         __syncthreads();
-        const int j = __builtin_amdgcn_readfirstlane(*s_next);
+        const int j = __builtin_amdgcn_readfirstlane(__float_as_int(smem[0]));
         __syncthreads();
         if (j >= ND) {
             leave();
@@ -656,12 +657,6 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
     for (;;) {
         const bool last = (t + 1 == c_hi);            /* last tile of its chunk */
         /* ---- U: registers -> LDS planes (groups NTB ..; a chunk's first tile also 0..NTB-1) ---- */
-        if (first && tid < NTB) {
-            float xi[8], xq[8];
-            group_to_float<INFMT, MIX, NW>(rawH, xi, xq,
-                                           p.n0 + (unsigned long long)((long long)t * G::TI + 8LL * tid - 8 * NTB), p);
-            group_to_lds<R>(sI, sQ, tid, xi, xq);
-        }
 #pragma unroll
         for (int k = 0; k < G::GPT; ++k) {
             const int v = NTB + gtid + 256 * k;
@@ -673,6 +668,12 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
 #endif
             group_to_lds<R>(sI, sQ, v, xi, xq);
         }
+        if (first && tid < NTB) {          /* after the tile's own groups: rawH was requested last */
+            float xi[8], xq[8];
+            group_to_float<INFMT, MIX, NW>(rawH, xi, xq,
+                                           p.n0 + (unsigned long long)((long long)t * G::TI + 8LL * tid - 8 * NTB), p);
+            group_to_lds<R>(sI, sQ, tid, xi, xq);
+        }
         /* ---- S (deferred): the PREVIOUS tile's stores go out here, behind this
          * tile's load wait.  gfx9 has one vmcnt for loads and stores and hipcc
          * waits vmcnt(0) whenever both kinds are pending, so stores issued just
@@ -682,7 +683,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
          * for everything outstanding (vmcnt(0)), which here is nothing new -- after the
          * stores it would wait for their acknowledgements                             */
         if (last && tid == 0)
-            *s_next = (int)grabv;
+            smem[0] = __int_as_float((int)grabv);
         if (!FUSE2 && tprev >= 0)
             store_tile(tprev);
 #ifndef PDDC_ABLATE_BARRIERS
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         /* ---- P: next tile's loads (and, one tile before a chunk ends, the next chunk) ---- */
         int tn = t + 1, n_lo = c_lo, n_hi = c_hi;
         if (last) {
-            const int j = __builtin_amdgcn_readfirstlane(*s_next);
+            const int j = __builtin_amdgcn_readfirstlane(__float_as_int(smem[0]));
             if (j < ND) {
                 n_lo = dyn0 + j * K;
                 n_hi = min(n_lo + K, ntiles);
@@ -1003,100 +1004,218 @@ hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, h
 /* ======================================================================== */
 /* k_fir_generic : any decimation, any tap count, float2 in / float2 out    */
 /* ======================================================================== */
-/* One output per thread, 256 outputs per block.  The block's input span
- * (255*D + ntaps samples) is staged planar in LDS with a pad that makes the
- * lane stride odd, the taps sit in LDS and are read as broadcasts.  This is
- * the low-rate path (stages 2.. of a cascade, and odd first stages).        */
-__global__ __launch_bounds__(256) void k_fir_generic(const float *__restrict__ in, const float *__restrict__ hist,
+/* The low-rate path (stages 2.. of a cascade, and odd first stages).  A block of
+ * NT threads makes NT*P outputs; its input span ((NT*P-1)*D + ntaps samples) is
+ * staged as interleaved float2 in LDS.  A thread owns P CONSECUTIVE outputs
+ * q..q+P-1 and walks the union of their windows once, 8 samples per step: the
+ * sample x[q*D - j] serves output q+p with tap p*D + j, a wave-uniform index,
+ * so the taps come through the scalar cache (s_load of 8 at a time from a table
+ * zero-padded by 3*D+8 on both sides) and one ds_read_b64 feeds P packed FMAs.
+ * The lane stride S = P*D must be odd in 8-byte units for conflict-free reads:
+ * the launcher takes P odd for odd D; for even S sample i sits at i + (i >> a),
+ * 2^a the largest power of two in S (stride S + S/2^a, odd).  The steps are
+ * aligned to 8 samples of the block's local index, so for a >= 3 (and for no
+ * pad at all, a = 31) the 8 reads of a step are one address plus immediates;
+ * the scalar unit -- one per CU -- is the bottleneck of this kernel otherwise
+ * (per-sample uniform index arithmetic made it 29 us instead of 13).
+ * Block 0 also writes the next call's history (the last H samples of
+ * [hist | batch]) when asked.                                                */
+template <int P>
+__global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ in, const float2 *__restrict__ hist,
                                                       int H, long long first, long long n_out, int D,
-                                                      const float *__restrict__ taps, int ntaps,
-                                                      float *__restrict__ out, int span, int padshift)
+                                                      const float PDDC_CONSTANT *taps, int ntaps,
+                                                      float2 *__restrict__ out, int span, int a,
+                                                      float2 *__restrict__ hist_out, long long n_batch)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    /* layout: taps[ntaps_pad] | I plane | Q plane */
-    const int ntp = (ntaps + 3) & ~3;
-    float *sT = smem;
-    const int plane = span + (padshift >= 0 ? (span >> padshift) : 0) + 4;
-    float *sI = sT + ntp;
-    float *sQ = sI + plane;
-    const int tid = threadIdx.x;
-    const long long q0 = (long long)blockIdx.x * 256;
-    /* inputs needed: x[first + q0*D - (ntaps-1)  ..  first + (q0+255)*D] */
+    extern __shared__ __attribute__((aligned(16))) float2 sd[];
+    /* layout: span samples | 8 zero samples (the first, aligned step of the tap loop may
+     * look up to 7 samples past a thread's windows, with zero taps); sample i at i + (i >> a) */
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int S = P * D;
+    const long long q0 = (long long)blockIdx.x * (NT * P);
+    /* inputs needed: x[first + q0*D - (ntaps-1)  ..  first + (q0+NT*P-1)*D] */
     const long long x0 = first + q0 * D - (ntaps - 1);
-    for (int k = tid; k < ntp; k += 256)
-        sT[k] = k < ntaps ? taps[k] : 0.0f;
-    long long last_needed = first + (n_out - 1) * (long long)D;    /* last valid input index */
-    for (int i = tid; i < span; i += 256) {
-        const long long xi = x0 + i;
-        float2 v = make_float2(0.0f, 0.0f);
-        if (xi < 0) {
-            if (xi >= -(long long)H)          /* history: the H samples that precede the batch */
-                v = *reinterpret_cast<const float2 *>(hist + 2 * (xi + H));
-        } else if (xi <= last_needed) {
-            v = *reinterpret_cast<const float2 *>(in + 2 * xi);
+    const long long last_needed = first + (n_out - 1) * (long long)D;    /* last valid input index */
+    if (tid < 8) {
+        const int i = span + tid;
+        sd[i + (i >> a)] = make_float2(0.0f, 0.0f);
+    }
+    if (x0 >= 0 && x0 + span - 1 <= last_needed) {
+        /* interior block: branch-free, so the loads of 8 rounds are in flight together
+         * (with the guarded form below every round waits for its own load: 21 serial
+         * round trips made this kernel 36 us for the x320 cascade's last stage)       */
+        const float2 *src = in + x0;
+        for (int i = tid; i < span; i += 8 * NT) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {          /* clamped, not branched: all 8 loads go out together */
+                const int ii = i + NT * u;
+                v[u] = src[ii < span ? ii : span - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ii = i + NT * u;
+                if (ii < span)
+                    sd[ii + (ii >> a)] = v[u];
+            }
         }
-        const int o = i + (padshift >= 0 ? (i >> padshift) : 0);
-        sI[o] = v.x;
-        sQ[o] = v.y;
+    } else {
+        for (int i = tid; i < span; i += NT) {
+            const long long xi = x0 + i;
+            float2 v = make_float2(0.0f, 0.0f);
+            if (xi < 0) {
+                if (xi >= -(long long)H)          /* history: the H samples that precede the batch */
+                    v = hist[xi + H];
+            } else if (xi <= last_needed) {
+                v = in[xi];
+            }
+            sd[i + (i >> a)] = v;
+        }
+    }
+    if (hist_out != nullptr && blockIdx.x == 0) {
+        for (int i = tid; i < H; i += NT) {
+            const long long j = (long long)i + n_batch;
+            hist_out[i] = j < H ? hist[j] : in[j - H];
+        }
     }
     __syncthreads();
-    const long long q = q0 + tid;
-    if (q < n_out) {
-        /* output q uses local inputs i = tid*D + (ntaps-1) - k */
-        float ar0 = 0.0f, ai0 = 0.0f, ar1 = 0.0f, ai1 = 0.0f;
-        const int top = tid * D + (ntaps - 1);
-        int k = 0;
-        for (; k + 1 < ntaps; k += 2) {
-            const int i0 = top - k, i1 = top - k - 1;
-            const int o0 = i0 + (padshift >= 0 ? (i0 >> padshift) : 0);
-            const int o1 = i1 + (padshift >= 0 ? (i1 >> padshift) : 0);
-            const float h0 = sT[k], h1 = sT[k + 1];
-            ar0 = fmaf(h0, sI[o0], ar0);
-            ai0 = fmaf(h0, sQ[o0], ai0);
-            ar1 = fmaf(h1, sI[o1], ar1);
-            ai1 = fmaf(h1, sQ[o1], ai1);
+    f32x2 acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+        acc[p] = f32x2{ 0.0f, 0.0f };
+    /* sample x[q*D - j], q = q0 + P*tid, has local index S*tid + r with r = ntaps-1-j (wave-
+     * uniform) and sits at lane + r + (r >> a): S*tid is a multiple of 2^a, so the pad splits */
+    const float2 *lane = sd + (S + (S >> a)) * tid;
+    const bool linear = a >= 3;                    /* (r >> a) is constant over an aligned step */
+    for (int r0 = ((ntaps - 1) + (P - 1) * D) | 7; r0 >= 0; r0 -= 8) {
+        const int jb = (ntaps - 1) - r0;           /* tap of output q for the step's first sample */
+        float hh[P][8];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                hh[p][u] = taps[p * D + jb + u];
+        if (linear) {
+            const float2 *x8 = lane + (r0 + (r0 >> a)) - 7;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float2 xv = x8[7 - u];
+                const f32x2 x = { xv.x, xv.y };
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc[p] = __builtin_elementwise_fma(f32x2{ hh[p][u], hh[p][u] }, x, acc[p]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 - u;
+                const float2 xv = lane[r + (r >> a)];
+                const f32x2 x = { xv.x, xv.y };
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc[p] = __builtin_elementwise_fma(f32x2{ hh[p][u], hh[p][u] }, x, acc[p]);
+            }
         }
-        if (k < ntaps) {
-            const int i0 = top - k;
-            const int o0 = i0 + (padshift >= 0 ? (i0 >> padshift) : 0);
-            ar0 = fmaf(sT[k], sI[o0], ar0);
-            ai0 = fmaf(sT[k], sQ[o0], ai0);
-        }
-        *reinterpret_cast<float2 *>(out + 2 * q) = make_float2(ar0 + ar1, ai0 + ai1);
     }
+    const long long q = q0 + (long long)P * tid;
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+        if (q + p < n_out)
+            out[q + p] = make_float2(acc[p].x, acc[p].y);
 }
 
+/* `taps` must be readable (zeros) over [-3*D - 8, ntaps + 3*D + 8): the pipeline uploads
+ * its tap tables that way.  hist_out (or NULL) receives the last H samples of
+ * [hist(H) | in(n_batch)]; it must not alias hist.                                  */
 hipError_t launch_fir_generic(const float *in, const float *hist, int H, long long first, long long n_out,
-                              int D, const float *taps, int ntaps, float *out, hipStream_t s)
+                              int D, const float *taps, int ntaps, float *out, float *hist_out,
+                              long long n_batch, hipStream_t s)
 {
     if (n_out <= 0)
         return hipSuccess;
-    const int span = 255 * D + ntaps;
-    /* pad one float every 2^padshift samples when D is even so the lane stride is odd */
-    int padshift = -1;
-    if ((D & 1) == 0) {
-        padshift = 0;
-        while ((1 << (padshift + 1)) <= D && (D % (1 << (padshift + 1))) == 0)
-            ++padshift;                       /* largest power of two dividing D */
-    }
-    const int plane = span + (padshift >= 0 ? (span >> padshift) : 0) + 4;
-    const int ntp = (ntaps + 3) & ~3;
-    const size_t lds = (size_t)(ntp + 2 * plane) * sizeof(float);
-    if (lds > 160 * 1024)
-        return hipErrorInvalidValue;
-    static int attr_lds[64] = { 0 };            /* per device */
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if ((int)lds > attr_lds[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_generic),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-        attr_lds[dev & 63] = (int)lds;
+    static int ncu_of[64] = { 0 };
+    if (ncu_of[dev & 63] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        ncu_of[dev & 63] = n;
     }
-    const dim3 grid((unsigned)((n_out + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(k_fir_generic, grid, blk, lds, s, in, hist, H, first, n_out, D, taps, ntaps, out, span,
-                       padshift);
+    const int ncu = ncu_of[dev & 63];
+    /* shape: P outputs per thread (fewer LDS reads per output; odd for odd D so that the lane
+     * stride needs no pad), NT threads per block, picked with a small cost model: a round of
+     * resident blocks costs the staging round trips (~2 us per 8 loads per thread) plus the
+     * tap loop of the waves sharing a SIMD; a second, nearly empty round of blocks doubles a
+     * kernel this short                                                                       */
+    static const int shapes[][2] = { { 256, 4 }, { 128, 4 }, { 64, 4 }, { 256, 3 }, { 128, 3 }, { 64, 3 },
+                                     { 256, 2 }, { 128, 2 }, { 64, 2 }, { 256, 1 }, { 64, 1 } };
+    int NT = 0, P = 0, span = 0, a = 31;
+    size_t lds = 0;
+    double best = -1.0;
+    int force_nt = 0, force_p = 0;                     /* development: PDDC_GEN_SHAPE=NT,P */
+    if (const char *e = getenv("PDDC_GEN_SHAPE"))
+        (void)sscanf(e, "%d,%d", &force_nt, &force_p);
+    for (const auto &sh : shapes) {
+        const int nt = sh[0], pp = sh[1];
+        if (force_nt ? (nt != force_nt || pp != force_p) : ((D & 1) ? (pp == 2 || pp == 4) : pp == 3))
+            continue;
+        const int sp = (nt * pp - 1) * D + ntaps;
+        const int S = pp * D;
+        const int aa = (S & 1) ? 31 : __builtin_ctz((unsigned)S);
+        const size_t l = (size_t)(sp + 8 + ((sp + 8) >> aa) + 2) * sizeof(float2);
+        if (l > (pp == 1 ? 160u : 64u) * 1024u)
+            continue;
+        const long long blocks = (n_out + nt * pp - 1) / (nt * pp);
+        long long per_cu = (long long)(160 * 1024 / (l + 512));
+        if (per_cu > 2048 / nt)
+            per_cu = 2048 / nt;
+        if (per_cu > 16)
+            per_cu = 16;
+        if (per_cu < 1)
+            per_cu = 1;
+        const long long rounds = (blocks + per_cu * ncu - 1) / (per_cu * ncu);
+        long long resident = (blocks + ncu - 1) / ncu;          /* blocks sharing a CU in a round */
+        if (resident > per_cu)
+            resident = per_cu;
+        const double waves_per_simd = (double)resident * nt / 256.0;
+        const double t_stage = 2.0 * (double)((sp + 8 * nt - 1) / (8 * nt));
+        const double per_sample = (aa >= 3 ? pp + 1.5 : pp + 4.0);       /* issue slots per window sample */
+        const double t_fir = (double)((pp - 1) * D + ntaps) * per_sample * 4.0 / 2000.0 *
+                             (waves_per_simd < 1.0 ? 1.0 : waves_per_simd);
+        const double t = (double)rounds * (t_stage + t_fir);
+        if (best < 0.0 || t < best) {
+            best = t;
+            NT = nt, P = pp, span = sp, a = aa, lds = l;
+        }
+    }
+    if (NT == 0)
+        return hipErrorInvalidValue;           /* span does not fit LDS even one output per thread */
+    const dim3 grid((unsigned)((n_out + (long long)NT * P - 1) / ((long long)NT * P))), blk((unsigned)NT);
+#define PDDC_GEN(PP)                                                                               \
+    do {                                                                                          \
+        static int attr_lds[64] = { 0 };            /* per device */                             \
+        if ((int)lds > attr_lds[dev & 63]) {                                                      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_generic<PP>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess)                                                                  \
+                return e;                                                                         \
+            attr_lds[dev & 63] = (int)lds;                                                        \
+        }                                                                                         \
+        hipLaunchKernelGGL(k_fir_generic<PP>, grid, blk, lds, s, reinterpret_cast<const float2 *>(in), \
+                           reinterpret_cast<const float2 *>(hist), H, first, n_out, D,            \
+                           (const float PDDC_CONSTANT *)taps, ntaps, reinterpret_cast<float2 *>(out), span, a, \
+                           reinterpret_cast<float2 *>(hist_out), n_batch);                        \
+    } while (0)
+    if (P == 4)
+        PDDC_GEN(4);
+    else if (P == 3)
+        PDDC_GEN(3);
+    else if (P == 2)
+        PDDC_GEN(2);
+    else
+        PDDC_GEN(1);
+#undef PDDC_GEN
     return hipGetLastError();
 }
 

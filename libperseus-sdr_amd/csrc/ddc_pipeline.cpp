@@ -13,6 +13,7 @@
 #include "../../include/perseus_ddc.h"
 #include "ddc_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -50,7 +51,8 @@ struct Stage {
     int interp = 1;               /* L of a rational L/decim stage (1 = plain decimator) */
     int ntaps = 0;
     std::vector<float> taps;      /* host copy (after optional fp16 rounding)  */
-    float *d_taps = nullptr;      /* h[k] linear                                */
+    float *d_taps = nullptr;      /* h[k] linear: points INTO d_taps_base (zero-padded on both sides) */
+    float *d_taps_base = nullptr; /* the allocation                             */
     float *d_taps_blk = nullptr;  /* [ntb][8] block-reversed (fused kernel)     */
     int ntb = 0;                  /* tap blocks if fused-capable, else 0        */
     int hist = 0;                 /* history length in samples (mult. of 8)     */
@@ -126,16 +128,25 @@ static int pick_ntb(int ntaps)
 static int upload_taps(pddc_pipeline *p, int si)
 {
     Stage &s = p->st[si];
-    if (s.d_taps) {
-        hipFree(s.d_taps);
+    if (s.d_taps_base) {
+        hipFree(s.d_taps_base);
+        s.d_taps_base = nullptr;
         s.d_taps = nullptr;
     }
     if (s.d_taps_blk) {
         hipFree(s.d_taps_blk);
         s.d_taps_blk = nullptr;
     }
-    HIP_TRY(hipMalloc(&s.d_taps, sizeof(float) * (size_t)s.ntaps));
-    HIP_TRY(hipMemcpy(s.d_taps, s.taps.data(), sizeof(float) * (size_t)s.ntaps, hipMemcpyHostToDevice));
+    /* zero-padded by 3*D + 8 on both sides: k_fir_generic reads tap p*D + j for every j of
+     * a thread's P <= 4 merged windows (in aligned steps of 8) without bounds checks */
+    {
+        const size_t Z = 3 * (size_t)s.decim + 8;
+        std::vector<float> padded(Z + (size_t)s.ntaps + Z + 8, 0.0f);
+        std::copy(s.taps.begin(), s.taps.begin() + s.ntaps, padded.begin() + (long)Z);
+        HIP_TRY(hipMalloc(&s.d_taps_base, sizeof(float) * padded.size()));
+        HIP_TRY(hipMemcpy(s.d_taps_base, padded.data(), sizeof(float) * padded.size(), hipMemcpyHostToDevice));
+        s.d_taps = s.d_taps_base + Z;
+    }
     s.ntb = stage_fused_capable(s) ? pick_ntb(s.ntaps) : 0;
     /* a second stage that can be fused behind stage 0 always uses 8 tap blocks
      * (64-sample history), fused or not, so both paths share one state format */
@@ -391,8 +402,8 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
     hipSetDevice(p->device);
     hipDeviceSynchronize();
     for (int i = 0; i < PDDC_MAX_STAGES; ++i) {
-        if (p->st[i].d_taps)
-            hipFree(p->st[i].d_taps);
+        if (p->st[i].d_taps_base)
+            hipFree(p->st[i].d_taps_base);
         if (p->st[i].d_taps_blk)
             hipFree(p->st[i].d_taps_blk);
         if (p->st[i].d_buf)
@@ -719,7 +730,9 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             } else if (n_in[i + 1] > 0) {
                 HIP_TRY(launch_fir_generic(static_cast<const float *>(x), static_cast<const float *>(h_in),
                                            st.hist, (long long)off[i], (long long)n_in[i + 1], st.decim,
-                                           st.d_taps, st.ntaps, dst, s));
+                                           st.d_taps, st.ntaps, dst, static_cast<float *>(h_out),
+                                           (long long)n_in[i], s));
+                hist_done = true;             /* block 0 of the kernel wrote the new history */
             }
         }
         if (n_in[i] > 0) {
