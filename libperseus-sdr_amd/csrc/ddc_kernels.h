@@ -36,6 +36,12 @@ struct Fir8Args {
     float       lo_s[8];
 };
 
+/* k_fir8 with packed input does not scale the unpacked integers (value * 256): the taps of
+ * that stage must be uploaded multiplied by this, RN(1/8388607) / 256 -- the factor that
+ * k_unpack24 applies per sample (bit-exact with the reference there; here the FIR tolerance
+ * of 1e-6 applies and one rounding moves from every sample to every tap)                   */
+constexpr float kFir8PackedTapScale = 0x1.000002p-31f;
+
 /* tile geometry of k_fir8<NTB,R>: inputs per block tile */
 constexpr int fir8_tile_inputs(int R) { return 1024 * R; }
 size_t fir8_lds_bytes(int ntb, int R);

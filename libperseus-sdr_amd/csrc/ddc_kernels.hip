@@ -88,23 +88,21 @@ __device__ __forceinline__ void nco_lo(uint32_t phase, float &c, float &s)
     sn = fmaf(sn, t, t);
     float cs = fmaf(t2, fmaf(t2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
     cs = fmaf(t2 * t2, cs, fmaf(t2, -0.5f, 1.0f));
-    float cc, ss;
-    switch (q & 3u) {
-    case 0:  cc = cs;  ss = sn;  break;
-    case 1:  cc = -sn; ss = cs;  break;
-    case 2:  cc = -cs; ss = -sn; break;
-    default: cc = sn;  ss = -cs; break;
-    }
-    c = cc;
-    s = -ss;     /* exp(-j theta) */
+    /* theta = q*pi/2 + t.  Branch-free quadrant fix-up (a switch here costs four divergent
+     * regions per call): odd quadrants swap sin and cos, the signs are XORed in          */
+    const bool odd = (q & 1u) != 0;
+    const float cc = odd ? sn : cs;
+    const float ss = odd ? cs : sn;
+    const uint32_t neg_c = ((q + 1u) & 2u) << 30;              /* cos < 0 in quadrants 1, 2 */
+    const uint32_t neg_s = ((q & 2u) << 30) ^ 0x80000000u;     /* sin < 0 in 2, 3; and exp(-j theta) */
+    c = __uint_as_float(__float_as_uint(cc) ^ neg_c);
+    s = __uint_as_float(__float_as_uint(ss) ^ neg_s);
 }
 
-/* mix 8 consecutive samples starting at absolute index nabs */
+/* mix 8 consecutive samples whose first one has the local oscillator value cb + j*sb */
 template <typename P>
-__device__ __forceinline__ void mix8(float (&xi)[8], float (&xq)[8], unsigned long long nabs, const P &p)
+__device__ __forceinline__ void mix8_lo(float (&xi)[8], float (&xq)[8], float cb, float sb, const P &p)
 {
-    float cb, sb;
-    nco_lo((uint32_t)nabs * p.freg, cb, sb);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         /* LO(nabs+e) = LO(nabs) * step[e] */
@@ -115,6 +113,15 @@ __device__ __forceinline__ void mix8(float (&xi)[8], float (&xq)[8], unsigned lo
         xi[e] = r;
         xq[e] = i;
     }
+}
+
+/* mix 8 consecutive samples starting at absolute index nabs */
+template <typename P>
+__device__ __forceinline__ void mix8(float (&xi)[8], float (&xq)[8], unsigned long long nabs, const P &p)
+{
+    float cb, sb;
+    nco_lo((uint32_t)nabs * p.freg, cb, sb);
+    mix8_lo(xi, xq, cb, sb, p);
 }
 
 /* ======================================================================== */
@@ -320,10 +327,13 @@ __device__ __forceinline__ void group_to_float(const u32x4 (&raw)[NW], float (&x
                                  raw[1].z, raw[1].w, raw[2].x, raw[2].y, raw[2].z, raw[2].w };
         int32_t I[8], Q[8];
         unpack8_msb(w, I, Q);
+        /* no scaling here: the host folds RN(1/8388607)/256 into this stage's taps
+         * (kFir8PackedTapScale), which saves 16 multiplies per group; the samples travel
+         * through mix and LDS as the MSB-aligned integers, exact in fp32               */
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            xi[e] = (float)I[e] * kUnpackScale;
-            xq[e] = (float)Q[e] * kUnpackScale;
+            xi[e] = (float)I[e];
+            xq[e] = (float)Q[e];
         }
     } else {
 #pragma unroll
@@ -337,6 +347,15 @@ __device__ __forceinline__ void group_to_float(const u32x4 (&raw)[NW], float (&x
     }
     if (MIX)     /* zero-filled groups stay zero; the index wraps correctly for negative offsets */
         mix8(xi, xq, nabs, p);
+}
+
+/* same, with the local oscillator value of the group's first sample supplied */
+template <int INFMT, int NW>
+__device__ __forceinline__ void group_to_float_lo(const u32x4 (&raw)[NW], float (&xi)[8], float (&xq)[8], float cb,
+                                                  float sb, const Fir8Args &p)
+{
+    group_to_float<INFMT, false, NW>(raw, xi, xq, 0ull, p);
+    mix8_lo(xi, xq, cb, sb, p);
 }
 
 /* rotated LDS write of group v: e=0 -> slot 7 of group v-1 ; e=1..7 -> slots 0..6 of group v */
@@ -645,6 +664,17 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         }
     };
 
+    /* NCO: exp(-j*2*pi*freg*8*(gtid+256k)/2^32), the rotation from a tile's first sample to
+     * this thread's k-th group (the phase is linear in the sample index, so LO(a+b) = LO(a)*LO(b)) */
+    float lo_wc[G::GPT], lo_ws[G::GPT];
+#pragma unroll
+    for (int k = 0; k < G::GPT; ++k) {
+        lo_wc[k] = 1.0f;
+        lo_ws[k] = 0.0f;
+        if (MIX)
+            nco_lo((uint32_t)(8 * (gtid + 256 * k)) * p.freg, lo_wc[k], lo_ws[k]);
+    }
+
     int  t = (FUSE2 && c_lo > 0) ? c_lo - 1 : c_lo;   /* tile in work (a fused chunk starts one tile early) */
     bool first = true;                                /* t opens a chunk: history comes from rawH            */
     int  tprev = -1;                                  /* tile whose outputs are staged, not yet stored        */
@@ -657,12 +687,20 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
     for (;;) {
         const bool last = (t + 1 == c_hi);            /* last tile of its chunk */
         /* ---- U: registers -> LDS planes (groups NTB ..; a chunk's first tile also 0..NTB-1) ---- */
+        /* NCO: LO(tile start) once per tile from the exact phase, times the thread's constant
+         * rotation to its group -- instead of a sin/cos evaluation per group                   */
+        float lo_tc = 1.0f, lo_ts = 0.0f;
+        if (MIX)
+            nco_lo((uint32_t)(p.n0 + (unsigned long long)((long long)t * G::TI)) * p.freg, lo_tc, lo_ts);
 #pragma unroll
         for (int k = 0; k < G::GPT; ++k) {
             const int v = NTB + gtid + 256 * k;
             float xi[8], xq[8];
-            group_to_float<INFMT, MIX, NW>(rawA[k], xi, xq,
-                                           p.n0 + (unsigned long long)((long long)t * G::TI + 8LL * (gtid + 256 * k)), p);
+            if (MIX)
+                group_to_float_lo<INFMT, NW>(rawA[k], xi, xq, lo_tc * lo_wc[k] - lo_ts * lo_ws[k],
+                                             lo_tc * lo_ws[k] + lo_ts * lo_wc[k], p);
+            else
+                group_to_float<INFMT, false, NW>(rawA[k], xi, xq, 0ull, p);
 #ifdef PDDC_ABLATE_LDSW
             if (xi[0] + xi[1] + xi[2] + xi[3] + xi[4] + xi[5] + xi[6] + xi[7] + xq[0] + xq[1] + xq[2] + xq[3] + xq[4] + xq[5] + xq[6] + xq[7] == 1.2345e-30f)
 #endif

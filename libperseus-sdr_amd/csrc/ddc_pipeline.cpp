@@ -154,11 +154,14 @@ static int upload_taps(pddc_pipeline *p, int si)
         s.ntb = 8;
     if (s.ntb) {
         /* hb[j][e] = h[8j + 7 - e], zero beyond ntaps */
+        /* stage 0's block table is only ever used by the packed-input kernel, which leaves
+         * the unpack scale to the taps */
+        const float tap_scale = si == 0 ? kFir8PackedTapScale : 1.0f;
         std::vector<float> blk((size_t)s.ntb * 8, 0.0f);
         for (int j = 0; j < s.ntb; ++j)
             for (int e = 0; e < 8; ++e) {
                 const int k = 8 * j + 7 - e;
-                blk[(size_t)j * 8 + e] = k < s.ntaps ? s.taps[k] : 0.0f;
+                blk[(size_t)j * 8 + e] = k < s.ntaps ? s.taps[k] * tap_scale : 0.0f;
             }
         HIP_TRY(hipMalloc(&s.d_taps_blk, sizeof(float) * blk.size()));
         HIP_TRY(hipMemcpy(s.d_taps_blk, blk.data(), sizeof(float) * blk.size(), hipMemcpyHostToDevice));
@@ -501,11 +504,14 @@ int pddc_pipeline_set_taps(pddc_pipeline *p, int stage, const float *taps, int n
     if (keep_ntb && s.ntb != keep_ntb) {
         /* keep the tile geometry (history length) chosen at create time */
         s.ntb = keep_ntb;
+        /* stage 0's block table is only ever used by the packed-input kernel, which leaves
+         * the unpack scale to the taps */
+        const float tap_scale = stage == 0 ? kFir8PackedTapScale : 1.0f;
         std::vector<float> blk((size_t)s.ntb * 8, 0.0f);
         for (int j = 0; j < s.ntb; ++j)
             for (int e = 0; e < 8; ++e) {
                 const int k = 8 * j + 7 - e;
-                blk[(size_t)j * 8 + e] = k < s.ntaps ? s.taps[k] : 0.0f;
+                blk[(size_t)j * 8 + e] = k < s.ntaps ? s.taps[k] * tap_scale : 0.0f;
             }
         hipFree(s.d_taps_blk);
         s.d_taps_blk = nullptr;
