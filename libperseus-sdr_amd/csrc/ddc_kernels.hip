@@ -448,6 +448,49 @@ void fir8_probe_dump()
 }
 #endif
 
+/* The same sliding window with the loops exchanged: tap block j outermost, the R groups
+ * that meet it (ub = r + NTB-1-j) held in VGPRs and shifted by one group per step.  Only one
+ * tap block is live at a time (8 SGPRs + the next s_load) instead of R of them: the R=8
+ * kernels otherwise keep 64 tap SGPRs live and spill (119 v_readlane per tile at 255 taps).  */
+#ifndef PDDC_TAP_OUTER_R8
+#define PDDC_TAP_OUTER_R8 1
+#endif
+static constexpr bool kTapOuterR8 = PDDC_TAP_OUTER_R8 != 0;
+template <int NTB, int R, int PAR, bool PADDED = true>
+__device__ __forceinline__ void fir_window_tap_outer(const float *base, const float PDDC_CONSTANT *hb, f32x2 (&acc)[R])
+{
+    auto load_group = [&](int ub, f32x2 (&w)[4]) {
+        const int go = 8 * ub + (PADDED ? 4 * ((ub + PAR * 4) >> 3) : 0);
+        const f32x4 d0 = *reinterpret_cast<const f32x4 *>(base + go);
+        const f32x4 d1 = *reinterpret_cast<const f32x4 *>(base + go + 4);
+        w[0] = f32x2{ d0.x, d0.y };
+        w[1] = f32x2{ d0.z, d0.w };
+        w[2] = f32x2{ d1.x, d1.y };
+        w[3] = f32x2{ d1.z, d1.w };
+    };
+    f32x2 W[R][4];
+#pragma unroll
+    for (int g = 0; g < R; ++g)
+        load_group(g, W[g]);
+#pragma unroll
+    for (int j = NTB - 1; j >= 0; --j) {
+        const f32x2 PDDC_CONSTANT *h = reinterpret_cast<const f32x2 PDDC_CONSTANT *>(hb + 8 * j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                acc[r] = __builtin_elementwise_fma(h[i], W[r][i], acc[r]);
+        if (j > 0) {
+#pragma unroll
+            for (int g = 0; g + 1 < R; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    W[g][i] = W[g + 1][i];
+            load_group(NTB - j + R - 1, W[R - 1]);
+        }
+    }
+}
+
 /* Persistent grid with a two-level tile schedule.  Tiles are grouped into
  * CHUNKS of consecutive tiles; inside a chunk the FIR history is carried in LDS.
  *   static part : block b first owns the S tiles [b*S, (b+1)*S)
@@ -771,6 +814,8 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
 #else
         if (R == 4 && par)
             fir_window<NTB, R, 1>(base, hb, acc);
+        else if (R == 8 && kTapOuterR8)
+            fir_window_tap_outer<NTB, R, 0>(base, hb, acc);
         else
             fir_window<NTB, R, 0>(base, hb, acc);
 #endif

@@ -364,10 +364,11 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
         if (s.hist == 0)
             s.hist = 8;
     }
-    /* outputs per lane of the fused kernel: 4 by default; the long (<= 256 tap) filters
-     * are VALU-bound and run ~8 % faster with 8 (half the LDS reads and tap loads per FMA) */
+    /* outputs per lane of the fused kernel: 8 for filters of 65..256 taps (40 % fewer LDS
+     * reads per output; with the tap-outer window loop no SGPR spills: 127 taps 0.374 ->
+     * 0.348 ms, 255 taps 0.52 -> 0.48 ms), 4 for the short first stages of a cascade */
     if (!getenv("PDDC_FIR8_R"))
-        p->R = p->st[0].ntb >= 32 ? 8 : 4;
+        p->R = p->st[0].ntb >= 16 ? 8 : 4;
     compute_lo_steps(p);
     hipError_t e = hipSuccess;
     for (int i = 0; i < nstages && e == hipSuccess; ++i) {
