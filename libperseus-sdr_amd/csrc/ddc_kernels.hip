@@ -115,6 +115,21 @@ __device__ __forceinline__ void mix8_lo(float (&xi)[8], float (&xq)[8], float cb
     }
 }
 
+/* (a + j b) * (c + j s) */
+__device__ __forceinline__ void cmul(float &a, float &b, float c, float s)
+{
+    const float r = a * c - b * s;
+    const float i = a * s + b * c;
+    a = r;
+    b = i;
+}
+
+/* both complex values of an interleaved (I0,Q0,I1,Q1) vector times (c + j s) */
+__device__ __forceinline__ f32x4 cmul2(f32x4 v, float c, float s)
+{
+    return f32x4{ v.x * c - v.y * s, v.x * s + v.y * c, v.z * c - v.w * s, v.z * s + v.w * c };
+}
+
 /* mix 8 consecutive samples starting at absolute index nabs */
 template <typename P>
 __device__ __forceinline__ void mix8(float (&xi)[8], float (&xq)[8], unsigned long long nabs, const P &p)
@@ -516,7 +531,7 @@ __device__ __forceinline__ void fir_window_tap_outer(const float *base, const fl
  *                 the very threads that overwrite them in the next U, so no
  *                 third barrier is needed).                                */
 template <int NTB, int R, int INFMT, bool MIX, int NTB2>
-__global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int ntiles, int S, int K)
+__global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, int K)
 {
 #ifdef PDDC_CLOCK_PROBE
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
@@ -596,6 +611,13 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         const u32x4 h2raw[4] = { src[0], src[1], src[2], src[3] };
         float xi[8], xq[8];
         group_to_float<IN_F32C, false, 4>(h2raw, xi, xq, 0ull, p);
+        if (MIX) {      /* stored values are final; inside tile 0 they must become final by * phi_0 */
+            float c0, s0;
+            nco_lo((uint32_t)p.n0 * p.freg, c0, s0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                cmul(xi[e], xq[e], c0, -s0);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {            /* position p2 = 8*tid + e - 1, offset 8 + p2 */
             sI2[7 + 8 * tid + e] = xi[e];
@@ -654,11 +676,13 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
     const long long n_out = p.n_in >> 3;
 
     /* S (fused): the tile's TO2 second-stage outputs, 16 bytes per thread */
-    auto store_tile2 = [&](int tile) {
+    auto store_tile2 = [&](int tile, float pc, float ps) {
         constexpr int NCH2 = G2::TO2 / 2;
         if (tid < NCH2) {
             const long long m = (long long)tile * G2::TO2 + 2LL * tid;     /* no ragged tiles when fused */
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(ot2 + 4 * tid);
+            f32x4 v = *reinterpret_cast<const f32x4 *>(ot2 + 4 * tid);
+            if (MIX)                        /* tile-relative NCO: the tile's phasor goes on at the very end */
+                v = cmul2(v, pc, ps);
             float *dstp = p.out + 2 * m;
             asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dstp), "v"(v) : "memory");
         }
@@ -666,7 +690,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
     const float PDDC_CONSTANT *hb2 = (const float PDDC_CONSTANT *)p.taps2_blk;
 
     /* S: coalesced stores of one finished tile from the staging area */
-    auto store_tile = [&](int tile) {
+    auto store_tile = [&](int tile, float pc, float ps) {
         const long long tile_o0 = (long long)tile * G::TO;
         constexpr int NCH = G::TO / 2;                             /* 16-byte chunks */
         if (tile_o0 + G::TO <= n_out) {                            /* whole tile in range (uniform) */
@@ -676,7 +700,9 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
                 const int qs = q ^ ((q >> 3) & 7);
                 /* streaming (nt) store: measured 0.349 vs 0.371 ms for this 6:1
                  * read/write mix (tools/ubench/stream_mix.hip) */
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(ot + 4 * qs);
+                f32x4 v = *reinterpret_cast<const f32x4 *>(ot + 4 * qs);
+                if (MIX)
+                    v = cmul2(v, pc, ps);
                 float *dstp = p.out + 2 * (tile_o0 + 2LL * q);
                 /* Issued from inline asm on purpose: hipcc then does not count the store
                  * in its vmcnt bookkeeping, so the waits it places for the prefetched
@@ -697,7 +723,11 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
             for (int it = 0; it < NCH / 256; ++it) {
                 const int q = tid + 256 * it;
                 const int qs = q ^ ((q >> 3) & 7);
-                const float4 v = *reinterpret_cast<const float4 *>(ot + 4 * qs);
+                float4 v = *reinterpret_cast<const float4 *>(ot + 4 * qs);
+                if (MIX) {
+                    cmul(v.x, v.y, pc, ps);
+                    cmul(v.z, v.w, pc, ps);
+                }
                 const long long m = tile_o0 + 2LL * q;
                 if (m + 1 < n_out)
                     *reinterpret_cast<float4 *>(p.out + 2 * m) = v;
@@ -707,22 +737,45 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         }
     };
 
-    /* NCO: exp(-j*2*pi*freg*8*(gtid+256k)/2^32), the rotation from a tile's first sample to
-     * this thread's k-th group (the phase is linear in the sample index, so LO(a+b) = LO(a)*LO(b)) */
-    float lo_wc[G::GPT], lo_ws[G::GPT];
+    /* NCO, tile-relative.  LO(n) of sample i of tile t factors as phi_t * w(i) with
+     * phi_t = LO(n0 + t*TI) and w(i) = exp(-j*2*pi*freg*i/2^32), i the index inside the tile
+     * (the phase is linear in the sample index).  U multiplies by w(i) only -- per-thread
+     * constants, no sin/cos and no rotation chain per group -- and everything downstream is
+     * linear, so phi_t is applied once per OUTPUT, at the stores.  A sample carried to the
+     * next tile as FIR history is rotated by conj(D), D = phi_(t+1)/phi_t = LO(TI).
+     * R=4: w for the thread's 8*GPT samples sits in registers; R=8 (no VGPRs to spare) keeps
+     * w of each group's first sample and steps through the group with the host's phasors.   */
+    constexpr bool WTAB = MIX && R == 4;
+    float w_c[WTAB ? G::GPT : 1][8], w_s[WTAB ? G::GPT : 1][8];
+    float wg_c[G::GPT], wg_s[G::GPT];
+    float d_c = 1.0f, d_s = 0.0f;
 #pragma unroll
     for (int k = 0; k < G::GPT; ++k) {
-        lo_wc[k] = 1.0f;
-        lo_ws[k] = 0.0f;
-        if (MIX)
-            nco_lo((uint32_t)(8 * (gtid + 256 * k)) * p.freg, lo_wc[k], lo_ws[k]);
+        wg_c[k] = 1.0f;
+        wg_s[k] = 0.0f;
+        if (MIX && !WTAB)
+            nco_lo((uint32_t)(8 * (gtid + 256 * k)) * p.freg, wg_c[k], wg_s[k]);
+        if (WTAB) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                nco_lo((uint32_t)(8 * (gtid + 256 * k) + e) * p.freg, w_c[k][e], w_s[k][e]);
+        }
     }
+    if (MIX)
+        nco_lo((uint32_t)G::TI * p.freg, d_c, d_s);
+    auto tile_phasor = [&](int tile, float &c, float &sn) {
+        c = 1.0f;
+        sn = 0.0f;
+        if (MIX)
+            nco_lo((uint32_t)(p.n0 + (unsigned long long)((long long)tile * G::TI)) * p.freg, c, sn);
+    };
 
     int  t = (FUSE2 && c_lo > 0) ? c_lo - 1 : c_lo;   /* tile in work (a fused chunk starts one tile early) */
     bool first = true;                                /* t opens a chunk: history comes from rawH            */
     int  tprev = -1;                                  /* tile whose outputs are staged, not yet stored        */
     bool prev_out2 = false;                           /* ... and (fused) whether it produced stage-2 outputs  */
     unsigned grabv = 0;                               /* thread 0: the chunk taken for after this one         */
+    float pp_c = 1.0f, pp_s = 0.0f;                   /* NCO phasor of tile tprev                             */
     prefetch(t, true);
     if (t + 1 == c_hi && tid == 0)
         grabv = atomicAdd(p.sched, 1u);
@@ -730,20 +783,20 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
     for (;;) {
         const bool last = (t + 1 == c_hi);            /* last tile of its chunk */
         /* ---- U: registers -> LDS planes (groups NTB ..; a chunk's first tile also 0..NTB-1) ---- */
-        /* NCO: LO(tile start) once per tile from the exact phase, times the thread's constant
-         * rotation to its group -- instead of a sin/cos evaluation per group                   */
-        float lo_tc = 1.0f, lo_ts = 0.0f;
-        if (MIX)
-            nco_lo((uint32_t)(p.n0 + (unsigned long long)((long long)t * G::TI)) * p.freg, lo_tc, lo_ts);
+        float pt_c, pt_s;                                /* this tile's phasor, used when its outputs leave */
+        tile_phasor(t, pt_c, pt_s);
 #pragma unroll
         for (int k = 0; k < G::GPT; ++k) {
             const int v = NTB + gtid + 256 * k;
             float xi[8], xq[8];
-            if (MIX)
-                group_to_float_lo<INFMT, NW>(rawA[k], xi, xq, lo_tc * lo_wc[k] - lo_ts * lo_ws[k],
-                                             lo_tc * lo_ws[k] + lo_ts * lo_wc[k], p);
-            else
-                group_to_float<INFMT, false, NW>(rawA[k], xi, xq, 0ull, p);
+            group_to_float<INFMT, false, NW>(rawA[k], xi, xq, 0ull, p);
+            if (WTAB) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    cmul(xi[e], xq[e], w_c[WTAB ? k : 0][e], w_s[WTAB ? k : 0][e]);
+            } else if (MIX) {
+                mix8_lo(xi, xq, wg_c[k], wg_s[k], p);
+            }
 #ifdef PDDC_ABLATE_LDSW
             if (xi[0] + xi[1] + xi[2] + xi[3] + xi[4] + xi[5] + xi[6] + xi[7] + xq[0] + xq[1] + xq[2] + xq[3] + xq[4] + xq[5] + xq[6] + xq[7] == 1.2345e-30f)
 #endif
@@ -751,8 +804,8 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         }
         if (first && tid < NTB) {          /* after the tile's own groups: rawH was requested last */
             float xi[8], xq[8];
-            group_to_float<INFMT, MIX, NW>(rawH, xi, xq,
-                                           p.n0 + (unsigned long long)((long long)t * G::TI + 8LL * tid - 8 * NTB), p);
+            /* tile-relative index 8*tid - 8*NTB < 0: the 32-bit phase wraps correctly */
+            group_to_float<INFMT, MIX, NW>(rawH, xi, xq, (unsigned long long)(long long)(8 * tid - 8 * NTB), p);
             group_to_lds<R>(sI, sQ, tid, xi, xq);
         }
         /* ---- S (deferred): the PREVIOUS tile's stores go out here, behind this
@@ -766,12 +819,12 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         if (last && tid == 0)
             smem[0] = __int_as_float((int)grabv);
         if (!FUSE2 && tprev >= 0)
-            store_tile(tprev);
+            store_tile(tprev, pp_c, pp_s);
 #ifndef PDDC_ABLATE_BARRIERS
         __syncthreads();                                           /* A */
 #endif
         if (FUSE2 && prev_out2)        /* written by waves 0/1 after the previous barrier B */
-            store_tile2(tprev);
+            store_tile2(tprev, pp_c, pp_s);
 
         /* ---- P: next tile's loads (and, one tile before a chunk ends, the next chunk) ---- */
         int tn = t + 1, n_lo = c_lo, n_hi = c_hi;
@@ -846,10 +899,20 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
         if (!last && gtid >= 256 - NTB) {
             const int gd = gtid - (256 - NTB);                      /* 0..NTB-1 */
             const int os = goff<R>(G::GT + gd), od = goff<R>(gd);
-            const float4 i0 = *reinterpret_cast<const float4 *>(sI + os);
-            const float4 i1 = *reinterpret_cast<const float4 *>(sI + os + 4);
-            const float4 q0 = *reinterpret_cast<const float4 *>(sQ + os);
-            const float4 q1 = *reinterpret_cast<const float4 *>(sQ + os + 4);
+            float4 i0 = *reinterpret_cast<const float4 *>(sI + os);
+            float4 i1 = *reinterpret_cast<const float4 *>(sI + os + 4);
+            float4 q0 = *reinterpret_cast<const float4 *>(sQ + os);
+            float4 q1 = *reinterpret_cast<const float4 *>(sQ + os + 4);
+            if (MIX) {          /* into the next tile's frame: * conj(D) */
+                cmul(i0.x, q0.x, d_c, -d_s);
+                cmul(i0.y, q0.y, d_c, -d_s);
+                cmul(i0.z, q0.z, d_c, -d_s);
+                cmul(i0.w, q0.w, d_c, -d_s);
+                cmul(i1.x, q1.x, d_c, -d_s);
+                cmul(i1.y, q1.y, d_c, -d_s);
+                cmul(i1.z, q1.z, d_c, -d_s);
+                cmul(i1.w, q1.w, d_c, -d_s);
+            }
             *reinterpret_cast<float4 *>(sI + od) = i0;
             *reinterpret_cast<float4 *>(sQ + od) = q0;
             *reinterpret_cast<float2 *>(sI + od + 4) = make_float2(i1.x, i1.y);
@@ -881,8 +944,26 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
             }
             if (!last && lane < NTB2) {
                 const int os = 8 + 8 * (G2::GT2 + lane), od = 8 + 8 * lane;
-                const float4 a0 = *reinterpret_cast<const float4 *>(pl2 + os);
-                const float4 a1 = *reinterpret_cast<const float4 *>(pl2 + os + 4);
+                float4 a0 = *reinterpret_cast<const float4 *>(pl2 + os);
+                float4 a1 = *reinterpret_cast<const float4 *>(pl2 + os + 4);
+                if (MIX) {
+                    /* * conj(D), like the first stage's history.  The rotation needs the other
+                     * plane's tail too: read-only here (written before B), and each wave still
+                     * writes only its own plane, so the two waves do not race                 */
+                    const float *ol2 = wave ? sI2 : sQ2;
+                    const float4 b0 = *reinterpret_cast<const float4 *>(ol2 + os);
+                    const float4 b1 = *reinterpret_cast<const float4 *>(ol2 + os + 4);
+                    /* wave 0: I' = I*dc + Q*ds ; wave 1: Q' = Q*dc - I*ds */
+                    const float sg = wave ? -d_s : d_s;
+                    a0.x = a0.x * d_c + b0.x * sg;
+                    a0.y = a0.y * d_c + b0.y * sg;
+                    a0.z = a0.z * d_c + b0.z * sg;
+                    a0.w = a0.w * d_c + b0.w * sg;
+                    a1.x = a1.x * d_c + b1.x * sg;
+                    a1.y = a1.y * d_c + b1.y * sg;
+                    a1.z = a1.z * d_c + b1.z * sg;
+                    a1.w = a1.w * d_c + b1.w * sg;
+                }
                 *reinterpret_cast<float4 *>(pl2 + od) = a0;
                 *reinterpret_cast<float2 *>(pl2 + od + 4) = make_float2(a1.x, a1.y);
                 pl2[od + 6] = a1.z;
@@ -891,6 +972,8 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
             }
         }
         tprev = t;
+        pp_c = pt_c;
+        pp_s = pt_s;
         prev_out2 = FUSE2 && t >= c_lo;
         if (tn < 0)
             break;
@@ -903,14 +986,17 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : 2)) void k_fir8(Fir8Args p, int 
     if (FUSE2) {
         __syncthreads();                 /* ot2 and the stage-2 planes of the last tile are complete */
         if (prev_out2)
-            store_tile2(tprev);
+            store_tile2(tprev, pp_c, pp_s);
         /* the last 8*NTB2 stage-1 outputs are the second stage's next history */
         if (p.hist2_out != nullptr && tprev == ntiles - 1 && tid < 8 * NTB2) {
             const int o = 8 + (G::TO + tid - 1);       /* position of stage-1 output TO - 8*NTB2 + tid */
-            static_cast<float2 *>(p.hist2_out)[tid] = make_float2(sI2[o], sQ2[o]);
+            float hi = sI2[o], hq = sQ2[o];
+            if (MIX)
+                cmul(hi, hq, pp_c, pp_s);              /* stored in final form */
+            static_cast<float2 *>(p.hist2_out)[tid] = make_float2(hi, hq);
         }
     } else {
-        store_tile(tprev);
+        store_tile(tprev, pp_c, pp_s);
     }
 
     /* the block that ran the last tile leaves the batch's last 8*NTB input
