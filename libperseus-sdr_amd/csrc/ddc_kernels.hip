@@ -18,14 +18,17 @@
  *   k_synth_lcg    device-side synthetic source.
  *
  * k_fir8 design (DESIGN.md "Kernels"):
- *   - persistent grid (4 blocks per CU at R=4); a block = 256 threads = 4 waves
- *     owns a contiguous run of tiles; tile = 1024*R input samples
+ *   - persistent grid (2 blocks per CU); a block = 256 threads = 4 waves; tile = 1024*R
+ *     input samples; two-level schedule: a static run of tiles per block, then
+ *     dynamic chunks from an atomic counter (the two blocks of a CU run unevenly)
  *   - load phase: every thread pulls whole 48-byte groups (8 samples) with
  *     3x global_load_dwordx4 one tile ahead (registers), unpacks with
- *     v_perm_b32 / v_cvt_f32_i32 / one multiply (bit-exact with the reference),
- *     optionally mixes with the NCO, and writes PLANAR I / Q floats to LDS,
- *     rotated by one sample so that FIR windows are 16-byte aligned; the
- *     last NTB groups of a tile stay in LDS as the next tile's history
+ *     v_perm_b32 / v_cvt_f32_i32 (the 1/8388607 scale lives in the taps),
+ *     optionally mixes with the NCO in tile-relative form (per-thread constant
+ *     phasors; the tile's phasor goes on once per output at the stores), and
+ *     writes PLANAR I / Q floats to LDS, rotated by one sample so that FIR windows
+ *     are 16-byte aligned; the last NTB groups of a tile stay in LDS as the next
+ *     tile's history
  *   - FIR phase: waves 0,2 filter the I plane, waves 1,3 the Q plane; each
  *     lane owns R consecutive outputs (a register sliding window over
  *     R+NTB-1 aligned 8-sample LDS groups, 2x ds_read_b128 each, conflict
@@ -34,13 +37,14 @@
  *     no VGPR and no LDS traffic; the FMAs are PACKED (v_pk_fma_f32: every
  *     VALU op costs ~4 clocks per wave64 on this chip and the packed form does
  *     two FMAs in that slot), each output's dot product split into its even
- *     and odd terms so both operands are natural adjacent pairs
+ *     and odd terms so both operands are natural adjacent pairs; at R=8 the tap
+ *     block is the outer loop, so one block of taps is live instead of eight
  *   - store phase: results are transposed through LDS (XOR-swizzled 16-byte
  *     chunks) into interleaved float2 and leave as coalesced nontemporal
  *     dwordx4 stores, one tile late so they sit behind the next load wait
  *   - optional fused second decimate-by-8 stage on the tile's outputs (NTB2)
  *   No MFMA: 9 flop/B, a banded single-filter FIR would waste 2/3 of a matrix
- *   op, and the stream is memory-bound (BASELINE.json north_star).
+ *   op, and the stream is memory- and power-bound.
  */
 #include "ddc_kernels.h"
 
