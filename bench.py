@@ -269,10 +269,19 @@ def main():
             res["cpu_baseline"] = None
     else:
         res = None
+    # RCCL writes its version banner to C stdout, which is block buffered on a pipe and would
+    # otherwise come out at process exit -- after the JSON line, on any rank.  Every rank flushes
+    # it now, then all ranks meet, then rank 0 prints the one JSON line last.
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if shard.is_dist():
+        barrier()
         dist.destroy_process_group()
-    if res is not None:                     # the JSON line is the last thing this process prints
-        sys.stdout.flush()
+    if res is not None:
         print(json.dumps(res), flush=True)
 
 

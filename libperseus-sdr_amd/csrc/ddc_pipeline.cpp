@@ -395,6 +395,9 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
         pddc_pipeline_destroy(p);
         return rc;
     }
+    if (getenv("PDDC_DEBUG"))
+        fprintf(stderr, "[pddc] pipeline %p sched %p taps_blk %p %p\n", (void *)p, (void *)p->d_sched,
+                (void *)p->st[0].d_taps_blk, (void *)p->st[1].d_taps_blk);
     *out = p;
     return PDDC_OK;
 }
@@ -593,6 +596,9 @@ static int ensure_buf(Stage &s, size_t need)
     s.buf_cap = 0;
     HIP_TRY(hipMalloc(&s.d_buf, sizeof(float) * 2 * cap));
     s.buf_cap = cap;
+    if (getenv("PDDC_DEBUG"))
+        fprintf(stderr, "[pddc] stage buffer %p (%zu samples) hist %p %p\n", (void *)s.d_buf, cap, s.d_hist[0],
+                s.d_hist[1]);
     return PDDC_OK;
 }
 
