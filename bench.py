@@ -229,7 +229,9 @@ def main():
                   "note": "hot path + RCCL gather of the /%d float32 output to rank 0, gather of batch k "
                           "overlapped with the kernels of batch k+1" % decim,
                   "out_bytes_per_rank_per_step": int(n_out * 8),
-                  "root_ingest_GBps": round((world - 1) * (n_out * 8) * a.steps / tgv / 1e9, 2)}
+                  "root_ingest_GBps": round((world - 1) * (n_out * 8) * a.steps / tgv / 1e9, 2),
+                  # xGMI is point to point: each peer reaches rank 0 over its own link
+                  "per_link_GBps": round((n_out * 8) * a.steps / tgv / 1e9, 2) if world > 1 else 0.0}
 
     if rank == 0:
         total_samples = world * ns * a.steps

@@ -112,6 +112,15 @@ int pddc_pipeline_create(pddc_pipeline **out, int device,
 int pddc_pipeline_destroy(pddc_pipeline *p);
 /* zero FIR histories, decimation phases and the NCO sample counter            */
 int pddc_pipeline_reset(pddc_pipeline *p);
+/* reset, then place the stream at absolute input sample `abs_sample` with zero history:
+ * the NCO phase and every stage's decimation phase are those of a stream that started at
+ * sample 0.  This is what lets ONE stream be cut into time chunks for several GPUs
+ * (SURVEY.md 8e (2)): a rank seeks to (chunk start - halo), processes halo + chunk and drops
+ * the first halo/decimation outputs; the NCO needs no hand-over because its phase is a pure
+ * function of the absolute index (perseus-sdr.c:584).  abs_sample must lie on an output
+ * boundary of every stage (a multiple of the product of the decimation factors is enough)
+ * and be a multiple of PDDC_INPUT_GRANULE.                                                */
+int pddc_pipeline_seek(pddc_pipeline *p, uint64_t abs_sample);
 int pddc_pipeline_set_freg(pddc_pipeline *p, uint32_t freg);
 int pddc_pipeline_set_center_freq(pddc_pipeline *p, double center_freq_hz);
 int pddc_pipeline_set_taps(pddc_pipeline *p, int stage, const float *taps, int ntaps);

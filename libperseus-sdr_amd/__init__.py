@@ -88,6 +88,7 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(StageDesc), C.c_int, C.c_uint32]
     L.pddc_pipeline_destroy.argtypes = [vp]
     L.pddc_pipeline_reset.argtypes = [vp]
+    L.pddc_pipeline_seek.argtypes = [vp, C.c_uint64]
     L.pddc_pipeline_set_freg.argtypes = [vp, C.c_uint32]
     L.pddc_pipeline_set_center_freq.argtypes = [vp, C.c_double]
     L.pddc_pipeline_set_taps.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int]
@@ -104,7 +105,7 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_time_stage0.argtypes = [vp, vp, sz, vp, C.c_int, vp, C.POINTER(C.c_float)]
     for name in ("pddc_unpack24_f32", "pddc_unpack24_i32", "pddc_pack24_f32", "pddc_synth_lcg", "pddc_set_device",
                  "pddc_malloc", "pddc_free", "pddc_memcpy_h2d", "pddc_memcpy_d2h", "pddc_stream_sync",
-                 "pddc_pipeline_create", "pddc_pipeline_destroy", "pddc_pipeline_reset",
+                 "pddc_pipeline_create", "pddc_pipeline_destroy", "pddc_pipeline_reset", "pddc_pipeline_seek",
                  "pddc_pipeline_set_freg", "pddc_pipeline_set_center_freq", "pddc_pipeline_set_taps",
                  "pddc_pipeline_total_decim", "pddc_pipeline_uses_fused", "pddc_pipeline_process",
                  "pddc_pipeline_push_host", "pddc_pipeline_time_stage0"):
@@ -150,6 +151,11 @@ class Pipeline:
 
     def reset(self):
         check(ddc_lib().pddc_pipeline_reset(self._h))
+
+    def seek(self, abs_sample: int):
+        """Zero history, stream positioned at absolute input sample `abs_sample` (NCO and
+        decimation phases of a stream that started at 0): time-chunk sharding, shard.py."""
+        check(ddc_lib().pddc_pipeline_seek(self._h, int(abs_sample)))
 
     def set_freg(self, freg: int):
         check(ddc_lib().pddc_pipeline_set_freg(self._h, freg & 0xFFFFFFFF))

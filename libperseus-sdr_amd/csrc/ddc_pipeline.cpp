@@ -472,6 +472,32 @@ int pddc_pipeline_set_center_freq(pddc_pipeline *p, double hz)
 
 uint32_t pddc_pipeline_get_freg(const pddc_pipeline *p) { return p ? p->freg : 0; }
 
+int pddc_pipeline_seek(pddc_pipeline *p, uint64_t abs_sample)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    /* every stage must land on an output boundary, and the rational stages on a phase-0 one */
+    unsigned long long pos = abs_sample;
+    unsigned long long at[PDDC_MAX_STAGES];
+    for (int i = 0; i < p->nstages; ++i) {
+        const Stage &s = p->st[i];
+        at[i] = pos;
+        if (pos % (unsigned long long)s.decim)
+            return fail(PDDC_EINVAL, "position %llu is not on an output boundary of stage %d",
+                        (unsigned long long)abs_sample, i);
+        pos = pos / (unsigned long long)s.decim * (unsigned long long)(s.interp > 1 ? s.interp : 1);
+    }
+    if (abs_sample % PDDC_INPUT_GRANULE)
+        return fail(PDDC_EINVAL, "position must be a multiple of %d", PDDC_INPUT_GRANULE);
+    int rc = pddc_pipeline_reset(p);
+    if (rc)
+        return rc;
+    p->n0 = abs_sample;
+    for (int i = 0; i < p->nstages; ++i)
+        p->st[i].consumed = at[i];
+    return PDDC_OK;
+}
+
 int pddc_pipeline_total_decim(const pddc_pipeline *p)
 {
     if (!p)

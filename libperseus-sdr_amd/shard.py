@@ -1,7 +1,9 @@
 """Multi-GPU sharding of the stream: one process per GPU, one independent
 stream per rank (the reference models up to 8 receivers as 8 independent
-descriptors, perseus-sdr.c:43-47).  The data path needs no
-collective; RCCL (torch.distributed backend "nccl") is used only to
+descriptors, perseus-sdr.c:43-47) -- or ONE stream cut into
+contiguous time chunks, chunk g on GPU g, each re-reading a halo of history
+(8e (2): time_chunks / cascade_halo / Pipeline.seek).  The data path needs no
+collective either way; RCCL (torch.distributed backend "nccl") is used only to
   - broadcast the configuration (taps, NCO word, stage plan) from rank 0,
   - reduce the step time (MAX over ranks) for the benchmark,
   - optionally gather the decimated output to rank 0 (BASELINE config 4).
@@ -30,6 +32,46 @@ def is_dist() -> bool:
 def stream_seed(rank: int, base: int = 12345) -> int:
     """LCG seed of the stream owned by `rank` (BASELINE.md 3 / SURVEY.md 8d: seeds 12345+g)."""
     return (base + rank) & 0xFFFFFFFF
+
+
+def cascade_halo(stages, align: int = 8) -> int:
+    """Input samples of history a cascade of (D, taps[, L]) decimators needs in front of a
+    chunk so that every output of the chunk is exact: h1 + D1*h2 + D1*D2*h3 ...,
+    h_i = ntaps_i - 1, rounded up to a multiple of `align` and of the overall decimation."""
+    span, dprod = 0, 1
+    for st in stages:
+        d, h = int(st[0]), np.asarray(st[1])
+        if len(st) > 2 and st[2] and int(st[2]) > 1:
+            raise ValueError("time-chunk sharding covers integer decimators only")
+        span += dprod * (h.size - 1)
+        dprod *= d
+    unit = int(np.lcm(dprod, align))
+    return ((span + unit - 1) // unit) * unit
+
+
+def time_chunks(total_samples: int, world: int, unit: int):
+    """Cut [0, total_samples) into `world` contiguous chunks whose boundaries are multiples
+    of `unit` (the overall decimation, or the kernel tile to stay on the fused path).
+    Returns [(start, length)] per rank; the last rank takes the remainder."""
+    if total_samples % unit:
+        raise ValueError("total_samples must be a multiple of unit")
+    per = (total_samples // unit // world) * unit
+    out = []
+    for r in range(world):
+        start = r * per
+        out.append((start, per if r < world - 1 else total_samples - start))
+    return out
+
+
+def process_time_chunk(pipe, d_packed_with_halo, start: int, halo: int, total_decim: int):
+    """Run one time chunk on this rank's pipeline: `d_packed_with_halo` holds the samples
+    [start - halo', start + length) of the ONE stream, halo' = min(halo, start) (the stream's
+    first chunk has nothing in front of it and starts from zero history like the stream itself).
+    Returns the chunk's outputs (a view that drops the halo's)."""
+    h = min(halo, start)
+    pipe.seek(start - h)
+    y = pipe.process(d_packed_with_halo)
+    return y[h // total_decim:]
 
 
 def broadcast_config(cfg: dict | None, device, src: int = 0) -> dict:

@@ -81,3 +81,72 @@ def test_single_process_helpers_are_noops():
     t = torch.arange(4)
     assert shard.gather_to_root(t)[0] is t
     assert shard.stream_seed(3) == 12348
+
+
+# ------------------------------------------------ ONE stream cut into time chunks
+def _oracle_chunk(O, packed_seg, stages, freg, n0):
+    """What a rank's pipeline computes after seek(n0): zero history, absolute NCO phase."""
+    x = O.nco_mix(O.unpack24_f32(packed_seg).astype(np.float64), freg, n0)
+    for d, h in stages:
+        x = O.fir_decim(x, h, d)
+    return np.asarray(x, dtype=np.float64)
+
+
+def _time_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = importlib.import_module("libperseus-sdr_amd.shard")
+    from oracle import oracle as O
+    stages = [(8, load_taps("c320_s1_d8_32")), (8, load_taps("c320_s2_d8_64")), (5, load_taps("c320_s3_d5_161"))]
+    freg, dtot = 381178347, 320
+    total = 320 * 64 * 6
+    halo = shard.cascade_halo(stages)
+    start, length = shard.time_chunks(total, world, dtot)[rank]
+    h = min(halo, start)
+    stream = O.lcg_bytes(6 * total, 12345)                      # every rank can generate the ONE stream
+    seg = stream[6 * (start - h):6 * (start + length)]
+    y = _oracle_chunk(O, seg, stages, freg, start - h)[2 * (h // dtot):]
+    t = torch.from_numpy(np.ascontiguousarray(y))
+    bufs = [torch.empty(2 * (ln // dtot), dtype=torch.float64) for _, ln in shard.time_chunks(total, world, dtot)] \
+        if rank == 0 else None
+    dist.gather(t, bufs, dst=0)
+    res = {"rank": rank, "halo": halo, "chunk": (start, length)}
+    if rank == 0:
+        stitched = np.concatenate([b.numpy() for b in bufs])
+        ref = _oracle_chunk(O, stream, stages, freg, 0)
+        res["err"] = float(np.abs(stitched - ref).max() / np.abs(ref).max())
+        res["n"] = (stitched.size, ref.size)
+    q.put(res)
+    dist.destroy_process_group()
+
+
+def test_time_chunk_sharding_stitches_to_the_single_stream(O):
+    """Two ranks, one stream: each rank's [halo | chunk] from zero history, halo outputs
+    dropped, gathered in rank order == the single-stream result (NCO phase from the
+    absolute index, no hand-over)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_time_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r["rank"]: r for r in (q.get(timeout=180) for _ in range(world))}
+    for p in procs:
+        p.join(60)
+    assert res[0]["halo"] % 320 == 0 and res[0]["halo"] >= 31 + 8 * 63 + 64 * 160
+    assert res[1]["chunk"][0] == res[0]["chunk"][1]
+    assert res[0]["n"][0] == res[0]["n"][1]
+    assert res[0]["err"] < 1e-12
+
+
+def test_time_chunk_helpers():
+    shard = importlib.import_module("libperseus-sdr_amd.shard")
+    ch = shard.time_chunks(8192 * 10, 4, 8192)
+    assert ch == [(0, 16384), (16384, 16384), (32768, 16384), (49152, 32768)]
+    assert sum(ln for _, ln in ch) == 81920
+    with pytest.raises(ValueError):
+        shard.time_chunks(1000, 2, 320)
+    assert shard.cascade_halo([(8, np.zeros(127, np.float32))]) == 128
+    with pytest.raises(ValueError):
+        shard.cascade_halo([(25, np.zeros(100, np.float32), 12)])

@@ -5,6 +5,7 @@ Bars: unpack bit-exact; FIR / NCO stages max|y-ref|/max|ref| <= 1e-6
 (BASELINE.json north_star; metric defined in oracle.rel_err / DESIGN.md).
 """
 import hashlib
+import importlib
 import json
 import os
 
@@ -624,6 +625,42 @@ def test_fused_stage_pair_equals_unfused_whole_buffer(pkg, dev, O, monkeypatch):
     assert float((a2 - b2).abs().max()) / scale <= 1e-6
     fused.close()
     plain.close()
+
+
+# ------------------------------------- ONE stream cut into time chunks for several GPUs
+@pytest.mark.parametrize("name", ["d8_127", "c320"])
+def test_time_chunk_sharding_on_one_gpu(pkg, dev, O, name):
+    """four "ranks" (run one after the other here) each take a contiguous
+    time chunk of the same stream: seek(chunk start - halo), process halo + chunk, drop the
+    halo's outputs.  Stitched, that is the single-stream result -- with the NCO, whose phase
+    comes from the absolute sample index alone."""
+    shard = importlib.import_module("libperseus-sdr_amd.shard")
+    if name == "d8_127":
+        stages, mix, unit = [(8, load_taps("d8_127"))], True, 8192
+    else:
+        stages, mix, unit = [(8, load_taps("c320_s1_d8_32")), (8, load_taps("c320_s2_d8_64")),
+                             (5, load_taps("c320_s3_d5_161"))], True, 4096 * 5
+    dtot = int(np.prod([d for d, _ in stages]))
+    total = unit * 14
+    stream = O.lcg_bytes(6 * total, 12345)
+    ref = O.ddc_chain(stream, stages, freg=381178347, mix=mix)
+    halo = shard.cascade_halo(stages, align=unit)                 # whole tiles: stays on the fused kernels
+    parts = []
+    for start, length in shard.time_chunks(total, 4, unit):
+        h = min(halo, start)
+        pipe = pkg.Pipeline(stages, mix=mix)
+        pipe.set_freg(381178347)
+        y = shard.process_time_chunk(pipe, to_dev(stream[6 * (start - h):6 * (start + length)], dev), start, halo, dtot)
+        parts.append(y.cpu().numpy().reshape(-1))
+        pipe.close()
+    y = np.concatenate(parts)
+    assert y.size == ref.size
+    assert O.rel_err(y, ref) <= FIR_TOL
+    # a position off the output grid is refused
+    pipe = pkg.Pipeline(stages, mix=mix)
+    with pytest.raises(Exception):
+        pipe.seek(dtot + 4)
+    pipe.close()
 
 
 # --------------------------------------------- randomized chunking (state machine)
