@@ -1,0 +1,34 @@
+#!/bin/bash
+# HBM traffic of the dominant kernel of every bench workload, from separate --pmc passes
+# (FETCH_SIZE undercounts 16 B/lane streams by 2x on gfx950: MI355X_MICROARCH.md, HBM section).
+# Usage on the GPU box: tools/pmc_traffic.sh [outdir]   -> <outdir>/pmc_traffic.json
+OUT=${1:-gpurun_out/pmc_traffic}
+mkdir -p $OUT
+export TMPDIR=/tmp
+for W in d8_127 d8_255 c320 unpack; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/${W}_$C -- python3 bench.py --no-cpu --workload $W --steps 5 --warmup 1 > $OUT/${W}_$C.log 2>&1
+  done
+done
+python3 - $OUT <<'PY'
+import csv, glob, json, sys
+out = sys.argv[1]
+kern = {"d8_127": "k_fir8", "d8_255": "k_fir8", "c320": "k_fir8", "unpack": "k_unpack24"}
+alg = {"d8_127": 7.0, "d8_255": 7.0, "c320": 6.125, "unpack": 14.0}      # bytes per input sample of that kernel
+res = {}
+for w, k in kern.items():
+    v = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        vals = []
+        for f in glob.glob(f"{out}/{w}_{c}/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if k in r["Kernel_Name"] and r["Counter_Name"] == c:
+                    vals.append(float(r["Counter_Value"]))
+        v[c] = sum(vals) / len(vals) if vals else None
+    if v["FETCH_SIZE"] is not None and v["WRITE_SIZE"] is not None:
+        res[w] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+        print(f"{w:8s} {k:12s} corrected HBM bytes per launch {res[w]:.4e}   algorithmic {alg[w] * 2**28:.4e}")
+res["note"] = ("HBM bytes per launch of the dominant kernel (2^28 samples): (2*FETCH_SIZE + WRITE_SIZE) KiB from separate "
+               "rocprofv3 --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (tools/pmc_traffic.sh)")
+json.dump(res, open(f"{out}/pmc_traffic.json", "w"), indent=1)
+PY
