@@ -534,6 +534,8 @@ __device__ __forceinline__ void fir_window_tap_outer(const float *base, const fl
  *              C  the last NTB groups become the next tile's history (copied by
  *                 the very threads that overwrite them in the next U, so no
  *                 third barrier is needed).                                */
+/* (PDDC_ABLATE_LOADS / _FIR / _STORES: timing-only builds with one part of the kernel removed,
+ * tools/ablate.sh; their outputs are garbage.)                                              */
 template <int NTB, int R, int INFMT, bool MIX, int NTB2>
 __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, int K)
 {
@@ -801,9 +803,6 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
             } else if (MIX) {
                 mix8_lo(xi, xq, wg_c[k], wg_s[k], p);
             }
-#ifdef PDDC_ABLATE_LDSW
-            if (xi[0] + xi[1] + xi[2] + xi[3] + xi[4] + xi[5] + xi[6] + xi[7] + xq[0] + xq[1] + xq[2] + xq[3] + xq[4] + xq[5] + xq[6] + xq[7] == 1.2345e-30f)
-#endif
             group_to_lds<R>(sI, sQ, v, xi, xq);
         }
         if (first && tid < NTB) {          /* after the tile's own groups: rawH was requested last */
@@ -824,9 +823,7 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
             smem[0] = __int_as_float((int)grabv);
         if (!FUSE2 && tprev >= 0)
             store_tile(tprev, pp_c, pp_s);
-#ifndef PDDC_ABLATE_BARRIERS
         __syncthreads();                                           /* A */
-#endif
         if (FUSE2 && prev_out2)        /* written by waves 0/1 after the previous barrier B */
             store_tile2(tprev, pp_c, pp_s);
 
@@ -895,9 +892,7 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
                 ot[4 * qs + (f & 3)] = acc[r].x + acc[r].y;
             }
         }
-#ifndef PDDC_ABLATE_BARRIERS
         __syncthreads();                                           /* B */
-#endif
 
         /* ---- C: tail groups -> history of the next tile of the chunk -------- */
         if (!last && gtid >= 256 - NTB) {
