@@ -148,6 +148,22 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
 /* Host batch: H2D copy, process, D2H copy, synchronous.                        */
 int pddc_pipeline_push_host(pddc_pipeline *p, const void *h_packed, size_t nsamples,
                             void *h_out_f32, size_t out_capacity, size_t *n_out);
+/* The same, returning at once: the batch travels H2D -> kernels -> D2H on three streams
+ * through one of two staging slots, so with two batches in flight the copy in, the kernels
+ * and the copy out of neighbouring batches overlap (the pinned, double-buffered host ring
+ * the reference's 6 KB callback buffers need).  *n_out is known at
+ * return (it depends on sizes only); h_packed and h_out must stay valid, and h_out unread,
+ * until pddc_pipeline_wait_ticket(*ticket) -- at most two tickets (0, 1) are outstanding,
+ * pushing a third batch reuses the older slot and waits for it on the device side.  For
+ * the copies to be truly asynchronous both host buffers should come from pddc_host_alloc
+ * (pinned memory); pageable memory works but the runtime stages it.                      */
+int pddc_pipeline_push_host_async(pddc_pipeline *p, const void *h_packed, size_t nsamples,
+                                  void *h_out_f32, size_t out_capacity, size_t *n_out, int *ticket);
+int pddc_pipeline_wait_ticket(pddc_pipeline *p, int ticket);
+int pddc_pipeline_wait(pddc_pipeline *p);          /* everything pushed so far is complete */
+/* pinned host memory for the two calls above */
+int pddc_host_alloc(void **h_ptr, size_t nbytes);
+int pddc_host_free(void *h_ptr);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------- */
 /* Times `iters` back-to-back launches of the pipeline's stage-0 kernel alone

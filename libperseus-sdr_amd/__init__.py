@@ -102,13 +102,19 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_uses_fused_pair.restype = C.c_int
     L.pddc_pipeline_process.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp]
     L.pddc_pipeline_push_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.pddc_pipeline_push_host_async.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(C.c_int)]
+    L.pddc_pipeline_wait_ticket.argtypes = [vp, C.c_int]
+    L.pddc_pipeline_wait.argtypes = [vp]
+    L.pddc_host_alloc.argtypes = [C.POINTER(vp), sz]
+    L.pddc_host_free.argtypes = [vp]
     L.pddc_pipeline_time_stage0.argtypes = [vp, vp, sz, vp, C.c_int, vp, C.POINTER(C.c_float)]
     for name in ("pddc_unpack24_f32", "pddc_unpack24_i32", "pddc_pack24_f32", "pddc_synth_lcg", "pddc_set_device",
                  "pddc_malloc", "pddc_free", "pddc_memcpy_h2d", "pddc_memcpy_d2h", "pddc_stream_sync",
                  "pddc_pipeline_create", "pddc_pipeline_destroy", "pddc_pipeline_reset", "pddc_pipeline_seek",
                  "pddc_pipeline_set_freg", "pddc_pipeline_set_center_freq", "pddc_pipeline_set_taps",
                  "pddc_pipeline_total_decim", "pddc_pipeline_uses_fused", "pddc_pipeline_process",
-                 "pddc_pipeline_push_host", "pddc_pipeline_time_stage0"):
+                 "pddc_pipeline_push_host", "pddc_pipeline_time_stage0", "pddc_pipeline_push_host_async",
+                 "pddc_pipeline_wait_ticket", "pddc_pipeline_wait", "pddc_host_alloc", "pddc_host_free"):
         getattr(L, name).restype = C.c_int
     _ddc = L
     return L
@@ -207,10 +213,41 @@ class Pipeline:
         check(ddc_lib().pddc_pipeline_push_host(self._h, b.ctypes.data, ns, out.ctypes.data, cap, C.byref(n)))
         return out[:n.value]
 
+    def push_host_async(self, h_in: int, nsamples: int, h_out: int, out_cap: int):
+        """Raw-pointer form (pinned buffers from host_alloc): returns (n_out, ticket)."""
+        n, t = C.c_size_t(0), C.c_int(-1)
+        check(ddc_lib().pddc_pipeline_push_host_async(self._h, h_in, nsamples, h_out, out_cap, C.byref(n), C.byref(t)))
+        return n.value, t.value
+
+    def wait_ticket(self, ticket: int):
+        check(ddc_lib().pddc_pipeline_wait_ticket(self._h, ticket))
+
+    def wait(self):
+        check(ddc_lib().pddc_pipeline_wait(self._h))
+
     def time_stage0(self, d_in: int, nsamples: int, d_out: int, iters: int, stream: int = 0) -> float:
         ms = C.c_float(0)
         check(ddc_lib().pddc_pipeline_time_stage0(self._h, d_in, nsamples, d_out, iters, stream, C.byref(ms)))
         return float(ms.value)
+
+
+class PinnedBuffer:
+    """nbytes of pinned host memory (pddc_host_alloc) viewed as a numpy uint8 array."""
+
+    def __init__(self, nbytes: int):
+        import numpy as np
+        p = C.c_void_p()
+        check(ddc_lib().pddc_host_alloc(C.byref(p), nbytes))
+        self.ptr, self.nbytes = p.value, nbytes
+        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self.ptr))
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            ddc_lib().pddc_host_free(self.ptr)
+            self.ptr = None
+
+    __del__ = free
 
 
 def unpack24_f32(packed_u8, stream=None):

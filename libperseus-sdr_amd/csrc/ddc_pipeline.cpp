@@ -78,11 +78,19 @@ struct pddc_pipeline {
     float lo_c[8], lo_s[8];
     unsigned long long n0 = 0;    /* absolute sample counter (stage 0 input)    */
     int R = 4;                    /* outputs per lane of the fused kernel (4: 16 waves/CU) */
-    /* staging for push_host */
-    uint8_t *d_in = nullptr;
-    size_t d_in_cap = 0;
-    float *d_out = nullptr;
-    size_t d_out_cap = 0;
+    /* staging for push_host / push_host_async: two slots, so that the H2D copy of batch k+1,
+     * the kernels of batch k and the D2H copy of batch k-1 run at the same time (three streams,
+     * PCIe is full duplex); a slot is reused only after its previous D2H has finished        */
+    struct HostSlot {
+        uint8_t *d_in = nullptr;
+        size_t in_cap = 0;            /* samples */
+        float *d_out = nullptr;
+        size_t out_cap = 0;           /* samples */
+        hipEvent_t ev_in = nullptr, ev_comp = nullptr, ev_out = nullptr;
+        bool used = false;
+    } slot[2];
+    int next_slot = 0;
+    hipStream_t s_in = nullptr, s_out = nullptr;   /* copy streams; own_stream computes */
     float *d_fout = nullptr;      /* float output of the last stage when the caller wants packed */
     size_t d_fout_cap = 0;
     hipStream_t own_stream = nullptr;
@@ -419,10 +427,22 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
             if (p->st[i].d_hist[b])
                 hipFree(p->st[i].d_hist[b]);
     }
-    if (p->d_in)
-        hipFree(p->d_in);
-    if (p->d_out)
-        hipFree(p->d_out);
+    for (auto &sl : p->slot) {
+        if (sl.d_in)
+            hipFree(sl.d_in);
+        if (sl.d_out)
+            hipFree(sl.d_out);
+        if (sl.ev_in)
+            hipEventDestroy(sl.ev_in);
+        if (sl.ev_comp)
+            hipEventDestroy(sl.ev_comp);
+        if (sl.ev_out)
+            hipEventDestroy(sl.ev_out);
+    }
+    if (p->s_in)
+        hipStreamDestroy(p->s_in);
+    if (p->s_out)
+        hipStreamDestroy(p->s_out);
     if (p->d_fout)
         hipFree(p->d_fout);
     if (p->d_sched)
@@ -789,49 +809,138 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
     return PDDC_OK;
 }
 
-int pddc_pipeline_push_host(pddc_pipeline *p, const void *h_packed, size_t nsamples, void *h_out,
-                            size_t out_capacity, size_t *n_out_ret)
+int pddc_host_alloc(void **h_ptr, size_t nbytes)
+{
+    if (!h_ptr || nbytes == 0)
+        return fail(PDDC_EINVAL, "bad argument");
+    int rc = require_device();
+    if (rc)
+        return rc;
+    hipError_t e = hipHostMalloc(h_ptr, nbytes, hipHostMallocDefault);
+    if (e != hipSuccess)
+        return fail(PDDC_ENOMEM, "hipHostMalloc(%zu): %s", nbytes, hipGetErrorString(e));
+    return PDDC_OK;
+}
+
+int pddc_host_free(void *h_ptr)
+{
+    if (h_ptr)
+        HIP_TRY(hipHostFree(h_ptr));
+    return PDDC_OK;
+}
+
+int pddc_pipeline_push_host_async(pddc_pipeline *p, const void *h_packed, size_t nsamples, void *h_out,
+                                  size_t out_capacity, size_t *n_out_ret, int *ticket)
 {
     if (!p)
         return fail(PDDC_EINVAL, "null pipeline");
     if (n_out_ret)
         *n_out_ret = 0;
+    if (ticket)
+        *ticket = -1;
     if (nsamples == 0)
         return PDDC_OK;
     if (!h_packed || !h_out)
         return fail(PDDC_EINVAL, "null host pointer");
     HIP_TRY(hipSetDevice(p->device));
+    if (!p->s_in) {
+        HIP_TRY(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+    }
+    const int si = p->next_slot;
+    pddc_pipeline::HostSlot &sl = p->slot[si];
+    if (!sl.ev_in) {
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_comp, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+    }
     const size_t max_out = pddc_pipeline_max_output(p, nsamples) + 1;
-    if (p->d_in_cap < nsamples) {
-        if (p->d_in)
-            HIP_TRY(hipFree(p->d_in));
-        p->d_in = nullptr;
-        HIP_TRY(hipMalloc(&p->d_in, nsamples * 6 + 64));
-        p->d_in_cap = nsamples;
+    if (sl.in_cap < nsamples || sl.out_cap < max_out) {
+        if (sl.used)                          /* growing a slot: its last batch must be out first */
+            HIP_TRY(hipEventSynchronize(sl.ev_out));
+        if (sl.in_cap < nsamples) {
+            if (sl.d_in)
+                HIP_TRY(hipFree(sl.d_in));
+            sl.d_in = nullptr;
+            sl.in_cap = 0;
+            HIP_TRY(hipMalloc(&sl.d_in, nsamples * 6 + 64));
+            sl.in_cap = nsamples;
+        }
+        if (sl.out_cap < max_out) {
+            if (sl.d_out)
+                HIP_TRY(hipFree(sl.d_out));
+            sl.d_out = nullptr;
+            sl.out_cap = 0;
+            HIP_TRY(hipMalloc(&sl.d_out, max_out * 8 + 64));
+            sl.out_cap = max_out;
+        }
     }
-    if (p->d_out_cap < max_out) {
-        if (p->d_out)
-            HIP_TRY(hipFree(p->d_out));
-        p->d_out = nullptr;
-        HIP_TRY(hipMalloc(&p->d_out, max_out * 8 + 64));
-        p->d_out_cap = max_out;
-    }
-    hipStream_t s = p->own_stream;
-    HIP_TRY(hipMemcpyAsync(p->d_in, h_packed, nsamples * 6, hipMemcpyHostToDevice, s));
+    /* H2D: the slot's input buffer is free once the kernels of its previous batch are done */
+    if (sl.used)
+        HIP_TRY(hipStreamWaitEvent(p->s_in, sl.ev_comp, 0));
+    HIP_TRY(hipMemcpyAsync(sl.d_in, h_packed, nsamples * 6, hipMemcpyHostToDevice, p->s_in));
+    HIP_TRY(hipEventRecord(sl.ev_in, p->s_in));
+    /* kernels: after this batch has arrived and the slot's previous output has left */
+    HIP_TRY(hipStreamWaitEvent(p->own_stream, sl.ev_in, 0));
+    if (sl.used)
+        HIP_TRY(hipStreamWaitEvent(p->own_stream, sl.ev_out, 0));
     size_t n_out = 0;
-    int rc = pddc_pipeline_process(p, p->d_in, nsamples, p->d_out, p->d_out_cap, &n_out, s);
+    int rc = pddc_pipeline_process(p, sl.d_in, nsamples, sl.d_out, sl.out_cap, &n_out, p->own_stream);
     if (rc)
         return rc;
+    HIP_TRY(hipEventRecord(sl.ev_comp, p->own_stream));
+    sl.used = true;
+    p->next_slot = si ^ 1;
     if (n_out > out_capacity) {
-        hipStreamSynchronize(s);
+        hipStreamSynchronize(p->own_stream);
+        HIP_TRY(hipEventRecord(sl.ev_out, p->s_out));     /* keep the slot's event chain consistent */
         return fail(PDDC_ECAPACITY, "output capacity %zu < %zu", out_capacity, n_out);
     }
+    HIP_TRY(hipStreamWaitEvent(p->s_out, sl.ev_comp, 0));
     if (n_out)
-        HIP_TRY(hipMemcpyAsync(h_out, p->d_out, n_out * ((p->flags & PDDC_F_OUT_PACKED24) ? 6 : 8),
-                               hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpyAsync(h_out, sl.d_out, n_out * ((p->flags & PDDC_F_OUT_PACKED24) ? 6 : 8),
+                               hipMemcpyDeviceToHost, p->s_out));
+    HIP_TRY(hipEventRecord(sl.ev_out, p->s_out));
     if (n_out_ret)
         *n_out_ret = n_out;
+    if (ticket)
+        *ticket = si;
+    return PDDC_OK;
+}
+
+int pddc_pipeline_wait_ticket(pddc_pipeline *p, int ticket)
+{
+    if (!p || ticket < 0 || ticket > 1)
+        return fail(PDDC_EINVAL, "bad ticket");
+    if (!p->slot[ticket].used)
+        return fail(PDDC_ESTATE, "nothing was pushed on ticket %d", ticket);
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventSynchronize(p->slot[ticket].ev_out));
+    return PDDC_OK;
+}
+
+int pddc_pipeline_wait(pddc_pipeline *p)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    HIP_TRY(hipSetDevice(p->device));
+    if (p->s_in)
+        HIP_TRY(hipStreamSynchronize(p->s_in));
+    HIP_TRY(hipStreamSynchronize(p->own_stream));
+    if (p->s_out)
+        HIP_TRY(hipStreamSynchronize(p->s_out));
+    return PDDC_OK;
+}
+
+int pddc_pipeline_push_host(pddc_pipeline *p, const void *h_packed, size_t nsamples, void *h_out,
+                            size_t out_capacity, size_t *n_out_ret)
+{
+    int ticket = -1;
+    int rc = pddc_pipeline_push_host_async(p, h_packed, nsamples, h_out, out_capacity, n_out_ret, &ticket);
+    if (rc)
+        return rc;
+    if (ticket >= 0)
+        return pddc_pipeline_wait_ticket(p, ticket);
     return PDDC_OK;
 }
 

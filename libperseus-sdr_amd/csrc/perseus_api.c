@@ -103,9 +103,16 @@ struct perseus_descr_ds {
     /* DDC mode */
     ddc_plan plan;
     pddc_pipeline *pipe;
-    uint8_t *batch_in;          /* batch_samples * 6                             */
-    float *batch_out;           /* pipeline output of one batch                  */
+    /* two pinned batch buffers each way: while the GPU works on one batch (H2D, kernels,
+     * D2H on three streams) the source fills the next (pddc_pipeline_push_host_async)  */
+    uint8_t *batch_in[2];       /* batch_samples * 6                             */
+    float *batch_out[2];        /* pipeline output of one batch                  */
     size_t out_cap;             /* in complex samples                            */
+    int cur;                    /* buffer pair the next batch goes into          */
+    int pend_ticket;            /* batch in flight (-1: none), its pair and size */
+    int pend_slot;
+    size_t pend_nout;
+    int input_done;             /* the source has nothing more to give           */
     uint8_t *fifo;              /* decimated float bytes awaiting callbacks      */
     size_t fifo_len, fifo_cap;
     uint64_t adc_samples;       /* ADC-rate samples produced so far              */
@@ -324,6 +331,39 @@ static void pump_wire(perseus_descr *d)
         d->source_done = 1;
 }
 
+/* fill the next batch buffer from the source and hand it to the GPU; returns at once */
+static void submit_batch(perseus_descr *d)
+{
+    const int k = d->cur;
+    const size_t want = (size_t)d->cfg.batch_samples * 6;
+    size_t got = source_fill(d, d->batch_in[k], want);
+    got -= got % 48;                         /* whole groups of 8 samples */
+    if (got == 0) {
+        d->input_done = 1;
+        return;
+    }
+    const size_t ns = got / 6;
+    pace_until(d, (double)(d->adc_samples + ns), d->adc_clk_freq);
+    /* retune takes effect at the batch boundary (reference clients retune while
+     * streaming, examples/fifo.c:43-49) */
+    pddc_pipeline_set_freg(d->pipe, d->freg);
+    size_t n_out = 0;
+    int ticket = -1;
+    int rc = pddc_pipeline_push_host_async(d->pipe, d->batch_in[k], ns, d->batch_out[k], d->out_cap, &n_out, &ticket);
+    if (rc != PDDC_OK) {
+        dbgprintf(0, "GPU pipeline failed (%d: %s); stream stopped", rc, pddc_last_error());
+        d->input_done = 1;
+        return;
+    }
+    d->adc_samples += ns;
+    d->pend_ticket = ticket;
+    d->pend_slot = k;
+    d->pend_nout = n_out;
+    d->cur = k ^ 1;
+    if (got < want)
+        d->input_done = 1;                   /* bounded source (file) ended */
+}
+
 static void pump_ddc(perseus_descr *d)
 {
     /* drain the FIFO first: one callback per call keeps devices interleaved */
@@ -335,26 +375,26 @@ static void pump_ddc(perseus_descr *d)
         deliver(d, 1);
         return;
     }
-    const size_t want = (size_t)d->cfg.batch_samples * 6;
-    size_t got = source_fill(d, d->batch_in, want);
-    got -= got % 48;                         /* whole groups of 8 samples */
-    if (got == 0) {
+    if (d->pend_ticket < 0 && !d->input_done)
+        submit_batch(d);
+    if (d->pend_ticket < 0) {
         d->source_done = 1;
         return;
     }
-    const size_t ns = got / 6;
-    pace_until(d, (double)(d->adc_samples + ns), d->adc_clk_freq);
-    /* retune takes effect at the batch boundary (reference clients retune while
-     * streaming, examples/fifo.c:43-49) */
-    pddc_pipeline_set_freg(d->pipe, d->freg);
-    size_t n_out = 0;
-    int rc = pddc_pipeline_push_host(d->pipe, d->batch_in, ns, d->batch_out, d->out_cap, &n_out);
-    if (rc != PDDC_OK) {
-        dbgprintf(0, "GPU pipeline failed (%d: %s); stream stopped", rc, pddc_last_error());
+    const int ticket = d->pend_ticket, k = d->pend_slot;
+    const size_t n_out = d->pend_nout;
+    d->pend_ticket = -1;
+    /* free-running source: prepare and submit the following batch BEFORE waiting for this
+     * one, so source, PCIe and kernels overlap.  A paced (real-time) source is not read
+     * ahead: that would only add a batch period of latency                               */
+    if (!d->cfg.pace && !d->input_done)
+        submit_batch(d);
+    if (pddc_pipeline_wait_ticket(d->pipe, ticket) != PDDC_OK) {
+        dbgprintf(0, "GPU pipeline failed (%s); stream stopped", pddc_last_error());
+        d->input_done = 1;
         d->source_done = 1;
         return;
     }
-    d->adc_samples += ns;
     const size_t nb = n_out * (d->cfg.mode == PERSEUS_AMD_MODE_DDC_WIRE ? 6 : 8);
     if (d->fifo_len + nb > d->fifo_cap) {
         size_t cap = (d->fifo_len + nb) * 2;
@@ -366,10 +406,10 @@ static void pump_ddc(perseus_descr *d)
         d->fifo = nf;
         d->fifo_cap = cap;
     }
-    memcpy(d->fifo + d->fifo_len, d->batch_out, nb);
+    memcpy(d->fifo + d->fifo_len, d->batch_out[k], nb);
     d->fifo_len += nb;
-    if (got < want)
-        d->source_done = 1;                  /* bounded source (file) ended */
+    if (d->input_done && d->pend_ticket < 0)
+        d->source_done = 1;
 }
 
 static void *worker_fn(void *arg)
@@ -727,10 +767,14 @@ static void free_stream(perseus_descr *d)
 {
     free(d->ring);
     d->ring = NULL;
-    free(d->batch_in);
-    d->batch_in = NULL;
-    free(d->batch_out);
-    d->batch_out = NULL;
+    if (d->pipe)
+        pddc_pipeline_wait(d->pipe);         /* nothing may still be copying into the buffers */
+    for (int k = 0; k < 2; k++) {
+        pddc_host_free(d->batch_in[k]);
+        d->batch_in[k] = NULL;
+        pddc_host_free(d->batch_out[k]);
+        d->batch_out[k] = NULL;
+    }
     free(d->fifo);
     d->fifo = NULL;
     d->fifo_len = d->fifo_cap = 0;
@@ -809,12 +853,15 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
             return errorset(PERSEUS_DEVCONF, "GPU pipeline creation failed (%d): %s", rc, pddc_last_error());
         }
         pddc_pipeline_set_freg(d->pipe, d->freg);
-        d->batch_in = (uint8_t *)malloc((size_t)d->cfg.batch_samples * 6);
         d->out_cap = pddc_pipeline_max_output(d->pipe, d->cfg.batch_samples) + 8;
-        d->batch_out = (float *)malloc(d->out_cap * 8);
+        int hrc = 0;
+        for (int k = 0; k < 2; k++) {
+            hrc |= pddc_host_alloc((void **)&d->batch_in[k], (size_t)d->cfg.batch_samples * 6);
+            hrc |= pddc_host_alloc((void **)&d->batch_out[k], d->out_cap * 8);
+        }
         d->fifo_cap = d->out_cap * 8 + 2 * (size_t)buffersize;
         d->fifo = (uint8_t *)malloc(d->fifo_cap);
-        if (!d->batch_in || !d->batch_out || !d->fifo) {
+        if (hrc || !d->fifo) {
             free_stream(d);
             return errorset(PERSEUS_NOMEM, "can't allocate the batch buffers");
         }
@@ -826,6 +873,9 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
     d->delivered = d->dropped = 0;
     d->bytes_received = 0;
     d->adc_samples = 0;
+    d->cur = 0;
+    d->pend_ticket = -1;
+    d->input_done = 0;
     d->fifo_len = 0;
     d->source_done = 0;
     d->cancelling = 0;

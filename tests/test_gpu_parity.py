@@ -229,6 +229,45 @@ def test_push_host_roundtrip(pkg, dev, O):
 
 
 # ------------------------------------------------------------ error behaviour
+def test_push_host_async_double_buffered(pkg, dev, O):
+    """Pinned buffers, two batches in flight (H2D of k+1, kernels of k, D2H of k-1 on three
+    streams), slots reused five times, a short last batch: the stream is the oracle's."""
+    stages = [(8, load_taps("c320_s1_d8_32")), (8, load_taps("c320_s2_d8_64")), (5, load_taps("c320_s3_d5_161"))]
+    batch = 4096 * 20
+    cuts = [batch] * 5 + [320 * 7]
+    total = sum(cuts)
+    stream = O.lcg_bytes(6 * total, 4242)
+    ref = O.ddc_chain(stream, stages, freg=381178347, mix=True)
+    pipe = pkg.Pipeline(stages, mix=True)
+    pipe.set_freg(381178347)
+    cap = pipe.max_output(batch) + 1
+    h_in = [pkg.PinnedBuffer(6 * batch) for _ in range(2)]
+    h_out = [pkg.PinnedBuffer(8 * cap) for _ in range(2)]
+    parts, pending, pos = [], None, 0
+    for k, ns in enumerate(cuts):
+        b = k & 1
+        h_in[b].array[:6 * ns] = stream[6 * pos:6 * (pos + ns)]
+        n, t = pipe.push_host_async(h_in[b].ptr, ns, h_out[b].ptr, cap)
+        assert t == b
+        if pending is not None:                       # collect batch k-1 while batch k is in flight
+            pb, pn, pt = pending
+            pipe.wait_ticket(pt)
+            parts.append(h_out[pb].array[:8 * pn].view(np.float32).copy())
+        pending = (b, n, t)
+        pos += ns
+    pipe.wait()
+    pb, pn, pt = pending
+    parts.append(h_out[pb].array[:8 * pn].view(np.float32).copy())
+    y = np.concatenate(parts)
+    assert y.size == ref.size
+    assert O.rel_err(y, ref) <= FIR_TOL
+    with pytest.raises(Exception):
+        pipe.wait_ticket(5)
+    pipe.close()
+    for hb in h_in + h_out:
+        hb.free()
+
+
 def test_argument_errors(pkg, dev, O):
     h = load_taps("d8_127")
     pipe = pkg.Pipeline([(8, h)])
