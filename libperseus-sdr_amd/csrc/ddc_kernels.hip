@@ -397,9 +397,19 @@ __device__ __forceinline__ void group_to_lds(float *sI, float *sQ, int v, const 
 /* The register sliding window of one lane: R outputs over R+NTB-1 aligned
  * 8-sample groups.  PAR (R=4 only) says whether the lane's half segment starts
  * 4 groups into a padded 8-group row, which moves the pad inside the window.  */
+/* Partial sums per output: the packed FMA already splits a dot product into even and odd
+ * terms; filters of 200+ taps split once more (pair index parity), which halves the length of
+ * every fp32 accumulation chain again (255 taps: max error 5.7e-7 -> 3e-7 of full scale).   */
+template <int NTB>
+struct FirAcc {
+    static constexpr int N = NTB >= 32 ? 2 : 1;
+};
+
 template <int NTB, int R, int PAR, bool PADDED = true>
-__device__ __forceinline__ void fir_window(const float *base, const float PDDC_CONSTANT *hb, f32x2 (&acc)[R])
+__device__ __forceinline__ void fir_window(const float *base, const float PDDC_CONSTANT *hb,
+                                           f32x2 (&acc)[R][FirAcc<NTB>::N])
 {
+    constexpr int NA = FirAcc<NTB>::N;
 #pragma unroll
     for (int ub = 0; ub < R + NTB - 1; ++ub) {
         const int go = 8 * ub + (PADDED ? 4 * ((ub + PAR * 4) >> 3) : 0);
@@ -415,7 +425,7 @@ __device__ __forceinline__ void fir_window(const float *base, const float PDDC_C
                 const int j = r + NTB - 1 - ub;
                 if (j >= 0 && j < NTB) {
                     const f32x2 PDDC_CONSTANT *h = reinterpret_cast<const f32x2 PDDC_CONSTANT *>(hb + 8 * j);
-                    acc[r] = __builtin_elementwise_fma(h[i], xs[i], acc[r]);
+                    acc[r][i % NA] = __builtin_elementwise_fma(h[i], xs[i], acc[r][i % NA]);
                 }
             }
         }
@@ -476,8 +486,10 @@ void fir8_probe_dump()
 #endif
 static constexpr bool kTapOuterR8 = PDDC_TAP_OUTER_R8 != 0;
 template <int NTB, int R, int PAR, bool PADDED = true>
-__device__ __forceinline__ void fir_window_tap_outer(const float *base, const float PDDC_CONSTANT *hb, f32x2 (&acc)[R])
+__device__ __forceinline__ void fir_window_tap_outer(const float *base, const float PDDC_CONSTANT *hb,
+                                                     f32x2 (&acc)[R][FirAcc<NTB>::N])
 {
+    constexpr int NA = FirAcc<NTB>::N;
     auto load_group = [&](int ub, f32x2 (&w)[4]) {
         const int go = 8 * ub + (PADDED ? 4 * ((ub + PAR * 4) >> 3) : 0);
         const f32x4 d0 = *reinterpret_cast<const f32x4 *>(base + go);
@@ -498,7 +510,7 @@ __device__ __forceinline__ void fir_window_tap_outer(const float *base, const fl
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                acc[r] = __builtin_elementwise_fma(h[i], W[r][i], acc[r]);
+                acc[r][i % NA] = __builtin_elementwise_fma(h[i], W[r][i], acc[r][i % NA]);
         if (j > 0) {
 #pragma unroll
             for (int g = 0; g + 1 < R; ++g)
@@ -857,22 +869,29 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
         asm volatile("" : "+s"(hb));      /* keep the tap s_loads inside the tile loop (no SGPR spills) */
         if (FUSE2)
             asm volatile("" : "+s"(hb2));
-        f32x2 acc[R];
+        constexpr int NA = FirAcc<NTB>::N;
+        f32x2 accp[R][NA];
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            acc[r] = f32x2{ 0.0f, 0.0f };
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+                accp[r][a] = f32x2{ 0.0f, 0.0f };
 #ifdef PDDC_ABLATE_FIR
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            acc[r] = *reinterpret_cast<const f32x2 *>(base + 8 * r);
+            accp[r][0] = *reinterpret_cast<const f32x2 *>(base + 8 * r);
 #else
         if (R == 4 && par)
-            fir_window<NTB, R, 1>(base, hb, acc);
+            fir_window<NTB, R, 1>(base, hb, accp);
         else if (R == 8 && kTapOuterR8)
-            fir_window_tap_outer<NTB, R, 0>(base, hb, acc);
+            fir_window_tap_outer<NTB, R, 0>(base, hb, accp);
         else
-            fir_window<NTB, R, 0>(base, hb, acc);
+            fir_window<NTB, R, 0>(base, hb, accp);
 #endif
+        f32x2 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            acc[r] = NA == 2 ? accp[r][0] + accp[r][NA - 1] : accp[r][0];
         if (FUSE2) {
             /* results -> the second stage's input plane, rotated like the first:
              * position p2 = m + 8*NTB2 - 1 for tile-relative output m = R*L + r,
@@ -932,14 +951,14 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
             float *pl2 = wave ? sQ2 : sI2;
             if (t >= c_lo) {
                 constexpr int R2 = G2::R2 > 0 ? G2::R2 : 1;
-                f32x2 acc2[R2];
+                f32x2 acc2[R2][1];                 /* NTB2 <= 8: one packed accumulator per output */
 #pragma unroll
                 for (int r = 0; r < R2; ++r)
-                    acc2[r] = f32x2{ 0.0f, 0.0f };
+                    acc2[r][0] = f32x2{ 0.0f, 0.0f };
                 fir_window<(NTB2 > 0 ? NTB2 : 1), R2, 0, false>(pl2 + 8 + 8 * R2 * lane, hb2, acc2);
 #pragma unroll
                 for (int r = 0; r < R2; ++r)
-                    ot2[2 * (R2 * lane + r) + wave] = acc2[r].x + acc2[r].y;
+                    ot2[2 * (R2 * lane + r) + wave] = acc2[r][0].x + acc2[r][0].y;
             }
             if (!last && lane < NTB2) {
                 const int os = 8 + 8 * (G2::GT2 + lane), od = 8 + 8 * lane;
@@ -1247,10 +1266,15 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ 
         }
     }
     __syncthreads();
-    f32x2 acc[P];
+    /* four partial sums per output (window sample index mod 4): the rounding error of a long
+     * fp32 accumulation grows with the length of the chain, and the 1e-6 budget is shared by
+     * all stages of a cascade                                                               */
+    f32x2 acc[P][4];
 #pragma unroll
     for (int p = 0; p < P; ++p)
-        acc[p] = f32x2{ 0.0f, 0.0f };
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4)
+            acc[p][a4] = f32x2{ 0.0f, 0.0f };
     /* sample x[q*D - j], q = q0 + P*tid, has local index S*tid + r with r = ntaps-1-j (wave-
      * uniform) and sits at lane + r + (r >> a): S*tid is a multiple of 2^a, so the pad splits */
     const float2 *lane = sd + (S + (S >> a)) * tid;
@@ -1271,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ 
                 const f32x2 x = { xv.x, xv.y };
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    acc[p] = __builtin_elementwise_fma(f32x2{ hh[p][u], hh[p][u] }, x, acc[p]);
+                    acc[p][u & 3] = __builtin_elementwise_fma(f32x2{ hh[p][u], hh[p][u] }, x, acc[p][u & 3]);
             }
         } else {
 #pragma unroll
@@ -1281,15 +1305,17 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ 
                 const f32x2 x = { xv.x, xv.y };
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    acc[p] = __builtin_elementwise_fma(f32x2{ hh[p][u], hh[p][u] }, x, acc[p]);
+                    acc[p][u & 3] = __builtin_elementwise_fma(f32x2{ hh[p][u], hh[p][u] }, x, acc[p][u & 3]);
             }
         }
     }
     const long long q = q0 + (long long)P * tid;
 #pragma unroll
     for (int p = 0; p < P; ++p)
-        if (q + p < n_out)
-            out[q + p] = make_float2(acc[p].x, acc[p].y);
+        if (q + p < n_out) {
+            const f32x2 sum = (acc[p][0] + acc[p][1]) + (acc[p][2] + acc[p][3]);
+            out[q + p] = make_float2(sum.x, sum.y);
+        }
 }
 
 /* `taps` must be readable (zeros) over [-3*D - 8, ntaps + 3*D + 8): the pipeline uploads

@@ -1,0 +1,48 @@
+# one-off randomized stress of the stream state machine against the oracle: random plans, cuts,
+# NCO words, scheduler settings (PDDC_FIR8_BLOCKS / DYN_PCT / CHUNK / R).  Usage: python tools/stress_gpu.py [n]
+import sys, os, importlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+from conftest import load_taps
+pkg = importlib.import_module("libperseus-sdr_amd")
+from oracle import oracle as O
+dev = torch.device("cuda:0")
+n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+h1, h2, h3 = load_taps("c320_s1_d8_32"), load_taps("c320_s2_d8_64"), load_taps("c320_s3_d5_161")
+worst = 0.0
+for it in range(n_iter):
+    rng = np.random.default_rng(5000 + it)
+    g = (rng.standard_normal(12 * 20) / 20).astype(np.float32)
+    plans = [[(8, load_taps("d8_127"))], [(8, load_taps("d8_255"))], [(8, h1), (8, h2), (5, h3)], [(8, h1), (8, h2)],
+             [(8, h1), (5, h3[:41]), (25, g, 12)], [(10, h3[:77])], [(8, h2), (4, h1)], [(5, h3), (8, h1)]]
+    stages = plans[int(rng.integers(0, len(plans)))]
+    os.environ["PDDC_FIR8_BLOCKS"] = str(int(rng.choice([1, 2, 3, 5, 16, 512])))
+    os.environ["PDDC_FIR8_DYN_PCT"] = str(int(rng.choice([0, 10, 20, 50, 100])))
+    os.environ["PDDC_FIR8_CHUNK"] = str(int(rng.choice([1, 2, 3, 4, 8])))
+    os.environ["PDDC_FIR8_R"] = str(int(rng.choice([4, 8])))
+    mix = bool(rng.integers(0, 2))
+    freg = int(rng.integers(0, 2**32))
+    ns = 8 * int(rng.integers(1, 4096 * 12))
+    if rng.integers(0, 2):
+        ns = 8192 * int(rng.integers(1, 40))
+    packed = O.lcg_bytes(6 * ns, 9000 + it)
+    ref = O.ddc_chain(packed, stages, freg=freg, mix=mix)
+    cuts = sorted(set([0, ns] + [8 * int(c) for c in rng.integers(1, max(2, ns // 8), size=4)] +
+                      [4096 * int(c) for c in rng.integers(0, max(1, ns // 4096), size=3) if 0 < 4096 * int(c) < ns]))
+    pipe = pkg.Pipeline(stages, mix=mix)
+    pipe.set_freg(freg)
+    parts = [pipe.process(torch.from_numpy(packed[6 * a:6 * b].copy()).to(dev)).cpu().numpy().reshape(-1)
+             for a, b in zip(cuts[:-1], cuts[1:])]
+    y = np.concatenate(parts) if parts else np.zeros(0, np.float32)
+    pipe.close()
+    ok = y.size == ref.size
+    err = O.rel_err(y, ref) if ok and ref.size else 0.0
+    worst = max(worst, err)
+    tag = "ok " if ok and err <= 1e-6 else "BAD"
+    print(f"{tag} it {it} stages {[(s[0], len(s[1])) for s in stages]} mix {mix} ns {ns} cuts {len(cuts)-1} "
+          f"blocks {os.environ['PDDC_FIR8_BLOCKS']} dyn {os.environ['PDDC_FIR8_DYN_PCT']} K {os.environ['PDDC_FIR8_CHUNK']} "
+          f"R {os.environ['PDDC_FIR8_R']} err {err:.2e}", flush=True)
+    if tag == "BAD":
+        sys.exit(1)
+print("worst", worst)
