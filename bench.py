@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="untimed back-to-back launches before the W warmup steps: after idle the\n"
                          "chip's power management first boosts, then overshoots downwards for some tens\n"
