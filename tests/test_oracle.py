@@ -130,3 +130,27 @@ def test_taps_manifest(O):
         h = load_taps(name)
         assert h.size == m["ntaps"] and abs(float(h.astype(np.float64).sum()) - 1.0) < 1e-6
         assert m["stop_atten_db"] >= 85
+
+
+def test_fir_and_resampler_against_scipy_upfirdn(O):
+    """Third, independent statement of the decimator and of the rational resampler: scipy's
+    polyphase upfirdn (upsample by L, FIR, keep every D-th) on the same data.  The oracle is the
+    definition of the FIR/NCO arithmetic (no reference arithmetic exists for it); this pins its
+    indexing conventions (zero history, y[m] = sum h[k] x[mD-k], phase of the L/M stage)."""
+    signal = pytest.importorskip("scipy.signal")
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(2 * 4000)                       # interleaved I/Q, float64
+    xc = x[0::2] + 1j * x[1::2]
+    for D, nt in ((8, 127), (5, 161), (1, 9), (10, 77)):
+        h = (rng.standard_normal(nt) / nt).astype(np.float32)
+        y = O.fir_decim(x, h, D)
+        ref = signal.upfirdn(h.astype(np.float64), xc, up=1, down=D)[: y.size // 2]
+        got = y[0::2] + 1j * y[1::2]
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), (D, nt)
+    for L, M, per in ((12, 25, 20), (3, 2, 16), (19, 40, 30)):
+        g = (rng.standard_normal(L * per) / per).astype(np.float32)
+        y = O.resample(x, g, L, M)
+        ref = signal.upfirdn(g.astype(np.float64), xc, up=L, down=M)[: y.size // 2]
+        got = y[0::2] + 1j * y[1::2]
+        assert got.size == (xc.size * L + M - 1) // M
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), (L, M)
