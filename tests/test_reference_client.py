@@ -67,3 +67,21 @@ def test_reference_client_exhaustive_2p24(tmp_path, O):
     assert raw.size == (1 << 24) * 8, p.stderr[-400:]
     assert hashlib.sha256(raw.tobytes()).hexdigest() == sha["exhaustive_f32"]
     assert np.array_equal(raw.view(np.uint32), O.unpack24_f32(packed).view(np.uint32))
+
+
+def test_second_reference_client_simple_c(tmp_path, O):
+    """examples/simple.c, the reference's minimal client (its own copy of the int32 callback,
+    simple.c:33-61; 96 kS/s, 7.05 MHz, a fixed 10 s run, output ./perseusdata.bin): unmodified,
+    against the drop-in library, bit-equal to the oracle."""
+    simple = os.path.join(ROOT, "oracle", "_ref", "simple_ref")
+    if not os.path.exists(simple):
+        pytest.skip("simple_ref not built")
+    env = dict(os.environ, PERSEUS_AMD_PACE="0", PERSEUS_AMD_MODE="wire", PERSEUS_AMD_SOURCE="lcg:4321",
+               PERSEUS_AMD_MAX_BUFFERS="64")
+    env.pop("PERSEUS_AMD_DEVICES", None)
+    p = subprocess.run([simple], env=env, cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert "1 Perseus receiver(s) found" in p.stderr and "Bye" in p.stderr
+    assert p.returncode == 1                                   # simple.c:145 returns 1 on the normal path
+    i = np.fromfile(tmp_path / "perseusdata.bin", dtype=np.int32)
+    assert i.size == 64 * 2048
+    assert np.array_equal(i, O.unpack24_i32(O.lcg_bytes(64 * 6144, 4321)))
