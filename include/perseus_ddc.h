@@ -20,6 +20,12 @@
  *   pddc_pipeline_push_host   what perseus-in.c:206-207 hands to the client
  *                          callback, batched (see perseus-sdr.h in this directory
  *                          for the drop-in callback API built on top of this).
+ *   pddc_pipeline_push_host_async / _wait_ticket / pddc_host_alloc
+ *                          the ring of 8 in-flight USB transfers of perseus-in.c:39-118
+ *                          (queue create / submit / resubmit), as two pinned batches in
+ *                          flight: copy in, kernels and copy out of neighbouring batches overlap
+ *   pddc_pipeline_seek     (none) positions a pipeline inside ONE stream so that several
+ *                          GPUs can take contiguous time chunks of it
  *
  * Sample formats
  *   packed : 6 bytes / complex sample, I0 I1 I2 Q0 Q1 Q2, 24-bit two's
