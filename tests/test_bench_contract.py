@@ -55,7 +55,7 @@ def test_loader_fails_loudly_without_the_hip_library(pkg, monkeypatch):
 
 
 def test_committed_bench_line_schema():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01", "v6_final_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01", "v8_final_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -65,3 +65,24 @@ def test_committed_bench_line_schema():
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["traffic"] and abs(rf["traffic"] / (7 * 2 ** 28) - 1) < 0.01      # no wasted re-reads
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+
+
+@pytest.mark.gpu
+def test_bench_line_end_to_end_on_the_gpu():
+    """The real thing, small: one JSON line, last on stdout, metric string verbatim from
+    BASELINE.json, roofline and cpu_baseline objects present and self-consistent."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--log2n", "24",
+                        "--settle-ms", "20", "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    d = json.loads(lines[-1])
+    assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    assert d["unit"] == "MS/s" and d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert abs(d["value"] - (1 << 24) * 8 / (d["ms_per_step"] * 8 * 1e-3) / 1e6) / d["value"] < 0.01
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["kernel"] == "k_fir8"
+    assert abs(rf["achieved"] - 7.0 * (1 << 24) / (rf["kernel_ms"] * 1e-3) / 1e9) / rf["achieved"] < 0.01
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "MS/s"
