@@ -2,27 +2,39 @@
 """bench.py -- throughput of the I/Q ingest + decimation hot path on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N>1 is launched by torch.distributed.run (one rank per GPU, RCCL).
+  N>1 either arrives already launched by torch.distributed.run (RANK / LOCAL_RANK /
+  WORLD_SIZE in the environment), or -- as a plain command -- this process starts the N
+  ranks itself as child processes BEFORE it has imported torch or touched a GPU, relays
+  rank 0's JSON line and exits with the worst child status.
 A "step" is one pass of the hot path over one device-resident batch:
   BASELINE.json configs[1]: 2^28 complex samples of synthetic 24-bit I/Q (LCG,
   seed 12345+rank) -> fused unpack + 127-tap polyphase decimate-by-8 -> float32.
-The stream shards as independent streams (one per GPU), so there
-is no data-path collective in the timed region: scaling is "weak".  `--gather`
-additionally measures config 4's RCCL gather of the /8 output to rank 0 and
-reports it in the "gather" object (never in `value`).
+The stream shards as independent streams (one per GPU), so there is no
+data-path collective in the timed region: scaling is "weak".  At N>1 the bench also
+runs BASELINE config 4 -- every rank's decimated output gathered on rank 0's GPU over
+xGMI -- and reports it in the "gather" object (never in `value`): once for this
+workload (/8: xGMI-link-bound) and once for the /320 cascade (where the gather vanishes).
+All GPU collectives are the C library's own RCCL calls (pddc_comm_*, ddc_multi.cpp);
+torch.distributed is only the rendezvous (a gloo group carrying the 128-byte RCCL id).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel
-(k_fir8): algorithmic bytes = 7 B per input sample (6 packed in + 8/8 out,
-SURVEY.md 8d) over the kernel's average duration measured with HIP events on
-the launch stream.  `cpu_baseline` times the oracle's float path
-(oracle/perseus_oracle.c orc_stage1_f32, kind "port") on this box's cores
-over a bounded sample of the same workload (N=1, rank 0 only).
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_fir8):
+algorithmic bytes = 7 B per input sample (6 packed in + 8/8 out) over the
+kernel's average duration measured with HIP events on the launch stream;
+`roofline.copy_ceiling_GBps` is a device-to-device copy of the same number of bytes
+measured in this run.  `verified` is a parity check of the LAST timed step's output
+against the CPU oracle on windows placed at the tile scheduler's seams (outside the
+timed region).  `cpu_baseline` times the oracle's float path (oracle/perseus_oracle.c
+orc_stage1_f32, kind "port") on this box's cores over a bounded sample of the same
+workload (N=1, rank 0 only).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,9 +42,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PARITY_METRIC = "max|y-ref| / max|ref| per window (full-scale-relative), ref = CPU oracle with double accumulation"
+PARITY_TOL = 1e-6               # BASELINE.json north_star: FIR within 1e-6 of the CPU reference
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -46,11 +60,16 @@ def parse():
     ap.add_argument("--workload", default="d8_127",
                     choices=["d8_127", "d8_255", "c320", "unpack"],
                     help="d8_127 = BASELINE configs[1] (default); others are sweep points")
-    ap.add_argument("--taps-fp16", action="store_true")
-    ap.add_argument("--gather", action="store_true", help="also measure RCCL gather of the output (N>1)")
+    ap.add_argument("--taps-fp16", action="store_true",
+                    help="round the taps to binary16 values (BASELINE config 5); they are still stored as fp32")
+    ap.add_argument("--gather", action="store_true", help="run the gather leg at N=1 too (1-rank RCCL group)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the gather leg at N>1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle window check of the last output")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--gather-timeout", type=float, default=240.0,
+                    help="watchdog for the gather leg: past this the line is printed without it")
+    return ap.parse_args(argv)
 
 
 def load_taps(name):
@@ -58,6 +77,60 @@ def load_taps(name):
     return np.fromfile(os.path.join(ROOT, "tests", "golden", f"taps_{name}.f32"), dtype=np.float32)
 
 
+# ----------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` as a plain command
+# ----------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv, timeout_s=3000.0):
+    """Start the N ranks as children of a parent that has made no GPU call (never re-exec a
+    process that has touched the GPU), relay rank 0's JSON line, return the worst status."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0 = ""
+    deadline = time.time() + timeout_s
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        pass
+    worst = 0
+    for p in procs:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()                     # the exact child we started
+            p.wait()
+        if p.returncode != 0:
+            worst = p.returncode if worst == 0 or p.returncode > 0 else worst
+    line = None
+    for ln in (out0 or "").splitlines():
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}"):
+            line = t
+        elif t:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif worst == 0:
+        worst = 1
+    return worst
+
+
+# ----------------------------------------------------------------------------------------
+# CPU leg
+# ----------------------------------------------------------------------------------------
 def cpu_baseline(workload, seconds):
     """Oracle float path on the host cores, bounded sample (kind: port)."""
     import numpy as np
@@ -69,7 +142,6 @@ def cpu_baseline(workload, seconds):
         # the reference's own client (compiled from its sources, oracle/Makefile `ref`):
         # user_data_callback_c_f with its per-sample fwrite, fed unpaced by the drop-in library
         import re
-        import subprocess
         env = dict(os.environ, PERSEUS_AMD_PACE="0", PERSEUS_AMD_SOURCE="zero", PERSEUS_AMD_MODE="wire")
         t = max(1, int(round(min(seconds, 5.0))))
         p = subprocess.run([ref_bin, "-a", "-t", str(t), "-p", "-s", "2000000", "-d", "3", "-o", "/dev/null"],
@@ -113,67 +185,158 @@ def _baseline_metric():
 BASELINE_METRIC = _baseline_metric()
 
 
-def main():
-    a = parse()
+def workload_def(name, pkg=None):
+    """-> dict(stages, mix, freg, bytes_per_sample, decim, label)."""
+    if name == "c320":
+        return {"stages": [(8, load_taps("c320_s1_d8_32")), (8, load_taps("c320_s2_d8_64")),
+                           (5, load_taps("c320_s3_d5_161"))],
+                "mix": True, "freg": 381178347,        # 7.1 MHz at 80 MHz (perseus-sdr.c:584)
+                "bytes_per_sample": 6.0 + 8.0 / 320.0, "decim": 320, "kernel_bytes_per_sample": 6.125,
+                "label": "80 MS/s synthetic 24-bit I/Q, NCO mix 7.1 MHz + cascade /320 (8*8*5)"}
+    if name == "unpack":
+        return {"stages": None, "mix": False, "freg": 0, "bytes_per_sample": 14.0, "decim": 1,
+                "kernel_bytes_per_sample": 14.0, "label": "24-bit packed I/Q -> float32 unpack only"}
+    h = load_taps(name)
+    return {"stages": [(8, h)], "mix": False, "freg": 0, "bytes_per_sample": 7.0, "decim": 8,
+            "kernel_bytes_per_sample": 7.0,
+            "label": f"80 MS/s synthetic 24-bit I/Q, unpack + {h.size}-tap polyphase decimate-by-8"}
+
+
+# ----------------------------------------------------------------------------------------
+# parity check of an output batch against the oracle, on windows (outside the timed region)
+# ----------------------------------------------------------------------------------------
+def window_positions(n_first, n_count, sched, dtot, width, k_random, seed):
+    """Batch-relative output indices where windows start: the scheduler's seams + random."""
+    import numpy as np
+    pos = {0, max(0, n_count - width)}
+    if sched:
+        per_tile = sched["tile"] / dtot                      # outputs per stage-0 tile
+        S, nb, nt = sched["S"], sched["nblocks"], sched["ntiles"]
+        seams = [nb * S, nb * S + sched["K"], nt - 1]        # first dynamic chunk, the next one, last tile
+        if S > 0:
+            seams += [S, (nb // 2) * S, (nb - 1) * S]        # block-range seams of the static part
+        for t in seams:
+            o = int(t * per_tile) - width // 2
+            pos.add(min(max(0, o), max(0, n_count - width)))
+    rng = np.random.default_rng(seed)
+    for _ in range(k_random):
+        pos.add(int(rng.integers(0, max(1, n_count - width))))
+    return sorted(pos)
+
+
+def verify_last_output(O, shard, fetch_bytes, out_np_fn, ns, wl, n0_last, sched, k_random=20, seed=2026):
+    """Compare windows of the last step's output with the oracle.
+
+    The pipeline saw the same `ns`-sample batch again and again, i.e. a periodic stream;
+    the last batch starts at absolute sample n0_last.  Absolute output M of the cascade is
+    produced in the batch that contains ADC sample dtot*M.  For a window of absolute outputs
+    [M0, M1) the oracle runs from zero history over ADC samples [dtot*M0 - halo, dtot*M1)
+    (NCO phase from the absolute index) and drops the halo's outputs.
+    fetch_bytes(a, b) -> packed bytes of absolute samples [a, b); out_np_fn(j0, j1) -> the
+    batch's outputs [j0, j1) as float32 [n, 2]."""
+    import numpy as np
+    stages, dtot = wl["stages"], wl["decim"]
+    halo = shard.cascade_halo(stages)
+    m_first = -(-n0_last // dtot)
+    m_end = -(-(n0_last + ns) // dtot)
+    n_count = m_end - m_first
+    width = 256 if dtot <= 8 else 64
+    worst, nwin = 0.0, 0
+    for j0 in window_positions(m_first, n_count, sched, dtot, width, k_random, seed):
+        j1 = min(j0 + width, n_count)
+        M0, M1 = m_first + j0, m_first + j1
+        a = max(dtot * M0 - halo, 0)                 # < 0 only in the very first batch: zero history
+        seg = fetch_bytes(a, dtot * M1)
+        x = O.unpack24_f32(seg)
+        x = O.nco_mix(x, wl["freg"], a) if wl["mix"] else x.astype(np.float64)
+        for st in stages:
+            x = O.fir_decim(x, st[1], int(st[0]))
+        ref = np.asarray(x, dtype=np.float64).reshape(-1, 2)[(dtot * M0 - a) // dtot:]
+        got = out_np_fn(j0, j1).astype(np.float64)
+        ref = ref[:got.shape[0]]
+        den = np.abs(ref).max()
+        err = float(np.abs(got - ref).max() / den) if den > 0 else float(np.abs(got).max())
+        worst = max(worst, err)
+        nwin += 1
+    return {"windows": nwin, "window_outputs": width, "max_rel_err": float(f"{worst:.3e}"), "tol": PARITY_TOL,
+            "ok": bool(worst <= PARITY_TOL), "n_outputs": int(n_count), "metric": PARITY_METRIC,
+            "of": "last timed step's output, windows on the tile scheduler's seams + %d random" % k_random}
+
+
+def traffic_from_profile(workload, kernel_sig, log2n, taps_fp16):
+    """HBM bytes per launch from the committed offline PMC passes -- reported only when the
+    file says it was measured for THIS kernel source and launch shape; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None, "no profiles/pmc_traffic.json"
+    ent = d.get(workload)
+    prov = d.get("provenance", {})
+    if not isinstance(ent, (int, float)):
+        return None, "workload not in profiles/pmc_traffic.json"
+    if not prov:
+        return None, "profiles/pmc_traffic.json carries no provenance"
+    if prov.get("log2n") != log2n or taps_fp16:
+        return None, "offline PMC was taken at another launch shape"
+    if prov.get("kernel_source_sha16") != kernel_sig:
+        return None, ("stale: offline PMC was taken for kernel source %s, this build is %s"
+                      % (prov.get("kernel_source_sha16"), kernel_sig))
+    return float(ent), ("offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh), commit %s, "
+                        "kernel source %s" % (prov.get("commit", "?"), kernel_sig))
+
+
+def kernel_source_sig():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ddc_kernels.hip", "ddc_kernels.h"):
+        h.update(open(os.path.join(ROOT, "libperseus-sdr_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ----------------------------------------------------------------------------------------
+def run_rank(a):
     import numpy as np
     import torch
-    import torch.distributed as dist
     pkg = importlib.import_module("libperseus-sdr_amd")
     shard = importlib.import_module("libperseus-sdr_amd.shard")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local = shard.env_rank_world()
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs WORLD_SIZE={a.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    dry = os.environ.get("PDDC_BENCH_BACKEND") == "gloo"       # CPU plumbing test of the launcher path
+    if dry:
+        return run_rank_dry(a, shard, rank, world, local)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    force_dist = os.environ.get("PDDC_BENCH_FORCE_DIST") == "1"     # 1-rank RCCL group (testing)
-    if world > 1 or force_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    force_dist = os.environ.get("PDDC_BENCH_FORCE_DIST") == "1" or a.gather      # 1-rank RCCL group
+    grp = shard.RcclGroup(pkg, rank, world, local) if (world > 1 or force_dist) else shard.Group()
 
     ns = 1 << a.log2n
-    # ---- workload ---------------------------------------------------------
-    if a.workload == "c320":
-        stages = [(8, load_taps("c320_s1_d8_32")), (8, load_taps("c320_s2_d8_64")),
-                  (5, load_taps("c320_s3_d5_161"))]
-        mix, bytes_per_sample, decim = True, 6.0 + 8.0 / 320.0, 320
-        wl = "80 MS/s synthetic 24-bit I/Q, NCO mix 7.1 MHz + cascade /320 (8*8*5)"
-    elif a.workload == "unpack":
-        stages, mix, bytes_per_sample, decim = None, False, 14.0, 1
-        wl = "24-bit packed I/Q -> float32 unpack only"
-    else:
-        h = load_taps(a.workload)
-        stages, mix, bytes_per_sample, decim = [(8, h)], False, 7.0, 8
-        wl = f"80 MS/s synthetic 24-bit I/Q, unpack + {h.size}-tap polyphase decimate-by-8"
-
-    # configuration (taps, NCO word, plan) comes from rank 0 over RCCL: a few KB, once
-    if stages is not None:
-        cfg = shard.broadcast_config({"freg": pkg.ddc_lib().pddc_nco_freg(7.1e6, 80e6) if mix else 0,
-                                      "stages": stages} if rank == 0 else None, dev)
-        stages = cfg["stages"]
+    wl = workload_def(a.workload)
+    stages = wl["stages"]
     d_in = pkg.synth_lcg(6 * ns, shard.stream_seed(rank), 0, dev)   # device resident before timing
     stream = torch.cuda.current_stream(dev).cuda_stream
+    calls = [0]
     if stages is not None:
-        pipe = pkg.Pipeline(stages, device=local, mix=mix, taps_fp16=a.taps_fp16)
-        if mix:
-            pipe.set_freg(cfg["freg"])
+        # configuration (taps, NCO word, plan) comes from rank 0 over RCCL: a few KB, once
+        pipe = grp.make_pipeline(pkg, stages, wl["freg"], wl["mix"], a.taps_fp16)
         out = torch.empty((pipe.max_output(ns) + 8, 2), dtype=torch.float32, device=dev)
+        out_k = torch.empty_like(out) if pipe.fused else None      # the kernel-only timing writes here
 
         def step():
+            calls[0] += 1
             return pipe.process_ptr(d_in.data_ptr(), ns, out.data_ptr(), out.shape[0], stream)
     else:
+        pipe = None
         out = torch.empty((ns, 2), dtype=torch.float32, device=dev)
 
         def step():
+            calls[0] += 1
             pkg.check(pkg.ddc_lib().pddc_unpack24_f32(d_in.data_ptr(), ns, out.data_ptr(), stream))
             return ns
-
-    barrier = shard.barrier
 
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < a.settle_ms:    # untimed, back-to-back (no idle gaps):
@@ -183,78 +346,81 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize(dev)
-    barrier()
+    grp.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     ev0.record()
+    n_last = 0
     for _ in range(a.steps):
-        step()
+        n_last = step()
     ev1.record()
     torch.cuda.synchronize(dev)
-    barrier()
+    grp.barrier()
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)                       # HIP events on the launch stream
-
-    dt_max = shard.max_over_ranks(dt, dev)
-
-    # dominant-kernel duration: stage-0 kernel alone, HIP events on the same stream
-    kern_ms = None
+    # dominant-kernel duration: stage-0 kernel alone, HIP events on the same stream, back to back with
+    # the timed region (the clocks are still the sustained-load ones) and into a buffer of its own, so
+    # that `out` still holds the last timed step's output for the check below
     if stages is not None and pipe.fused:
-        kern_ms = pipe.time_stage0(d_in.data_ptr(), ns, out.data_ptr(), max(a.steps, 5), stream)
+        kern_ms = pipe.time_stage0(d_in.data_ptr(), ns, out_k.data_ptr(), max(a.steps, 5), stream)
     else:
         kern_ms = ev_ms / a.steps
+    dt_max = grp.max_seconds(dt)
 
-    gather = None
-    if a.gather and shard.is_dist() and stages is not None:
-        # BASELINE config 4: gather every rank's /8 output on rank 0.  Double-buffered and
-        # asynchronous: the xGMI transfer of batch k overlaps the kernels of batch k+1.
-        n_out = pipe.max_output(ns)
-        outs = [out, torch.empty_like(out)]
-        bufs = [torch.empty((n_out, 2), dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
+    # ---- parity of what was just timed (outside the timed region, every rank its own stream)
+    verified = None
+    if not a.no_verify:
+        from oracle import oracle as O
+        O.build()
 
-        def gstep(k, pending):
-            o = outs[k & 1]
-            pipe.process_ptr(d_in.data_ptr(), ns, o.data_ptr(), o.shape[0], stream)
-            if pending is not None:
-                pending.wait()                       # batch k-1 has left before its buffer is reused at k+1
-            return shard.gather_to_root_async(o[:n_out], bufs)
+        def fetch(a0, b0):                              # absolute samples of the periodic stream
+            idx = (torch.arange(6 * a0, 6 * b0, device=dev, dtype=torch.int64) % (6 * ns))
+            return d_in[idx].cpu().numpy()
 
-        pending = None
-        for k in range(2):
-            pending = gstep(k, pending)
-        if pending is not None:
-            pending.wait()
-        torch.cuda.synchronize(dev)
-        barrier()
-        t0 = time.perf_counter()
-        pending = None
-        for k in range(a.steps):
-            pending = gstep(k, pending)
-        if pending is not None:
-            pending.wait()
-        torch.cuda.synchronize(dev)
-        barrier()
-        tgv = shard.max_over_ranks(time.perf_counter() - t0, dev)
-        gather = {"value": round(world * ns * a.steps / tgv / 1e6, 1), "unit": "MS/s",
-                  "note": "hot path + RCCL gather of the /%d float32 output to rank 0, gather of batch k "
-                          "overlapped with the kernels of batch k+1" % decim,
-                  "out_bytes_per_rank_per_step": int(n_out * 8),
-                  "root_ingest_GBps": round((world - 1) * (n_out * 8) * a.steps / tgv / 1e9, 2),
-                  # xGMI is point to point: each peer reaches rank 0 over its own link
-                  "per_link_GBps": round((n_out * 8) * a.steps / tgv / 1e9, 2) if world > 1 else 0.0}
+        if stages is not None:
+            n0_last = (calls[0] - 1) * ns
+            sched = pipe.schedule(ns) if pipe.fused else None
+            verified = verify_last_output(O, shard, fetch, lambda j0, j1: out[j0:j1].cpu().numpy(), ns, wl, n0_last,
+                                          sched)
+            verified["n_outputs_ok"] = bool(n_last == verified["n_outputs"])
+            verified["ok"] = bool(verified["ok"] and verified["n_outputs_ok"])
+        else:                                           # unpack only: bit-exact windows
+            rng = np.random.default_rng(2026)
+            starts = [0, ns - 4096] + [int(v) for v in rng.integers(0, ns - 4096, 20)]
+            bad = 0
+            for s0 in starts:
+                ref = O.unpack24_f32(fetch(s0, s0 + 4096)).view(np.uint32)
+                got = out[s0:s0 + 4096].cpu().numpy().reshape(-1).view(np.uint32)
+                bad += int((ref != got).sum())
+            verified = {"windows": len(starts), "window_outputs": 4096, "mismatching_words": bad, "ok": bad == 0,
+                        "metric": "bit-exact vs the CPU oracle (examples/perseustest.c:466-502)"}
 
+    # measured copy ceiling: a device-to-device copy that moves as many bytes through HBM as
+    # one launch of the dominant kernel does (nbytes read + nbytes written)
+    copy_gbps = None
+    try:
+        nb = int(wl["kernel_bytes_per_sample"] * ns / 2) // 256 * 256
+        src = d_in[:nb] if nb <= d_in.numel() else torch.empty(nb, dtype=torch.uint8, device=dev)
+        dst = torch.empty(nb, dtype=torch.uint8, device=dev)
+        ms = pkg.measure_copy(dst.data_ptr(), src.data_ptr(), nb, 20, stream)
+        copy_gbps = 2.0 * nb / (ms * 1e-3) / 1e9
+        del dst, src
+    except Exception as e:                              # never lose the line over the extra figure
+        print(f"[bench] copy ceiling failed: {e}", file=sys.stderr)
+
+    names = grp.all_gather_object(torch.cuda.get_device_name(dev))
+    oks = grp.all_gather_object(None if verified is None else bool(verified["ok"]))
+    res = None
     if rank == 0:
         total_samples = world * ns * a.steps
         value = total_samples / dt_max / 1e6
-        achieved = bytes_per_sample * ns / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and a.log2n == 28 and not a.taps_fp16:   # measured for this exact launch shape
-            try:
-                traffic = json.load(open(pmc)).get(a.workload)
-            except Exception:
-                traffic = None
+        fused = stages is not None and pipe.fused
+        bps = wl["kernel_bytes_per_sample"] if fused else wl["bytes_per_sample"]
+        achieved = bps * ns / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = traffic_from_profile(a.workload, kernel_source_sig(), a.log2n, a.taps_fp16)
+        if verified is not None:
+            verified["all_ranks_ok"] = bool(all(o for o in oks))
         res = {
             "metric": BASELINE_METRIC,
             "value": round(value, 1), "unit": "MS/s",
@@ -262,26 +428,154 @@ def main():
             "ms_per_step": round(dt_max / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl, "samples_per_gpu_per_step": ns,
+            "config": {"workload": wl["label"], "samples_per_gpu_per_step": ns,
                        "input": "LCG bytes seed 12345+rank, device resident",
                        "sharding": "independent stream per GPU, no data-path collective",
-                       "taps_storage": "fp16" if a.taps_fp16 else "fp32"},
+                       "taps_storage": "fp32 (values rounded to binary16)" if a.taps_fp16 else "fp32"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic,
-                         "kernel": "k_fir8" if (stages is not None and pipe.fused) else "pipeline",
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "copy_ceiling_GBps": round(copy_gbps, 1) if copy_gbps else None,
+                         "frac_of_copy_ceiling": round(achieved / copy_gbps, 4) if copy_gbps else None,
+                         "kernel": "k_fir8" if fused else "pipeline",
                          "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_sample": bytes_per_sample},
+                         "algorithmic_bytes_per_sample": bps},
             "events_ms_per_step": round(ev_ms / a.steps, 4),
+            "verified": verified,
+            "ranks_seen": grp.world, "devices": names,
+            "collectives": "RCCL called from the C library (pddc_comm_*); torch.distributed = rendezvous only"
+                           if grp.comm is not None else None,
+            "cpu_baseline": None,
         }
-        if gather:
-            res["gather"] = gather
-        if world == 1 and not a.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_seconds)
-        else:
-            res["cpu_baseline"] = None
-    else:
-        res = None
+        PARTIAL["res"] = res
+
+    # ---- BASELINE config 4: gather of every rank's output on rank 0's GPU (RCCL, C library)
+    if grp.comm is not None and stages is not None and not a.no_gather:
+        g = guarded_gather_legs(a, pkg, shard, grp, dev, stream, ns, d_in, wl, pipe, out)
+        if res is not None:
+            res["gather"] = g
+    if res is not None and world == 1 and not a.no_cpu:
+        res["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_seconds)
+    finish(grp, res)
+
+
+def gather_leg(a, pkg, grp, dev, stream, ns, d_in, pipe, out_shape_rows, decim, label):
+    """hot path + gather of its output to rank 0, batch k's transfer under batch k+1's kernels."""
+    import torch
+    world, rank = grp.world, grp.rank
+    n_out = pipe.max_output(ns)
+    nbytes = n_out * 8
+    outs = [torch.empty((out_shape_rows, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+    recv = torch.empty((world, n_out, 2), dtype=torch.float32, device=dev) if rank == 0 else None
+    rptr = recv.data_ptr() if recv is not None else 0
+
+    def gstep(k):
+        o = outs[k & 1]
+        grp.comm.gather_fence(stream)          # the transfer that last read this buffer pair is done
+        pipe.process_ptr(d_in.data_ptr(), ns, o.data_ptr(), o.shape[0], stream)
+        grp.comm.gather_async(o.data_ptr(), nbytes, rptr, 0, stream)
+
+    for k in range(2):
+        gstep(k)
+    grp.comm.gather_wait()
+    torch.cuda.synchronize(dev)
+    grp.barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        gstep(k)
+    grp.comm.gather_wait()
+    torch.cuda.synchronize(dev)
+    grp.barrier()
+    tg = grp.max_seconds(time.perf_counter() - t0)
+    ok = None
+    if rank == 0:                               # rank 0's own block is its own last output
+        ok = bool(torch.equal(recv[0], outs[(a.steps - 1) & 1][:n_out]))
+    return {"workload": label, "value": round(world * ns * a.steps / tg / 1e6, 1), "unit": "MS/s",
+            "ms_per_step": round(tg / a.steps * 1e3, 4),
+            "out_bytes_per_rank_per_step": int(nbytes),
+            "root_ingest_GBps": round((world - 1) * nbytes * a.steps / tg / 1e9, 2),
+            # xGMI is point to point: each peer reaches rank 0 over its own link
+            "per_link_GBps": round(nbytes * a.steps / tg / 1e9, 2) if world > 1 else 0.0,
+            "root_block_matches_own_output": ok}
+
+
+def guarded_gather_legs(a, pkg, shard, grp, dev, stream, ns, d_in, wl, pipe, out):
+    """Both gather legs under a watchdog: a collective that never completes must not cost the
+    run its line -- the watchdog prints it without the gather and ends the process."""
+    res = {"note": "hot path + RCCL gather (grouped ncclSend/ncclRecv from the C library, peer -> rank 0, one xGMI "
+                   "link per peer) of the float32 output; batch k's transfer runs under batch k+1's kernels. "
+                   "Never part of `value`."}
+    state = {"fired": False}
+
+    def on_timeout():
+        state["fired"] = True
+        print(f"[bench] rank {grp.rank}: gather leg exceeded {a.gather_timeout:.0f} s", file=sys.stderr, flush=True)
+        if grp.rank == 0 and PARTIAL.get("res") is not None:
+            r = PARTIAL["res"]
+            r["gather"] = {"error": f"gather leg did not finish within {a.gather_timeout:.0f} s"}
+            print(json.dumps(r), flush=True)
+        os._exit(0)
+
+    timer = threading.Timer(a.gather_timeout, on_timeout)
+    timer.daemon = True
+    timer.start()
+    try:
+        res["this_workload"] = gather_leg(a, pkg, grp, dev, stream, ns, d_in, pipe, out.shape[0], wl["decim"],
+                                          wl["label"])
+        if a.workload != "c320" and (grp.world > 1 or os.environ.get("PDDC_BENCH_GATHER_C320") == "1"):
+            w2 = workload_def("c320")
+            p2 = grp.make_pipeline(pkg, w2["stages"], w2["freg"], w2["mix"])
+            res["c320"] = gather_leg(a, pkg, grp, dev, stream, ns, d_in, p2, p2.max_output(ns) + 8, 320, w2["label"])
+            p2.close()
+    except Exception as e:
+        res["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        timer.cancel()
+    return res
+
+
+PARTIAL = {}
+
+
+def run_rank_dry(a, shard, rank, world, local):
+    """PDDC_BENCH_BACKEND=gloo: the launcher / rendezvous / relay path on CPU, for the tests.
+    No GPU exists there, so nothing is measured: the CPU oracle stands in for the pipeline only to
+    give the ranks distinct data to gather, and the line says so."""
+    import numpy as np
+    import torch
+    from oracle import oracle as O
+    O.build()
+    grp = shard.TorchGroup(rank, world, local)
+    wl = workload_def(a.workload)
+    ns = 1 << min(a.log2n, 13)
+    cfg = shard.broadcast_config({"freg": wl["freg"], "stages": wl["stages"]} if rank == 0 else None, grp.device)
+    packed = O.lcg_bytes(6 * ns, shard.stream_seed(rank))
+    t0 = time.perf_counter()
+    y = None
+    for _ in range(a.steps):
+        y = O.ddc_chain(packed, cfg["stages"], cfg["freg"], wl["mix"])
+    dt = grp.max_seconds(time.perf_counter() - t0)
+    bufs = shard.gather_to_root(torch.from_numpy(y.copy()))
+    ok = None
+    if rank == 0:
+        ok = all(np.array_equal(bufs[r].numpy(), O.ddc_chain(O.lcg_bytes(6 * ns, shard.stream_seed(r)), cfg["stages"],
+                                                              cfg["freg"], wl["mix"])) for r in range(world))
+    hosts = grp.all_gather_object(f"cpu:{rank}")
+    res = None
+    if rank == 0:
+        res = {"metric": BASELINE_METRIC, "value": 0.0, "unit": "MS/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": wl["label"], "samples_per_gpu_per_step": ns},
+               "dry_run": "PDDC_BENCH_BACKEND=gloo: launcher/rendezvous plumbing test on CPU, the oracle stands in "
+                          "for the HIP pipeline, nothing is measured",
+               "ranks_seen": world, "devices": hosts,
+               "gather": {"this_workload": {"root_blocks_match_each_ranks_stream": ok}},
+               "roofline": None, "cpu_baseline": None}
+    finish(grp, res)
+
+
+def finish(grp, res):
     # RCCL writes its version banner to C stdout, which is block buffered on a pipe and would
     # otherwise come out at process exit -- after the JSON line, on any rank.  Every rank flushes
     # it now, then all ranks meet, then rank 0 prints the one JSON line last.
@@ -291,11 +585,18 @@ def main():
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
-    if shard.is_dist():
-        barrier()
-        dist.destroy_process_group()
+    grp.barrier()
+    grp.close()
     if res is not None:
         print(json.dumps(res), flush=True)
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain command: become the launcher.  Nothing above has imported torch or touched a GPU.
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    run_rank(a)
 
 
 if __name__ == "__main__":

@@ -58,6 +58,7 @@ extern "C" {
 #define PDDC_ENOMEM     -4   /* allocation failed                              */
 #define PDDC_ECAPACITY  -5   /* output buffer too small                        */
 #define PDDC_ESTATE     -6   /* call not valid in the pipeline's current state */
+#define PDDC_ECOMM      -7   /* an RCCL call failed                             */
 
 #define PDDC_ADC_CLK_HZ        80000000.0   /* perseus-sdr.h:44 */
 #define PDDC_MAX_STAGES        4
@@ -127,7 +128,12 @@ int pddc_pipeline_reset(pddc_pipeline *p);
  * boundary of every stage (a multiple of the product of the decimation factors is enough)
  * and be a multiple of PDDC_INPUT_GRANULE.                                                */
 int pddc_pipeline_seek(pddc_pipeline *p, uint64_t abs_sample);
+/* New tuning word from the next sample on.  The NCO is a phase accumulator, like the FPGA's:
+ * phase(n) = n*freg + offset (mod 2^32), and a retune at sample n moves the offset by
+ * n*(freg_old - freg_new) so that the phase is continuous there (no phase jump on retune).
+ * reset()/seek() clear the offset (phase of a stream that began at sample 0 with this word). */
 int pddc_pipeline_set_freg(pddc_pipeline *p, uint32_t freg);
+uint32_t pddc_pipeline_get_phase_offset(const pddc_pipeline *p);
 int pddc_pipeline_set_center_freq(pddc_pipeline *p, double center_freq_hz);
 int pddc_pipeline_set_taps(pddc_pipeline *p, int stage, const float *taps, int ntaps);
 uint32_t pddc_pipeline_get_freg(const pddc_pipeline *p);
@@ -177,6 +183,76 @@ int pddc_host_free(void *h_ptr);
  * State is not advanced (history taken as is).                                 */
 int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsamples,
                               void *d_out_f32, int iters, void *stream, float *avg_ms);
+
+/* The tile schedule a process() of nsamples would launch the fused stage-0 kernel with:
+ * out = { inputs per tile, tiles, persistent blocks, S, K } -- block b first owns the S
+ * tiles [b*S, (b+1)*S), the tiles from blocks*S on are handed out in chunks of K.  For
+ * tests and bench.py, which place their comparison windows on these seams.           */
+int pddc_pipeline_schedule(const pddc_pipeline *p, size_t nsamples, int out[5]);
+/* Device-to-device streaming copy of nbytes (16 B per lane, nontemporal stores), `iters`
+ * times, timed with HIP events on `stream`: the measured copy ceiling bench.py prints
+ * next to the 8 TB/s spec figure (SURVEY.md 8d "Which roofline").  A copy moves
+ * 2*nbytes through HBM.  Pointers and size: multiples of 16.                         */
+int pddc_measure_copy(void *d_dst, const void *d_src, size_t nbytes, int iters, void *stream, float *avg_ms);
+
+/* ---- multi-GPU: RCCL over xGMI (ddc_multi.cpp) --------------------------------
+ * The reference models up to 8 receivers as 8 independent descriptors, each with
+ * its own transfer queue and callback (perseus-sdr.c:43-47, perseus-in.h:87): the
+ * stream shards as one receiver per GPU and the data path needs no collective.
+ * What these calls carry between GPUs is the configuration (root -> all) and,
+ * for BASELINE config 4, every GPU's decimated output to one root GPU.  They
+ * stand where the reference has nothing (its receivers never talk to each other);
+ * the hand-over point to the client stays perseus-in.c:206-207.
+ *
+ * One communicator rank per GPU.  pddc_comm_init_rank: one process per GPU -- rank 0
+ * calls pddc_comm_get_unique_id and hands the 128 bytes to the others through
+ * whatever started the processes (bench.py: the torch.distributed store).
+ * pddc_comm_init_all: ONE process driving ndev GPUs (a C host holding several
+ * perseus_descr); its collective calls -- one per communicator, same arguments --
+ * go between pddc_comm_group_start() and pddc_comm_group_end().
+ * All sizes in bytes.  Errors: PDDC_ECOMM + pddc_last_error().                  */
+typedef struct pddc_comm pddc_comm;
+#define PDDC_COMM_ID_BYTES 128
+int pddc_comm_get_unique_id(void *id128);
+int pddc_comm_init_rank(pddc_comm **out, int nranks, int rank, const void *id128, int device);
+int pddc_comm_init_all(pddc_comm **comms /* [ndev] */, int ndev, const int *devices /* NULL: 0..ndev-1 */);
+int pddc_comm_destroy(pddc_comm *c);
+int pddc_comm_rank(const pddc_comm *c);
+int pddc_comm_size(const pddc_comm *c);
+int pddc_comm_device(const pddc_comm *c);
+int pddc_comm_group_start(void);
+int pddc_comm_group_end(void);
+/* root's d_buf -> everybody's d_buf (ncclBroadcast), asynchronous on `stream`     */
+int pddc_comm_bcast(pddc_comm *c, void *d_buf, size_t nbytes, int root, void *stream);
+/* the same for a host buffer, synchronous (one process per GPU only)              */
+int pddc_comm_bcast_host(pddc_comm *c, void *h_buf, size_t nbytes, int root);
+/* *h_val = max over ranks; pddc_comm_barrier = the same with nothing to say        */
+int pddc_comm_allreduce_max_f64(pddc_comm *c, double *h_val);
+int pddc_comm_barrier(pddc_comm *c);
+/* Gather: every rank's nbytes at d_send land on the root at d_recv + rank*nbytes
+ * (d_recv is read on the root only).  Grouped ncclSend/ncclRecv, peer -> root: the
+ * root's xGMI links carry one peer each.  Asynchronous on `stream`.                */
+int pddc_comm_gather(pddc_comm *c, const void *d_send, size_t nbytes, void *d_recv, int root, void *stream);
+/* The same on the communicator's own side stream, started once everything queued on
+ * `after_stream` so far (the kernels that wrote d_send) is done -- the transfer of
+ * batch k then runs under the kernels of batch k+1.  Before d_send is overwritten
+ * (or d_recv read) either make a stream wait with _fence, or the host with _wait.  */
+int pddc_comm_gather_async(pddc_comm *c, const void *d_send, size_t nbytes, void *d_recv, int root,
+                           void *after_stream);
+int pddc_comm_gather_fence(pddc_comm *c, void *stream);
+int pddc_comm_gather_wait(pddc_comm *c);
+
+/* The configuration a broadcast carries: stage plan + taps + NCO word + flags, as one
+ * flat little-endian buffer.  pack: returns the bytes used (buf == NULL: the bytes
+ * needed), 0 on error.  unpack: stages[i].taps point INTO buf.                      */
+size_t pddc_plan_pack(const pddc_stage_desc *stages, int nstages, uint32_t freg, uint32_t flags,
+                      void *buf, size_t capacity);
+int pddc_plan_unpack(const void *buf, size_t nbytes, pddc_stage_desc *stages /* [PDDC_MAX_STAGES] */,
+                     int *nstages, uint32_t *freg, uint32_t *flags);
+/* Root supplies the plan (others pass NULL/0); every rank gets a pipeline on its
+ * communicator's GPU, created from the broadcast plan, NCO word set.                */
+int pddc_comm_bcast_pipeline(pddc_comm *c, int root, const pddc_stage_desc *stages, int nstages,
+                             uint32_t freg, uint32_t flags, pddc_pipeline **out);
 
 #ifdef __cplusplus
 }

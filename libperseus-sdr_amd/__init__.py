@@ -28,7 +28,8 @@ CSRC = os.path.join(_HERE, "csrc")
 DDC_LIB = os.path.join(_HERE, "libperseus_ddc.so")
 SDR_LIB = os.path.join(_HERE, "libperseus-sdr.so")
 
-PDDC_OK, PDDC_EINVAL, PDDC_ENODEV, PDDC_EHIP, PDDC_ENOMEM, PDDC_ECAPACITY, PDDC_ESTATE = 0, -1, -2, -3, -4, -5, -6
+PDDC_OK, PDDC_EINVAL, PDDC_ENODEV, PDDC_EHIP, PDDC_ENOMEM, PDDC_ECAPACITY, PDDC_ESTATE, PDDC_ECOMM = 0, -1, -2, -3, -4, -5, -6, -7
+PDDC_COMM_ID_BYTES = 128
 PDDC_F_MIX, PDDC_F_TAPS_FP16, PDDC_F_NO_FAST, PDDC_F_OUT_PACKED24 = 1, 2, 4, 8
 
 
@@ -94,6 +95,8 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_set_taps.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int]
     L.pddc_pipeline_get_freg.argtypes = [vp]
     L.pddc_pipeline_get_freg.restype = C.c_uint32
+    L.pddc_pipeline_get_phase_offset.argtypes = [vp]
+    L.pddc_pipeline_get_phase_offset.restype = C.c_uint32
     L.pddc_pipeline_total_decim.argtypes = [vp]
     L.pddc_pipeline_max_output.argtypes = [vp, sz]
     L.pddc_pipeline_max_output.restype = sz
@@ -108,6 +111,38 @@ def ddc_lib() -> C.CDLL:
     L.pddc_host_alloc.argtypes = [C.POINTER(vp), sz]
     L.pddc_host_free.argtypes = [vp]
     L.pddc_pipeline_time_stage0.argtypes = [vp, vp, sz, vp, C.c_int, vp, C.POINTER(C.c_float)]
+    L.pddc_pipeline_schedule.argtypes = [vp, sz, C.POINTER(C.c_int)]
+    L.pddc_pipeline_schedule.restype = C.c_int
+    L.pddc_measure_copy.argtypes = [vp, vp, sz, C.c_int, vp, C.POINTER(C.c_float)]
+    L.pddc_measure_copy.restype = C.c_int
+    # multi-GPU section (RCCL, ddc_multi.cpp)
+    L.pddc_comm_get_unique_id.argtypes = [vp]
+    L.pddc_comm_init_rank.argtypes = [C.POINTER(vp), C.c_int, C.c_int, vp, C.c_int]
+    L.pddc_comm_init_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
+    L.pddc_comm_destroy.argtypes = [vp]
+    L.pddc_comm_rank.argtypes = [vp]
+    L.pddc_comm_size.argtypes = [vp]
+    L.pddc_comm_device.argtypes = [vp]
+    L.pddc_comm_bcast.argtypes = [vp, vp, sz, C.c_int, vp]
+    L.pddc_comm_bcast_host.argtypes = [vp, vp, sz, C.c_int]
+    L.pddc_comm_allreduce_max_f64.argtypes = [vp, C.POINTER(C.c_double)]
+    L.pddc_comm_barrier.argtypes = [vp]
+    L.pddc_comm_gather.argtypes = [vp, vp, sz, vp, C.c_int, vp]
+    L.pddc_comm_gather_async.argtypes = [vp, vp, sz, vp, C.c_int, vp]
+    L.pddc_comm_gather_fence.argtypes = [vp, vp]
+    L.pddc_comm_gather_wait.argtypes = [vp]
+    L.pddc_plan_pack.argtypes = [C.POINTER(StageDesc), C.c_int, C.c_uint32, C.c_uint32, vp, sz]
+    L.pddc_plan_pack.restype = sz
+    L.pddc_plan_unpack.argtypes = [vp, sz, C.POINTER(StageDesc), C.POINTER(C.c_int), C.POINTER(C.c_uint32),
+                                   C.POINTER(C.c_uint32)]
+    L.pddc_comm_bcast_pipeline.argtypes = [vp, C.c_int, C.POINTER(StageDesc), C.c_int, C.c_uint32, C.c_uint32,
+                                           C.POINTER(vp)]
+    for name in ("pddc_comm_get_unique_id", "pddc_comm_init_rank", "pddc_comm_init_all", "pddc_comm_destroy",
+                 "pddc_comm_rank", "pddc_comm_size", "pddc_comm_device", "pddc_comm_group_start",
+                 "pddc_comm_group_end", "pddc_comm_bcast", "pddc_comm_bcast_host", "pddc_comm_allreduce_max_f64",
+                 "pddc_comm_barrier", "pddc_comm_gather", "pddc_comm_gather_async", "pddc_comm_gather_fence",
+                 "pddc_comm_gather_wait", "pddc_plan_unpack", "pddc_comm_bcast_pipeline"):
+        getattr(L, name).restype = C.c_int
     for name in ("pddc_unpack24_f32", "pddc_unpack24_i32", "pddc_pack24_f32", "pddc_synth_lcg", "pddc_set_device",
                  "pddc_malloc", "pddc_free", "pddc_memcpy_h2d", "pddc_memcpy_d2h", "pddc_stream_sync",
                  "pddc_pipeline_create", "pddc_pipeline_destroy", "pddc_pipeline_reset", "pddc_pipeline_seek",
@@ -148,6 +183,16 @@ class Pipeline:
         self._h = h
         self.decim = L.pddc_pipeline_total_decim(h)
 
+    @classmethod
+    def from_handle(cls, handle, out_packed: bool = False):
+        """Wrap a pddc_pipeline* made by the library itself (Comm.bcast_pipeline)."""
+        self = cls.__new__(cls)
+        self._taps = []
+        self.out_packed = out_packed
+        self._h = handle
+        self.decim = ddc_lib().pddc_pipeline_total_decim(handle)
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
             ddc_lib().pddc_pipeline_destroy(self._h)
@@ -172,6 +217,11 @@ class Pipeline:
     @property
     def freg(self) -> int:
         return int(ddc_lib().pddc_pipeline_get_freg(self._h))
+
+    @property
+    def phase_offset(self) -> int:
+        """phase(n) = n*freg + phase_offset (mod 2^32); non-zero only after a retune mid-stream."""
+        return int(ddc_lib().pddc_pipeline_get_phase_offset(self._h))
 
     @property
     def fused(self) -> bool:
@@ -225,10 +275,132 @@ class Pipeline:
     def wait(self):
         check(ddc_lib().pddc_pipeline_wait(self._h))
 
+    def schedule(self, nsamples: int) -> dict:
+        """Tile schedule of the fused stage-0 kernel for a batch of nsamples."""
+        o = (C.c_int * 5)()
+        check(ddc_lib().pddc_pipeline_schedule(self._h, nsamples, o))
+        return {"tile": o[0], "ntiles": o[1], "nblocks": o[2], "S": o[3], "K": o[4]}
+
     def time_stage0(self, d_in: int, nsamples: int, d_out: int, iters: int, stream: int = 0) -> float:
         ms = C.c_float(0)
         check(ddc_lib().pddc_pipeline_time_stage0(self._h, d_in, nsamples, d_out, iters, stream, C.byref(ms)))
         return float(ms.value)
+
+
+def _stage_array(stages):
+    """[(D, taps[, L])] -> (StageDesc array, the numpy arrays that own the taps)."""
+    import numpy as np
+    keep = [np.ascontiguousarray(st[1], dtype=np.float32) for st in stages]
+    arr = (StageDesc * max(len(stages), 1))()
+    for i, st in enumerate(stages):
+        arr[i].decim = int(st[0])
+        arr[i].interp = int(st[2]) if len(st) > 2 and st[2] else 0
+        arr[i].ntaps = int(keep[i].size)
+        arr[i].taps = keep[i].ctypes.data_as(C.POINTER(C.c_float))
+    return arr, keep
+
+
+def plan_pack(stages, freg: int = 0, flags: int = 0) -> bytes:
+    """pddc_plan_pack: the flat buffer a configuration broadcast carries."""
+    L = ddc_lib()
+    arr, _keep = _stage_array(stages)
+    need = L.pddc_plan_pack(arr, len(stages), freg & 0xFFFFFFFF, flags, None, 0)
+    if need == 0:
+        raise PddcError(PDDC_EINVAL, L.pddc_last_error().decode(errors="replace"))
+    buf = C.create_string_buffer(need)
+    used = L.pddc_plan_pack(arr, len(stages), freg & 0xFFFFFFFF, flags, buf, need)
+    assert used == need
+    return buf.raw
+
+
+def plan_unpack(raw: bytes):
+    """pddc_plan_unpack -> {"freg", "flags", "stages": [(D, taps, L)]}."""
+    import numpy as np
+    L = ddc_lib()
+    buf = C.create_string_buffer(raw, len(raw))
+    arr = (StageDesc * 4)()
+    n, freg, flags = C.c_int(0), C.c_uint32(0), C.c_uint32(0)
+    check(L.pddc_plan_unpack(buf, len(raw), arr, C.byref(n), C.byref(freg), C.byref(flags)))
+    stages = []
+    for i in range(n.value):
+        t = np.ctypeslib.as_array(arr[i].taps, shape=(arr[i].ntaps,)).copy()
+        stages.append((arr[i].decim, t, arr[i].interp))
+    return {"freg": freg.value, "flags": flags.value, "stages": stages}
+
+
+class Comm:
+    """One RCCL communicator rank on one GPU (pddc_comm_*, include/perseus_ddc.h): the
+    C library calls librccl itself, torch is not involved."""
+
+    def __init__(self, handle):
+        self._h = handle
+        L = ddc_lib()
+        self.rank, self.size, self.device = L.pddc_comm_rank(handle), L.pddc_comm_size(handle), \
+            L.pddc_comm_device(handle)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(PDDC_COMM_ID_BYTES)
+        check(ddc_lib().pddc_comm_get_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def init_rank(cls, nranks: int, rank: int, uid: bytes, device: int):
+        h = C.c_void_p()
+        check(ddc_lib().pddc_comm_init_rank(C.byref(h), nranks, rank, C.create_string_buffer(uid, len(uid)), device))
+        return cls(h)
+
+    @classmethod
+    def init_all(cls, devices):
+        n = len(devices)
+        hs = (C.c_void_p * n)()
+        check(ddc_lib().pddc_comm_init_all(hs, n, (C.c_int * n)(*devices)))
+        return [cls(C.c_void_p(hs[i])) for i in range(n)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            ddc_lib().pddc_comm_destroy(self._h)
+            self._h = None
+
+    def bcast(self, d_ptr: int, nbytes: int, root: int = 0, stream: int = 0):
+        check(ddc_lib().pddc_comm_bcast(self._h, d_ptr, nbytes, root, stream))
+
+    def bcast_bytes(self, raw, root: int = 0) -> bytes:
+        """Host-level broadcast of a byte string whose length every rank knows."""
+        buf = C.create_string_buffer(raw, len(raw))
+        check(ddc_lib().pddc_comm_bcast_host(self._h, buf, len(raw), root))
+        return buf.raw
+
+    def bcast_pipeline(self, stages=None, freg: int = 0, flags: int = 0, root: int = 0) -> "Pipeline":
+        """Root passes the plan; every rank returns a Pipeline built from the broadcast."""
+        L = ddc_lib()
+        h = C.c_void_p()
+        if self.rank == root:
+            arr, _keep = _stage_array(stages)
+            check(L.pddc_comm_bcast_pipeline(self._h, root, arr, len(stages), freg & 0xFFFFFFFF, flags, C.byref(h)))
+        else:
+            check(L.pddc_comm_bcast_pipeline(self._h, root, None, 0, 0, 0, C.byref(h)))
+        return Pipeline.from_handle(h, out_packed=bool(flags & PDDC_F_OUT_PACKED24))
+
+    def max_f64(self, v: float) -> float:
+        x = C.c_double(v)
+        check(ddc_lib().pddc_comm_allreduce_max_f64(self._h, C.byref(x)))
+        return x.value
+
+    def barrier(self):
+        check(ddc_lib().pddc_comm_barrier(self._h))
+
+    def gather(self, d_send: int, nbytes: int, d_recv: int, root: int = 0, stream: int = 0):
+        check(ddc_lib().pddc_comm_gather(self._h, d_send, nbytes, d_recv, root, stream))
+
+    def gather_async(self, d_send: int, nbytes: int, d_recv: int, root: int = 0, after_stream: int = 0):
+        check(ddc_lib().pddc_comm_gather_async(self._h, d_send, nbytes, d_recv, root, after_stream))
+
+    def gather_fence(self, stream: int = 0):
+        check(ddc_lib().pddc_comm_gather_fence(self._h, stream))
+
+    def gather_wait(self):
+        check(ddc_lib().pddc_comm_gather_wait(self._h))
 
 
 class PinnedBuffer:
@@ -277,6 +449,13 @@ def pack24_f32(x_f32, stream=None):
     st = stream if stream is not None else torch.cuda.current_stream(x_f32.device).cuda_stream
     check(ddc_lib().pddc_pack24_f32(x_f32.data_ptr(), ns, out.data_ptr(), st))
     return out[:6 * ns]
+
+
+def measure_copy(d_dst: int, d_src: int, nbytes: int, iters: int = 20, stream: int = 0) -> float:
+    """Average milliseconds of a device-to-device copy of nbytes (pddc_measure_copy)."""
+    ms = C.c_float(0)
+    check(ddc_lib().pddc_measure_copy(d_dst, d_src, nbytes, iters, stream, C.byref(ms)))
+    return float(ms.value)
 
 
 def synth_lcg(nbytes: int, seed: int = 12345, byte_offset: int = 0, device="cuda:0", stream=None):

@@ -32,8 +32,14 @@ struct Fir8Args {
     long long   n_in;        /* samples in the batch, multiple of 8            */
     unsigned long long n0;   /* absolute index of batch sample 0 (NCO phase)   */
     uint32_t    freg;        /* NCO tuning word                                */
+    uint32_t    phase_off = 0;   /* phase(n) = n*freg + phase_off (mod 2^32): keeps the phase continuous
+                                across retunes (the FPGA's accumulator never jumps)          */
+    uint32_t    freg_hist = 0;   /* tuning word the samples in `hist` were mixed with (== freg unless
+                                this is the first batch after a retune)                       */
     float       lo_c[8];     /* cos/sin of step e*freg, e=0..7 (host, double)  */
     float       lo_s[8];
+    float       lo_c_hist[8];   /* the same for freg_hist                        */
+    float       lo_s_hist[8];
 };
 
 /* k_fir8 with packed input does not scale the unpacked integers (value * 256): the taps of
@@ -46,6 +52,9 @@ constexpr float kFir8PackedTapScale = 0x1.000002p-31f;
 constexpr int fir8_tile_inputs(int R) { return 1024 * R; }
 size_t fir8_lds_bytes(int ntb, int R);
 bool   fir8_supported(int ntb, int R);
+/* the two-level tile schedule a launch over n_in samples would use (tests place their
+ * comparison windows on its seams) */
+void   fir8_schedule_query(long long n_in, int R, bool fused, int *ntiles, int *nblocks, int *S, int *K);
 void   fir8_set_grid_blocks(int nblocks);   /* persistent grid override (0 = resident blocks x CUs) */
 
 /* packed -> [mix] -> /8 -> /8 in one kernel: `out` receives the SECOND stage's
@@ -57,7 +66,7 @@ hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipSt
 hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s);
 
 hipError_t launch_unpack24(const void *d_in, long long nsamples, void *d_out, bool to_i32,
-                           bool mix, unsigned long long n0, uint32_t freg,
+                           bool mix, unsigned long long n0, uint32_t freg, uint32_t phase_off,
                            const float *lo_c, const float *lo_s, hipStream_t s);
 
 /* generic decimating FIR on float2: out[q] = sum_k h[k]*x[first + q*D - k],
@@ -81,6 +90,9 @@ hipError_t launch_resample(const float *in, const float *hist, int H, unsigned l
 
 /* float32 I/Q -> 24-bit packed (6 B/sample); in and out 16-byte aligned */
 hipError_t launch_pack24(const float *in, long long nsamples, void *out, hipStream_t s);
+
+/* plain streaming copy of nbytes (multiple of 16, both pointers 16-byte aligned) */
+hipError_t launch_stream_copy(const void *src, void *dst, size_t nbytes, hipStream_t s);
 
 hipError_t launch_synth_lcg(void *dst, size_t nbytes, uint32_t seed, uint64_t byte_offset,
                             hipStream_t s);

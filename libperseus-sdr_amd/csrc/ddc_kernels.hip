@@ -134,12 +134,15 @@ __device__ __forceinline__ f32x4 cmul2(f32x4 v, float c, float s)
     return f32x4{ v.x * c - v.y * s, v.x * s + v.y * c, v.z * c - v.w * s, v.z * s + v.w * c };
 }
 
-/* mix 8 consecutive samples starting at absolute index nabs */
+/* mix 8 consecutive samples whose first one has index nabs: phase = nabs*freg + off (mod 2^32).
+ * `off` is the pipeline's phase offset for absolute indices (it keeps the phase continuous across
+ * retunes, like the FPGA's phase accumulator) and 0 for tile-relative ones                     */
 template <typename P>
-__device__ __forceinline__ void mix8(float (&xi)[8], float (&xq)[8], unsigned long long nabs, const P &p)
+__device__ __forceinline__ void mix8(float (&xi)[8], float (&xq)[8], unsigned long long nabs, const P &p,
+                                     uint32_t off = 0u)
 {
     float cb, sb;
-    nco_lo((uint32_t)nabs * p.freg, cb, sb);
+    nco_lo((uint32_t)nabs * p.freg + off, cb, sb);
     mix8_lo(xi, xq, cb, sb, p);
 }
 
@@ -152,6 +155,7 @@ struct UnpackArgs {
     long long      ns;
     unsigned long long n0;
     uint32_t       freg;
+    uint32_t       phase_off;
     float          lo_c[8];
     float          lo_s[8];
 };
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void k_unpack24(UnpackArgs p)
                 xq[e] = (float)Q[e] * kUnpackScale;
             }
             if (MIX)
-                mix8(xi, xq, p.n0 + (unsigned long long)s0, p);
+                mix8(xi, xq, p.n0 + (unsigned long long)s0, p, p.phase_off);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 o[2 * e]     = __float_as_uint(xi[e]);
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256) void k_unpack24(UnpackArgs p)
 }
 
 hipError_t launch_unpack24(const void *d_in, long long ns, void *d_out, bool to_i32, bool mix,
-                           unsigned long long n0, uint32_t freg, const float *lo_c,
+                           unsigned long long n0, uint32_t freg, uint32_t phase_off, const float *lo_c,
                            const float *lo_s, hipStream_t s)
 {
     if (ns <= 0)
@@ -265,6 +269,7 @@ hipError_t launch_unpack24(const void *d_in, long long ns, void *d_out, bool to_
     a.ns = ns;
     a.n0 = n0;
     a.freg = freg;
+    a.phase_off = phase_off;
     for (int e = 0; e < 8; ++e) {
         a.lo_c[e] = lo_c ? lo_c[e] : 1.0f;
         a.lo_s[e] = lo_s ? lo_s[e] : 0.0f;
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
         group_to_float<IN_F32C, false, 4>(h2raw, xi, xq, 0ull, p);
         if (MIX) {      /* stored values are final; inside tile 0 they must become final by * phi_0 */
             float c0, s0;
-            nco_lo((uint32_t)p.n0 * p.freg, c0, s0);
+            nco_lo((uint32_t)p.n0 * p.freg + p.phase_off, c0, s0);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 cmul(xi[e], xq[e], c0, -s0);
@@ -785,7 +790,7 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
         c = 1.0f;
         sn = 0.0f;
         if (MIX)
-            nco_lo((uint32_t)(p.n0 + (unsigned long long)((long long)tile * G::TI)) * p.freg, c, sn);
+            nco_lo((uint32_t)(p.n0 + (unsigned long long)((long long)tile * G::TI)) * p.freg + p.phase_off, c, sn);
     };
 
     int  t = (FUSE2 && c_lo > 0) ? c_lo - 1 : c_lo;   /* tile in work (a fused chunk starts one tile early) */
@@ -819,8 +824,24 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
         }
         if (first && tid < NTB) {          /* after the tile's own groups: rawH was requested last */
             float xi[8], xq[8];
-            /* tile-relative index 8*tid - 8*NTB < 0: the 32-bit phase wraps correctly */
-            group_to_float<INFMT, MIX, NW>(rawH, xi, xq, (unsigned long long)(long long)(8 * tid - 8 * NTB), p);
+            group_to_float<INFMT, false, NW>(rawH, xi, xq, 0ull, p);
+            if (MIX) {
+                /* tile-relative index i = 8*tid - 8*NTB < 0 (the 32-bit phase wraps correctly).  The
+                 * samples in front of tile 0 belong to the previous batch: in the first batch after a
+                 * retune they were mixed with the OLD tuning word -- the switch is sample-accurate at
+                 * the batch boundary and phase-continuous there, like the FPGA's phase accumulator --
+                 * so relative to this tile's phasor they carry exp(-j*2*pi*i*freg_old/2^32).  The old
+                 * word and its step phasors come with the arguments (== the current ones otherwise). */
+                const bool old = (t == 0);                       /* uniform */
+                float cb, sb;
+                nco_lo((uint32_t)(8 * tid - 8 * NTB) * (old ? p.freg_hist : p.freg), cb, sb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sc = old ? p.lo_c_hist[e] : p.lo_c[e];
+                    const float ss = old ? p.lo_s_hist[e] : p.lo_s[e];
+                    cmul(xi[e], xq[e], cb * sc - sb * ss, cb * ss + sb * sc);
+                }
+            }
             group_to_lds<R>(sI, sQ, tid, xi, xq);
         }
         /* ---- S (deferred): the PREVIOUS tile's stores go out here, behind this
@@ -1068,6 +1089,17 @@ static Fir8Sched fir8_schedule(int ntiles, int R, bool fused)
     const int pct = dyn_pct >= 0 ? dyn_pct : (fused ? 0 : 20);
     sc.S = (int)((long long)ntiles * (100 - pct) / 100 / sc.nblocks);
     return sc;
+}
+
+void fir8_schedule_query(long long n_in, int R, bool fused, int *ntiles, int *nblocks, int *S, int *K)
+{
+    const long long TI = 1024LL * R;
+    const int nt = (int)((n_in + TI - 1) / TI);
+    const Fir8Sched sc = fir8_schedule(nt, R, fused);
+    *ntiles = nt;
+    *nblocks = sc.nblocks;
+    *S = sc.S;
+    *K = sc.K;
 }
 
 template <int NTB, int R>
@@ -1568,6 +1600,40 @@ hipError_t launch_hist_update(void *dst, const void *hist, int H, const void *ba
     hipLaunchKernelGGL(k_hist_update, dim3(1), dim3(256), 0, s, static_cast<uint32_t *>(dst),
                        static_cast<const uint32_t *>(hist), Hw, static_cast<const uint32_t *>(batch),
                        (long long)elem_bytes * n / 4);
+    return hipGetLastError();
+}
+
+/* ======================================================================== */
+/* k_stream_copy : the measured copy ceiling (bench.py roofline.copy_ceiling) */
+/* ======================================================================== */
+/* 16 bytes per lane, four loads in flight per thread, nontemporal stores: the plain
+ * streaming copy the HBM figures of MI355X_MICROARCH.md are quoted for.            */
+__global__ __launch_bounds__(256) void k_stream_copy(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst,
+                                                      long long n16)
+{
+    const long long stride = (long long)gridDim.x * 1024;
+    for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < n16; i += stride) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = (i + 256 * u < n16) ? src[i + 256 * u] : u32x4{ 0u, 0u, 0u, 0u };
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + 256 * u < n16)
+                __builtin_nontemporal_store(v[u], dst + i + 256 * u);
+    }
+}
+
+hipError_t launch_stream_copy(const void *src, void *dst, size_t nbytes, hipStream_t s)
+{
+    const long long n16 = (long long)(nbytes / 16);
+    if (n16 <= 0)
+        return hipSuccess;
+    long long blocks = (n16 + 1023) / 1024;
+    if (blocks > 4096)
+        blocks = 4096;
+    hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const u32x4 *>(src),
+                       static_cast<u32x4 *>(dst), n16);
     return hipGetLastError();
 }
 

@@ -35,6 +35,16 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
+/* the same for the library's other translation units (ddc_multi.cpp); not exported */
+extern "C" __attribute__((visibility("hidden"))) int pddc_set_error_(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e__ = (expr);                                                                   \
@@ -75,7 +85,16 @@ struct pddc_pipeline {
     int nstages = 0;
     Stage st[PDDC_MAX_STAGES];
     uint32_t freg = 0;
+    /* phase(n) = n*freg + phase_off (mod 2^32).  A retune at sample n changes freg and moves
+     * phase_off by n*(freg_old - freg_new), so the phase is continuous there -- the FPGA's NCO
+     * is a phase accumulator, a new tuning word changes its increment, never its value.
+     * freg_applied: the word the last processed batch was mixed with (the fused kernel re-mixes
+     * its raw packed history and needs it for the first batch after a retune).               */
+    uint32_t phase_off = 0;
+    uint32_t freg_applied = 0;
+    bool fresh = true;            /* nothing processed since create / reset / seek */
     float lo_c[8], lo_s[8];
+    float lo_c_applied[8], lo_s_applied[8];   /* step phasors of freg_applied */
     unsigned long long n0 = 0;    /* absolute sample counter (stage 0 input)    */
     int R = 4;                    /* outputs per lane of the fused kernel (4: 16 waves/CU) */
     /* staging for push_host / push_host_async: two slots, so that the H2D copy of batch k+1,
@@ -106,14 +125,20 @@ static float round_to_half(float v)
     return (float)h;
 }
 
-static void compute_lo_steps(pddc_pipeline *p)
+static void lo_steps(uint32_t freg, float *c, float *s)
 {
     const double k = 6.283185307179586476925286766559 / 4294967296.0;
     for (int e = 0; e < 8; ++e) {
-        const uint32_t ph = (uint32_t)((uint64_t)e * p->freg);
-        p->lo_c[e] = (float)std::cos(k * (double)ph);
-        p->lo_s[e] = (float)(-std::sin(k * (double)ph));
+        const uint32_t ph = (uint32_t)((uint64_t)e * freg);
+        c[e] = (float)std::cos(k * (double)ph);
+        s[e] = (float)(-std::sin(k * (double)ph));
     }
+}
+
+static void compute_lo_steps(pddc_pipeline *p)
+{
+    lo_steps(p->freg, p->lo_c, p->lo_s);
+    lo_steps(p->freg_applied, p->lo_c_applied, p->lo_s_applied);
 }
 
 static bool stage_fused_capable(const Stage &s)
@@ -274,7 +299,7 @@ int pddc_unpack24_f32(const void *d_packed, size_t nsamples, void *d_out, void *
         return rc;
     if ((rc = check_unpack_args(d_packed, d_out, nsamples)))
         return rc;
-    HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, d_out, false, false, 0, 0, nullptr, nullptr,
+    HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, d_out, false, false, 0, 0, 0, nullptr, nullptr,
                             (hipStream_t)stream));
     return PDDC_OK;
 }
@@ -286,7 +311,7 @@ int pddc_unpack24_i32(const void *d_packed, size_t nsamples, void *d_out, void *
         return rc;
     if ((rc = check_unpack_args(d_packed, d_out, nsamples)))
         return rc;
-    HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, d_out, true, false, 0, 0, nullptr, nullptr,
+    HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, d_out, true, false, 0, 0, 0, nullptr, nullptr,
                             (hipStream_t)stream));
     return PDDC_OK;
 }
@@ -460,6 +485,10 @@ int pddc_pipeline_reset(pddc_pipeline *p)
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipDeviceSynchronize());
     p->n0 = 0;
+    p->phase_off = 0;
+    p->freg_applied = p->freg;
+    compute_lo_steps(p);
+    p->fresh = true;
     HIP_TRY(hipMemset(p->d_sched, 0, 64));
     for (int i = 0; i < p->nstages; ++i) {
         Stage &s = p->st[i];
@@ -475,10 +504,21 @@ int pddc_pipeline_set_freg(pddc_pipeline *p, uint32_t freg)
 {
     if (!p)
         return fail(PDDC_EINVAL, "null pipeline");
-    p->freg = freg;
-    compute_lo_steps(p);
+    if (freg != p->freg) {
+        if (p->fresh) {
+            /* before the first batch: the stream starts with this word, offset 0 */
+            p->freg_applied = freg;
+        } else {
+            /* takes effect at sample n0 (the next one to be processed), phase-continuous there */
+            p->phase_off += (uint32_t)p->n0 * (p->freg - freg);
+        }
+        p->freg = freg;
+        compute_lo_steps(p);
+    }
     return PDDC_OK;
 }
+
+uint32_t pddc_pipeline_get_phase_offset(const pddc_pipeline *p) { return p ? p->phase_off : 0; }
 
 int pddc_pipeline_set_center_freq(pddc_pipeline *p, double hz)
 {
@@ -652,10 +692,14 @@ static void fill_fir8_args(const pddc_pipeline *p, Fir8Args &a)
 {
     a.n0 = p->n0;
     a.freg = p->freg;
+    a.phase_off = p->phase_off;
+    a.freg_hist = p->freg_applied;
     a.sched = p->d_sched;
     for (int e = 0; e < 8; ++e) {
         a.lo_c[e] = p->lo_c[e];
         a.lo_s[e] = p->lo_s[e];
+        a.lo_c_hist[e] = p->lo_c_applied[e];
+        a.lo_s_hist[e] = p->lo_s_applied[e];
     }
 }
 
@@ -764,7 +808,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                 if ((rc = ensure_buf(st, nsamples + 8)))
                     return rc;
                 HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, st.d_buf, false, mix, p->n0, p->freg,
-                                        p->lo_c, p->lo_s, s));
+                                        p->phase_off, p->lo_c, p->lo_s, s));
             }
             x = st.d_buf;
             const bool fast = i > 0 && st.ntb != 0 && !(p->flags & PDDC_F_NO_FAST) &&
@@ -804,6 +848,11 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
     if (p->flags & PDDC_F_OUT_PACKED24)
         HIP_TRY(launch_pack24(p->d_fout, (long long)n_final, d_out, s));
     p->n0 += nsamples;
+    if (p->freg_applied != p->freg) {
+        p->freg_applied = p->freg;
+        compute_lo_steps(p);
+    }
+    p->fresh = false;
     if (n_out_ret)
         *n_out_ret = n_final;
     return PDDC_OK;
@@ -941,6 +990,45 @@ int pddc_pipeline_push_host(pddc_pipeline *p, const void *h_packed, size_t nsamp
         return rc;
     if (ticket >= 0)
         return pddc_pipeline_wait_ticket(p, ticket);
+    return PDDC_OK;
+}
+
+int pddc_pipeline_schedule(const pddc_pipeline *p, size_t nsamples, int out[5])
+{
+    if (!p || !out)
+        return fail(PDDC_EINVAL, "null argument");
+    if (!stage0_fused(p))
+        return fail(PDDC_ESTATE, "stage 0 does not run the fused kernel");
+    const bool fuse2 = stages01_fusable(p, nsamples);
+    out[0] = fir8_tile_inputs(p->R);
+    fir8_schedule_query((long long)nsamples, p->R, fuse2, &out[1], &out[2], &out[3], &out[4]);
+    return PDDC_OK;
+}
+
+int pddc_measure_copy(void *d_dst, const void *d_src, size_t nbytes, int iters, void *stream_v, float *avg_ms)
+{
+    if (!d_dst || !d_src || !avg_ms || iters < 1 || nbytes == 0)
+        return fail(PDDC_EINVAL, "bad argument");
+    int rc = require_device();
+    if (rc)
+        return rc;
+    hipStream_t s = (hipStream_t)stream_v;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    if (((uintptr_t)d_dst | (uintptr_t)d_src | nbytes) & 15)
+        return fail(PDDC_EINVAL, "copy measurement wants 16-byte aligned pointers and size");
+    HIP_TRY(launch_stream_copy(d_src, d_dst, nbytes, s));      /* warm */
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        HIP_TRY(launch_stream_copy(d_src, d_dst, nbytes, s));
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *avg_ms = ms / (float)iters;
     return PDDC_OK;
 }
 

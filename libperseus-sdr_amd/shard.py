@@ -18,6 +18,9 @@ import torch
 import torch.distributed as dist
 
 
+MAX_STAGES = 4                  # PDDC_MAX_STAGES (include/perseus_ddc.h)
+
+
 def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), \
         int(os.environ.get("LOCAL_RANK", "0"))
@@ -75,28 +78,34 @@ def process_time_chunk(pipe, d_packed_with_halo, start: int, halo: int, total_de
 
 
 def broadcast_config(cfg: dict | None, device, src: int = 0) -> dict:
-    """Rank `src` supplies {"freg": int, "stages": [(D, taps ndarray), ...]}; every
-    rank returns the same dict.  A few KB: one small tensor broadcast per item."""
+    """Rank `src` supplies {"freg": int, "stages": [(D, taps[, L]), ...]}; every rank
+    returns the same dict with 3-tuples (D, taps, L), L = 1 for a plain decimator.  A few
+    KB: one header + one tensor per stage.  This is the torch.distributed form (any backend;
+    the CPU tests use gloo); on GPUs the C library broadcasts the plan itself over RCCL
+    (RcclGroup.make_pipeline -> pddc_comm_bcast_pipeline)."""
     if not is_dist():
         return cfg
     rank = dist.get_rank()
-    hdr = torch.zeros(2 + 2 * 8, dtype=torch.int64, device=device)
+    hdr = torch.zeros(2 + 3 * MAX_STAGES, dtype=torch.int64, device=device)
     if rank == src:
+        if len(cfg["stages"]) > MAX_STAGES:
+            raise ValueError(f"at most {MAX_STAGES} stages (PDDC_MAX_STAGES)")
         hdr[0] = int(cfg["freg"])
         hdr[1] = len(cfg["stages"])
-        for i, (d, h) in enumerate(cfg["stages"]):
-            hdr[2 + 2 * i] = int(d)
-            hdr[3 + 2 * i] = int(np.asarray(h).size)
+        for i, st in enumerate(cfg["stages"]):
+            hdr[2 + 3 * i] = int(st[0])
+            hdr[3 + 3 * i] = int(np.asarray(st[1]).size)
+            hdr[4 + 3 * i] = int(st[2]) if len(st) > 2 and st[2] and int(st[2]) > 1 else 1
     dist.broadcast(hdr, src)
     n = int(hdr[1])
     stages = []
     for i in range(n):
-        d, nt = int(hdr[2 + 2 * i]), int(hdr[3 + 2 * i])
+        d, nt, li = int(hdr[2 + 3 * i]), int(hdr[3 + 3 * i]), int(hdr[4 + 3 * i])
         t = torch.zeros(nt, dtype=torch.float32, device=device)
         if rank == src:
             t.copy_(torch.from_numpy(np.ascontiguousarray(cfg["stages"][i][1], dtype=np.float32)))
         dist.broadcast(t, src)
-        stages.append((d, t.cpu().numpy()))
+        stages.append((d, t.cpu().numpy(), li))
     return {"freg": int(hdr[0]), "stages": stages}
 
 
@@ -136,3 +145,107 @@ def gather_to_root(mine: torch.Tensor, bufs=None, dst: int = 0):
         return bufs
     dist.gather(mine, None, dst=dst)
     return None
+
+
+# --------------------------------------------------------------------------
+# The group of ranks bench.py runs in.  Control plane (rendezvous, the 128-byte
+# RCCL id, small Python objects): a gloo process group over the launcher's store.
+# GPU collectives: the C library's own RCCL calls (pddc_comm_*, ddc_multi.cpp) --
+# torch's NCCL backend is not initialised at all.
+# --------------------------------------------------------------------------
+class Group:
+    """A single rank (no launcher): every collective is the identity."""
+    rank, world, local = 0, 1, 0
+    comm = None
+
+    def make_pipeline(self, pkg, stages, freg, mix, taps_fp16=False):
+        p = pkg.Pipeline(stages, device=self.local, mix=mix, taps_fp16=taps_fp16)
+        if mix:
+            p.set_freg(freg)
+        return p
+
+    def max_seconds(self, t: float) -> float:
+        return t
+
+    def barrier(self):
+        pass
+
+    def all_gather_object(self, obj):
+        return [obj]
+
+    def close(self):
+        pass
+
+
+class RcclGroup(Group):
+    """One process per GPU.  `force_single` builds a 1-rank communicator so that a 1-GPU
+    box still runs every RCCL call of the N>1 path."""
+
+    def __init__(self, pkg, rank, world, local, pg_backend="gloo"):
+        self.rank, self.world, self.local = rank, world, local
+        self.pkg = pkg
+        self._own_pg = False
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group(pg_backend, rank=rank, world_size=world)
+            self._own_pg = True
+        uid = [pkg.Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        self.comm = pkg.Comm.init_rank(world, rank, uid[0], local)
+
+    def make_pipeline(self, pkg, stages, freg, mix, taps_fp16=False):
+        """Rank 0's plan reaches every rank through ncclBroadcast inside the C library."""
+        flags = (pkg.PDDC_F_MIX if mix else 0) | (pkg.PDDC_F_TAPS_FP16 if taps_fp16 else 0)
+        return self.comm.bcast_pipeline(stages if self.rank == 0 else None, freg if self.rank == 0 else 0,
+                                        flags if self.rank == 0 else 0, root=0)
+
+    def max_seconds(self, t: float) -> float:
+        return self.comm.max_f64(t)
+
+    def barrier(self):
+        self.comm.barrier()
+
+    def all_gather_object(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+        if self._own_pg:
+            dist.barrier()
+            dist.destroy_process_group()
+            self._own_pg = False
+
+
+class TorchGroup(Group):
+    """torch.distributed on any backend.  Used by the CPU plumbing tests (gloo), where no
+    GPU -- hence no RCCL -- exists; never on a GPU box."""
+
+    def __init__(self, rank, world, local, backend="gloo"):
+        self.rank, self.world, self.local = rank, world, local
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        self.device = torch.device("cpu")
+
+    def max_seconds(self, t: float) -> float:
+        return max_over_ranks(t, self.device)
+
+    def barrier(self):
+        dist.barrier()
+
+    def all_gather_object(self, obj):
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        dist.barrier()
+        dist.destroy_process_group()

@@ -61,6 +61,9 @@ def lib() -> C.CDLL:
         L.orc_rate_index.restype = C.c_int
         L.orc_nco_mix_f64.argtypes = [f32p, C.c_size_t, C.c_uint64, C.c_uint32, f64p]
         L.orc_nco_mix_f64.restype = None
+        L.orc_nco_mix_retuned_f64.argtypes = [f32p, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64),
+                                              C.POINTER(C.c_uint32), C.c_int, f64p]
+        L.orc_nco_mix_retuned_f64.restype = None
         L.orc_fir_decim_f64.argtypes = [f64p, C.c_size_t, f32p, C.c_int, C.c_int, f64p]
         L.orc_fir_decim_f64.restype = C.c_size_t
         L.orc_ddc_chain.argtypes = [u8p, C.c_size_t, C.c_uint32, C.c_int, C.c_int,
@@ -178,6 +181,43 @@ def nco_mix(x_iq: np.ndarray, freg: int, n0: int = 0) -> np.ndarray:
     out = np.empty(x.size, dtype=np.float64)
     lib().orc_nco_mix_f64(_p(x, C.c_float), x.size // 2, n0, freg, _p(out, C.c_double))
     return out
+
+
+def nco_mix_retuned(x_iq: np.ndarray, segments, n0: int = 0) -> np.ndarray:
+    """NCO as a phase accumulator retuned while running: segments = [(first_sample, freg), ...],
+    first_sample ascending and 0 for the first; phase-continuous at every switch."""
+    x = np.ascontiguousarray(x_iq, dtype=np.float32)
+    starts = (C.c_uint64 * len(segments))(*[int(a) for a, _ in segments])
+    words = (C.c_uint32 * len(segments))(*[int(f) & 0xFFFFFFFF for _, f in segments])
+    out = np.empty(x.size, dtype=np.float64)
+    lib().orc_nco_mix_retuned_f64(_p(x, C.c_float), x.size // 2, n0, starts, words, len(segments),
+                                  _p(out, C.c_double))
+    return out
+
+
+def nco_mix_retuned_numpy(x_iq: np.ndarray, segments, n0: int = 0) -> np.ndarray:
+    """Second, independent statement of the retuned accumulator (cumulative sum of the word)."""
+    x = np.asarray(x_iq, dtype=np.float64).reshape(-1, 2)
+    n = np.arange(n0, n0 + x.shape[0], dtype=np.uint64)
+    starts = np.array([a for a, _ in segments], dtype=np.uint64)
+    words = np.array([f for _, f in segments], dtype=np.uint64)
+    acc0 = np.zeros(len(segments), dtype=np.uint64)
+    for i in range(1, len(segments)):
+        acc0[i] = (acc0[i - 1] + (starts[i] - starts[i - 1]) * words[i - 1]) & np.uint64(0xFFFFFFFF)
+    sg = np.searchsorted(starts, n, side="right") - 1
+    ph = (acc0[sg] + (n - starts[sg]) * words[sg]) & np.uint64(0xFFFFFFFF)
+    a = ph.astype(np.float64) * (2.0 * np.pi / 4294967296.0)
+    z = (x[:, 0] + 1j * x[:, 1]) * np.exp(-1j * a)
+    return np.stack([z.real, z.imag], axis=1).reshape(-1)
+
+
+def ddc_chain_retuned(packed: np.ndarray, stages, segments) -> np.ndarray:
+    """unpack -> retuned NCO -> FIR chain (plain decimators or rational stages), double, result float32."""
+    x = nco_mix_retuned(unpack24_f32(packed), segments, 0)
+    for st in stages:
+        L = int(st[2]) if len(st) > 2 and st[2] and int(st[2]) > 1 else 1
+        x = resample(x, st[1], L, int(st[0])) if L > 1 else fir_decim(x, st[1], int(st[0]))
+    return np.asarray(x, dtype=np.float32)
 
 
 def fir_decim(x_iq: np.ndarray, taps: np.ndarray, D: int) -> np.ndarray:

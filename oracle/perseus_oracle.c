@@ -161,6 +161,39 @@ void orc_nco_mix_f64(const float *x_iq, size_t ns, uint64_t n0, uint32_t freg,
     }
 }
 
+/* The same NCO as a phase ACCUMULATOR that is retuned while it runs (authored; models the FPGA's
+ * NCO, whose tuning word perseus_set_ddc_center_freq rewrites while streaming, perseus-sdr.c:584,
+ * examples/fifo.c:43-49): sample n is mixed with exp(-j*2*pi*acc(n)/2^32), acc(0) = 0,
+ * acc(n+1) = acc(n) + freg(n) mod 2^32, where freg(n) = word[i] for seg_start[i] <= n < seg_start[i+1].
+ * A new word changes the increment, never the accumulated phase (phase-continuous retune).
+ * seg_start[0] must be 0; n0 = absolute index of x_iq[0].                                          */
+void orc_nco_mix_retuned_f64(const float *x_iq, size_t ns, uint64_t n0, const uint64_t *seg_start,
+                             const uint32_t *word, int nseg, double *out_iq)
+{
+    const double two_pi_over_2p32 = 6.283185307179586476925286766559 / 4294967296.0;
+    /* acc at the start of each segment */
+    uint32_t acc0[64];
+    if (nseg < 1 || nseg > 64 || seg_start[0] != 0)
+        return;
+    acc0[0] = 0;
+    for (int i = 1; i < nseg; i++)
+        acc0[i] = acc0[i - 1] + (uint32_t)((seg_start[i] - seg_start[i - 1]) * (uint64_t)word[i - 1]);
+    int sg = 0;
+    for (size_t n = 0; n < ns; n++) {
+        const uint64_t na = n0 + n;
+        while (sg + 1 < nseg && na >= seg_start[sg + 1])
+            sg++;
+        while (sg > 0 && na < seg_start[sg])
+            sg--;
+        const uint32_t ph = acc0[sg] + (uint32_t)((na - seg_start[sg]) * (uint64_t)word[sg]);
+        const double a = two_pi_over_2p32 * (double)ph;
+        const double c = cos(a), s = -sin(a);
+        const double xr = x_iq[2 * n], xi = x_iq[2 * n + 1];
+        out_iq[2 * n + 0] = xr * c - xi * s;
+        out_iq[2 * n + 1] = xr * s + xi * c;
+    }
+}
+
 size_t orc_fir_decim_f64(const double *x, size_t ns, const float *taps,
                          int ntaps, int D, double *y)
 {

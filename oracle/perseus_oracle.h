@@ -68,6 +68,12 @@ int orc_rate_index(int sps, const int *table, int n);
 void orc_nco_mix_f64(const float *x_iq, size_t nsamples, uint64_t n0,
                      uint32_t freg, double *out_iq);
 
+/* The NCO as a phase accumulator retuned while it runs (authored): acc(0)=0, acc(n+1)=acc(n)+
+ * freg(n), freg(n) = word[i] for seg_start[i] <= n < seg_start[i+1]; seg_start[0] == 0, nseg <= 64.
+ * Phase-continuous at every retune, like a hardware NCO.  n0 = absolute index of x_iq[0].     */
+void orc_nco_mix_retuned_f64(const float *x_iq, size_t nsamples, uint64_t n0, const uint64_t *seg_start,
+                             const uint32_t *word, int nseg, double *out_iq);
+
 /* y[m] = sum_{k<ntaps} h[k]*x[m*D-k], x[i<0]=0, m = 0..ceil(n/D)-1.
  * returns number of outputs written. */
 size_t orc_fir_decim_f64(const double *x_iq, size_t nsamples,

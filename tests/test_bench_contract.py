@@ -54,8 +54,14 @@ def test_loader_fails_loudly_without_the_hip_library(pkg, monkeypatch):
     assert "no CPU fallback" in str(e.value)
 
 
+def _latest_committed_bench_line():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*final_bench*.json")))
+    return json.load(open(files[-1]))
+
+
 def test_committed_bench_line_schema():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01", "v8_final_bench.json")))
+    d = _latest_committed_bench_line()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -63,8 +69,68 @@ def test_committed_bench_line_schema():
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert rf["traffic"] and abs(rf["traffic"] / (7 * 2 ** 28) - 1) < 0.01      # no wasted re-reads
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+
+
+def test_traffic_is_reported_only_with_matching_provenance(tmp_path, monkeypatch):
+    """roofline.traffic comes from offline PMC passes; bench.py must refuse to print it for a
+    kernel source or launch shape other than the one it was measured on."""
+    b = _bench()
+    sig = b.kernel_source_sig()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    json.dump({"d8_127": 1.88e9, "provenance": {"kernel_source_sha16": sig, "log2n": 28, "commit": "abc"}},
+              open(prof / "pmc_traffic.json", "w"))
+    v, src = b.traffic_from_profile("d8_127", sig, 28, False)
+    assert v == 1.88e9 and "abc" in src
+    assert b.traffic_from_profile("d8_127", "0" * 16, 28, False)[0] is None          # other kernel source
+    assert "stale" in b.traffic_from_profile("d8_127", "0" * 16, 28, False)[1]
+    assert b.traffic_from_profile("d8_127", sig, 24, False)[0] is None               # other launch shape
+    assert b.traffic_from_profile("d8_127", sig, 28, True)[0] is None
+    assert b.traffic_from_profile("c320", sig, 28, False)[0] is None                 # not measured
+    json.dump({"d8_127": 1.88e9}, open(prof / "pmc_traffic.json", "w"))               # no provenance at all
+    assert b.traffic_from_profile("d8_127", sig, 28, False)[0] is None
+
+
+def test_plain_command_launcher_two_ranks_gloo():
+    """`python bench.py --gpus 2` as a plain command: the parent starts the ranks itself (it never
+    imports torch), relays ONE JSON line.  On CPU the children run the gloo plumbing mode."""
+    env = dict(os.environ, PDDC_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "c320"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["devices"] == ["cpu:0", "cpu:1"]
+    assert d["gather"]["this_workload"]["root_blocks_match_each_ranks_stream"] is True
+    assert "dry_run" in d and d["value"] == 0.0                   # nothing is claimed as measured
+
+
+def test_launcher_parent_makes_no_gpu_call():
+    """The launching parent must not import torch (never exec/spawn from a process that touched the GPU)."""
+    code = ("import sys, bench\n"
+            "sys.argv = ['bench.py', '--gpus', '2']\n"
+            "bench.launch_ranks = lambda n, argv: (print('torch' in sys.modules), 0)[1]\n"
+            "bench.main()\n")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert p.stdout.strip() == "False", (p.stdout, p.stderr[-500:])
+
+
+def test_launcher_reports_failure_when_ranks_fail():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("PDDC_BENCH_BACKEND", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and "no CPU path" in p.stderr
 
 
 @pytest.mark.gpu
@@ -86,3 +152,10 @@ def test_bench_line_end_to_end_on_the_gpu():
     assert abs(rf["achieved"] - 7.0 * (1 << 24) / (rf["kernel_ms"] * 1e-3) / 1e9) / rf["achieved"] < 0.01
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "MS/s"
+    # self-contained roofline: measured copy ceiling, labelled traffic, parity in the line
+    assert rf["copy_ceiling_GBps"] and 2000 < rf["copy_ceiling_GBps"] < 8000
+    assert abs(rf["frac_of_copy_ceiling"] - rf["achieved"] / rf["copy_ceiling_GBps"]) < 1e-3
+    assert rf["traffic"] is None and "launch shape" in rf["traffic_source"]        # measured at 2^28 only
+    v = d["verified"]
+    assert v["ok"] is True and v["windows"] >= 20 and v["max_rel_err"] <= 1e-6 and "max|y-ref|" in v["metric"]
+    assert d["config"]["taps_storage"] == "fp32"

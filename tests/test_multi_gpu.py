@@ -1,0 +1,136 @@
+"""The multi-GPU section of the C ABI (include/perseus_ddc.h, ddc_multi.cpp): RCCL called by
+the C library itself.  CPU tests: plan (de)serialisation, loud failure without a device.
+GPU tests (one GPU on the box): 1-rank communicators exercise every RCCL call of the N>1
+path -- unique id, ncclCommInitRank / ncclCommInitAll, ncclBroadcast of the plan,
+ncclAllReduce, the gather's send/recv group and its side-stream form."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_taps
+
+
+def test_plan_pack_unpack_roundtrip(pkg):
+    stages = [(8, load_taps("c320_s1_d8_32")), (10, load_taps("c320_s2_d8_64")),
+              (25, np.linspace(-1, 1, 48, dtype=np.float32), 12)]
+    raw = pkg.plan_pack(stages, freg=381178347, flags=pkg.PDDC_F_MIX | pkg.PDDC_F_OUT_PACKED24)
+    assert len(raw) == 4 * (4 + 3 * 3 + 32 + 64 + 48)
+    d = pkg.plan_unpack(raw)
+    assert d["freg"] == 381178347 and d["flags"] == 9
+    assert [(s[0], s[2]) for s in d["stages"]] == [(8, 1), (10, 1), (25, 12)]
+    for a, b in zip(stages, d["stages"]):
+        assert np.array_equal(np.asarray(a[1], np.float32), b[1])
+
+
+def test_plan_unpack_rejects_garbage(pkg):
+    with pytest.raises(pkg.PddcError):
+        pkg.plan_unpack(b"\x00" * 64)
+    raw = bytearray(pkg.plan_pack([(8, np.ones(16, np.float32))]))
+    with pytest.raises(pkg.PddcError):
+        pkg.plan_unpack(bytes(raw[:40]))                # truncated taps
+    raw[12] = 9                                         # nstages out of range
+    with pytest.raises(pkg.PddcError):
+        pkg.plan_unpack(bytes(raw))
+    with pytest.raises(pkg.PddcError):
+        pkg.plan_pack([])                               # no stages
+
+
+def test_comm_needs_a_device(pkg):
+    L = pkg.ddc_lib()
+    if L.pddc_device_count() > 0:
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    uid = C.create_string_buffer(128)
+    assert L.pddc_comm_init_rank(C.byref(h), 1, 0, uid, 0) == pkg.PDDC_ENODEV
+    assert b"no CPU fallback" in L.pddc_last_error()
+    hs = (C.c_void_p * 1)()
+    assert L.pddc_comm_init_all(hs, 1, None) == pkg.PDDC_ENODEV
+    assert L.pddc_comm_init_rank(C.byref(h), 2, 5, uid, 0) == pkg.PDDC_EINVAL     # rank out of range
+
+
+@pytest.mark.gpu
+def test_comm_single_rank_broadcast_pipeline_and_gather(pkg, O, dev):
+    import torch
+    uid = pkg.Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = pkg.Comm.init_rank(1, 0, uid, 0)
+    assert (comm.rank, comm.size, comm.device) == (0, 1, 0)
+    stages = [(8, load_taps("c320_s1_d8_32")), (8, load_taps("c320_s2_d8_64")), (5, load_taps("c320_s3_d5_161"))]
+    freg = 381178347
+    pipe = comm.bcast_pipeline(stages, freg=freg, flags=pkg.PDDC_F_MIX)        # plan went through ncclBroadcast
+    assert pipe.freg == freg and pipe.decim == 320
+    ns = 8192 * 40
+    packed = O.lcg_bytes(6 * ns, 12345)
+    d_in = torch.from_numpy(packed).to(dev)
+    y = pipe.process(d_in)
+    ref = O.ddc_chain(packed, stages, freg, True)
+    assert O.rel_err(y.cpu().numpy().reshape(-1), ref) <= 1e-6
+    direct = pkg.Pipeline(stages, mix=True)
+    direct.set_freg(freg)
+    assert torch.equal(direct.process(d_in), y)                                  # same plan, bit for bit
+    # gather on the compute stream, then the side-stream form
+    st = torch.cuda.current_stream(dev).cuda_stream
+    recv = torch.zeros_like(y)
+    comm.gather(y.data_ptr(), y.numel() * 4, recv.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    assert torch.equal(recv, y)
+    recv.zero_()
+    comm.gather_async(y.data_ptr(), y.numel() * 4, recv.data_ptr(), 0, st)
+    comm.gather_fence(st)
+    comm.gather_wait()
+    assert torch.equal(recv, y)
+    assert comm.max_f64(1.25) == 1.25
+    comm.barrier()
+    assert comm.bcast_bytes(b"taps+freg", 0) == b"taps+freg"
+    buf = torch.arange(1024, dtype=torch.int32, device=dev)
+    comm.bcast(buf.data_ptr(), 4096, 0, st)
+    torch.cuda.synchronize()
+    assert int(buf[1023]) == 1023
+    pipe.close()
+    direct.close()
+    comm.close()
+
+
+@pytest.mark.gpu
+def test_comm_init_all_grouped_calls(pkg, O, dev):
+    """One process, all its GPUs (here: the one visible): ncclCommInitAll + grouped per-communicator calls."""
+    import torch
+    L = pkg.ddc_lib()
+    comms = pkg.Comm.init_all([0])
+    assert len(comms) == 1 and comms[0].size == 1
+    with pytest.raises(pkg.PddcError):
+        pkg.Comm.init_all([0, 0])                       # one rank per GPU, said loudly
+    x = torch.from_numpy(O.lcg_bytes(4096, 7)).to(dev)
+    recv = torch.zeros_like(x)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    pkg.check(L.pddc_comm_group_start())
+    for c in comms:
+        c.gather(x.data_ptr(), x.numel(), recv.data_ptr(), 0, st)
+    pkg.check(L.pddc_comm_group_end())
+    torch.cuda.synchronize()
+    assert torch.equal(recv, x)
+    for c in comms:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_bench_gather_leg_on_one_rank():
+    """bench.py --gather: the N>1 code path (RcclGroup, plan broadcast, double-buffered gather on the side
+    stream) on a 1-rank communicator."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--log2n", "24",
+                        "--settle-ms", "20", "--no-cpu", "--gather"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PDDC_BENCH_GATHER_C320="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert d["ranks_seen"] == 1 and "RCCL called from the C library" in d["collectives"]
+    g = d["gather"]
+    assert "error" not in g, g
+    assert g["this_workload"]["root_block_matches_own_output"] is True
+    assert g["this_workload"]["out_bytes_per_rank_per_step"] == (1 << 24) // 8 * 8
+    assert g["c320"]["root_block_matches_own_output"] is True and g["c320"]["value"] > 0
+    assert d["verified"]["ok"] is True
