@@ -31,10 +31,13 @@ def _worker(rank, world, port, q):
     dev = torch.device("cpu")
     cfg = None
     if rank == 0:
-        cfg = {"freg": 381178347, "stages": [(8, load_taps("c320_s1_d8_32")), (5, load_taps("c320_s3_d5_161"))]}
+        # 2-tuples and a rational (D, taps, L) stage, as the ten-rate plans have them
+        cfg = {"freg": 381178347, "stages": [(8, load_taps("c320_s1_d8_32")), (5, load_taps("c320_s3_d5_161")),
+                                              (25, np.linspace(-1, 1, 48, dtype=np.float32), 12)]}
     cfg = shard.broadcast_config(cfg, dev)
-    ok_cfg = cfg["freg"] == 381178347 and [d for d, _ in cfg["stages"]] == [8, 5] and \
-        np.array_equal(cfg["stages"][1][1], load_taps("c320_s3_d5_161"))
+    ok_cfg = cfg["freg"] == 381178347 and [(st[0], st[2]) for st in cfg["stages"]] == [(8, 1), (5, 1), (25, 12)] and \
+        np.array_equal(cfg["stages"][1][1], load_taps("c320_s3_d5_161")) and \
+        np.array_equal(cfg["stages"][2][1], np.linspace(-1, 1, 48, dtype=np.float32))
     # each rank owns an independent stream; the checker (oracle) stands in for the GPU path here
     ns = 8 * 512
     packed = O.lcg_bytes(6 * ns, shard.stream_seed(rank))
