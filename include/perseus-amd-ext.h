@@ -16,6 +16,10 @@
  *   PERSEUS_AMD_BATCH     ddc mode: ADC-rate samples per GPU batch (default 2^22)
  *   PERSEUS_AMD_DROP      fault injection: every k-th transfer completes short
  *                         and is dropped like perseus-in.c:209-216 (default 0 = never)
+ *   PERSEUS_AMD_FAULTS    fault script, e.g. "timeout@9,oos@12,error@20,short%7,eof@500"
+ *                         (see perseus_amd_config.fault_script)
+ *   PERSEUS_AMD_EP_PACKET endpoint max packet size the receiver reports: 512 (default) | 510
+ *   PERSEUS_AMD_CPU_SOURCE  DDC modes: 1 = generate the LCG stream on the host (default: on the GPU)
  *   PERSEUS_AMD_MAX_BUFFERS  the source ends after this many transfers (default 0 = unbounded)
  */
 #ifndef PERSEUS_AMD_EXT_H
@@ -58,9 +62,32 @@ typedef struct {
     int         gpu_device;   /* DDC: HIP device index (-1: descriptor index % n) */
     uint32_t    batch_samples;/* DDC: ADC-rate samples per GPU batch (mult. of 8) */
     int         drop_every;   /* fault injection, 0 = off                         */
-    uint64_t    max_buffers;  /* stop the source after this many callbacks (0 = unbounded;
+    uint64_t    max_buffers;  /* stop the source after this many transfers (0 = unbounded;
                                  a FILE source also stops at end of file)          */
+    int         ep_packet_size;/* what the data endpoint reports as its max packet size: 512 (default)
+                                 or 510 -- buffer sizes must then be multiples of 6144 or of 510
+                                 bytes; anything else makes start fail like the reference
+                                 (perseus-sdr.c:664-680)                            */
+    int         cpu_source;   /* DDC modes, LCG source: 1 = generate on the host and copy in; 0 (default)
+                                 = generate on the GPU (same bytes, no host->device traffic) */
+    const char *fault_script; /* what the virtual USB side does wrong, reference semantics
+                                 (perseus-in.c:199-257): "kind@n" at transfer n, "kind%k" every k-th,
+                                 comma separated; kinds short, timeout, oos, error, stall, nodev,
+                                 overflow, eof.  NULL = no faults                    */
 } perseus_amd_config;
+
+typedef struct {
+    uint64_t delivered;       /* callbacks made                                    */
+    uint64_t dropped;         /* short or out-of-sequence transfers                */
+    uint64_t timeouts;        /* tolerated, resubmitted                            */
+    uint64_t dead_transfers;  /* killed by a fatal status; 8 = queue completed     */
+    uint64_t transfers;       /* completions seen by the dispatcher                */
+    uint64_t bytes_received;
+    uint64_t adc_samples;     /* DDC modes: ADC-rate samples handed to the GPU     */
+    uint64_t batches;
+    int      gpu_device;      /* -1: no GPU pipeline                               */
+    int      gpu_source;      /* 1: the synthetic stream is generated on the GPU   */
+} perseus_amd_stats;
 
 /* valid between perseus_open() and perseus_start_async_input() */
 int perseus_amd_get_config(perseus_descr *descr, perseus_amd_config *cfg);
@@ -75,6 +102,12 @@ uint64_t perseus_amd_buffers_delivered(perseus_descr *descr);
 uint64_t perseus_amd_buffers_dropped(perseus_descr *descr);
 /* 1 while the source still has data (a bounded source ends by itself) */
 int      perseus_amd_source_running(perseus_descr *descr);
+int      perseus_amd_get_stats(perseus_descr *descr, perseus_amd_stats *st);
+/* DDC modes: the tuning-word segments of the current (or last) stream: segment i starts at ADC
+ * sample first_sample[i] with NCO word word[i]; a retune made while streaming takes effect at a
+ * GPU batch boundary, sample-accurately and phase-continuously.  Returns the number of segments
+ * (fills at most `capacity`).                                                              */
+int      perseus_amd_get_retune_log(perseus_descr *descr, uint64_t *first_sample, uint32_t *word, int capacity);
 
 /* DDC mode: the decimation plan chosen for the selected rate.  Returns the
  * number of stages, fills decim[]/ntaps[]

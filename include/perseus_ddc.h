@@ -140,6 +140,9 @@ uint32_t pddc_pipeline_get_freg(const pddc_pipeline *p);
 int pddc_pipeline_total_decim(const pddc_pipeline *p);
 /* upper bound of outputs a process() of nsamples_in can produce               */
 size_t pddc_pipeline_max_output(const pddc_pipeline *p, size_t nsamples_in);
+/* exactly what the NEXT process()/push of nsamples_in will produce (depends on the
+ * decimation phases the stream is at)                                          */
+size_t pddc_pipeline_next_output(const pddc_pipeline *p, size_t nsamples_in);
 /* 1 if stage 0 runs the fused unpack+mix+polyphase kernel for this geometry   */
 int pddc_pipeline_uses_fused(const pddc_pipeline *p);
 /* 1 if a process() of nsamples would run stages 0 AND 1 as one kernel (both
@@ -171,6 +174,14 @@ int pddc_pipeline_push_host(pddc_pipeline *p, const void *h_packed, size_t nsamp
  * (pinned memory); pageable memory works but the runtime stages it.                      */
 int pddc_pipeline_push_host_async(pddc_pipeline *p, const void *h_packed, size_t nsamples,
                                   void *h_out_f32, size_t out_capacity, size_t *n_out, int *ticket);
+/* The same with the synthetic source of BASELINE.md section 3 generated ON the device (the
+ * batch is bytes [byte_offset, byte_offset + 6*nsamples) of the LCG stream of `seed`,
+ * bit-identical to the host loop): no host -> device traffic, so a C host driving several
+ * virtual receivers is not bound by a single-thread CPU generator.                         */
+int pddc_pipeline_push_synth_async(pddc_pipeline *p, uint32_t seed, uint64_t byte_offset, size_t nsamples,
+                                   void *h_out_f32, size_t out_capacity, size_t *n_out, int *ticket);
+/* 1 if the batch of `ticket` has completely arrived in its h_out, 0 if not yet (non-blocking) */
+int pddc_pipeline_ticket_done(pddc_pipeline *p, int ticket);
 int pddc_pipeline_wait_ticket(pddc_pipeline *p, int ticket);
 int pddc_pipeline_wait(pddc_pipeline *p);          /* everything pushed so far is complete */
 /* pinned host memory for the two calls above */

@@ -106,6 +106,13 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_process.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp]
     L.pddc_pipeline_push_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     L.pddc_pipeline_push_host_async.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(C.c_int)]
+    L.pddc_pipeline_push_synth_async.argtypes = [vp, C.c_uint32, C.c_uint64, sz, vp, sz, C.POINTER(sz),
+                                                 C.POINTER(C.c_int)]
+    L.pddc_pipeline_push_synth_async.restype = C.c_int
+    L.pddc_pipeline_ticket_done.argtypes = [vp, C.c_int]
+    L.pddc_pipeline_ticket_done.restype = C.c_int
+    L.pddc_pipeline_next_output.argtypes = [vp, sz]
+    L.pddc_pipeline_next_output.restype = sz
     L.pddc_pipeline_wait_ticket.argtypes = [vp, C.c_int]
     L.pddc_pipeline_wait.argtypes = [vp]
     L.pddc_host_alloc.argtypes = [C.POINTER(vp), sz]
@@ -268,6 +275,16 @@ class Pipeline:
         n, t = C.c_size_t(0), C.c_int(-1)
         check(ddc_lib().pddc_pipeline_push_host_async(self._h, h_in, nsamples, h_out, out_cap, C.byref(n), C.byref(t)))
         return n.value, t.value
+
+    def push_synth_async(self, seed: int, byte_offset: int, nsamples: int, h_out: int, out_cap: int):
+        """Device-generated LCG batch (no H2D): returns (n_out, ticket)."""
+        n, t = C.c_size_t(0), C.c_int(-1)
+        check(ddc_lib().pddc_pipeline_push_synth_async(self._h, seed & 0xFFFFFFFF, byte_offset, nsamples, h_out,
+                                                       out_cap, C.byref(n), C.byref(t)))
+        return n.value, t.value
+
+    def next_output(self, n: int) -> int:
+        return int(ddc_lib().pddc_pipeline_next_output(self._h, n))
 
     def wait_ticket(self, ticket: int):
         check(ddc_lib().pddc_pipeline_wait_ticket(self._h, ticket))
@@ -481,7 +498,15 @@ class EepromProdId(C.Structure):
 class AmdConfig(C.Structure):
     _fields_ = [("mode", C.c_int), ("source", C.c_int), ("lcg_seed", C.c_uint32),
                 ("file_path", C.c_char_p), ("pace", C.c_int), ("gpu_device", C.c_int),
-                ("batch_samples", C.c_uint32), ("drop_every", C.c_int), ("max_buffers", C.c_uint64)]
+                ("batch_samples", C.c_uint32), ("drop_every", C.c_int), ("max_buffers", C.c_uint64),
+                ("ep_packet_size", C.c_int), ("cpu_source", C.c_int), ("fault_script", C.c_char_p)]
+
+
+class AmdStats(C.Structure):
+    _fields_ = [("delivered", C.c_uint64), ("dropped", C.c_uint64), ("timeouts", C.c_uint64),
+                ("dead_transfers", C.c_uint64), ("transfers", C.c_uint64), ("bytes_received", C.c_uint64),
+                ("adc_samples", C.c_uint64), ("batches", C.c_uint64), ("gpu_device", C.c_int),
+                ("gpu_source", C.c_int)]
 
 
 _sdr = None
@@ -531,6 +556,8 @@ def sdr_lib() -> C.CDLL:
     L.perseus_amd_buffers_dropped.argtypes = [vp]
     L.perseus_amd_buffers_dropped.restype = C.c_uint64
     L.perseus_amd_source_running.argtypes = [vp]
+    L.perseus_amd_get_stats.argtypes = [vp, C.POINTER(AmdStats)]
+    L.perseus_amd_get_retune_log.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_int]
     L.perseus_amd_get_plan.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                        C.POINTER(C.POINTER(C.c_float))]
     L.perseus_amd_get_plan_interp.argtypes = [vp, C.POINTER(C.c_int)]

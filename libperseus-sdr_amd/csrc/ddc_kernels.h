@@ -77,6 +77,10 @@ hipError_t launch_fir_generic(const float *in, const float *hist, int H, long lo
                               int D, const float *taps, int ntaps, float *out, float *hist_out,
                               long long n_batch, hipStream_t s);
 
+/* false when even the smallest block shape of the generic kernel cannot stage its input span
+ * ((63*D + ntaps + 10) samples) in the 160 KiB of LDS: such a stage is refused at create time */
+bool fir_generic_supported(int D, int ntaps);
+
 /* dst = last H elements of [hist(H) | batch(n)], elem_bytes each (H*elem_bytes <= 16 KiB);
  * dst may alias hist */
 hipError_t launch_hist_update(void *dst, const void *hist, int H, const void *batch, long long n,

@@ -1350,34 +1350,21 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ 
         }
 }
 
-/* `taps` must be readable (zeros) over [-3*D - 8, ntaps + 3*D + 8): the pipeline uploads
- * its tap tables that way.  hist_out (or NULL) receives the last H samples of
- * [hist(H) | in(n_batch)]; it must not alias hist.                                  */
-hipError_t launch_fir_generic(const float *in, const float *hist, int H, long long first, long long n_out,
-                              int D, const float *taps, int ntaps, float *out, float *hist_out,
-                              long long n_batch, hipStream_t s)
-{
-    if (n_out <= 0)
-        return hipSuccess;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static int ncu_of[64] = { 0 };
-    if (ncu_of[dev & 63] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        ncu_of[dev & 63] = n;
-    }
-    const int ncu = ncu_of[dev & 63];
-    /* shape: P outputs per thread (fewer LDS reads per output; odd for odd D so that the lane
-     * stride needs no pad), NT threads per block, picked with a small cost model: a round of
-     * resident blocks costs the staging round trips (~2 us per 8 loads per thread) plus the
-     * tap loop of the waves sharing a SIMD; a second, nearly empty round of blocks doubles a
-     * kernel this short                                                                       */
-    static const int shapes[][2] = { { 256, 4 }, { 128, 4 }, { 64, 4 }, { 256, 3 }, { 128, 3 }, { 64, 3 },
-                                     { 256, 2 }, { 128, 2 }, { 64, 2 }, { 256, 1 }, { 64, 1 } };
+struct GenShape {
     int NT = 0, P = 0, span = 0, a = 31;
     size_t lds = 0;
+};
+
+/* shape: P outputs per thread (fewer LDS reads per output; odd for odd D so that the lane
+ * stride needs no pad), NT threads per block, picked with a small cost model: a round of
+ * resident blocks costs the staging round trips (~2 us per 8 loads per thread) plus the
+ * tap loop of the waves sharing a SIMD; a second, nearly empty round of blocks doubles a
+ * kernel this short.  NT == 0: no shape fits the 160 KiB of LDS.                         */
+static GenShape pick_generic_shape(long long n_out, int D, int ntaps, int ncu)
+{
+    static const int shapes[][2] = { { 256, 4 }, { 128, 4 }, { 64, 4 }, { 256, 3 }, { 128, 3 }, { 64, 3 },
+                                     { 256, 2 }, { 128, 2 }, { 64, 2 }, { 256, 1 }, { 64, 1 } };
+    GenShape g;
     double best = -1.0;
     int force_nt = 0, force_p = 0;                     /* development: PDDC_GEN_SHAPE=NT,P */
     if (const char *e = getenv("PDDC_GEN_SHAPE"))
@@ -1386,7 +1373,10 @@ hipError_t launch_fir_generic(const float *in, const float *hist, int H, long lo
         const int nt = sh[0], pp = sh[1];
         if (force_nt ? (nt != force_nt || pp != force_p) : ((D & 1) ? (pp == 2 || pp == 4) : pp == 3))
             continue;
-        const int sp = (nt * pp - 1) * D + ntaps;
+        const long long sp_ll = (long long)(nt * pp - 1) * D + ntaps;
+        if (sp_ll > (1 << 20))
+            continue;
+        const int sp = (int)sp_ll;
         const int S = pp * D;
         const int aa = (S & 1) ? 31 : __builtin_ctz((unsigned)S);
         const size_t l = (size_t)(sp + 8 + ((sp + 8) >> aa) + 2) * sizeof(float2);
@@ -1412,9 +1402,40 @@ hipError_t launch_fir_generic(const float *in, const float *hist, int H, long lo
         const double t = (double)rounds * (t_stage + t_fir);
         if (best < 0.0 || t < best) {
             best = t;
-            NT = nt, P = pp, span = sp, a = aa, lds = l;
+            g.NT = nt, g.P = pp, g.span = sp, g.a = aa, g.lds = l;
         }
     }
+    return g;
+}
+
+/* can launch_fir_generic stage a block of this decimator in LDS at all? */
+bool fir_generic_supported(int D, int ntaps)
+{
+    return D >= 1 && ntaps >= 1 && pick_generic_shape(1 << 20, D, ntaps, 256).NT != 0;
+}
+
+/* `taps` must be readable (zeros) over [-3*D - 8, ntaps + 3*D + 8): the pipeline uploads
+ * its tap tables that way.  hist_out (or NULL) receives the last H samples of
+ * [hist(H) | in(n_batch)]; it must not alias hist.                                  */
+hipError_t launch_fir_generic(const float *in, const float *hist, int H, long long first, long long n_out,
+                              int D, const float *taps, int ntaps, float *out, float *hist_out,
+                              long long n_batch, hipStream_t s)
+{
+    if (n_out <= 0)
+        return hipSuccess;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static int ncu_of[64] = { 0 };
+    if (ncu_of[dev & 63] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        ncu_of[dev & 63] = n;
+    }
+    const int ncu = ncu_of[dev & 63];
+    const GenShape g = pick_generic_shape(n_out, D, ntaps, ncu);
+    const int NT = g.NT, P = g.P, span = g.span, a = g.a;
+    const size_t lds = g.lds;
     if (NT == 0)
         return hipErrorInvalidValue;           /* span does not fit LDS even one output per thread */
     const dim3 grid((unsigned)((n_out + (long long)NT * P - 1) / ((long long)NT * P))), blk((unsigned)NT);

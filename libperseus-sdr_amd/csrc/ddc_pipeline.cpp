@@ -355,6 +355,13 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
         const int max_taps = stages[i].interp > 1 ? PDDC_MAX_TAPS : PDDC_MAX_TAPS_DECIM;
         if (stages[i].ntaps < 1 || stages[i].ntaps > max_taps || !stages[i].taps)
             return fail(PDDC_EINVAL, "stage %d: ntaps must be 1..%d", i, max_taps);
+        /* a plain decimator may always end up on the generic kernel (ragged batches, odd phases):
+         * its smallest block shape must fit the LDS, or the first process() would fail half way */
+        if (stages[i].interp <= 1 && !fir_generic_supported(stages[i].decim, stages[i].ntaps))
+            return fail(PDDC_EINVAL,
+                        "stage %d: decimate-by-%d with %d taps does not fit: (63*D + ntaps + 10) samples of 8 bytes "
+                        "must fit the 160 KiB of LDS (D <= ~320 for short filters); split the stage",
+                        i, stages[i].decim, stages[i].ntaps);
     }
     int rc = require_device();
     if (rc)
@@ -580,6 +587,8 @@ int pddc_pipeline_set_taps(pddc_pipeline *p, int stage, const float *taps, int n
     const int need_hist = s.interp > 1 ? (ntaps + s.interp - 1) / s.interp : ntaps - 1;
     if (ntaps < 1 || need_hist > s.hist || (s.ntb && ntaps > 8 * s.ntb))
         return fail(PDDC_EINVAL, "ntaps %d does not fit the stage geometry (history %d)", ntaps, s.hist);
+    if (s.interp <= 1 && !fir_generic_supported(s.decim, ntaps))
+        return fail(PDDC_EINVAL, "decimate-by-%d with %d taps does not fit the LDS", s.decim, ntaps);
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipDeviceSynchronize());
     const int keep_ntb = s.ntb;
@@ -630,6 +639,23 @@ static void stage_outputs(unsigned long long consumed, size_t n, int D, int L, s
     *first_off = (size_t)off;
     *m0 = mm;
     *n_out = n > off ? (size_t)((n - off - 1) / (size_t)D + 1) : 0;
+}
+
+/* outputs the NEXT process() of nsamples will produce, from the stream position alone */
+static size_t predict_outputs(const pddc_pipeline *p, size_t nsamples)
+{
+    size_t n = nsamples, off, nout;
+    unsigned long long m0;
+    for (int i = 0; i < p->nstages; ++i) {
+        stage_outputs(p->st[i].consumed, n, p->st[i].decim, p->st[i].interp, &off, &m0, &nout);
+        n = nout;
+    }
+    return n;
+}
+
+size_t pddc_pipeline_next_output(const pddc_pipeline *p, size_t nsamples_in)
+{
+    return p ? predict_outputs(p, nsamples_in) : 0;
 }
 
 size_t pddc_pipeline_max_output(const pddc_pipeline *p, size_t n)
@@ -757,6 +783,10 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         return PDDC_OK;
     };
 
+    /* Stream state (which history buffer is current, inputs consumed per stage, the sample
+     * counter) is committed only after every launch of the batch has been accepted: a failure
+     * half way leaves the pipeline exactly where it was, and the batch can be retried.       */
+    bool flip[PDDC_MAX_STAGES] = { false, false, false, false };
     int first = 0;
     if (stages01_fusable(p, nsamples)) {
         /* stages 0 and 1 in ONE kernel: the 8 B/sample-at-1/8-rate intermediate
@@ -777,10 +807,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         a.n_in = (long long)nsamples;
         fill_fir8_args(p, a);
         HIP_TRY(launch_fir8_fused2(s0.ntb, p->R, mix, a, s));
-        s0.cur ^= 1;
-        s1.cur ^= 1;
-        s0.consumed += n_in[0];
-        s1.consumed += n_in[1];
+        flip[0] = flip[1] = true;
         first = 2;
     }
     for (int i = first; i < p->nstages; ++i) {
@@ -841,12 +868,16 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         if (n_in[i] > 0) {
             if (!hist_done)
                 HIP_TRY(launch_hist_update(h_out, h_in, st.hist, x, (long long)n_in[i], st.hist_elem, s));
-            st.cur ^= 1;
+            flip[i] = true;
         }
-        st.consumed += n_in[i];
     }
     if (p->flags & PDDC_F_OUT_PACKED24)
         HIP_TRY(launch_pack24(p->d_fout, (long long)n_final, d_out, s));
+    for (int i = 0; i < p->nstages; ++i) {          /* commit */
+        if (flip[i])
+            p->st[i].cur ^= 1;
+        p->st[i].consumed += n_in[i];
+    }
     p->n0 += nsamples;
     if (p->freg_applied != p->freg) {
         p->freg_applied = p->freg;
@@ -878,8 +909,10 @@ int pddc_host_free(void *h_ptr)
     return PDDC_OK;
 }
 
-int pddc_pipeline_push_host_async(pddc_pipeline *p, const void *h_packed, size_t nsamples, void *h_out,
-                                  size_t out_capacity, size_t *n_out_ret, int *ticket)
+/* one batch through a staging slot: input either copied from the host (h_packed) or generated
+ * on the device (synthetic LCG source: no host -> device traffic at all), kernels, output D2H */
+static int push_async(pddc_pipeline *p, const void *h_packed, bool synth, uint32_t seed, uint64_t byte_offset,
+                      size_t nsamples, void *h_out, size_t out_capacity, size_t *n_out_ret, int *ticket)
 {
     if (!p)
         return fail(PDDC_EINVAL, "null pipeline");
@@ -889,8 +922,17 @@ int pddc_pipeline_push_host_async(pddc_pipeline *p, const void *h_packed, size_t
         *ticket = -1;
     if (nsamples == 0)
         return PDDC_OK;
-    if (!h_packed || !h_out)
+    if ((!synth && !h_packed) || !h_out)
         return fail(PDDC_EINVAL, "null host pointer");
+    if (nsamples % PDDC_INPUT_GRANULE)
+        return fail(PDDC_EINVAL, "nsamples (%zu) must be a multiple of %d", nsamples, PDDC_INPUT_GRANULE);
+    /* the caller's buffer is checked BEFORE anything is launched: a batch that does not fit is
+     * refused with the stream position untouched, and can be pushed again with a larger buffer */
+    {
+        const size_t need = predict_outputs(p, nsamples);
+        if (need > out_capacity)
+            return fail(PDDC_ECAPACITY, "output capacity %zu < %zu", out_capacity, need);
+    }
     HIP_TRY(hipSetDevice(p->device));
     if (!p->s_in) {
         HIP_TRY(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
@@ -924,10 +966,13 @@ int pddc_pipeline_push_host_async(pddc_pipeline *p, const void *h_packed, size_t
             sl.out_cap = max_out;
         }
     }
-    /* H2D: the slot's input buffer is free once the kernels of its previous batch are done */
+    /* H2D (or the generator): the slot's input buffer is free once the kernels of its previous batch are done */
     if (sl.used)
         HIP_TRY(hipStreamWaitEvent(p->s_in, sl.ev_comp, 0));
-    HIP_TRY(hipMemcpyAsync(sl.d_in, h_packed, nsamples * 6, hipMemcpyHostToDevice, p->s_in));
+    if (synth)
+        HIP_TRY(launch_synth_lcg(sl.d_in, nsamples * 6, seed, byte_offset, p->s_in));
+    else
+        HIP_TRY(hipMemcpyAsync(sl.d_in, h_packed, nsamples * 6, hipMemcpyHostToDevice, p->s_in));
     HIP_TRY(hipEventRecord(sl.ev_in, p->s_in));
     /* kernels: after this batch has arrived and the slot's previous output has left */
     HIP_TRY(hipStreamWaitEvent(p->own_stream, sl.ev_in, 0));
@@ -940,11 +985,6 @@ int pddc_pipeline_push_host_async(pddc_pipeline *p, const void *h_packed, size_t
     HIP_TRY(hipEventRecord(sl.ev_comp, p->own_stream));
     sl.used = true;
     p->next_slot = si ^ 1;
-    if (n_out > out_capacity) {
-        hipStreamSynchronize(p->own_stream);
-        HIP_TRY(hipEventRecord(sl.ev_out, p->s_out));     /* keep the slot's event chain consistent */
-        return fail(PDDC_ECAPACITY, "output capacity %zu < %zu", out_capacity, n_out);
-    }
     HIP_TRY(hipStreamWaitEvent(p->s_out, sl.ev_comp, 0));
     if (n_out)
         HIP_TRY(hipMemcpyAsync(h_out, sl.d_out, n_out * ((p->flags & PDDC_F_OUT_PACKED24) ? 6 : 8),
@@ -955,6 +995,33 @@ int pddc_pipeline_push_host_async(pddc_pipeline *p, const void *h_packed, size_t
     if (ticket)
         *ticket = si;
     return PDDC_OK;
+}
+
+int pddc_pipeline_push_host_async(pddc_pipeline *p, const void *h_packed, size_t nsamples, void *h_out,
+                                  size_t out_capacity, size_t *n_out_ret, int *ticket)
+{
+    return push_async(p, h_packed, false, 0, 0, nsamples, h_out, out_capacity, n_out_ret, ticket);
+}
+
+int pddc_pipeline_push_synth_async(pddc_pipeline *p, uint32_t seed, uint64_t byte_offset, size_t nsamples,
+                                   void *h_out, size_t out_capacity, size_t *n_out_ret, int *ticket)
+{
+    return push_async(p, nullptr, true, seed, byte_offset, nsamples, h_out, out_capacity, n_out_ret, ticket);
+}
+
+int pddc_pipeline_ticket_done(pddc_pipeline *p, int ticket)
+{
+    if (!p || ticket < 0 || ticket > 1)
+        return fail(PDDC_EINVAL, "bad ticket");
+    if (!p->slot[ticket].used)
+        return fail(PDDC_ESTATE, "nothing was pushed on ticket %d", ticket);
+    HIP_TRY(hipSetDevice(p->device));
+    hipError_t e = hipEventQuery(p->slot[ticket].ev_out);
+    if (e == hipSuccess)
+        return 1;
+    if (e == hipErrorNotReady)
+        return 0;
+    return fail(PDDC_EHIP, "hipEventQuery: %s", hipGetErrorString(e));
 }
 
 int pddc_pipeline_wait_ticket(pddc_pipeline *p, int ticket)

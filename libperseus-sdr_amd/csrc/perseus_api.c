@@ -11,9 +11,16 @@
  *     :736-774; perseus-in.c:187-264)
  *   - a ring of 8 transfer buffers in one contiguous allocation; the callback
  *     buffer is library-owned and valid only during the call (perseus-in.c:63-96)
- *   - short / out-of-sequence transfers are dropped, logged at level 0
- *     (perseus-in.c:204-216); perseus_stop_async_input() returns only when no
+ *   - the transfer dispatcher (perseus-in.c:187-264): a completed transfer reaches the
+ *     client only if it is the expected slot AND full length; short and out-of-sequence
+ *     ones are dropped and logged at level 0, a timeout is tolerated (level 1) and the
+ *     transfer goes round again, error / stall / no-device / overflow kill that one
+ *     transfer and the queue completes when all 8 are dead; the expected slot moves to
+ *     idx+1 after every live completion.  perseus_stop_async_input() returns only when no
  *     further callback can occur and prints the rate line (perseus-sdr.c:709-722)
+ *   - up to 8 receivers, each with its own queue (perseus-sdr.c:43-47, perseus-in.h:87):
+ *     in DDC mode receiver i runs on GPU i % ngpu and the delivery thread first SUBMITS a
+ *     batch for every receiver, then collects them, so the GPUs work at the same time
  *   - NCO word, preselector choice, attenuator encoding, nearest-rate selection
  *     (perseus-sdr.c:584, :589-615, :496-517, :776-811)
  * What is replaced: libusb/FX2/FPGA-bitstream plumbing -> a sample source
@@ -65,6 +72,26 @@ typedef struct {
     float *taps[4];
 } ddc_plan;
 
+/* transfer status, the cases of the reference's dispatcher (perseus-in.c:199-257) */
+enum { XFER_COMPLETED = 0, XFER_TIMED_OUT, XFER_ERROR, XFER_STALL, XFER_NO_DEVICE, XFER_OVERFLOW };
+
+/* fault injection: what the virtual USB side does wrong, and when */
+enum { FAULT_NONE = 0, FAULT_SHORT, FAULT_TIMEOUT, FAULT_OOS, FAULT_ERROR, FAULT_STALL, FAULT_NODEV, FAULT_OVERFLOW,
+       FAULT_EOF };
+typedef struct {
+    int kind;
+    uint64_t at;                /* transfer number (1 = first), or 0             */
+    uint64_t every;             /* every k-th transfer, or 0                     */
+} fault_rule;
+#define MAX_FAULTS 32
+#define MAX_RETUNES 256
+
+typedef struct {
+    int ticket;                 /* pddc staging slot                             */
+    int k;                      /* batch buffer pair                             */
+    size_t nout;
+} pending_batch;
+
 struct perseus_descr_ds {
     int index;
     int present;                /* enumerated by perseus_init                   */
@@ -93,9 +120,15 @@ struct perseus_descr_ds {
     void *cb_extra;
     uint32_t buffersize;
     uint8_t *ring;              /* QUEUE_SIZE * buffersize                       */
-    int idx;                    /* next ring slot                                */
+    int next_slot;              /* slot the virtual USB side fills next          */
+    int idx_expected;           /* slot the dispatcher expects (perseus-in.c:55,260) */
+    int slot_dead[QUEUE_SIZE];  /* transfer killed by a fatal status, never resubmitted */
+    int n_dead;
     uint64_t seq;               /* transfers completed by the source             */
-    atomic_ullong delivered, dropped;
+    atomic_ullong delivered, dropped, timeouts;
+    fault_rule faults[MAX_FAULTS];
+    int n_faults;
+    char fault_script[256];
     unsigned long bytes_received;
     struct timeval t_start, t_stop;
     uint32_t lcg_state;
@@ -109,13 +142,19 @@ struct perseus_descr_ds {
     float *batch_out[2];        /* pipeline output of one batch                  */
     size_t out_cap;             /* in complex samples                            */
     int cur;                    /* buffer pair the next batch goes into          */
-    int pend_ticket;            /* batch in flight (-1: none), its pair and size */
-    int pend_slot;
-    size_t pend_nout;
+    pending_batch pend[2];      /* batches in flight, oldest first               */
+    int n_pend;
     int input_done;             /* the source has nothing more to give           */
-    uint8_t *fifo;              /* decimated float bytes awaiting callbacks      */
-    size_t fifo_len, fifo_cap;
-    uint64_t adc_samples;       /* ADC-rate samples produced so far              */
+    int gpu_source;             /* the LCG stream is generated on the device     */
+    int gpu_dev;                /* HIP device of the current / last stream, -1: none */
+    uint8_t *fifo;              /* ring of decimated bytes awaiting callbacks    */
+    size_t fifo_rd, fifo_len, fifo_cap;
+    uint64_t adc_samples;       /* ADC-rate samples handed to the GPU so far     */
+    uint64_t batches;
+    uint32_t freg_applied;      /* word the last submitted batch was mixed with  */
+    uint64_t retune_at[MAX_RETUNES];   /* first ADC sample of every tuning-word segment */
+    uint32_t retune_word[MAX_RETUNES];
+    int n_retunes;
     pthread_mutex_t pump_lock;  /* held by the delivery thread while it works on this descriptor */
 };
 
@@ -297,119 +336,320 @@ static void pace_until(perseus_descr *d, double samples_done, double rate)
     }
 }
 
-/* hand one ring slot to the client, or drop it like a short transfer */
-static void deliver(perseus_descr *d, int full)
+/* ---- fault injection script ------------------------------------------------------
+ * "kind@n" = at transfer number n (1 = first), "kind%k" = every k-th transfer, comma separated;
+ * kinds: short timeout oos error stall nodev overflow eof.  Example: "short%7,timeout@9,error@20" */
+static int parse_faults(perseus_descr *d, const char *script)
 {
-    uint8_t *slot = d->ring + (size_t)d->idx * d->buffersize;
-    d->seq++;
-    const int inject = d->cfg.drop_every > 0 && (d->seq % (uint64_t)d->cfg.drop_every) == 0;
-    if (full && !inject) {
-        d->bytes_received += d->buffersize;
-        perseus_input_callback cb = d->cb;
-        if (cb && !d->cancelling) {
-            cb(slot, (int)d->buffersize, d->cb_extra);
-            d->delivered++;
-        }
-    } else {
-        d->dropped++;
-        dbgprintf(0, "short or out-of-sequence transfer %llu dropped", (unsigned long long)d->seq);
+    static const struct { const char *name; int kind; } names[] = {
+        { "short", FAULT_SHORT }, { "timeout", FAULT_TIMEOUT }, { "oos", FAULT_OOS }, { "error", FAULT_ERROR },
+        { "stall", FAULT_STALL }, { "nodev", FAULT_NODEV }, { "overflow", FAULT_OVERFLOW }, { "eof", FAULT_EOF },
+    };
+    d->n_faults = 0;
+    if (d->cfg.drop_every > 0) {
+        d->faults[d->n_faults++] = (fault_rule){ FAULT_SHORT, 0, (uint64_t)d->cfg.drop_every };
     }
-    d->idx = (d->idx + 1) % QUEUE_SIZE;
+    if (!script)
+        return 0;
+    const char *p = script;
+    while (*p) {
+        while (*p == ',' || *p == ' ')
+            p++;
+        if (!*p)
+            break;
+        int kind = FAULT_NONE;
+        size_t len = 0;
+        for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); i++) {
+            len = strlen(names[i].name);
+            if (strncmp(p, names[i].name, len) == 0 && (p[len] == '@' || p[len] == '%')) {
+                kind = names[i].kind;
+                break;
+            }
+        }
+        if (kind == FAULT_NONE || d->n_faults >= MAX_FAULTS)
+            return -1;
+        const char mode = p[len];
+        char *endp = NULL;
+        const unsigned long long v = strtoull(p + len + 1, &endp, 10);
+        if (endp == p + len + 1 || v == 0)
+            return -1;
+        d->faults[d->n_faults++] = (fault_rule){ kind, mode == '@' ? v : 0, mode == '%' ? v : 0 };
+        p = endp;
+    }
+    return 0;
 }
 
-static void pump_wire(perseus_descr *d)
+static int fault_for(const perseus_descr *d, uint64_t n)     /* n = 1-based transfer number */
 {
-    uint8_t *slot = d->ring + (size_t)d->idx * d->buffersize;
-    const size_t got = source_fill(d, slot, d->buffersize);
-    if (got == 0) {
-        d->source_done = 1;
+    for (int i = 0; i < d->n_faults; i++)
+        if ((d->faults[i].at && d->faults[i].at == n) || (d->faults[i].every && n % d->faults[i].every == 0))
+            return d->faults[i].kind;
+    return FAULT_NONE;
+}
+
+/* ---- the dispatcher: what the reference does with one completed transfer
+ * (perseus-in.c:187-264), status by status -------------------------------------- */
+static void dispatch(perseus_descr *d, int idx, int status, uint32_t actual)
+{
+    if (d->cancelling)
         return;
+    switch (status) {
+    case XFER_COMPLETED:
+        d->bytes_received += actual;
+        if (idx == d->idx_expected) {
+            if (actual == d->buffersize) {
+                perseus_input_callback cb = d->cb;
+                if (cb) {
+                    cb(d->ring + (size_t)idx * d->buffersize, (int)d->buffersize, d->cb_extra);
+                    d->delivered++;
+                }
+            } else {
+                d->dropped++;
+                dbgprintf(0, "transfer %d shorter than requested (%u of %u bytes): dropped", idx, actual,
+                          d->buffersize);
+            }
+        } else {
+            d->dropped++;
+            dbgprintf(0, "transfer %d out of sequence (slot %d was expected): dropped", idx, d->idx_expected);
+        }
+        break;
+    case XFER_TIMED_OUT:
+        d->timeouts++;
+        dbgprintf(1, "transfer %d timed out (%u bytes so far): resubmitted", idx, actual);
+        break;
+    default: {
+        static const char *what[] = { "", "", "failed", "stalled", "lost its device", "overflowed" };
+        dbgprintf(0, "transfer %d %s: not resubmitted", idx, status <= XFER_OVERFLOW ? what[status] : "failed");
+        if (!d->slot_dead[idx]) {
+            d->slot_dead[idx] = 1;
+            d->n_dead++;
+        }
+        if (d->n_dead == QUEUE_SIZE) {                /* perseus_input_queue_check_completion */
+            dbgprintf(0, "all %d transfers are dead: the input queue has completed", QUEUE_SIZE);
+            d->source_done = 1;
+        }
+        return;                                       /* the expected slot does not move */
+    }
+    }
+    d->idx_expected = (idx + 1) % QUEUE_SIZE;
+}
+
+static int next_live_slot(perseus_descr *d)
+{
+    for (int k = 0; k < QUEUE_SIZE; k++) {
+        const int sidx = (d->next_slot + k) % QUEUE_SIZE;
+        if (!d->slot_dead[sidx]) {
+            d->next_slot = (sidx + 1) % QUEUE_SIZE;
+            return sidx;
+        }
+    }
+    return -1;
+}
+
+/* One turn of the virtual USB side: the next live transfer completes with whatever the fault
+ * script says.  `fill` brings buffersize bytes of payload into a slot (wire source or the
+ * decimated FIFO) and returns the bytes it had; `avail` says how many whole buffers `fill`
+ * can still provide without blocking (an out-of-sequence pair needs two).
+ * Returns 0 when nothing could be done (no payload, queue dead).                          */
+typedef size_t (*fill_fn)(perseus_descr *d, uint8_t *slot);
+
+static int turn(perseus_descr *d, fill_fn fill, size_t avail)
+{
+    if (d->n_dead == QUEUE_SIZE) {
+        d->source_done = 1;
+        return 0;
+    }
+    const int fault = fault_for(d, d->seq + 1);
+    if (fault == FAULT_EOF) {
+        d->source_done = 1;
+        d->input_done = 1;
+        return 0;
+    }
+    if (fault == FAULT_TIMEOUT || (fault >= FAULT_ERROR && fault <= FAULT_OVERFLOW)) {
+        /* nothing arrived: no payload is consumed */
+        const int sidx = next_live_slot(d);
+        d->seq++;
+        dispatch(d, sidx, fault == FAULT_TIMEOUT ? XFER_TIMED_OUT : XFER_ERROR + (fault - FAULT_ERROR), 0);
+        return 1;
+    }
+    if (avail == 0)
+        return 0;
+    if (fault == FAULT_OOS) {
+        /* two neighbouring transfers complete in the wrong order */
+        if (avail < 2 || QUEUE_SIZE - d->n_dead < 2)
+            return 0;
+        const int a = next_live_slot(d), b = next_live_slot(d);
+        const size_t ga = fill(d, d->ring + (size_t)a * d->buffersize);
+        const size_t gb = fill(d, d->ring + (size_t)b * d->buffersize);
+        d->seq += 2;
+        dispatch(d, b, XFER_COMPLETED, (uint32_t)gb);
+        dispatch(d, a, XFER_COMPLETED, (uint32_t)ga);
+        return 1;
+    }
+    const int sidx = next_live_slot(d);
+    size_t got = fill(d, d->ring + (size_t)sidx * d->buffersize);
+    d->seq++;
+    if (got == 0) {                                   /* the source had nothing at all */
+        d->source_done = 1;
+        return 0;
+    }
+    if (fault == FAULT_SHORT && got == d->buffersize)
+        got = d->buffersize / 2;                      /* the payload was consumed, half of it "arrived" */
+    dispatch(d, sidx, XFER_COMPLETED, (uint32_t)got);
+    return 1;
+}
+
+/* ---- wire mode: the source plays the receiver ----------------------------------------- */
+static size_t fill_wire(perseus_descr *d, uint8_t *slot)
+{
+    const size_t got = source_fill(d, slot, d->buffersize);
+    if (got < d->buffersize)
+        d->input_done = 1;                            /* bounded source (file) ended */
+    return got;
+}
+
+static int pump_wire(perseus_descr *d)
+{
+    if (d->input_done) {
+        d->source_done = 1;
+        return 0;
     }
     pace_until(d, (double)(d->seq + 1) * (d->buffersize / 6), (double)d->sample_rate);
-    deliver(d, got == d->buffersize);
-    if (got < d->buffersize)
-        d->source_done = 1;
+    return turn(d, fill_wire, 2);
+}
+
+/* ---- DDC mode: ADC-rate batches -> GPU -> FIFO of decimated bytes -> transfers ---------- */
+static size_t fifo_room(const perseus_descr *d) { return d->fifo_cap - d->fifo_len; }
+
+static void fifo_put(perseus_descr *d, const uint8_t *src, size_t n)
+{
+    size_t wr = (d->fifo_rd + d->fifo_len) % d->fifo_cap;
+    const size_t first = n < d->fifo_cap - wr ? n : d->fifo_cap - wr;
+    memcpy(d->fifo + wr, src, first);
+    memcpy(d->fifo, src + first, n - first);
+    d->fifo_len += n;
+}
+
+static size_t fill_fifo(perseus_descr *d, uint8_t *slot)
+{
+    const size_t n = d->buffersize;
+    if (d->fifo_len < n)
+        return 0;
+    const size_t first = n < d->fifo_cap - d->fifo_rd ? n : d->fifo_cap - d->fifo_rd;
+    memcpy(slot, d->fifo + d->fifo_rd, first);
+    memcpy(slot + first, d->fifo, n - first);
+    d->fifo_rd = (d->fifo_rd + n) % d->fifo_cap;
+    d->fifo_len -= n;
+    return n;
+}
+
+static size_t out_bytes_per_sample(const perseus_descr *d)
+{
+    return d->cfg.mode == PERSEUS_AMD_MODE_DDC_WIRE ? 6 : 8;
 }
 
 /* fill the next batch buffer from the source and hand it to the GPU; returns at once */
 static void submit_batch(perseus_descr *d)
 {
     const int k = d->cur;
-    const size_t want = (size_t)d->cfg.batch_samples * 6;
-    size_t got = source_fill(d, d->batch_in[k], want);
-    got -= got % 48;                         /* whole groups of 8 samples */
-    if (got == 0) {
-        d->input_done = 1;
-        return;
+    size_t ns = d->cfg.batch_samples;
+    if (!d->gpu_source) {
+        size_t got = source_fill(d, d->batch_in[k], ns * 6);
+        got -= got % 48;                         /* whole groups of 8 samples */
+        if (got < ns * 6)
+            d->input_done = 1;                   /* bounded source (file) ended */
+        ns = got / 6;
+        if (ns == 0)
+            return;
     }
-    const size_t ns = got / 6;
     pace_until(d, (double)(d->adc_samples + ns), d->adc_clk_freq);
-    /* retune takes effect at the batch boundary (reference clients retune while
-     * streaming, examples/fifo.c:43-49) */
-    pddc_pipeline_set_freg(d->pipe, d->freg);
+    /* A retune takes effect at the batch boundary (reference clients retune while streaming,
+     * examples/fifo.c:43-49): sample-accurate there and phase-continuous, and logged so that
+     * a test can build the same piecewise stream (perseus_amd_get_retune_log).              */
+    const uint32_t word = d->freg;
+    if (d->batches == 0 || word != d->freg_applied) {
+        if (d->n_retunes < MAX_RETUNES) {
+            d->retune_at[d->n_retunes] = d->adc_samples;
+            d->retune_word[d->n_retunes] = word;
+            d->n_retunes++;
+        }
+        d->freg_applied = word;
+        dbgprintf(3, "NCO word %u from ADC sample %llu", word, (unsigned long long)d->adc_samples);
+    }
+    pddc_pipeline_set_freg(d->pipe, word);
     size_t n_out = 0;
     int ticket = -1;
-    int rc = pddc_pipeline_push_host_async(d->pipe, d->batch_in[k], ns, d->batch_out[k], d->out_cap, &n_out, &ticket);
+    int rc;
+    if (d->gpu_source)
+        rc = pddc_pipeline_push_synth_async(d->pipe, d->cfg.lcg_seed, d->adc_samples * 6, ns, d->batch_out[k],
+                                            d->out_cap, &n_out, &ticket);
+    else
+        rc = pddc_pipeline_push_host_async(d->pipe, d->batch_in[k], ns, d->batch_out[k], d->out_cap, &n_out, &ticket);
     if (rc != PDDC_OK) {
         dbgprintf(0, "GPU pipeline failed (%d: %s); stream stopped", rc, pddc_last_error());
         d->input_done = 1;
         return;
     }
     d->adc_samples += ns;
-    d->pend_ticket = ticket;
-    d->pend_slot = k;
-    d->pend_nout = n_out;
+    d->batches++;
+    d->pend[d->n_pend++] = (pending_batch){ ticket, k, n_out };
     d->cur = k ^ 1;
-    if (got < want)
-        d->input_done = 1;                   /* bounded source (file) ended */
 }
 
-static void pump_ddc(perseus_descr *d)
+/* pass 1: keep the GPU fed.  A free-running source has two batches in flight (source, PCIe and
+ * kernels overlap); a paced, real-time one is not read ahead, that would only add latency.   */
+static int ddc_submit(perseus_descr *d)
 {
-    /* drain the FIFO first: one callback per call keeps devices interleaved */
-    if (d->fifo_len >= d->buffersize) {
-        uint8_t *slot = d->ring + (size_t)d->idx * d->buffersize;
-        memcpy(slot, d->fifo, d->buffersize);
-        memmove(d->fifo, d->fifo + d->buffersize, d->fifo_len - d->buffersize);
-        d->fifo_len -= d->buffersize;
-        deliver(d, 1);
-        return;
-    }
-    if (d->pend_ticket < 0 && !d->input_done)
+    int did = 0;
+    const int depth = d->cfg.pace ? 1 : 2;
+    const size_t worst = d->out_cap * out_bytes_per_sample(d);
+    while (d->n_pend < depth && !d->input_done && !d->source_done &&
+           fifo_room(d) >= worst * (size_t)(d->n_pend + 1)) {
+        if (d->cfg.max_buffers && d->seq >= d->cfg.max_buffers)
+            break;
         submit_batch(d);
-    if (d->pend_ticket < 0) {
-        d->source_done = 1;
-        return;
+        did = 1;
+        if (d->n_pend == 0)
+            break;
     }
-    const int ticket = d->pend_ticket, k = d->pend_slot;
-    const size_t n_out = d->pend_nout;
-    d->pend_ticket = -1;
-    /* free-running source: prepare and submit the following batch BEFORE waiting for this
-     * one, so source, PCIe and kernels overlap.  A paced (real-time) source is not read
-     * ahead: that would only add a batch period of latency                               */
-    if (!d->cfg.pace && !d->input_done)
-        submit_batch(d);
-    if (pddc_pipeline_wait_ticket(d->pipe, ticket) != PDDC_OK) {
+    return did;
+}
+
+/* pass 2: take the oldest batch's output into the FIFO (waits for it: every receiver's batch was
+ * submitted in pass 1, so the GPUs are all busy while this thread waits for the first of them) */
+static int ddc_collect(perseus_descr *d)
+{
+    if (d->n_pend == 0)
+        return 0;
+    const pending_batch b = d->pend[0];
+    d->pend[0] = d->pend[1];
+    d->n_pend--;
+    if (pddc_pipeline_wait_ticket(d->pipe, b.ticket) != PDDC_OK) {
         dbgprintf(0, "GPU pipeline failed (%s); stream stopped", pddc_last_error());
         d->input_done = 1;
         d->source_done = 1;
-        return;
+        return 0;
     }
-    const size_t nb = n_out * (d->cfg.mode == PERSEUS_AMD_MODE_DDC_WIRE ? 6 : 8);
-    if (d->fifo_len + nb > d->fifo_cap) {
-        size_t cap = (d->fifo_len + nb) * 2;
-        uint8_t *nf = (uint8_t *)realloc(d->fifo, cap);
-        if (!nf) {
+    fifo_put(d, (const uint8_t *)d->batch_out[b.k], b.nout * out_bytes_per_sample(d));
+    return 1;
+}
+
+/* pass 3: frame the FIFO into transfers and dispatch them */
+static int ddc_deliver(perseus_descr *d, int budget)
+{
+    int did = 0;
+    while (budget-- > 0 && !d->source_done && !d->cancelling) {
+        if (d->cfg.max_buffers && d->seq >= d->cfg.max_buffers) {
             d->source_done = 1;
-            return;
+            break;
         }
-        d->fifo = nf;
-        d->fifo_cap = cap;
+        if (!turn(d, fill_fifo, d->fifo_len / d->buffersize))
+            break;
+        did = 1;
     }
-    memcpy(d->fifo + d->fifo_len, d->batch_out[k], nb);
-    d->fifo_len += nb;
-    if (d->input_done && d->pend_ticket < 0)
+    if (d->input_done && d->n_pend == 0 && d->fifo_len < d->buffersize)
         d->source_done = 1;
+    return did;
 }
 
 static void *worker_fn(void *arg)
@@ -417,24 +657,30 @@ static void *worker_fn(void *arg)
     (void)arg;
     while (!g_thread_stop) {
         int busy = 0;
-        for (int i = 0; i < g_entries; i++) {
-            perseus_descr *d = &g_list[i];
-            if (!d->streaming || d->cancelling)
-                continue;
-            if (d->cfg.max_buffers && d->delivered + d->dropped >= d->cfg.max_buffers)
-                d->source_done = 1;
-            if (d->source_done && !(d->cfg.mode != PERSEUS_AMD_MODE_WIRE && d->fifo_len >= d->buffersize &&
-                                    !(d->cfg.max_buffers && d->delivered + d->dropped >= d->cfg.max_buffers)))
-                continue;
-            busy = 1;
-            pthread_mutex_lock(&d->pump_lock);
-            if (d->streaming && !d->cancelling) {
-                if (d->cfg.mode != PERSEUS_AMD_MODE_WIRE)
-                    pump_ddc(d);
-                else
-                    pump_wire(d);
+        for (int pass = 0; pass < 3; pass++) {
+            for (int i = 0; i < g_entries; i++) {
+                perseus_descr *d = &g_list[i];
+                if (!d->streaming || d->cancelling || d->source_done)
+                    continue;
+                if (pass < 2 && d->cfg.mode == PERSEUS_AMD_MODE_WIRE)
+                    continue;
+                pthread_mutex_lock(&d->pump_lock);
+                if (d->streaming && !d->cancelling && !d->source_done) {
+                    if (d->cfg.mode == PERSEUS_AMD_MODE_WIRE) {
+                        if (d->cfg.max_buffers && d->seq >= d->cfg.max_buffers)
+                            d->source_done = 1;
+                        else
+                            busy |= pump_wire(d);
+                    } else if (pass == 0) {
+                        busy |= ddc_submit(d);
+                    } else if (pass == 1) {
+                        busy |= ddc_collect(d);
+                    } else {
+                        busy |= ddc_deliver(d, 64);
+                    }
+                }
+                pthread_mutex_unlock(&d->pump_lock);
             }
-            pthread_mutex_unlock(&d->pump_lock);
         }
         if (!busy)
             usleep(1000);
@@ -482,6 +728,18 @@ static void default_config(perseus_descr *d)
         d->cfg.drop_every = atoi(e);
     if ((e = getenv("PERSEUS_AMD_MAX_BUFFERS")))
         d->cfg.max_buffers = strtoull(e, NULL, 0);
+    d->cfg.ep_packet_size = 512;
+    if ((e = getenv("PERSEUS_AMD_EP_PACKET")))
+        d->cfg.ep_packet_size = atoi(e);
+    d->cfg.cpu_source = 0;
+    if ((e = getenv("PERSEUS_AMD_CPU_SOURCE")))
+        d->cfg.cpu_source = atoi(e) != 0;
+    d->fault_script[0] = 0;
+    d->cfg.fault_script = NULL;
+    if ((e = getenv("PERSEUS_AMD_FAULTS"))) {
+        snprintf(d->fault_script, sizeof(d->fault_script), "%s", e);
+        d->cfg.fault_script = d->fault_script;
+    }
 }
 
 int perseus_init(void)
@@ -777,7 +1035,8 @@ static void free_stream(perseus_descr *d)
     }
     free(d->fifo);
     d->fifo = NULL;
-    d->fifo_len = d->fifo_cap = 0;
+    d->fifo_rd = d->fifo_len = d->fifo_cap = 0;
+    d->n_pend = 0;
     if (d->pipe) {
         pddc_pipeline_destroy(d->pipe);
         d->pipe = NULL;
@@ -799,10 +1058,22 @@ int perseus_start_async_input(perseus_descr *d, uint32_t buffersize, perseus_inp
         return errorset(PERSEUS_ASYNCSTARTED, "async input already started");
     if (buffersize > 16320)
         return errorset(PERSEUS_ERRPARAM, "max bulk buffer size is 16320 bytes");
-    /* the virtual receiver has 512-byte endpoints (reference perseus-sdr.c:670-673) */
-    if (buffersize == 0 || (buffersize % 6144) != 0)
-        return errorset(PERSEUS_BUFFERSIZE,
-                        "buffer size should be an integer multiple of 6144 bytes (1024 I/Q samples)");
+    /* the endpoint's max packet size decides the granule (reference perseus-sdr.c:664-680); the
+     * virtual receiver reports 512 unless configured as a 510-byte (or a broken) endpoint */
+    switch (d->cfg.ep_packet_size) {
+    case 512:
+        if (buffersize == 0 || (buffersize % 6144) != 0)
+            return errorset(PERSEUS_BUFFERSIZE,
+                            "buffer size should be an integer multiple of 6144 bytes (1024 I/Q samples)");
+        break;
+    case 510:
+        if (buffersize == 0 || (buffersize % 510) != 0)
+            return errorset(PERSEUS_BUFFERSIZE,
+                            "buffer size should be an integer multiple of 510 bytes (85 IQ samples)");
+        break;
+    default:
+        return errorset(PERSEUS_ERRPARAM, "Unexpected max packet size: %d", d->cfg.ep_packet_size);
+    }
 
     pthread_mutex_lock(&d->pump_lock);      /* the delivery thread reads these fields under the same lock */
     const int rc_start = start_locked(d, buffersize, cb, extra);
@@ -816,7 +1087,13 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
     if (!d->ring)
         return errorset(PERSEUS_NOMEM, "can't allocate the transfer buffers");
     d->buffersize = buffersize;
+    d->gpu_dev = -1;
+    d->gpu_source = 0;
     d->lcg_state = d->cfg.lcg_seed;
+    if (parse_faults(d, d->cfg.fault_script) < 0) {
+        free_stream(d);
+        return errorset(PERSEUS_ERRPARAM, "bad fault injection script \"%s\"", d->cfg.fault_script);
+    }
     if (d->cfg.source == PERSEUS_AMD_SRC_FILE) {
         d->fp = fopen(d->cfg.file_path ? d->cfg.file_path : "", "rb");
         if (!d->fp) {
@@ -846,6 +1123,7 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
                             pddc_last_error());
         }
         int dev = d->cfg.gpu_device >= 0 ? d->cfg.gpu_device : d->index % ndev;
+        d->gpu_dev = dev;
         int rc = pddc_pipeline_create(&d->pipe, dev, sd, d->plan.nstages,
                                       PDDC_F_MIX | (d->cfg.mode == PERSEUS_AMD_MODE_DDC_WIRE ? PDDC_F_OUT_PACKED24 : 0));
         if (rc != PDDC_OK) {
@@ -854,12 +1132,16 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
         }
         pddc_pipeline_set_freg(d->pipe, d->freg);
         d->out_cap = pddc_pipeline_max_output(d->pipe, d->cfg.batch_samples) + 8;
+        /* the synthetic stream is generated on the GPU (bit-identical to the host loop,
+         * pddc_synth_lcg) unless the configuration insists on the CPU generator */
+        d->gpu_source = d->cfg.source == PERSEUS_AMD_SRC_LCG && !d->cfg.cpu_source;
         int hrc = 0;
         for (int k = 0; k < 2; k++) {
-            hrc |= pddc_host_alloc((void **)&d->batch_in[k], (size_t)d->cfg.batch_samples * 6);
+            if (!d->gpu_source)
+                hrc |= pddc_host_alloc((void **)&d->batch_in[k], (size_t)d->cfg.batch_samples * 6);
             hrc |= pddc_host_alloc((void **)&d->batch_out[k], d->out_cap * 8);
         }
-        d->fifo_cap = d->out_cap * 8 + 2 * (size_t)buffersize;
+        d->fifo_cap = 3 * d->out_cap * 8 + 2 * (size_t)buffersize;
         d->fifo = (uint8_t *)malloc(d->fifo_cap);
         if (hrc || !d->fifo) {
             free_stream(d);
@@ -868,15 +1150,20 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
     }
     d->cb = cb;
     d->cb_extra = extra;
-    d->idx = 0;
+    d->next_slot = 0;
+    d->idx_expected = 0;
+    memset(d->slot_dead, 0, sizeof(d->slot_dead));
+    d->n_dead = 0;
     d->seq = 0;
-    d->delivered = d->dropped = 0;
+    d->delivered = d->dropped = d->timeouts = 0;
     d->bytes_received = 0;
     d->adc_samples = 0;
+    d->batches = 0;
+    d->n_retunes = 0;
     d->cur = 0;
-    d->pend_ticket = -1;
+    d->n_pend = 0;
     d->input_done = 0;
-    d->fifo_len = 0;
+    d->fifo_rd = d->fifo_len = 0;
     d->source_done = 0;
     d->cancelling = 0;
     gettimeofday(&d->t_start, NULL);
@@ -937,10 +1224,25 @@ int perseus_amd_set_config(perseus_descr *d, const perseus_amd_config *cfg)
         return errorset(PERSEUS_ERRPARAM, "bad source %d", cfg->source);
     if (cfg->batch_samples < 8 || cfg->batch_samples % 8)
         return errorset(PERSEUS_ERRPARAM, "batch_samples must be a positive multiple of 8");
+    if (cfg->ep_packet_size < 0 || cfg->ep_packet_size > 1024)
+        return errorset(PERSEUS_ERRPARAM, "bad endpoint packet size %d", cfg->ep_packet_size);
+    /* the strings are copied into the descriptor -- unless they already ARE the descriptor's
+     * copies (get_config -> modify -> set_config hands them back) */
+    const char *fp = cfg->file_path, *fs = cfg->fault_script;
     d->cfg = *cfg;
-    if (cfg->file_path) {
-        snprintf(d->file_path, sizeof(d->file_path), "%s", cfg->file_path);
+    if (d->cfg.ep_packet_size == 0)
+        d->cfg.ep_packet_size = 512;
+    if (fp) {
+        if (fp != d->file_path)
+            snprintf(d->file_path, sizeof(d->file_path), "%s", fp);
         d->cfg.file_path = d->file_path;
+    }
+    if (fs) {
+        if (fs != d->fault_script)
+            snprintf(d->fault_script, sizeof(d->fault_script), "%s", fs);
+        d->cfg.fault_script = d->fault_script;
+        if (parse_faults(d, d->fault_script) < 0)
+            return errorset(PERSEUS_ERRPARAM, "bad fault injection script \"%s\"", d->fault_script);
     }
     return errornone(0);
 }
@@ -954,12 +1256,41 @@ uint64_t perseus_amd_buffers_dropped(perseus_descr *d) { return d ? d->dropped :
 
 int perseus_amd_source_running(perseus_descr *d)
 {
-    if (!d || !d->streaming)
-        return 0;
-    if (!d->source_done)
-        return 1;
-    return d->cfg.mode != PERSEUS_AMD_MODE_WIRE && d->fifo_len >= d->buffersize &&
-           !(d->cfg.max_buffers && d->delivered + d->dropped >= d->cfg.max_buffers);
+    return d && d->streaming && !d->source_done;
+}
+
+int perseus_amd_get_stats(perseus_descr *d, perseus_amd_stats *st)
+{
+    if (d == NULL || st == NULL)
+        return errorset(PERSEUS_NULLDESCR, "null descriptor");
+    st->delivered = d->delivered;
+    st->dropped = d->dropped;
+    st->timeouts = d->timeouts;
+    st->dead_transfers = (uint64_t)d->n_dead;
+    st->transfers = d->seq;
+    st->bytes_received = d->bytes_received;
+    st->adc_samples = d->adc_samples;
+    st->batches = d->batches;
+    st->gpu_device = d->gpu_dev;
+    st->gpu_source = d->gpu_source;
+    return errornone(0);
+}
+
+int perseus_amd_get_retune_log(perseus_descr *d, uint64_t *first_sample, uint32_t *word, int capacity)
+{
+    if (d == NULL)
+        return errorset(PERSEUS_NULLDESCR, "null descriptor");
+    /* read under the pump lock: the delivery thread appends while streaming */
+    pthread_mutex_lock(&d->pump_lock);
+    const int n = d->n_retunes;
+    for (int i = 0; i < n && i < capacity; i++) {
+        if (first_sample)
+            first_sample[i] = d->retune_at[i];
+        if (word)
+            word[i] = d->retune_word[i];
+    }
+    pthread_mutex_unlock(&d->pump_lock);
+    return errornone(n);
 }
 
 int perseus_amd_get_plan_interp(perseus_descr *d, int interp[4])

@@ -1,0 +1,287 @@
+"""GPU tests (-m gpu) of the drop-in perseus_* API's DDC modes beyond the single-stream case:
+several receivers at once (reference: up to 8 descriptors, perseus-sdr.c:43-47), retune while
+streaming (examples/fifo.c:43-49), recorded-capture replay (perseustest.c:337,457,499 formats),
+transfer faults in DDC mode, the device-side synthetic source.
+
+Bars as everywhere: FIR / NCO max|y-ref|/max|ref| <= 1e-6 against the CPU oracle; byte-for-byte
+where two runs of the library must agree.
+"""
+import ctypes as C
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+FIR_TOL = 1e-6
+WIRE_LSB = 1.0 / 8388607
+
+
+@pytest.fixture()
+def L(pkg, dev, monkeypatch):
+    for k in ("PERSEUS_AMD_MODE", "PERSEUS_AMD_SOURCE", "PERSEUS_AMD_DEVICES", "PERSEUS_AMD_FAULTS",
+              "PERSEUS_AMD_DROP", "PERSEUS_AMD_BATCH", "PERSEUS_AMD_CPU_SOURCE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("PERSEUS_AMD_PACE", "0")
+    lib = pkg.sdr_lib()
+    lib.perseus_set_debug(0)
+    yield lib
+    lib.perseus_exit()
+
+
+def plan_of(L, d):
+    dec, nt, it = (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)()
+    n = L.perseus_amd_get_plan(d, dec, nt, None)
+    taps = [np.zeros(nt[i], np.float32) for i in range(n)]
+    arr = (C.POINTER(C.c_float) * 4)(*([t.ctypes.data_as(C.POINTER(C.c_float)) for t in taps] + [None] * (4 - n)))
+    L.perseus_amd_get_plan(d, dec, nt, arr)
+    L.perseus_amd_get_plan_interp(d, it)
+    return [(dec[i], taps[i], it[i]) for i in range(n)]
+
+
+def open_receiver(L, pkg, i, rate, hz, **cfgkw):
+    d = L.perseus_open(i)
+    assert d
+    assert L.perseus_firmware_download(d, None) == 0
+    assert L.perseus_set_sampling_rate(d, rate) == 0
+    assert L.perseus_set_ddc_center_freq(d, C.c_double(hz), 1) == 0
+    cfg = pkg.AmdConfig()
+    L.perseus_amd_get_config(d, C.byref(cfg))
+    cfg.pace = 0
+    for k, v in cfgkw.items():
+        setattr(cfg, k, v)
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0, L.perseus_errorstr()
+    return d
+
+
+def run_all(L, pkg, ds, bufsize=6144, on_buffer=None, timeout=120):
+    """-> (bytes per receiver, seconds from the first callback to the last)."""
+    outs = [[] for _ in ds]
+    stamps = []
+    cbs = []
+    for i, d in enumerate(ds):
+        def cb(b, n, x, i=i):
+            outs[i].append(C.string_at(b, n))
+            stamps.append(time.perf_counter())
+            if on_buffer:
+                on_buffer(i, len(outs[i]))
+            return 0
+        cbs.append(pkg.PERSEUS_CALLBACK(cb))
+    t0 = time.time()
+    for i, d in enumerate(ds):
+        assert L.perseus_start_async_input(d, bufsize, cbs[i], None) == 0, L.perseus_errorstr()
+    while any(L.perseus_amd_source_running(d) for d in ds) and time.time() - t0 < timeout:
+        time.sleep(0.002)
+    for d in ds:
+        assert L.perseus_stop_async_input(d) == 0
+    wall = (max(stamps) - min(stamps)) if stamps else 0.0
+    return [b"".join(o) for o in outs], wall
+
+
+# ------------------------------------------------------------------ several receivers at once
+def test_eight_receivers_share_one_gpu_and_overlap(L, pkg, O, monkeypatch):
+    """PERSEUS_AMD_DEVICES=8 on a 1-GPU box: all eight pipelines sit on GPU 0 (index % ngpu).
+    Every stream equals its single-stream run byte for byte and the oracle to 1e-6, and the
+    eight together take far less than eight times one (submit pass, then collect pass)."""
+    nbuf, batch, bufsize, rate, dtot = 600, 1 << 22, 12288, 125000, 640
+    monkeypatch.setenv("PERSEUS_AMD_DEVICES", "8")
+    assert L.perseus_init() == 8
+    ds = [open_receiver(L, pkg, i, rate, 7.1e6, mode=1, batch_samples=batch, max_buffers=nbuf) for i in range(8)]
+    stages = plan_of(L, ds[0])
+    st = pkg.AmdStats()
+    outs8, wall8 = run_all(L, pkg, ds, bufsize=bufsize)
+    L.perseus_amd_get_stats(ds[3], C.byref(st))
+    assert st.gpu_source == 1 and st.delivered == nbuf and st.batches >= 1 and st.gpu_device == 0
+    L.perseus_exit()
+    # one stream alone, same settings, seeds 12345 + i
+    singles, walls = [], []
+    for i in (0, 5, 5):
+        assert L.perseus_init() == 8
+        d = open_receiver(L, pkg, i, rate, 7.1e6, mode=1, batch_samples=batch, max_buffers=nbuf)
+        o, w = run_all(L, pkg, [d], bufsize=bufsize)
+        singles.append(o[0])
+        walls.append(w)
+        L.perseus_exit()
+    assert outs8[0] == singles[0] and outs8[5] == singles[1]
+    assert len(set(outs8)) == 8                                           # eight different streams
+    for i in (0, 7):
+        y = np.frombuffer(outs8[i], dtype=np.float32)[:2 * 4096]
+        ref = O.ddc_chain(O.lcg_bytes(6 * 4096 * dtot, 12345 + i), stages, freg=381178347, mix=True)
+        assert O.rel_err(y, ref[:y.size]) <= FIR_TOL
+    print(f"8 receivers on one GPU: {wall8 * 1e3:.1f} ms first-to-last callback; one alone: "
+          f"{min(walls) * 1e3:.1f} ms; ratio {wall8 / min(walls):.2f}")
+    assert wall8 < 8 * min(walls), (wall8, walls)
+
+
+# ------------------------------------------------------------------ N4: retune while streaming
+@pytest.mark.parametrize("mode,rate", [(1, 250000), (2, 2000000), (1, 96000)])
+def test_retune_while_streaming_matches_the_retuned_oracle(L, pkg, O, mode, rate):
+    """perseus_set_ddc_center_freq called while the stream runs (as examples/fifo.c does from its
+    control thread; here from inside the callback so the test is deterministic): the new word takes
+    effect at a GPU batch boundary, sample-accurately and phase-continuously.  The library says
+    where (perseus_amd_get_retune_log); the oracle mixes with a phase accumulator retuned at
+    exactly those samples."""
+    assert L.perseus_init() == 1
+    batch = 8 * 8192
+    nbuf = 60 if rate != 96000 else 12
+    d = open_receiver(L, pkg, 0, rate, 7.1e6, mode=mode, batch_samples=batch, max_buffers=nbuf)
+    stages = plan_of(L, d)
+    plan = {nbuf // 4: 7.05e6, nbuf // 2: 14.2e6, (3 * nbuf) // 4: 3.5e6}
+
+    def on_buffer(i, count):
+        if count in plan:
+            assert L.perseus_set_ddc_center_freq(d, C.c_double(plan[count]), 1) == 0
+
+    outs, _ = run_all(L, pkg, [d], on_buffer=on_buffer)
+    at, word = (C.c_uint64 * 16)(), (C.c_uint32 * 16)()
+    nseg = L.perseus_amd_get_retune_log(d, at, word, 16)
+    segs = [(int(at[i]), int(word[i])) for i in range(nseg)]
+    assert nseg == 4, segs
+    assert [w for _, w in segs] == [O.nco_freg(f) for f in (7.1e6, 7.05e6, 14.2e6, 3.5e6)]
+    assert segs[0][0] == 0 and all(a % batch == 0 and a > 0 for a, _ in segs[1:])
+    assert segs[1][0] < segs[2][0] < segs[3][0]
+    bps = 6 if mode == 2 else 8
+    nout = len(outs[0]) // bps
+    tot_l = int(np.prod([max(s[2], 1) for s in stages]))
+    tot_d = int(np.prod([s[0] for s in stages]))
+    need = (nout * tot_d + tot_l - 1) // tot_l + 8
+    need = (need + 7) // 8 * 8
+    ref = O.ddc_chain_retuned(O.lcg_bytes(6 * need, 12345), stages, segs)
+    if mode == 2:
+        y = O.unpack24_f32(np.frombuffer(outs[0], dtype=np.uint8))
+        tol = FIR_TOL + WIRE_LSB / np.max(np.abs(ref))
+    else:
+        y = np.frombuffer(outs[0], dtype=np.float32)
+        tol = FIR_TOL
+    assert segs[3][0] // tot_d * tot_l < nout                              # every segment is inside the output
+    assert O.rel_err(y, ref[:y.size]) <= tol
+    # and a retune that jumped in phase (the old n*freg form) would NOT pass: sanity of the test itself
+    jump = O.ddc_chain(O.lcg_bytes(6 * need, 12345), stages, freg=segs[-1][1], mix=True)
+    tail = slice(2 * (segs[3][0] // tot_d * tot_l + 64), y.size)
+    assert O.rel_err(y[tail], jump[tail]) > 1e-3
+
+
+def test_pipeline_retune_is_phase_continuous_on_every_path(pkg, dev, O):
+    """pddc_pipeline_set_freg between batches, C ABI level: fused stage 0, fused pair, generic path."""
+    import torch
+    from conftest import load_taps
+    cases = {
+        "fused /8 R=8": ([(8, load_taps("d8_127"))], {}),
+        "fused pair": ([(8, load_taps("c320_s1_d8_32")), (8, load_taps("c320_s2_d8_64")), (5, load_taps("c320_s3_d5_161"))], {}),
+        "generic": ([(8, load_taps("d8_127")), (5, load_taps("c320_s3_d5_161"))], {"no_fast": True}),
+        "generic first stage": ([(10, load_taps("c320_s3_d5_161")[:77]), (5, load_taps("c320_s3_d5_161"))], {}),
+    }
+    words = [381178347, 0x7FFFFFF1, 123456789, 3000000000]
+    nb = 8192 * 3
+    packed = O.lcg_bytes(6 * nb * len(words), 77)
+    for name, (stages, kw) in cases.items():
+        pipe = pkg.Pipeline(stages, mix=True, **kw)
+        ys = []
+        for k, w in enumerate(words):
+            pipe.set_freg(w)
+            ys.append(pipe.process(torch.from_numpy(packed[6 * nb * k:6 * nb * (k + 1)]).to(dev)).cpu().numpy())
+        assert pipe.phase_offset != 0
+        y = np.concatenate(ys).reshape(-1)
+        ref = O.ddc_chain_retuned(packed, stages, [(nb * k, w) for k, w in enumerate(words)])
+        assert O.rel_err(y, ref[:y.size]) <= FIR_TOL, name
+        pipe.reset()
+        assert pipe.phase_offset == 0
+        pipe.close()
+
+
+# ------------------------------------------------------------------ N2: capture replay through the DDC
+@pytest.mark.parametrize("mode", [1, 2])
+def test_capture_file_replay_through_the_gpu_path(L, pkg, O, tmp_path, mode):
+    """A raw 24-bit capture (the format the reference's clients record at the ADC side of this
+    library) replayed through PERSEUS_AMD_SOURCE=file in DDC mode; its length is neither a multiple
+    of the batch nor of 8 samples: the ragged tail is cut at the last whole group of 8."""
+    batch = 8 * 30000
+    ns_file = batch * 3 + 8 * 777 + 5                       # 3 full batches + a ragged one
+    n = np.arange(ns_file)
+    tone = 0.4 * np.exp(2j * np.pi * (7.101e6 / 80e6) * n) + 0.2 * np.exp(2j * np.pi * (7.0e6 / 80e6) * n)
+    rng = np.random.default_rng(5)
+    tone += 0.01 * (rng.standard_normal(ns_file) + 1j * rng.standard_normal(ns_file))
+    raw = O.pack24(np.rint(tone.real * 8388607).astype(np.int64), np.rint(tone.imag * 8388607).astype(np.int64))
+    raw = np.concatenate([raw, np.array([1, 2, 3], dtype=np.uint8)])      # and 3 stray bytes
+    path = tmp_path / "capture.raw"
+    raw.tofile(path)
+    assert L.perseus_init() == 1
+    d = open_receiver(L, pkg, 0, 250000, 7.1e6, mode=mode, source=2, file_path=str(path).encode(),
+                      batch_samples=batch)
+    stages = plan_of(L, d)
+    outs, _ = run_all(L, pkg, [d])
+    st = pkg.AmdStats()
+    L.perseus_amd_get_stats(d, C.byref(st))
+    used = (ns_file // 8) * 8
+    assert st.adc_samples == used and st.gpu_source == 0 and st.batches == 4
+    ref = O.ddc_chain(raw[:6 * used], stages, freg=381178347, mix=True)
+    bps = 6 if mode == 2 else 8
+    nfull = (ref.size // 2 * bps) // 6144                                  # whole callbacks only
+    assert len(outs[0]) == nfull * 6144 and nfull >= 2
+    if mode == 2:
+        y = O.unpack24_f32(np.frombuffer(outs[0], dtype=np.uint8))
+        tol = FIR_TOL + WIRE_LSB / np.max(np.abs(ref))
+    else:
+        y = np.frombuffer(outs[0], dtype=np.float32)
+        tol = FIR_TOL
+    assert O.rel_err(y, ref[:y.size]) <= tol
+    # the 1 kHz-offset tone is where it should be: strongest bin of the decimated spectrum
+    z = y[0::2] + 1j * y[1::2]
+    spec = np.abs(np.fft.fft(z[256:] * np.hanning(z.size - 256)))
+    f = np.fft.fftfreq(z.size - 256, 1 / 250000.0)[int(np.argmax(spec))]
+    assert abs(f - 1000.0) < 250000.0 / (z.size - 256) * 2
+
+
+# ------------------------------------------------------------------ faults in DDC mode
+def test_dropped_transfers_in_ddc_mode_leave_a_gap_not_a_glitch(L, pkg, O):
+    """The transfers of the DDC modes carry the GPU's OUTPUT (as the hardware's carry the FPGA's):
+    a dropped one is a gap of exactly one buffer in what the client sees -- the samples are skipped,
+    not zero-filled -- and the filters' history is untouched: every delivered buffer equals the
+    corresponding slice of the uninterrupted stream."""
+    assert L.perseus_init() == 1
+    script = b"short%5,timeout@7,oos@12,error@23"
+    d = open_receiver(L, pkg, 0, 2000000, 7.05e6, mode=1, batch_samples=8 * 20000, fault_script=script + b",eof@61")
+    stages = plan_of(L, d)
+    outs, _ = run_all(L, pkg, [d])
+    L.perseus_exit()
+    assert L.perseus_init() == 1
+    d = open_receiver(L, pkg, 0, 2000000, 7.05e6, mode=1, batch_samples=8 * 20000, max_buffers=60)
+    clean, _ = run_all(L, pkg, [d])
+    y = np.frombuffer(clean[0], dtype=np.float32)
+    ref = O.ddc_chain(O.lcg_bytes(6 * (y.size // 2) * 40, 12345), stages, freg=O.nco_freg(7.05e6), mix=True)
+    assert O.rel_err(y, ref[:y.size]) <= FIR_TOL
+    from test_perseus_api import reference_dispatcher, virtual_usb
+    exp, dead = reference_dispatcher(virtual_usb(10 ** 6, script.decode() + ",eof@61"))
+    got = [outs[0][k:k + 6144] for k in range(0, len(outs[0]), 6144)]
+    assert len(got) == len(exp) and len(dead) == 1
+    for g, k in zip(got, exp):
+        assert g == clean[0][k * 6144:(k + 1) * 6144]
+
+
+def test_gpu_source_and_cpu_source_are_the_same_stream(L, pkg, O):
+    outs = []
+    for cpu in (0, 1):
+        assert L.perseus_init() == 1
+        d = open_receiver(L, pkg, 0, 500000, 10.0e6, mode=2, batch_samples=8 * 50000, max_buffers=25, cpu_source=cpu)
+        o, _ = run_all(L, pkg, [d])
+        st = pkg.AmdStats()
+        L.perseus_amd_get_stats(d, C.byref(st))
+        assert st.gpu_source == 1 - cpu
+        outs.append(o[0])
+        L.perseus_exit()
+    assert outs[0] == outs[1] and len(outs[0]) == 25 * 6144
+
+
+def test_unpaced_plumbing_client_is_kernel_bound_not_source_bound(pkg, dev):
+    """with the synthetic stream generated on the device the unpaced client at
+    250 kS/s runs at >= 50x real time (it was ~2.3x with the single-thread CPU generator)."""
+    import re
+    exe = os.path.join(os.path.dirname(pkg.SDR_LIB), "perseus_plumbing")
+    env = dict(os.environ, PERSEUS_AMD_PACE="0", PERSEUS_AMD_MODE="ddc")
+    p = subprocess.run([exe, "-s", "250000", "-o", "none", "-t", "3", "-d", "3", "-a"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-1000:]
+    m = re.search(r"Rate: ([0-9.]+) kS/s", p.stderr)
+    assert m and float(m.group(1)) >= 50 * 250.0, p.stderr[-600:]

@@ -336,3 +336,156 @@ def test_fifo_control_thread_retunes_while_streaming(pkg, tmp_path):
     _, err = p.communicate(timeout=30)
     assert p.returncode == 0, err
     assert "final NCO word: 381178347" in err          # 7.1 MHz, perseus-sdr.c:584
+
+
+# ---------------------------------------------------------------------------
+# dispatcher semantics under injected faults (reference perseus-in.c:187-264)
+# ---------------------------------------------------------------------------
+def reference_dispatcher(events, nslots=8):
+    """Python restatement of the reference's input_queue_callback state machine, fed with the
+    completion events (slot, status, full?) the virtual USB side emitted: which payloads reach
+    the client.  status: 'ok' | 'timeout' | 'fatal'."""
+    expected, dead, delivered = 0, set(), []
+    for slot, status, full, payload in events:
+        if status == "ok":
+            if slot == expected and full:
+                delivered.append(payload)
+            expected = (slot + 1) % nslots                     # perseus-in.c:260
+        elif status == "timeout":
+            expected = (slot + 1) % nslots
+        else:
+            dead.add(slot)                                     # never resubmitted, expected unchanged
+            if len(dead) == nslots:
+                break
+    return delivered, dead
+
+
+def virtual_usb(nbuf_payload, script, nslots=8):
+    """What the fault script makes the virtual USB side emit, in the library's own terms
+    (perseus_api.c turn()): payload k = k-th buffersize bytes of the source."""
+    faults = {}
+    every = []
+    for item in script.split(","):
+        if "@" in item:
+            k, n = item.split("@")
+            faults[int(n)] = k
+        else:
+            k, n = item.split("%")
+            every.append((k, int(n)))
+    events, dead, nxt, seq, payload = [], set(), 0, 0, 0
+
+    def live():
+        nonlocal nxt
+        for j in range(nslots):
+            s = (nxt + j) % nslots
+            if s not in dead:
+                nxt = (s + 1) % nslots
+                return s
+        return None
+
+    while payload < nbuf_payload and len(dead) < nslots:
+        f = faults.get(seq + 1) or next((k for k, n in every if (seq + 1) % n == 0), None)
+        if f == "eof":
+            break
+        if f == "timeout":
+            events.append((live(), "timeout", False, None)); seq += 1
+        elif f in ("error", "stall", "nodev", "overflow"):
+            s = live(); dead.add(s); events.append((s, "fatal", False, None)); seq += 1
+        elif f == "oos":
+            a, b = live(), live()
+            events.append((b, "ok", True, payload + 1)); events.append((a, "ok", True, payload))
+            payload += 2; seq += 2
+        else:
+            events.append((live(), "ok", f != "short", payload)); payload += 1; seq += 1
+    return events
+
+
+@pytest.mark.parametrize("script", ["timeout@3", "oos@4", "error@5", "short@2,timeout@6,oos@9,stall@15",
+                                    "nodev@1,overflow@2", "short%3", "eof@7"])
+def test_fault_injection_follows_the_reference_dispatcher(L, O, pkg, script):
+    d = bring_up(L)
+    nbuf = 40
+    got, _, _ = run_stream(L, d, 0, fault_script=(script + ",eof@%d" % (nbuf + 1)).encode())
+    ref = O.lcg_bytes(nbuf * 6144, 12345).reshape(nbuf, 6144)
+    events = virtual_usb(nbuf, script + ",eof@%d" % (nbuf + 1))
+    exp, dead = reference_dispatcher(events)
+    assert [g for g in got] == [ref[k].tobytes() for k in exp], script
+    st = pkg.AmdStats()
+    assert L.perseus_amd_get_stats(d, C.byref(st)) == 0
+    assert st.delivered == len(exp) and st.dead_transfers == len(dead)
+    assert st.timeouts == sum(1 for e in events if e[1] == "timeout")
+    n_ok = sum(1 for e in events if e[1] == "ok")
+    assert st.dropped == n_ok - len(exp)
+
+
+def test_one_dead_transfer_costs_two_of_every_eight(L, O):
+    """A transfer killed by a fatal status is never resubmitted and the expected slot does not
+    move (perseus-in.c:222-257): from then on the transfer after the dead slot arrives 'out of
+    sequence' every round -- 6 of 8 buffers get through."""
+    d = bring_up(L)
+    got, _, _ = run_stream(L, d, 0, fault_script=b"error@4,eof@40")
+    # 3 delivered, slot 3 dies, then per round of 7 live transfers one is dropped
+    events = virtual_usb(10 ** 6, "error@4,eof@40")
+    exp, _ = reference_dispatcher(events)
+    assert len(got) == len(exp) and len(got) < 39 - 4
+    tail = len([e for e in events[4:] if e[1] == "ok"])
+    assert tail - (len(exp) - 3) >= tail // 7 - 1
+
+
+def test_all_transfers_dead_completes_the_queue_and_stop_still_returns(L, pkg):
+    d = bring_up(L)
+    script = ",".join("%s@%d" % (k, i + 1) for i, k in enumerate(["error", "stall", "nodev", "overflow"] * 2))
+    got, _, _ = run_stream(L, d, 0, fault_script=script.encode())        # run_stream asserts stop() == 0
+    assert got == []
+    st = pkg.AmdStats()
+    L.perseus_amd_get_stats(d, C.byref(st))
+    assert st.dead_transfers == 8 and st.delivered == 0
+
+
+def test_bad_fault_script_is_refused(L, pkg):
+    d = bring_up(L)
+    cfg = pkg.AmdConfig()
+    L.perseus_amd_get_config(d, C.byref(cfg))
+    cfg.fault_script = b"explode@3"
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == E["ERRPARAM"]
+    cfg.fault_script = b"short@0"
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == E["ERRPARAM"]
+
+
+def test_510_byte_endpoint_buffer_rule(L, O, pkg):
+    """perseus-sdr.c:674-677: a 510-byte endpoint wants multiples of 510 bytes (85 I/Q samples)."""
+    d = bring_up(L)
+    cfg = pkg.AmdConfig()
+    L.perseus_amd_get_config(d, C.byref(cfg))
+    assert cfg.ep_packet_size == 512
+    cfg.ep_packet_size, cfg.max_buffers, cfg.pace = 510, 6, 0
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    cb = pkg.PERSEUS_CALLBACK(lambda b, n, x: 0)
+    assert L.perseus_start_async_input(d, 6144, cb, None) == E["BUFFERSIZE"]
+    assert b"510 bytes (85 IQ samples)" in L.perseus_errorstr()
+    got, sizes, _ = run_stream(L, d, 6, bufsize=510 * 12, ep_packet_size=510)
+    assert sizes == [6120] * 6
+    assert b"".join(got) == O.lcg_bytes(6 * 6120, 12345).tobytes()
+    cfg.ep_packet_size = 64
+    L.perseus_amd_set_config(d, C.byref(cfg))
+    assert L.perseus_start_async_input(d, 6144, cb, None) == E["ERRPARAM"]
+    assert b"Unexpected max packet size: 64" in L.perseus_errorstr()
+
+
+def test_config_round_trip_keeps_its_strings(L, pkg, tmp_path):
+    """get_config -> modify -> set_config hands the library its own string buffers back."""
+    d = bring_up(L)
+    cfg = pkg.AmdConfig()
+    L.perseus_amd_get_config(d, C.byref(cfg))
+    path = str(tmp_path / "x.raw").encode()
+    cfg.source, cfg.file_path, cfg.fault_script = 2, path, b"short%9"
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    for _ in range(3):
+        c2 = pkg.AmdConfig()
+        assert L.perseus_amd_get_config(d, C.byref(c2)) == 0
+        assert c2.file_path == path and c2.fault_script == b"short%9"
+        c2.pace = 0
+        assert L.perseus_amd_set_config(d, C.byref(c2)) == 0         # same pointers come back in
+    c3 = pkg.AmdConfig()
+    L.perseus_amd_get_config(d, C.byref(c3))
+    assert c3.file_path == path and c3.fault_script == b"short%9"
