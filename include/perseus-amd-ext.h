@@ -87,6 +87,9 @@ typedef struct {
     uint64_t batches;
     int      gpu_device;      /* -1: no GPU pipeline                               */
     int      gpu_source;      /* 1: the synthetic stream is generated on the GPU   */
+    int      peak_receivers_in_flight;   /* library-wide since perseus_init(): the most receivers that had
+                                 a GPU batch in flight at the same moment (the delivery thread submits
+                                 for all of them before it waits for any)           */
 } perseus_amd_stats;
 
 /* valid between perseus_open() and perseus_start_async_input() */

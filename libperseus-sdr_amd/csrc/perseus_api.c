@@ -163,6 +163,7 @@ static int g_entries = 0;
 static pthread_t g_thread;
 static int g_thread_on = 0;
 static atomic_int g_thread_stop;
+static atomic_int g_peak_inflight;     /* most receivers that had a GPU batch in flight at the same time */
 
 /* ------------------------------------------------------------------------- */
 static double now_s(void)
@@ -658,6 +659,14 @@ static void *worker_fn(void *arg)
     while (!g_thread_stop) {
         int busy = 0;
         for (int pass = 0; pass < 3; pass++) {
+            if (pass == 1) {
+                /* every receiver's batch has been submitted, none has been waited for yet */
+                int inflight = 0;
+                for (int i = 0; i < g_entries; i++)
+                    inflight += g_list[i].streaming && g_list[i].n_pend > 0;
+                if (inflight > g_peak_inflight)
+                    g_peak_inflight = inflight;
+            }
             for (int i = 0; i < g_entries; i++) {
                 perseus_descr *d = &g_list[i];
                 if (!d->streaming || d->cancelling || d->source_done)
@@ -765,6 +774,7 @@ int perseus_init(void)
                   g_list[i].cfg.mode);
     }
     g_entries = n;
+    g_peak_inflight = 0;
     if (g_entries > 0) {
         g_thread_stop = 0;
         if (pthread_create(&g_thread, NULL, worker_fn, NULL) != 0)
@@ -1273,6 +1283,7 @@ int perseus_amd_get_stats(perseus_descr *d, perseus_amd_stats *st)
     st->batches = d->batches;
     st->gpu_device = d->gpu_dev;
     st->gpu_source = d->gpu_source;
+    st->peak_receivers_in_flight = g_peak_inflight;
     return errornone(0);
 }
 

@@ -83,8 +83,10 @@ def run_all(L, pkg, ds, bufsize=6144, on_buffer=None, timeout=120):
 # ------------------------------------------------------------------ several receivers at once
 def test_eight_receivers_share_one_gpu_and_overlap(L, pkg, O, monkeypatch):
     """PERSEUS_AMD_DEVICES=8 on a 1-GPU box: all eight pipelines sit on GPU 0 (index % ngpu).
-    Every stream equals its single-stream run byte for byte and the oracle to 1e-6, and the
-    eight together take far less than eight times one (submit pass, then collect pass)."""
+    Every stream equals its single-stream run byte for byte and the oracle to 1e-6, and all eight
+    have a batch on the GPU at the same moment (the delivery thread submits for every receiver
+    before it waits for any: on eight GPUs that is eight GPUs working at once).  On ONE GPU the
+    eight streams share the device, so the wall time is only sanity-checked, not 8x better."""
     nbuf, batch, bufsize, rate, dtot = 600, 1 << 22, 12288, 125000, 640
     monkeypatch.setenv("PERSEUS_AMD_DEVICES", "8")
     assert L.perseus_init() == 8
@@ -94,6 +96,7 @@ def test_eight_receivers_share_one_gpu_and_overlap(L, pkg, O, monkeypatch):
     outs8, wall8 = run_all(L, pkg, ds, bufsize=bufsize)
     L.perseus_amd_get_stats(ds[3], C.byref(st))
     assert st.gpu_source == 1 and st.delivered == nbuf and st.batches >= 1 and st.gpu_device == 0
+    assert st.peak_receivers_in_flight == 8
     L.perseus_exit()
     # one stream alone, same settings, seeds 12345 + i
     singles, walls = [], []
@@ -112,7 +115,7 @@ def test_eight_receivers_share_one_gpu_and_overlap(L, pkg, O, monkeypatch):
         assert O.rel_err(y, ref[:y.size]) <= FIR_TOL
     print(f"8 receivers on one GPU: {wall8 * 1e3:.1f} ms first-to-last callback; one alone: "
           f"{min(walls) * 1e3:.1f} ms; ratio {wall8 / min(walls):.2f}")
-    assert wall8 < 8 * min(walls), (wall8, walls)
+    assert wall8 < 20 * min(walls), (wall8, walls)
 
 
 # ------------------------------------------------------------------ N4: retune while streaming

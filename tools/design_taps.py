@@ -3,11 +3,11 @@
 
 The reference holds no tap values (they live in FPGA bitstreams),
 so these are authored.  scipy is only needed HERE (the build container); the
-results are committed as raw float32 fixtures under tests/golden/ and as a C
-table in libperseus-sdr_amd/csrc/default_taps.h, so neither the GPU box nor the
-product needs scipy.
+results are committed as raw float32 fixtures under tests/golden/, so the GPU box
+does not need scipy.  (The drop-in API designs the taps of its rate plans itself,
+Kaiser windows in perseus_api.c plan_build.)
 
-    python tools/design_taps.py          # rewrites fixtures + header
+    python tools/design_taps.py          # rewrites the fixtures
 """
 import json
 import os
@@ -17,7 +17,6 @@ from scipy import signal
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
-HDR = os.path.join(ROOT, "libperseus-sdr_amd", "csrc", "default_taps.h")
 
 # name, ntaps, fs, passband edge, stopband edge  (Hz); all low-pass, unity DC gain
 SETS = [
@@ -46,7 +45,6 @@ def atten_db(h, fs, fst):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     manifest = {}
-    tables = []
     for name, n, fs, fp, fst in SETS:
         h = design(n, fs, fp, fst)
         h.tofile(os.path.join(GOLD, f"taps_{name}.f32"))
@@ -56,17 +54,8 @@ def main():
             "sum": float(np.sum(h.astype(np.float64))),
             "file": f"taps_{name}.f32",
         }
-        body = ",\n    ".join(
-            ", ".join(f"{float(v):.9e}f" for v in h[i:i + 4]) for i in range(0, n, 4))
-        tables.append(f"static const float pddc_taps_{name}[{n}] = {{\n    {body}\n}};\n")
     with open(os.path.join(GOLD, "taps_manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
-    with open(HDR, "w") as f:
-        f.write("/* GENERATED by tools/design_taps.py -- do not edit.\n"
-                " * Authored low-pass tap sets (the reference has none: SURVEY.md 0.3). */\n"
-                "#ifndef PDDC_DEFAULT_TAPS_H\n#define PDDC_DEFAULT_TAPS_H\n\n")
-        f.write("\n".join(tables))
-        f.write("\n#endif\n")
     print(json.dumps(manifest, indent=1))
 
 
