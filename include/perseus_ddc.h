@@ -145,6 +145,10 @@ size_t pddc_pipeline_max_output(const pddc_pipeline *p, size_t nsamples_in);
 size_t pddc_pipeline_next_output(const pddc_pipeline *p, size_t nsamples_in);
 /* 1 if stage 0 runs the fused unpack+mix+polyphase kernel for this geometry   */
 int pddc_pipeline_uses_fused(const pddc_pipeline *p);
+/* 1 if stage 0 reads the packed samples itself (the fused decimate-by-8, or the generic decimator
+ * with its unpack-while-staging load phase for any other first decimation): no float32
+ * intermediate of the input is ever written; 6 + 8/D bytes per input sample                  */
+int pddc_pipeline_stage0_reads_packed(const pddc_pipeline *p);
 /* 1 if a process() of nsamples would run stages 0 AND 1 as one kernel (both
  * decimate-by-8, stage 1 <= 64 taps, nsamples a multiple of the kernel's tile):
  * the stage-0 output then never reaches HBM                                    */

@@ -101,6 +101,8 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_max_output.argtypes = [vp, sz]
     L.pddc_pipeline_max_output.restype = sz
     L.pddc_pipeline_uses_fused.argtypes = [vp]
+    L.pddc_pipeline_stage0_reads_packed.argtypes = [vp]
+    L.pddc_pipeline_stage0_reads_packed.restype = C.c_int
     L.pddc_pipeline_uses_fused_pair.argtypes = [vp, sz]
     L.pddc_pipeline_uses_fused_pair.restype = C.c_int
     L.pddc_pipeline_process.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp]
@@ -233,6 +235,10 @@ class Pipeline:
     @property
     def fused(self) -> bool:
         return bool(ddc_lib().pddc_pipeline_uses_fused(self._h))
+
+    @property
+    def stage0_reads_packed(self) -> bool:
+        return bool(ddc_lib().pddc_pipeline_stage0_reads_packed(self._h))
 
     def fused_pair(self, nsamples: int) -> bool:
         return bool(ddc_lib().pddc_pipeline_uses_fused_pair(self._h, nsamples))

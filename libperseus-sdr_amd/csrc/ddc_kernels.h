@@ -77,6 +77,16 @@ hipError_t launch_fir_generic(const float *in, const float *hist, int H, long lo
                               int D, const float *taps, int ntaps, float *out, float *hist_out,
                               long long n_batch, hipStream_t s);
 
+/* The same decimator fed with 24-bit PACKED samples (stage 0 of a plan whose first decimation is not
+ * 8): the block unpacks and -- `mix` -- mixes while it stages its input span; batch, hist (H samples,
+ * H % 8 == 0) and hist_out are packed, n_batch % 8 == 0.  phase(n) = n*freg + phase_off for the batch,
+ * and the history is mixed with freg_hist (phase-continuous at n0).                              */
+hipError_t launch_fir_generic_packed(const void *in_packed, const void *hist_packed, int H, long long first,
+                                     long long n_out, int D, const float *taps, int ntaps, float *out,
+                                     void *hist_out_packed, long long n_batch, bool mix, unsigned long long n0,
+                                     uint32_t freg, uint32_t phase_off, uint32_t freg_hist, const float *lo_c,
+                                     const float *lo_s, const float *lo_c_hist, const float *lo_s_hist, hipStream_t s);
+
 /* false when even the smallest block shape of the generic kernel cannot stage its input span
  * ((63*D + ntaps + 10) samples) in the 160 KiB of LDS: such a stage is refused at create time */
 bool fir_generic_supported(int D, int ntaps);

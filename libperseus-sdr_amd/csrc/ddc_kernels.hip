@@ -1239,12 +1239,25 @@ hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, h
  * (per-sample uniform index arithmetic made it 29 us instead of 13).
  * Block 0 also writes the next call's history (the last H samples of
  * [hist | batch]) when asked.                                                */
-template <int P>
+/* PACKED: the batch and its history are 24-bit packed samples (stage 0): the block unpacks --
+ * and, MIX, mixes with the NCO -- while it stages its span, so the float2 intermediate of an
+ * unpack kernel (8 B written + 8 B read per input sample) never exists: 6 + 8/D bytes per input
+ * sample for ANY decimation, not only the fused decimate-by-8 (the 1.6 MS/s plan is 10*5).    */
+struct GenMixArgs {
+    unsigned long long n0;      /* absolute index of batch sample 0                            */
+    uint32_t freg, phase_off;   /* phase(n) = n*freg + phase_off                               */
+    uint32_t freg_hist;         /* word the history samples were mixed with (first batch after a retune) */
+    float lo_c[8], lo_s[8];     /* step phasors of freg                                        */
+    float lo_c_hist[8], lo_s_hist[8];
+};
+
+template <int P, bool PACKED, bool MIX>
 __global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ in, const float2 *__restrict__ hist,
                                                       int H, long long first, long long n_out, int D,
                                                       const float PDDC_CONSTANT *taps, int ntaps,
                                                       float2 *__restrict__ out, int span, int a,
-                                                      float2 *__restrict__ hist_out, long long n_batch)
+                                                      float2 *__restrict__ hist_out, long long n_batch,
+                                                      GenMixArgs mx)
 {
     extern __shared__ __attribute__((aligned(16))) float2 sd[];
     /* layout: span samples | 8 zero samples (the first, aligned step of the tap loop may
@@ -1259,7 +1272,73 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ 
         const int i = span + tid;
         sd[i + (i >> a)] = make_float2(0.0f, 0.0f);
     }
-    if (x0 >= 0 && x0 + span - 1 <= last_needed) {
+    if (PACKED) {
+        /* whole groups of 8 samples (48 bytes, 16-byte aligned both in the batch and in the
+         * history, whose length is a multiple of 8), four groups in flight per thread */
+        const uint8_t *inb = reinterpret_cast<const uint8_t *>(in);
+        const uint8_t *hb8 = reinterpret_cast<const uint8_t *>(hist);
+        const long long xa = (x0 >= 0 ? x0 : x0 - 7) / 8 * 8;     /* floor to a multiple of 8 */
+        const int shift = (int)(x0 - xa);
+        const int ngroups = (span + shift + 7) >> 3;
+        /* the word and offset the samples in front of the batch were mixed with: the phase is
+         * continuous at n0, so off_old = phase_off + n0*(freg - freg_hist)                    */
+        const uint32_t off_old = mx.phase_off + (uint32_t)mx.n0 * (mx.freg - mx.freg_hist);
+        for (int g0 = tid; g0 < ngroups; g0 += 4 * NT) {
+            u32x4 raw[4][3];
+            long long s0[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + NT * u;
+                s0[u] = xa + 8LL * g;
+                const uint8_t *src = nullptr;
+                if (g < ngroups) {
+                    if (s0[u] < 0) {
+                        if (s0[u] >= -(long long)H)
+                            src = hb8 + (s0[u] + H) * 6;
+                    } else if (s0[u] < n_batch) {
+                        src = inb + s0[u] * 6;
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+                    raw[u][w] = src ? reinterpret_cast<const u32x4 *>(src)[w] : u32x4{ 0u, 0u, 0u, 0u };
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + NT * u;
+                if (g >= ngroups)
+                    continue;
+                const uint32_t w[12] = { raw[u][0].x, raw[u][0].y, raw[u][0].z, raw[u][0].w, raw[u][1].x, raw[u][1].y,
+                                         raw[u][1].z, raw[u][1].w, raw[u][2].x, raw[u][2].y, raw[u][2].z, raw[u][2].w };
+                int32_t I[8], Q[8];
+                unpack8_msb(w, I, Q);
+                float xi[8], xq[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xi[e] = (float)I[e] * kUnpackScale;
+                    xq[e] = (float)Q[e] * kUnpackScale;
+                }
+                if (MIX) {
+                    const bool old = s0[u] < 0;
+                    float cb, sb;
+                    nco_lo((uint32_t)(mx.n0 + (unsigned long long)s0[u]) * (old ? mx.freg_hist : mx.freg) +
+                               (old ? off_old : mx.phase_off), cb, sb);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float sc = old ? mx.lo_c_hist[e] : mx.lo_c[e];
+                        const float ss = old ? mx.lo_s_hist[e] : mx.lo_s[e];
+                        cmul(xi[e], xq[e], cb * sc - sb * ss, cb * ss + sb * sc);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = 8 * g - shift + e;               /* LDS index of sample xa + 8g + e */
+                    if (i >= 0 && i < span)
+                        sd[i + (i >> a)] = make_float2(xi[e], xq[e]);
+                }
+            }
+        }
+    } else if (x0 >= 0 && x0 + span - 1 <= last_needed) {
         /* interior block: branch-free, so the loads of 8 rounds are in flight together
          * (with the guarded form below every round waits for its own load: 21 serial
          * round trips made this kernel 36 us for the x320 cascade's last stage)       */
@@ -1292,9 +1371,20 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ 
         }
     }
     if (hist_out != nullptr && blockIdx.x == 0) {
-        for (int i = tid; i < H; i += NT) {
-            const long long j = (long long)i + n_batch;
-            hist_out[i] = j < H ? hist[j] : in[j - H];
+        if (PACKED) {                                   /* 6 bytes per sample, moved as dwords */
+            const int Hw = H * 6 / 4;
+            const long long nw = n_batch * 6 / 4;
+            const uint32_t *hw = reinterpret_cast<const uint32_t *>(hist), *bw = reinterpret_cast<const uint32_t *>(in);
+            uint32_t *ow = reinterpret_cast<uint32_t *>(hist_out);
+            for (int i = tid; i < Hw; i += NT) {
+                const long long j = (long long)i + nw;
+                ow[i] = j < Hw ? hw[j] : bw[j - Hw];
+            }
+        } else {
+            for (int i = tid; i < H; i += NT) {
+                const long long j = (long long)i + n_batch;
+                hist_out[i] = j < H ? hist[j] : in[j - H];
+            }
         }
     }
     __syncthreads();
@@ -1417,9 +1507,45 @@ bool fir_generic_supported(int D, int ntaps)
 /* `taps` must be readable (zeros) over [-3*D - 8, ntaps + 3*D + 8): the pipeline uploads
  * its tap tables that way.  hist_out (or NULL) receives the last H samples of
  * [hist(H) | in(n_batch)]; it must not alias hist.                                  */
+static hipError_t launch_fir_generic_any(const void *in, const void *hist, int H, long long first, long long n_out,
+                                         int D, const float *taps, int ntaps, float *out, void *hist_out,
+                                         long long n_batch, int packed_mode /* 0 float2, 1 packed, 2 packed + mix */,
+                                         const GenMixArgs &mx, hipStream_t s);
+
 hipError_t launch_fir_generic(const float *in, const float *hist, int H, long long first, long long n_out,
                               int D, const float *taps, int ntaps, float *out, float *hist_out,
                               long long n_batch, hipStream_t s)
+{
+    GenMixArgs mx = {};
+    return launch_fir_generic_any(in, hist, H, first, n_out, D, taps, ntaps, out, hist_out, n_batch, 0, mx, s);
+}
+
+hipError_t launch_fir_generic_packed(const void *in_packed, const void *hist_packed, int H, long long first,
+                                     long long n_out, int D, const float *taps, int ntaps, float *out,
+                                     void *hist_out_packed, long long n_batch, bool mix, unsigned long long n0,
+                                     uint32_t freg, uint32_t phase_off, uint32_t freg_hist, const float *lo_c,
+                                     const float *lo_s, const float *lo_c_hist, const float *lo_s_hist, hipStream_t s)
+{
+    if ((H & 7) || (n_batch & 7))
+        return hipErrorInvalidValue;
+    GenMixArgs mx = {};
+    mx.n0 = n0;
+    mx.freg = freg;
+    mx.phase_off = phase_off;
+    mx.freg_hist = freg_hist;
+    for (int e = 0; e < 8; ++e) {
+        mx.lo_c[e] = lo_c ? lo_c[e] : 1.0f;
+        mx.lo_s[e] = lo_s ? lo_s[e] : 0.0f;
+        mx.lo_c_hist[e] = lo_c_hist ? lo_c_hist[e] : 1.0f;
+        mx.lo_s_hist[e] = lo_s_hist ? lo_s_hist[e] : 0.0f;
+    }
+    return launch_fir_generic_any(in_packed, hist_packed, H, first, n_out, D, taps, ntaps, out, hist_out_packed, n_batch,
+                                  mix ? 2 : 1, mx, s);
+}
+
+static hipError_t launch_fir_generic_any(const void *in, const void *hist, int H, long long first, long long n_out,
+                                         int D, const float *taps, int ntaps, float *out, void *hist_out,
+                                         long long n_batch, int packed_mode, const GenMixArgs &mx, hipStream_t s)
 {
     if (n_out <= 0)
         return hipSuccess;
@@ -1439,20 +1565,29 @@ hipError_t launch_fir_generic(const float *in, const float *hist, int H, long lo
     if (NT == 0)
         return hipErrorInvalidValue;           /* span does not fit LDS even one output per thread */
     const dim3 grid((unsigned)((n_out + (long long)NT * P - 1) / ((long long)NT * P))), blk((unsigned)NT);
-#define PDDC_GEN(PP)                                                                               \
+#define PDDC_GEN3(PP, PK, MX)                                                                      \
     do {                                                                                          \
         static int attr_lds[64] = { 0 };            /* per device */                             \
         if ((int)lds > attr_lds[dev & 63]) {                                                      \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_generic<PP>), \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_generic<PP, PK, MX>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess)                                                                  \
                 return e;                                                                         \
             attr_lds[dev & 63] = (int)lds;                                                        \
         }                                                                                         \
-        hipLaunchKernelGGL(k_fir_generic<PP>, grid, blk, lds, s, reinterpret_cast<const float2 *>(in), \
+        hipLaunchKernelGGL((k_fir_generic<PP, PK, MX>), grid, blk, lds, s, reinterpret_cast<const float2 *>(in), \
                            reinterpret_cast<const float2 *>(hist), H, first, n_out, D,            \
                            (const float PDDC_CONSTANT *)taps, ntaps, reinterpret_cast<float2 *>(out), span, a, \
-                           reinterpret_cast<float2 *>(hist_out), n_batch);                        \
+                           reinterpret_cast<float2 *>(hist_out), n_batch, mx);                    \
+    } while (0)
+#define PDDC_GEN(PP)                                                                               \
+    do {                                                                                          \
+        if (packed_mode == 2)                                                                     \
+            PDDC_GEN3(PP, true, true);                                                            \
+        else if (packed_mode == 1)                                                                \
+            PDDC_GEN3(PP, true, false);                                                           \
+        else                                                                                      \
+            PDDC_GEN3(PP, false, false);                                                          \
     } while (0)
     if (P == 4)
         PDDC_GEN(4);
@@ -1463,6 +1598,7 @@ hipError_t launch_fir_generic(const float *in, const float *hist, int H, long lo
     else
         PDDC_GEN(1);
 #undef PDDC_GEN
+#undef PDDC_GEN3
     return hipGetLastError();
 }
 

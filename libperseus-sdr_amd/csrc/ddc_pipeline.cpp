@@ -117,6 +117,7 @@ struct pddc_pipeline {
 };
 
 static bool stage0_fused(const pddc_pipeline *p);
+static bool stage0_packed_generic(const pddc_pipeline *p);
 
 static float round_to_half(float v)
 {
@@ -413,7 +414,7 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
     hipError_t e = hipSuccess;
     for (int i = 0; i < nstages && e == hipSuccess; ++i) {
         Stage &s = p->st[i];
-        s.hist_elem = (i == 0 && stage0_fused(p)) ? PDDC_PACKED_BYTES : 8;
+        s.hist_elem = (i == 0 && (stage0_fused(p) || stage0_packed_generic(p))) ? PDDC_PACKED_BYTES : 8;
         for (int b = 0; b < 2 && e == hipSuccess; ++b)
             e = hipMalloc(&s.d_hist[b], (size_t)s.hist * (size_t)s.hist_elem + 64);
     }
@@ -674,6 +675,19 @@ static bool stage0_fused(const pddc_pipeline *p)
 
 int pddc_pipeline_uses_fused(const pddc_pipeline *p) { return p && stage0_fused(p) ? 1 : 0; }
 
+/* a first stage that is a plain decimator but not the fused decimate-by-8 (e.g. the /10 of the
+ * 1.6 MS/s plan): the generic kernel reads the packed samples itself (unpack and mix while it
+ * stages), so no float2 intermediate is written.  Its history is then kept packed too.        */
+static bool stage0_packed_generic(const pddc_pipeline *p)
+{
+    return p->st[0].interp == 1 && !stage0_fused(p) && !(p->flags & PDDC_F_NO_FAST);
+}
+
+int pddc_pipeline_stage0_reads_packed(const pddc_pipeline *p)
+{
+    return p && (stage0_fused(p) || stage0_packed_generic(p)) ? 1 : 0;
+}
+
 /* stages 0+1 run as one kernel when: stage 0 is the fused decimate-by-8, stage 1
  * is a plain decimate-by-8 with <= 64 taps, the batch is whole tiles, and both
  * stages sit on an 8-sample phase boundary */
@@ -829,6 +843,14 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             fill_fir8_args(p, a);
             HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s));
             hist_done = a.hist_out != nullptr;
+        } else if (i == 0 && stage0_packed_generic(p)) {
+            if (n_in[1] > 0) {
+                HIP_TRY(launch_fir_generic_packed(d_packed, h_in, st.hist, (long long)off[0], (long long)n_in[1],
+                                                  st.decim, st.d_taps, st.ntaps, dst, h_out, (long long)nsamples, mix,
+                                                  p->n0, p->freg, p->phase_off, p->freg_applied, p->lo_c, p->lo_s,
+                                                  p->lo_c_applied, p->lo_s_applied, s));
+                hist_done = true;             /* block 0 of the kernel wrote the new (packed) history */
+            }
         } else {
             if (i == 0) {
                 /* generic first stage: unpack(+mix) to float2, then the generic FIR */

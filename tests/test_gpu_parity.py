@@ -830,3 +830,74 @@ def test_reference_client_on_gpu_path_fpga_emulation(pkg, dev, O, tmp_path, monk
                       freg=O.nco_freg(7.1e6), mix=True)
     # float path tolerance + one 24-bit quantisation step of the wire format
     assert O.rel_err(y, ref[: y.size]) <= FIR_TOL + 1.0 / 8388607 / np.max(np.abs(ref))
+
+
+# ------------------------------ any first decimation reads the packed samples itself (no float2 intermediate)
+@pytest.mark.parametrize("D,nt,mix", [(10, 69, True), (10, 69, False), (5, 161, True), (3, 17, True), (1, 9, True),
+                                      (40, 401, False), (7, 250, True)])
+def test_packed_generic_first_stage(pkg, dev, O, D, nt, mix):
+    """Stage 0 of a plan whose first decimation is not 8 (the reference's 1.6 MS/s rate is 80 MS/s / (10*5)):
+    the generic decimator unpacks and mixes while it stages its input span; tiny and uneven batches carry the
+    packed history and the decimation phase."""
+    rng = np.random.default_rng(D * 1000 + nt)
+    h = (rng.standard_normal(nt) / np.sqrt(nt)).astype(np.float32)
+    ns = 8 * 2600
+    packed = O.lcg_bytes(6 * ns, 4242)
+    freg = 0x9E3779B1
+    ref = O.ddc_chain(packed, [(D, h)], freg=freg, mix=mix)
+    pipe = pkg.Pipeline([(D, h)], mix=mix)
+    assert pipe.stage0_reads_packed and not pipe.fused
+    if mix:
+        pipe.set_freg(freg)
+    cuts = [0, 8, 16, 8 * 30, 8 * 31, 8 * 700, 8 * 1999, ns]          # 8-sample batches: no output, history only
+    y = np.concatenate([pipe.process(to_dev(packed[6 * a:6 * b], dev)).cpu().numpy().reshape(-1)
+                        for a, b in zip(cuts[:-1], cuts[1:])])
+    assert y.size == ref.size
+    assert O.rel_err(y, ref) <= FIR_TOL
+    slow = pkg.Pipeline([(D, h)], mix=mix, no_fast=True)              # unpack kernel -> float2 -> generic
+    assert not slow.stage0_reads_packed
+    if mix:
+        slow.set_freg(freg)
+    ys = slow.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+    assert O.rel_err(ys, ref) <= FIR_TOL and O.rel_err(y, ys) <= FIR_TOL
+    pipe.close()
+    slow.close()
+
+
+def test_perseus_api_1600k_plan_is_fused_end_to_end(pkg, dev, O, monkeypatch):
+    """The 1.6 MS/s rate (10*5): first stage /10 through the packed-input generic kernel, vs the oracle."""
+    import ctypes as C
+    import time
+    monkeypatch.setenv("PERSEUS_AMD_PACE", "0")
+    monkeypatch.delenv("PERSEUS_AMD_DEVICES", raising=False)
+    L = pkg.sdr_lib()
+    L.perseus_set_debug(0)
+    assert L.perseus_init() == 1
+    d = L.perseus_open(0)
+    L.perseus_firmware_download(d, None)
+    assert L.perseus_set_sampling_rate(d, 1600000) == 0
+    assert L.perseus_set_ddc_center_freq(d, C.c_double(21.3e6), 1) == 0
+    cfg = pkg.AmdConfig()
+    L.perseus_amd_get_config(d, C.byref(cfg))
+    cfg.mode, cfg.pace, cfg.batch_samples, cfg.max_buffers = 1, 0, 8 * 25000, 12
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    dec, nt = (C.c_int * 4)(), (C.c_int * 4)()
+    n = L.perseus_amd_get_plan(d, dec, nt, None)
+    assert list(dec)[:n] == [10, 5]
+    taps = [np.zeros(nt[i], np.float32) for i in range(n)]
+    arr = (C.POINTER(C.c_float) * 4)(*[t.ctypes.data_as(C.POINTER(C.c_float)) for t in taps], None, None)
+    L.perseus_amd_get_plan(d, dec, nt, arr)
+    got = []
+    cb = pkg.PERSEUS_CALLBACK(lambda b, nbytes, x: got.append(C.string_at(b, nbytes)) or 0)
+    assert L.perseus_start_async_input(d, 6144, cb, None) == 0, L.perseus_errorstr()
+    t0 = time.time()
+    while L.perseus_amd_source_running(d) and time.time() - t0 < 60:
+        time.sleep(0.005)
+    assert L.perseus_stop_async_input(d) == 0
+    L.perseus_exit()
+    y = np.frombuffer(b"".join(got), dtype=np.float32)
+    assert y.size == 12 * 1536
+    need = (y.size // 2) * 50
+    ref = O.ddc_chain(O.lcg_bytes(6 * need, 12345), [(dec[i], taps[i]) for i in range(n)], freg=O.nco_freg(21.3e6),
+                      mix=True)
+    assert O.rel_err(y, ref[:y.size]) <= FIR_TOL
