@@ -3,11 +3,13 @@ stream per rank (the reference models up to 8 receivers as 8 independent
 descriptors, perseus-sdr.c:43-47) -- or ONE stream cut into
 contiguous time chunks, chunk g on GPU g, each re-reading a halo of history
 (8e (2): time_chunks / cascade_halo / Pipeline.seek).  The data path needs no
-collective either way; RCCL (torch.distributed backend "nccl") is used only to
-  - broadcast the configuration (taps, NCO word, stage plan) from rank 0,
-  - reduce the step time (MAX over ranks) for the benchmark,
-  - optionally gather the decimated output to rank 0 (BASELINE config 4).
-All functions work on any torch.distributed backend (tests use gloo on CPU).
+collective either way.  What crosses GPUs -- the configuration broadcast, the MAX
+of the step time, the optional gather of the decimated output (BASELINE config 4)
+-- is done by the C library's own RCCL calls (pddc_comm_*, csrc/ddc_multi.cpp)
+through RcclGroup below; torch.distributed only carries the rendezvous (a gloo
+group for the 128-byte RCCL id).  The module-level helpers (broadcast_config,
+gather_to_root, ...) are the torch.distributed forms the CPU tests run on gloo,
+where no GPU and hence no RCCL exists.
 """
 from __future__ import annotations
 

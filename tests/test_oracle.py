@@ -154,3 +154,23 @@ def test_fir_and_resampler_against_scipy_upfirdn(O):
         got = y[0::2] + 1j * y[1::2]
         assert got.size == (xc.size * L + M - 1) // M
         assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), (L, M)
+
+
+def test_retuned_nco_is_a_phase_accumulator(O):
+    """N4: the NCO retuned while it runs.  C statement vs the independent numpy one; one segment
+    equals the plain NCO; the phase is continuous at a switch (no jump), and a window of the stream
+    can be computed on its own (n0)."""
+    x = O.unpack24_f32(O.lcg_bytes(6 * 6000, 3))
+    assert np.array_equal(O.nco_mix_retuned(x, [(0, 381178347)]), O.nco_mix(x, 381178347, 0))
+    segs = [(0, 381178347), (1024, 123456789), (3000, 4000000000), (3008, 1)]
+    c = O.nco_mix_retuned(x, segs)
+    assert np.max(np.abs(c - O.nco_mix_retuned_numpy(x, segs))) < 1e-12
+    assert np.array_equal(O.nco_mix_retuned(x[2 * 2000:], segs, 2000), c[4000:])
+    # continuity: with a constant input the output's phase advances by exactly the word in force
+    ones = np.tile(np.array([1.0, 0.0], np.float32), 4000)
+    z = O.nco_mix_retuned(ones, segs)
+    ph = np.unwrap(np.angle(z[0::2] + 1j * z[1::2]))
+    step = -np.diff(ph) / (2 * np.pi) * 2 ** 32
+    for (a, w), b in zip(segs, [s[0] for s in segs[1:]] + [4000]):
+        ww = w if w < 2 ** 31 else w - 2 ** 32
+        assert np.allclose(step[a:b - 1], ww, atol=1e-3 * 2 ** 32 / (2 * np.pi) * 1e-6 + 2.0)

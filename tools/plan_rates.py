@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Throughput of the drop-in API's ten rate plans at the kernel ABI: device-resident
+2^26-sample batches through pddc_pipeline_process, NCO on.  For each plan: GS/s, ms per batch, whether stage 0
+reads the packed samples itself, and -- with --no-fast -- the unfused path (unpack kernel -> float2 -> generic).
+Run under `rocprofv3 --kernel-trace --stats` to get the per-kernel split (k_resample's share of a plan)."""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+pkg = importlib.import_module("libperseus-sdr_amd")
+ap = argparse.ArgumentParser()
+ap.add_argument("--log2n", type=int, default=26)
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--rates", default="")
+ap.add_argument("--no-fast", action="store_true")
+a = ap.parse_args()
+
+L = pkg.sdr_lib()
+os.environ["PERSEUS_AMD_DEVICES"] = "1"
+L.perseus_set_debug(0)
+assert L.perseus_init() == 1
+d = L.perseus_open(0)
+L.perseus_firmware_download(d, None)
+rates = (C.c_int * 12)()
+L.perseus_get_sampling_rates(None, rates, 12)
+want = [int(r) for r in a.rates.split(",") if r] or [r for r in rates if r]
+dev = torch.device("cuda:0")
+ns = 1 << a.log2n
+d_in = pkg.synth_lcg(6 * ns, 12345, 0, dev)
+st = torch.cuda.current_stream(dev).cuda_stream
+res = []
+for rate in want:
+    L.perseus_set_sampling_rate(d, rate)
+    dec, nt, it = (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)()
+    n = L.perseus_amd_get_plan(d, dec, nt, None)
+    taps = [np.zeros(nt[i], np.float32) for i in range(n)]
+    arr = (C.POINTER(C.c_float) * 4)(*([t.ctypes.data_as(C.POINTER(C.c_float)) for t in taps] + [None] * (4 - n)))
+    L.perseus_amd_get_plan(d, dec, nt, arr)
+    L.perseus_amd_get_plan_interp(d, it)
+    stages = [(dec[i], taps[i], it[i]) for i in range(n)]
+    pipe = pkg.Pipeline(stages, mix=True, no_fast=a.no_fast)
+    pipe.set_freg(381178347)
+    out = torch.empty((pipe.max_output(ns) + 8, 2), dtype=torch.float32, device=dev)
+    for _ in range(3):
+        pipe.process_ptr(d_in.data_ptr(), ns, out.data_ptr(), out.shape[0], st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        pipe.process_ptr(d_in.data_ptr(), ns, out.data_ptr(), out.shape[0], st)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / a.iters * 1e3
+    r = {"rate": rate, "plan": "*".join(f"{dec[i]}" + (f"(x{it[i]})" if it[i] > 1 else "") for i in range(n)),
+         "ntaps": [nt[i] for i in range(n)], "ms_per_2^%d" % a.log2n: round(ms, 4), "GS_per_s": round(ns / ms / 1e6, 1),
+         "stage0_reads_packed": pipe.stage0_reads_packed, "fused8": pipe.fused, "fused_pair": pipe.fused_pair(ns)}
+    res.append(r)
+    print(json.dumps(r), flush=True)
+    pipe.close()
+L.perseus_exit()
