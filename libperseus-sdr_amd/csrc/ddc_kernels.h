@@ -49,12 +49,14 @@ struct Fir8Args {
 constexpr float kFir8PackedTapScale = 0x1.000002p-31f;
 
 /* tile geometry of k_fir8<NTB,R>: inputs per block tile */
-constexpr int fir8_tile_inputs(int R) { return 1024 * R; }
+constexpr int fir8_tile_inputs(int R, int NT = 256) { return 4 * NT * R; }
 size_t fir8_lds_bytes(int ntb, int R);
 bool   fir8_supported(int ntb, int R);
 /* the two-level tile schedule a launch over n_in samples would use (tests place their
  * comparison windows on its seams) */
-void   fir8_schedule_query(long long n_in, int R, bool fused, int *ntiles, int *nblocks, int *S, int *K);
+void   fir8_schedule_query(long long n_in, int R, bool fused, int NT, int *ntiles, int *nblocks, int *S, int *K);
+/* block sizes of k_fir8: 256 threads always; 128 (four independent blocks per CU) for R = 8 packed first stages */
+bool   fir8_nt_supported(int ntb, int R, int NT);
 void   fir8_set_grid_blocks(int nblocks);   /* persistent grid override (0 = resident blocks x CUs) */
 
 /* packed -> [mix] -> /8 -> /8 in one kernel: `out` receives the SECOND stage's
@@ -63,7 +65,7 @@ bool fir8_fused2_supported(int ntb, int ntb2, int R);
 hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipStream_t s);
 
 /* returns hipSuccess or the launch error */
-hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s);
+hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s, int NT = 256);
 
 hipError_t launch_unpack24(const void *d_in, long long nsamples, void *d_out, bool to_i32,
                            bool mix, unsigned long long n0, uint32_t freg, uint32_t phase_off,

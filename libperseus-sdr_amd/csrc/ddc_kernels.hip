@@ -53,6 +53,13 @@
 
 #define PDDC_CONSTANT __attribute__((address_space(4)))
 
+#ifndef PDDC_PRIO_U
+#define PDDC_PRIO_U 0
+#endif
+#ifndef PDDC_PRIO_F
+#define PDDC_PRIO_F 2
+#endif
+
 namespace pddc {
 
 /* float = (float)(v24*256) * RN(1/2147483392): the int->float convert is exact
@@ -308,12 +315,12 @@ __device__ __forceinline__ int goff(int G)
     return 8 + 8 * G + 4 * (G / 8);
 }
 
-template <int NTB, int R>
+template <int NTB, int R, int NT = 256>
 struct Fir8Geom {
-    static constexpr int TI      = 1024 * R;            /* inputs per tile          */
-    static constexpr int TO      = 128 * R;             /* outputs per tile         */
+    static constexpr int TI      = 4 * NT * R;          /* inputs per tile: NT/2 lanes per plane x 8R */
+    static constexpr int TO      = TI / 8;              /* outputs per tile         */
     static constexpr int GT      = TI / 8;              /* new groups per tile      */
-    static constexpr int GPT     = GT / 256;            /* groups per thread / tile */
+    static constexpr int GPT     = GT / NT;             /* groups per thread / tile */
     static constexpr int NG      = GT + NTB;            /* groups incl. history     */
     static constexpr int PLANE   = 8 + 8 * NG + 4 * (NG / 8) + 8;   /* floats      */
     static constexpr int OT      = 2 * TO;              /* output staging, floats   */
@@ -553,9 +560,12 @@ __device__ __forceinline__ void fir_window_tap_outer(const float *base, const fl
  *                 third barrier is needed).                                */
 /* (PDDC_ABLATE_LOADS / _FIR / _STORES: timing-only builds with one part of the kernel removed,
  * tools/ablate.sh; their outputs are garbage.)                                              */
-template <int NTB, int R, int INFMT, bool MIX, int NTB2>
-__global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, int K)
+/* NT = threads per block.  256 (4 waves: two per plane) is the default; 128 (R = 8 only: one wave per
+ * plane, half the tile, half the LDS) lets four independent blocks share a CU instead of two.       */
+template <int NTB, int R, int INFMT, bool MIX, int NTB2, int NT = 256>
+__global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, int K)
 {
+    static_assert(NT == 256 || (NT == 128 && R == 8 && NTB2 == 0), "128-thread blocks: R = 8, no fused second stage");
 #ifdef PDDC_CLOCK_PROBE
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
         g_probe[blockIdx.x].c0 = clock64();
@@ -567,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
         g_probe[blockIdx.x].xcc = xcc;
     }
 #endif
-    using G = Fir8Geom<NTB, R>;
+    using G = Fir8Geom<NTB, R, NT>;
     using G2 = Fir8Geom2<NTB2, R>;
     constexpr bool FUSE2 = NTB2 > 0;     /* a second decimate-by-8 stage runs on the tile's outputs in LDS */
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -667,15 +677,15 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
 #ifdef PDDC_ABLATE_LOADS
                     rawA[k][w] = u32x4{ (unsigned)tile * 2654435761u + tid, (unsigned)(k + w) << 20, (unsigned)tile << 9, 77u * tid };
 #else
-                    rawA[k][w] = src0[(256 * k * 8 * ES) / 16 + w];
+                    rawA[k][w] = src0[(NT * k * 8 * ES) / 16 + w];
 #endif
         } else {                                        /* ragged last tile */
 #pragma unroll
             for (int k = 0; k < G::GPT; ++k) {
-                const bool have = tin0 + 8LL * (gtid + 256 * k) < p.n_in;
+                const bool have = tin0 + 8LL * (gtid + NT * k) < p.n_in;
 #pragma unroll
                 for (int w = 0; w < NW; ++w)
-                    rawA[k][w] = have ? src0[(256 * k * 8 * ES) / 16 + w] : u32x4{ 0u, 0u, 0u, 0u };
+                    rawA[k][w] = have ? src0[(NT * k * 8 * ES) / 16 + w] : u32x4{ 0u, 0u, 0u, 0u };
             }
         }
         if (with_hist && tid < NTB) {                   /* groups 0..NTB-1: the 8*NTB samples before the tile */
@@ -718,8 +728,8 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
         constexpr int NCH = G::TO / 2;                             /* 16-byte chunks */
         if (tile_o0 + G::TO <= n_out) {                            /* whole tile in range (uniform) */
 #pragma unroll
-            for (int it = 0; it < NCH / 256; ++it) {
-                const int q = tid + 256 * it;
+            for (int it = 0; it < NCH / NT; ++it) {
+                const int q = tid + NT * it;
                 const int qs = q ^ ((q >> 3) & 7);
                 /* streaming (nt) store: measured 0.349 vs 0.371 ms for this 6:1
                  * read/write mix (tools/ubench/stream_mix.hip) */
@@ -743,8 +753,8 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
             }
         } else {
 #pragma unroll
-            for (int it = 0; it < NCH / 256; ++it) {
-                const int q = tid + 256 * it;
+            for (int it = 0; it < NCH / NT; ++it) {
+                const int q = tid + NT * it;
                 const int qs = q ^ ((q >> 3) & 7);
                 float4 v = *reinterpret_cast<const float4 *>(ot + 4 * qs);
                 if (MIX) {
@@ -777,11 +787,11 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
         wg_c[k] = 1.0f;
         wg_s[k] = 0.0f;
         if (MIX && !WTAB)
-            nco_lo((uint32_t)(8 * (gtid + 256 * k)) * p.freg, wg_c[k], wg_s[k]);
+            nco_lo((uint32_t)(8 * (gtid + NT * k)) * p.freg, wg_c[k], wg_s[k]);
         if (WTAB) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                nco_lo((uint32_t)(8 * (gtid + 256 * k) + e) * p.freg, w_c[k][e], w_s[k][e]);
+                nco_lo((uint32_t)(8 * (gtid + NT * k) + e) * p.freg, w_c[k][e], w_s[k][e]);
         }
     }
     if (MIX)
@@ -804,13 +814,18 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
         grabv = atomicAdd(p.sched, 1u);
 
     for (;;) {
+        /* wave issue priority: the FIR phase runs at PDDC_PRIO_F (2), everything else at PDDC_PRIO_U (0).
+         * When the two waves of a SIMD both want to issue, the one inside its FMA run goes first and the
+         * other's loads / LDS traffic fill the gaps: 255 taps 0.481 -> 0.466 ms, 127 taps 0.3669 -> 0.3650,
+         * x320 cascade unchanged (same-box A/B, profiles/r02/ab_prio.txt); the reverse (loads first) gains nothing */
+        __builtin_amdgcn_s_setprio(PDDC_PRIO_U);
         const bool last = (t + 1 == c_hi);            /* last tile of its chunk */
         /* ---- U: registers -> LDS planes (groups NTB ..; a chunk's first tile also 0..NTB-1) ---- */
         float pt_c, pt_s;                                /* this tile's phasor, used when its outputs leave */
         tile_phasor(t, pt_c, pt_s);
 #pragma unroll
         for (int k = 0; k < G::GPT; ++k) {
-            const int v = NTB + gtid + 256 * k;
+            const int v = NTB + gtid + NT * k;
             float xi[8], xq[8];
             group_to_float<INFMT, false, NW>(rawA[k], xi, xq, 0ull, p);
             if (WTAB) {
@@ -887,6 +902,7 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
          * into its even and odd terms: acc.x += h[k]*x[i], acc.y += h[k-1]*x[i+1]
          * -- both operands are natural adjacent pairs (SGPR pair of taps, VGPR
          * pair of samples from one ds_read_b128), no broadcast, no shuffles.   */
+        __builtin_amdgcn_s_setprio(PDDC_PRIO_F);
         asm volatile("" : "+s"(hb));      /* keep the tap s_loads inside the tile loop (no SGPR spills) */
         if (FUSE2)
             asm volatile("" : "+s"(hb2));
@@ -935,8 +951,8 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
         __syncthreads();                                           /* B */
 
         /* ---- C: tail groups -> history of the next tile of the chunk -------- */
-        if (!last && gtid >= 256 - NTB) {
-            const int gd = gtid - (256 - NTB);                      /* 0..NTB-1 */
+        if (!last && gtid >= NT - NTB) {
+            const int gd = gtid - (NT - NTB);                       /* 0..NTB-1 */
             const int os = goff<R>(G::GT + gd), od = goff<R>(gd);
             float4 i0 = *reinterpret_cast<const float4 *>(sI + os);
             float4 i1 = *reinterpret_cast<const float4 *>(sI + os + 4);
@@ -1045,7 +1061,7 @@ __global__ __launch_bounds__(256, 2) void k_fir8(Fir8Args p, int ntiles, int S, 
         constexpr int HCH = 8 * NTB * ES / 16;                     /* 16-byte chunks */
         const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(p.in) +
                                                            (p.n_in - 8 * NTB) * ES);
-        for (int c = tid; c < HCH; c += 256)
+        for (int c = tid; c < HCH; c += NT)
             static_cast<uint4 *>(p.hist_out)[c] = src[c];
     }
     leave();
@@ -1073,7 +1089,7 @@ static int g_fir8_blocks = 0;       /* override (development) */
 struct Fir8Sched {
     int nblocks, S, K;
 };
-static Fir8Sched fir8_schedule(int ntiles, int R, bool fused)
+static Fir8Sched fir8_schedule(int ntiles, int R, bool fused, int NT = 256)
 {
     /* read per launch (two getenv calls against a launch of several microseconds), so a
      * test can switch schedules inside one process */
@@ -1083,29 +1099,30 @@ static Fir8Sched fir8_schedule(int ntiles, int R, bool fused)
     e = getenv("PDDC_FIR8_CHUNK");
     const int chunk = e ? atoi(e) : 0;
     Fir8Sched sc;
-    const int want = g_fir8_blocks > 0 ? g_fir8_blocks : kFir8DefaultBlocks;
+    /* 128-thread blocks: four per CU, tiles half as long (chunks of twice as many) */
+    const int want = g_fir8_blocks > 0 ? g_fir8_blocks : kFir8DefaultBlocks * (256 / NT);
     sc.nblocks = ntiles < want ? ntiles : want;
-    sc.K = chunk > 0 ? chunk : (fused ? 8 : (R == 4 ? 4 : 2));
+    sc.K = chunk > 0 ? chunk : (fused ? 8 : (R == 4 ? 4 : 2) * (256 / NT));
     const int pct = dyn_pct >= 0 ? dyn_pct : (fused ? 0 : 20);
     sc.S = (int)((long long)ntiles * (100 - pct) / 100 / sc.nblocks);
     return sc;
 }
 
-void fir8_schedule_query(long long n_in, int R, bool fused, int *ntiles, int *nblocks, int *S, int *K)
+void fir8_schedule_query(long long n_in, int R, bool fused, int NT, int *ntiles, int *nblocks, int *S, int *K)
 {
-    const long long TI = 1024LL * R;
+    const long long TI = 4LL * NT * R;
     const int nt = (int)((n_in + TI - 1) / TI);
-    const Fir8Sched sc = fir8_schedule(nt, R, fused);
+    const Fir8Sched sc = fir8_schedule(nt, R, fused, NT);
     *ntiles = nt;
     *nblocks = sc.nblocks;
     *S = sc.S;
     *K = sc.K;
 }
 
-template <int NTB, int R>
+template <int NTB, int R, int NT = 256>
 static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s)
 {
-    using G = Fir8Geom<NTB, R>;
+    using G = Fir8Geom<NTB, R, NT>;
     const size_t lds = (size_t)G::LDS_FLT * sizeof(float);
     const long long ntiles_ll = (a.n_in + G::TI - 1) / G::TI;
     if (ntiles_ll <= 0)
@@ -1115,8 +1132,8 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
     const int ntiles = (int)ntiles_ll;
     if (a.sched == nullptr)
         return hipErrorInvalidValue;
-    const Fir8Sched sc = fir8_schedule(ntiles, R, false);
-    const dim3 grid((unsigned)sc.nblocks), blk(256);
+    const Fir8Sched sc = fir8_schedule(ntiles, R, false, NT);
+    const dim3 grid((unsigned)sc.nblocks), blk(NT);
 #define PDDC_LAUNCH(FMT, MIXV)                                                                    \
     do {                                                                                          \
         static unsigned long long attr_done = 0;   /* one bit per device: the attribute is per device */ \
@@ -1124,21 +1141,23 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
         (void)hipGetDevice(&dev__);                                                               \
         if (!(attr_done >> (dev__ & 63) & 1ull)) {                                                \
             hipError_t e = hipFuncSetAttribute(                                                   \
-                reinterpret_cast<const void *>(&k_fir8<NTB, R, FMT, MIXV, 0>),                    \
+                reinterpret_cast<const void *>(&k_fir8<NTB, R, FMT, MIXV, 0, NT>),                \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
             if (e != hipSuccess)                                                                  \
                 return e;                                                                         \
             attr_done |= 1ull << (dev__ & 63);                                                    \
         }                                                                                         \
-        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV, 0>), grid, blk, lds, s, a, ntiles, sc.S, sc.K); \
+        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV, 0, NT>), grid, blk, lds, s, a, ntiles, sc.S, sc.K); \
     } while (0)
     if (fmt == IN_PACKED24) {
         if (mix)
             PDDC_LAUNCH(IN_PACKED24, true);
         else
             PDDC_LAUNCH(IN_PACKED24, false);
-    } else {
+    } else if constexpr (NT == 256) {
         PDDC_LAUNCH(IN_F32C, false);
+    } else {
+        return hipErrorInvalidValue;         /* 128-thread blocks exist for the packed first stage only */
     }
 #undef PDDC_LAUNCH
     return hipGetLastError();
@@ -1201,10 +1220,37 @@ hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipSt
 
 void fir8_set_grid_blocks(int nblocks) { g_fir8_blocks = nblocks > 0 ? nblocks : 0; }
 
-hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s)
+bool fir8_nt_supported(int ntb, int R, int NT)
+{
+#ifdef PDDC_EXPERIMENT_NT128
+    if (NT == 128 && R == 8 && (ntb == 8 || ntb == 16 || ntb == 32))
+        return true;
+#endif
+    (void)ntb;
+    (void)R;
+    return NT == 256;
+}
+
+hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s, int NT)
 {
     if (fmt == IN_F32C && mix)
         return hipErrorInvalidValue;
+#ifdef PDDC_EXPERIMENT_NT128
+    /* 128-thread blocks (four independent blocks per CU instead of two) -- measured, not faster: 127 taps
+     * 0.377 vs 0.367 ms, and at 255 taps only three such blocks fit the LDS (0.613 vs 0.482 ms); kept
+     * behind this macro for the record, not instantiated in the product build          */
+    if (NT == 128) {
+        if (fmt != IN_PACKED24 || R != 8)
+            return hipErrorInvalidValue;
+        if (ntb == 8) return launch_fir8_t<8, 8, 128>(fmt, mix, a, s);
+        if (ntb == 16) return launch_fir8_t<16, 8, 128>(fmt, mix, a, s);
+        if (ntb == 32) return launch_fir8_t<32, 8, 128>(fmt, mix, a, s);
+        return hipErrorInvalidValue;
+    }
+#else
+    if (NT != 256)
+        return hipErrorInvalidValue;
+#endif
 #define PDDC_CASE(N, RR)                                                                          \
     if (ntb == N && R == RR)                                                                      \
         return launch_fir8_t<N, RR>(fmt, mix, a, s)

@@ -97,6 +97,7 @@ struct pddc_pipeline {
     float lo_c_applied[8], lo_s_applied[8];   /* step phasors of freg_applied */
     unsigned long long n0 = 0;    /* absolute sample counter (stage 0 input)    */
     int R = 4;                    /* outputs per lane of the fused kernel (4: 16 waves/CU) */
+    int NT = 256;                 /* threads per block of the unfused stage-0 kernel (128: four blocks per CU) */
     /* staging for push_host / push_host_async: two slots, so that the H2D copy of batch k+1,
      * the kernels of batch k and the D2H copy of batch k-1 run at the same time (three streams,
      * PCIe is full duplex); a slot is reused only after its previous D2H has finished        */
@@ -410,6 +411,9 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
      * 0.348 ms, 255 taps 0.52 -> 0.48 ms), 4 for the short first stages of a cascade */
     if (!getenv("PDDC_FIR8_R"))
         p->R = p->st[0].ntb >= 16 ? 8 : 4;
+    if (const char *e = getenv("PDDC_FIR8_NT"))
+        if (fir8_nt_supported(p->st[0].ntb, p->R, atoi(e)))
+            p->NT = atoi(e);
     compute_lo_steps(p);
     hipError_t e = hipSuccess;
     for (int i = 0; i < nstages && e == hipSuccess; ++i) {
@@ -841,7 +845,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             a.taps_blk = st.d_taps_blk;
             a.n_in = (long long)nsamples;
             fill_fir8_args(p, a);
-            HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s));
+            HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s, p->NT));
             hist_done = a.hist_out != nullptr;
         } else if (i == 0 && stage0_packed_generic(p)) {
             if (n_in[1] > 0) {
@@ -1089,8 +1093,9 @@ int pddc_pipeline_schedule(const pddc_pipeline *p, size_t nsamples, int out[5])
     if (!stage0_fused(p))
         return fail(PDDC_ESTATE, "stage 0 does not run the fused kernel");
     const bool fuse2 = stages01_fusable(p, nsamples);
-    out[0] = fir8_tile_inputs(p->R);
-    fir8_schedule_query((long long)nsamples, p->R, fuse2, &out[1], &out[2], &out[3], &out[4]);
+    const int nt = fuse2 ? 256 : p->NT;
+    out[0] = fir8_tile_inputs(p->R, nt);
+    fir8_schedule_query((long long)nsamples, p->R, fuse2, nt, &out[1], &out[2], &out[3], &out[4]);
     return PDDC_OK;
 }
 
@@ -1161,7 +1166,7 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
         if (fuse2)
             HIP_TRY(launch_fir8_fused2(p->st[0].ntb, p->R, mix, a, s));
         else
-            HIP_TRY(launch_fir8(p->st[0].ntb, p->R, IN_PACKED24, mix, a, s));
+            HIP_TRY(launch_fir8(p->st[0].ntb, p->R, IN_PACKED24, mix, a, s, p->NT));
     }
     HIP_TRY(hipEventRecord(e1, s));
     HIP_TRY(hipEventSynchronize(e1));
