@@ -104,6 +104,14 @@ hipError_t launch_resample(const float *in, const float *hist, int H, unsigned l
                            unsigned long long m0, long long n_out, int L, int M, const float *taps, int ntaps,
                            float *out, hipStream_t s);
 
+/* The same from LDS-staged input and polyphase-ordered taps gpoly[ph*Kp + j] = h[j*L + ph] (K = ceil(ntaps/L)
+ * taps per phase, rows zero-padded to Kp, a multiple of 4); also writes the next history (hist_out, or NULL):
+ * the last H samples of [hist | in(n_batch)].  resample_lds_supported: the block's input span fits the LDS. */
+bool resample_lds_supported(int L, int M, int ntaps);
+hipError_t launch_resample_lds(const float *in, const float *hist, int H, unsigned long long consumed,
+                               unsigned long long m0, long long n_out, int L, int M, const float *gpoly, int K, int Kp,
+                               float *out, float *hist_out, long long n_batch, hipStream_t s);
+
 /* float32 I/Q -> 24-bit packed (6 B/sample); in and out 16-byte aligned */
 hipError_t launch_pack24(const float *in, long long nsamples, void *out, hipStream_t s);
 

@@ -1687,6 +1687,64 @@ __global__ __launch_bounds__(256) void k_resample(const float *__restrict__ in, 
     *reinterpret_cast<float2 *>(out + 2 * q) = make_float2(ar0 + ar1, ai0 + ai1);
 }
 
+/* The same with the block's input span staged in LDS and the taps in polyphase order
+ * g[ph][j] = h[j*L + ph] (rows of Kp floats, zero padded, Kp % 4 == 0): every load of the tap loop
+ * is independent of the others (float4 rows from L1/L2, samples from LDS), where the direct form
+ * above walks 50+ dependent L2 round trips per output (23 us for the 80 k outputs of a 2^26-sample
+ * batch of the 96 kS/s plan, 15 % of that plan's step).  Block 0 also leaves the next call's
+ * history, so no separate update kernel runs behind a rational stage.                          */
+__global__ __launch_bounds__(256) void k_resample_lds(const float2 *__restrict__ in, const float2 *__restrict__ hist,
+                                                       int H, unsigned long long consumed, unsigned long long m0,
+                                                       long long n_out, int L, int M, const float *__restrict__ gpoly,
+                                                       int K, int Kp, float2 *__restrict__ out, int span_max,
+                                                       float2 *__restrict__ hist_out, long long n_batch)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 xs[];
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const long long q0 = (long long)blockIdx.x * NT;
+    /* first input the block needs: n(q0) - (K - 1); n(m) = floor(m*M/L) - consumed (batch-relative) */
+    const unsigned long long t0 = (m0 + (unsigned long long)q0) * (unsigned long long)M;
+    const long long n_lo = (long long)(t0 / (unsigned long long)L) - (long long)consumed - (K - 1);
+    for (int i = tid; i < span_max; i += NT) {
+        const long long xi = n_lo + i;
+        float2 v = make_float2(0.0f, 0.0f);
+        if (xi < 0) {
+            if (xi >= -(long long)H)
+                v = hist[xi + H];
+        } else if (xi < n_batch) {
+            v = in[xi];
+        }
+        xs[i] = v;
+    }
+    if (hist_out != nullptr && blockIdx.x == 0) {
+        for (int i = tid; i < H; i += NT) {
+            const long long j = (long long)i + n_batch;
+            hist_out[i] = j < H ? hist[j] : in[j - H];
+        }
+    }
+    __syncthreads();
+    const long long q = q0 + tid;
+    if (q >= n_out)
+        return;
+    const unsigned long long t = (m0 + (unsigned long long)q) * (unsigned long long)M;
+    const int nl = (int)((long long)(t / (unsigned long long)L) - (long long)consumed - n_lo);   /* LDS index of x[n] */
+    const int ph = (int)(t % (unsigned long long)L);
+    const f32x4 *g = reinterpret_cast<const f32x4 *>(gpoly + (size_t)ph * Kp);
+    f32x2 acc[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+    for (int j4 = 0; j4 < Kp; j4 += 4) {
+        const f32x4 h4 = g[j4 >> 2];
+        const float hh[4] = { h4.x, h4.y, h4.z, h4.w };
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = nl - j4 - u;                      /* taps beyond K are zero, so clamp the index only */
+            const float2 xv = xs[idx >= 0 ? idx : 0];
+            acc[u] = __builtin_elementwise_fma(f32x2{ hh[u], hh[u] }, f32x2{ xv.x, xv.y }, acc[u]);
+        }
+    }
+    const f32x2 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    out[q] = make_float2(sum.x, sum.y);
+}
+
 hipError_t launch_resample(const float *in, const float *hist, int H, unsigned long long consumed,
                            unsigned long long m0, long long n_out, int L, int M, const float *taps, int ntaps,
                            float *out, hipStream_t s)
@@ -1695,6 +1753,48 @@ hipError_t launch_resample(const float *in, const float *hist, int H, unsigned l
         return hipSuccess;
     hipLaunchKernelGGL(k_resample, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, in, hist, H, consumed,
                        m0, n_out, L, M, taps, ntaps, out);
+    return hipGetLastError();
+}
+
+bool resample_lds_supported(int L, int M, int ntaps)
+{
+    if (L < 1 || M < 1)
+        return false;
+    const int K = (ntaps + L - 1) / L;
+    const long long span = (long long)(63) * M / L + K + 3;          /* at least 64 outputs per block must fit */
+    return span * 8 <= 64 * 1024;
+}
+
+hipError_t launch_resample_lds(const float *in, const float *hist, int H, unsigned long long consumed,
+                               unsigned long long m0, long long n_out, int L, int M, const float *gpoly, int K, int Kp,
+                               float *out, float *hist_out, long long n_batch, hipStream_t s)
+{
+    if (n_out <= 0)
+        return hipSuccess;
+    int NT = 256;
+    long long span = 0;
+    for (; NT >= 64; NT >>= 1) {
+        span = (long long)(NT - 1) * M / L + K + 3;
+        if (span * 8 <= 64 * 1024)
+            break;
+    }
+    if (NT < 64)
+        return hipErrorInvalidValue;
+    const size_t lds = (size_t)span * sizeof(float2);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static int attr_lds[64] = { 0 };
+    if ((int)lds > attr_lds[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resample_lds),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        attr_lds[dev & 63] = (int)lds;
+    }
+    hipLaunchKernelGGL(k_resample_lds, dim3((unsigned)((n_out + NT - 1) / NT)), dim3((unsigned)NT), lds, s,
+                       reinterpret_cast<const float2 *>(in), reinterpret_cast<const float2 *>(hist), H, consumed, m0, n_out,
+                       L, M, gpoly, K, Kp, reinterpret_cast<float2 *>(out), (int)span,
+                       reinterpret_cast<float2 *>(hist_out), n_batch);
     return hipGetLastError();
 }
 

@@ -64,6 +64,8 @@ struct Stage {
     float *d_taps = nullptr;      /* h[k] linear: points INTO d_taps_base (zero-padded on both sides) */
     float *d_taps_base = nullptr; /* the allocation                             */
     float *d_taps_blk = nullptr;  /* [ntb][8] block-reversed (fused kernel)     */
+    float *d_taps_poly = nullptr; /* rational stage: [L][Kp] polyphase rows g[ph][j] = h[j*L + ph] */
+    int poly_k = 0, poly_kp = 0;
     int ntb = 0;                  /* tap blocks if fused-capable, else 0        */
     int hist = 0;                 /* history length in samples (mult. of 8)     */
     int hist_elem = 8;            /* bytes per history sample: 6 packed, 8 float2 */
@@ -181,6 +183,22 @@ static int upload_taps(pddc_pipeline *p, int si)
         HIP_TRY(hipMalloc(&s.d_taps_base, sizeof(float) * padded.size()));
         HIP_TRY(hipMemcpy(s.d_taps_base, padded.data(), sizeof(float) * padded.size(), hipMemcpyHostToDevice));
         s.d_taps = s.d_taps_base + Z;
+    }
+    if (s.d_taps_poly) {
+        hipFree(s.d_taps_poly);
+        s.d_taps_poly = nullptr;
+    }
+    if (s.interp > 1 && resample_lds_supported(s.interp, s.decim, s.ntaps)) {
+        s.poly_k = (s.ntaps + s.interp - 1) / s.interp;
+        s.poly_kp = (s.poly_k + 3) / 4 * 4;
+        std::vector<float> g((size_t)s.interp * s.poly_kp, 0.0f);
+        for (int ph = 0; ph < s.interp; ++ph)
+            for (int j = 0; j < s.poly_k; ++j) {
+                const int k = j * s.interp + ph;
+                g[(size_t)ph * s.poly_kp + j] = k < s.ntaps ? s.taps[k] : 0.0f;
+            }
+        HIP_TRY(hipMalloc(&s.d_taps_poly, sizeof(float) * g.size()));
+        HIP_TRY(hipMemcpy(s.d_taps_poly, g.data(), sizeof(float) * g.size(), hipMemcpyHostToDevice));
     }
     s.ntb = stage_fused_capable(s) ? pick_ntb(s.ntaps) : 0;
     /* a second stage that can be fused behind stage 0 always uses 8 tap blocks
@@ -458,6 +476,8 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
             hipFree(p->st[i].d_taps_base);
         if (p->st[i].d_taps_blk)
             hipFree(p->st[i].d_taps_blk);
+        if (p->st[i].d_taps_poly)
+            hipFree(p->st[i].d_taps_poly);
         if (p->st[i].d_buf)
             hipFree(p->st[i].d_buf);
         for (int b = 0; b < 2; ++b)
@@ -879,10 +899,17 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                 HIP_TRY(launch_fir8(st.ntb, p->R, IN_F32C, false, a, s));
                 hist_done = a.hist_out != nullptr;
             } else if (st.interp > 1) {
-                if (n_in[i + 1] > 0)
+                if (n_in[i + 1] > 0 && st.d_taps_poly && !(p->flags & PDDC_F_NO_FAST)) {
+                    HIP_TRY(launch_resample_lds(static_cast<const float *>(x), static_cast<const float *>(h_in), st.hist,
+                                                st.consumed, m0[i], (long long)n_in[i + 1], st.interp, st.decim,
+                                                st.d_taps_poly, st.poly_k, st.poly_kp, dst, static_cast<float *>(h_out),
+                                                (long long)n_in[i], s));
+                    hist_done = true;
+                } else if (n_in[i + 1] > 0) {
                     HIP_TRY(launch_resample(static_cast<const float *>(x), static_cast<const float *>(h_in), st.hist,
                                             st.consumed, m0[i], (long long)n_in[i + 1], st.interp, st.decim,
                                             st.d_taps, st.ntaps, dst, s));
+                }
             } else if (n_in[i + 1] > 0) {
                 HIP_TRY(launch_fir_generic(static_cast<const float *>(x), static_cast<const float *>(h_in),
                                            st.hist, (long long)off[i], (long long)n_in[i + 1], st.decim,
