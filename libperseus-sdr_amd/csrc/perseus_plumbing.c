@@ -16,6 +16,9 @@
  *   -t sec    run time (10)                            -m count     stop after count buffers
  *   -o file   output ("perseusdata", "-" = stdout)     -p           float32 output (default int32)
  *   -d level  debug level (3)                          -F fifo      control FIFO (see below)
+ *   -N n      open n receivers (1..8, reference PERSEUS_MAX_DESCR; sets PERSEUS_AMD_DEVICES=n unless it is set):
+ *             every receiver gets the same settings and its own stream (seed 12345+i); in DDC mode receiver i
+ *             runs on GPU i % ngpu and all of them are in flight at once; output files get ".i" appended
  *
  * -F creates a named pipe and a control thread, as the reference example's fifo.c
  * does: each line is "<MHz as float>", "<Hz as integer>", "att <0..3>" or "quit";
@@ -29,6 +32,7 @@
 #include <stdatomic.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 typedef struct {
@@ -113,16 +117,18 @@ static void *fifo_thread(void *arg)
     return NULL;
 }
 
+#define MAX_RX 8
+
 int main(int argc, char **argv)
 {
-    int rate = 95000, nb = 6, bs = 1024, dbg = 3, seconds = 10, as_float = 0, test_fe = 1;
+    int rate = 95000, nb = 6, bs = 1024, dbg = 3, seconds = 10, as_float = 0, test_fe = 1, nrx = 1;
     long max_buffers = 0;
     double freq = 7000000.0;
     const char *outname = "perseusdata";
     const char *fifo = NULL;
     pthread_t fifo_tid;
     int c;
-    while ((c = getopt(argc, argv, "s:n:b:d:t:o:f:m:F:pah")) != -1) {
+    while ((c = getopt(argc, argv, "s:n:b:d:t:o:f:m:F:N:pah")) != -1) {
         switch (c) {
         case 's': rate = atoi(optarg); break;
         case 'n': nb = atoi(optarg); break;
@@ -133,6 +139,7 @@ int main(int argc, char **argv)
         case 'f': freq = atof(optarg); break;
         case 'm': max_buffers = atol(optarg); break;
         case 'F': fifo = optarg; break;
+        case 'N': nrx = atoi(optarg); break;
         case 'p': as_float = 1; break;
         case 'a': test_fe = 0; break;
         default:
@@ -140,6 +147,15 @@ int main(int argc, char **argv)
                     argv[0]);
             return 2;
         }
+    }
+    if (nrx < 1 || nrx > MAX_RX) {
+        fprintf(stderr, "-N wants 1..%d receivers\n", MAX_RX);
+        return 2;
+    }
+    if (nrx > 1) {
+        char v[8];
+        snprintf(v, sizeof(v), "%d", nrx);
+        setenv("PERSEUS_AMD_DEVICES", v, 0);
     }
     perseus_set_debug(dbg);
     int rates[16];
@@ -154,6 +170,76 @@ int main(int argc, char **argv)
     if (ndev <= 0) {
         perseus_exit();
         return 1;
+    }
+    if (nrx > 1) {
+        /* several receivers at once: same call sequence per receiver, one callback sink each */
+        if (ndev < nrx) {
+            fprintf(stderr, "only %d receivers present, %d wanted\n", ndev, nrx);
+            perseus_exit();
+            return 1;
+        }
+        perseus_descr *rx[MAX_RX];
+        sink sk[MAX_RX];
+        struct timeval t0, t1;
+        for (int i = 0; i < nrx; i++) {
+            rx[i] = perseus_open(i);
+            if (!rx[i] || perseus_firmware_download(rx[i], NULL) < 0 || perseus_set_sampling_rate(rx[i], rate) < 0) {
+                fprintf(stderr, "receiver %d: %s\n", i, perseus_errorstr());
+                perseus_exit();
+                return 1;
+            }
+            perseus_set_ddc_center_freq(rx[i], freq, 1);
+            perseus_amd_config cfg;
+            perseus_amd_get_config(rx[i], &cfg);
+            if (max_buffers > 0) {
+                cfg.max_buffers = (uint64_t)max_buffers;
+                perseus_amd_set_config(rx[i], &cfg);
+            }
+            sk[i] = (sink){ NULL, cfg.mode == PERSEUS_AMD_MODE_DDC, 0, 0 };
+            if (strcmp(outname, "none") != 0 && strcmp(outname, "-") != 0) {
+                char name[1100];
+                snprintf(name, sizeof(name), "%s.%d", outname, i);
+                sk[i].out = fopen(name, "wb");
+            }
+        }
+        gettimeofday(&t0, NULL);
+        for (int i = 0; i < nrx; i++)
+            if (perseus_start_async_input(rx[i], (uint32_t)(nb * bs), (as_float || sk[i].ddc) ? on_buffer_float : on_buffer_int32,
+                                          &sk[i]) < 0) {
+                fprintf(stderr, "receiver %d: start async input error: %s\n", i, perseus_errorstr());
+                perseus_exit();
+                return 1;
+            }
+        fprintf(stderr, "Collecting input samples from %d receivers... \n", nrx);
+        for (int t = 0; t < seconds * 100; t++) {
+            int running = 0;
+            for (int i = 0; i < nrx; i++)
+                running += perseus_amd_source_running(rx[i]);
+            if (!running)
+                break;
+            usleep(10000);
+        }
+        gettimeofday(&t1, NULL);
+        perseus_amd_stats st;
+        unsigned long long total = 0, adc = 0;
+        for (int i = 0; i < nrx; i++) {
+            perseus_amd_get_stats(rx[i], &st);
+            adc += st.adc_samples;
+            perseus_stop_async_input(rx[i]);
+            if (sk[i].out)
+                fclose(sk[i].out);
+            fprintf(stderr, "receiver %d (GPU %d): %llu buffers, %llu samples\n", i, st.gpu_device, sk[i].buffers, sk[i].samples);
+            total += sk[i].samples;
+        }
+        const double el = (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
+        fprintf(stderr, "%d receivers: %llu samples in %.3f s = %.1f kS/s aggregate", nrx, total, el, total / el / 1e3);
+        if (adc)
+            fprintf(stderr, " (%.1f MS/s of ADC-rate input through the GPUs; most receivers with a batch in flight "
+                            "at once: %d)", adc / el / 1e6, st.peak_receivers_in_flight);
+        fprintf(stderr, "\n");
+        perseus_exit();
+        fprintf(stderr, "Bye\n");
+        return 0;
     }
     perseus_descr *d = perseus_open(0);
     if (!d) {

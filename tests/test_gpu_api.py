@@ -288,3 +288,21 @@ def test_unpaced_plumbing_client_is_kernel_bound_not_source_bound(pkg, dev):
     assert p.returncode == 0, p.stderr[-1000:]
     m = re.search(r"Rate: ([0-9.]+) kS/s", p.stderr)
     assert m and float(m.group(1)) >= 50 * 250.0, p.stderr[-600:]
+
+
+def test_plumbing_client_eight_receivers_on_the_gpu_path(pkg, dev):
+    """The C client with -N 8 in DDC mode: eight pipelines, all in flight at once, no Python in the loop."""
+    import re
+    exe = os.path.join(os.path.dirname(pkg.SDR_LIB), "perseus_plumbing")
+    env = dict(os.environ, PERSEUS_AMD_PACE="0", PERSEUS_AMD_MODE="ddc")
+    env.pop("PERSEUS_AMD_DEVICES", None)
+    p = subprocess.run([exe, "-N", "8", "-s", "250000", "-o", "none", "-t", "2", "-d", "0"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-1000:]
+    assert "8 Perseus receivers found" in p.stderr
+    m = re.search(r"8 receivers: (\d+) samples in ([0-9.]+) s = ([0-9.]+) kS/s aggregate \(([0-9.]+) MS/s of ADC-rate input.*at once: (\d+)\)",
+                  p.stderr)
+    assert m, p.stderr[-600:]
+    assert int(m.group(5)) == 8
+    assert float(m.group(3)) >= 8 * 250.0 * 5           # the eight together well beyond 8 x real time
+    print("plumbing -N 8:", m.group(0))

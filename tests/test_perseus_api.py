@@ -489,3 +489,18 @@ def test_config_round_trip_keeps_its_strings(L, pkg, tmp_path):
     c3 = pkg.AmdConfig()
     L.perseus_amd_get_config(d, C.byref(c3))
     assert c3.file_path == path and c3.fault_script == b"short%9"
+
+
+def test_plumbing_client_several_receivers(pkg, O, tmp_path):
+    """-N: the reference's limit of 8 descriptors used for real -- n receivers, n independent streams."""
+    exe = os.path.join(os.path.dirname(pkg.SDR_LIB), "perseus_plumbing")
+    out = tmp_path / "rx"
+    env = dict(os.environ, PERSEUS_AMD_PACE="0")
+    env.pop("PERSEUS_AMD_DEVICES", None)
+    p = subprocess.run([exe, "-N", "3", "-m", "7", "-o", str(out), "-t", "10", "-d", "0"], env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stderr
+    assert "3 Perseus receivers found" in p.stderr and "3 receivers: 21504 samples" in p.stderr
+    for i in range(3):
+        got = np.fromfile(str(out) + f".{i}", dtype=np.int32)
+        assert np.array_equal(got, O.unpack24_i32(O.lcg_bytes(7 * 6144, 12345 + i)))
