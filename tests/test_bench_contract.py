@@ -109,6 +109,23 @@ def test_plain_command_launcher_two_ranks_gloo():
     assert "dry_run" in d and d["value"] == 0.0                   # nothing is claimed as measured
 
 
+def test_driver_style_launch_under_torch_distributed_run():
+    """What the driver does at N>1: python -m torch.distributed.run ... bench.py --gpus N.  The ranks find
+    RANK/WORLD_SIZE in the environment and skip the launcher (CPU: gloo plumbing mode)."""
+    env = dict(os.environ, PDDC_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_bench()._free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+    assert d["gather"]["this_workload"]["root_blocks_match_each_ranks_stream"] is True
+
+
 def test_launcher_parent_makes_no_gpu_call():
     """The launching parent must not import torch (never exec/spawn from a process that touched the GPU)."""
     code = ("import sys, bench\n"
