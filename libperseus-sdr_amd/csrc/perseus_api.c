@@ -658,15 +658,11 @@ static void *worker_fn(void *arg)
     (void)arg;
     while (!g_thread_stop) {
         int busy = 0;
+        int inflight = 0;
         for (int pass = 0; pass < 3; pass++) {
-            if (pass == 1) {
-                /* every receiver's batch has been submitted, none has been waited for yet */
-                int inflight = 0;
-                for (int i = 0; i < g_entries; i++)
-                    inflight += g_list[i].streaming && g_list[i].n_pend > 0;
-                if (inflight > g_peak_inflight)
-                    g_peak_inflight = inflight;
-            }
+            /* after pass 0 every receiver's batch has been submitted and none has been waited for yet */
+            if (pass == 1 && inflight > g_peak_inflight)
+                g_peak_inflight = inflight;
             for (int i = 0; i < g_entries; i++) {
                 perseus_descr *d = &g_list[i];
                 if (!d->streaming || d->cancelling || d->source_done)
@@ -682,6 +678,7 @@ static void *worker_fn(void *arg)
                             busy |= pump_wire(d);
                     } else if (pass == 0) {
                         busy |= ddc_submit(d);
+                        inflight += d->n_pend > 0;
                     } else if (pass == 1) {
                         busy |= ddc_collect(d);
                     } else {

@@ -504,3 +504,43 @@ def test_plumbing_client_several_receivers(pkg, O, tmp_path):
     for i in range(3):
         got = np.fromfile(str(out) + f".{i}", dtype=np.int32)
         assert np.array_equal(got, O.unpack24_i32(O.lcg_bytes(7 * 6144, 12345 + i)))
+
+
+def test_api_layer_is_threadsanitizer_clean(pkg, tmp_path):
+    """The delivery thread, a client thread retuning through the control FIFO (examples/fifo.c) and the
+    main thread stopping the stream, with transfer faults injected: no data race in perseus_api.c /
+    perseus_plumbing.c (the reference's volatile flags would not pass this).  CPU build only."""
+    csrc = os.path.join(ROOT, "libperseus-sdr_amd", "csrc")
+    exe = tmp_path / "plumb_tsan"
+    cc = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=thread", "-std=gnu11", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                         os.path.join(csrc, "perseus_api.c"), os.path.join(csrc, "perseus_plumbing.c"),
+                         "-L" + os.path.dirname(pkg.SDR_LIB), "-lperseus_ddc", "-lm", "-o", str(exe)],
+                        capture_output=True, text=True)
+    if cc.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime here: " + cc.stderr[-200:])
+    fifo = str(tmp_path / "ctl")
+    env = dict(os.environ, PERSEUS_AMD_PACE="1", PERSEUS_AMD_FAULTS="short%5,timeout@7,oos@12,error@40",
+               LD_LIBRARY_PATH=os.path.dirname(pkg.SDR_LIB) + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
+               TSAN_OPTIONS="exitcode=66")
+    env.pop("PERSEUS_AMD_MODE", None)
+    p = subprocess.Popen([str(exe), "-s", "2000000", "-o", "none", "-t", "20", "-d", "0", "-F", fifo, "-a"], env=env,
+                         stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while not os.path.exists(fifo) and time.time() - t0 < 20:
+        time.sleep(0.01)
+    with open(fifo, "w") as f:
+        for line in ("7.05\n", "att 2\n", "14200000\n", "7100000\n"):
+            f.write(line)
+            f.flush()
+            time.sleep(0.15)
+        f.write("quit\n")
+    _, err = p.communicate(timeout=60)
+    assert "WARNING: ThreadSanitizer" not in err, err[-3000:]
+    assert p.returncode == 0, err[-1000:]
+    assert "final NCO word: 381178347" in err
+    # several receivers through the same delivery thread
+    env["PERSEUS_AMD_PACE"] = "0"
+    p = subprocess.run([str(exe), "-N", "4", "-s", "250000", "-o", "none", "-t", "20", "-m", "400", "-d", "0"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[-3000:]
+    assert p.returncode == 0 and "4 receivers:" in p.stderr
