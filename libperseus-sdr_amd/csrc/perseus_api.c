@@ -382,8 +382,11 @@ static int parse_faults(perseus_descr *d, const char *script)
 
 static int fault_for(const perseus_descr *d, uint64_t n)     /* n = 1-based transfer number */
 {
-    for (int i = 0; i < d->n_faults; i++)
-        if ((d->faults[i].at && d->faults[i].at == n) || (d->faults[i].every && n % d->faults[i].every == 0))
+    for (int i = 0; i < d->n_faults; i++)                     /* a rule for exactly this transfer wins ... */
+        if (d->faults[i].at && d->faults[i].at == n)
+            return d->faults[i].kind;
+    for (int i = 0; i < d->n_faults; i++)                     /* ... over the periodic ones */
+        if (d->faults[i].every && n % d->faults[i].every == 0)
             return d->faults[i].kind;
     return FAULT_NONE;
 }
@@ -1126,8 +1129,8 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
         int ndev = pddc_device_count();
         if (ndev <= 0) {
             free_stream(d);
-            return errorset(PERSEUS_DEVNOTFOUND, "DDC mode needs a GPU and none is visible (no CPU fallback): %s",
-                            pddc_last_error());
+            return errorset(PERSEUS_DEVNOTFOUND, "DDC mode needs a GPU and none is visible (no CPU fallback)%s%s",
+                            ndev < 0 ? ": " : "", ndev < 0 ? pddc_last_error() : "");
         }
         int dev = d->cfg.gpu_device >= 0 ? d->cfg.gpu_device : d->index % ndev;
         d->gpu_dev = dev;

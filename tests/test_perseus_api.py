@@ -401,7 +401,7 @@ def virtual_usb(nbuf_payload, script, nslots=8):
 
 
 @pytest.mark.parametrize("script", ["timeout@3", "oos@4", "error@5", "short@2,timeout@6,oos@9,stall@15",
-                                    "nodev@1,overflow@2", "short%3", "eof@7"])
+                                    "nodev@1,overflow@2", "short%3", "eof@7", "short%5,timeout@10,eof@30"])
 def test_fault_injection_follows_the_reference_dispatcher(L, O, pkg, script):
     d = bring_up(L)
     nbuf = 40
