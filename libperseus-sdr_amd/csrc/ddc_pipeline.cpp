@@ -95,6 +95,18 @@ struct pddc_pipeline {
     uint32_t phase_off = 0;
     uint32_t freg_applied = 0;
     bool fresh = true;            /* nothing processed since create / reset / seek */
+    /* Tuning-word segments that still reach into stage 0's history window [n0 - H, n0): {first
+     * sample, word, offset}; the last one is the word in force.  Stage 0 keeps its history as raw
+     * packed samples and mixes them when it reads them, with ONE word (freg_applied): that is exact
+     * as long as the whole window was mixed with one word.  Batches shorter than the history with
+     * retunes between them break that; such a batch takes the float route (process(): "mixed
+     * history"), where each stretch of the history is mixed with its own word.                  */
+    struct WordSeg {
+        long long n_begin;
+        uint32_t freg, off;
+    };
+    std::vector<WordSeg> segs;
+    float *d_hist_f32 = nullptr;  /* stage 0's history as mixed float2, for that route */
     float lo_c[8], lo_s[8];
     float lo_c_applied[8], lo_s_applied[8];   /* step phasors of freg_applied */
     unsigned long long n0 = 0;    /* absolute sample counter (stage 0 input)    */
@@ -502,6 +514,8 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
         hipStreamDestroy(p->s_out);
     if (p->d_fout)
         hipFree(p->d_fout);
+    if (p->d_hist_f32)
+        hipFree(p->d_hist_f32);
     if (p->d_sched)
         hipFree(p->d_sched);
     if (p->own_stream)
@@ -521,6 +535,7 @@ int pddc_pipeline_reset(pddc_pipeline *p)
     p->freg_applied = p->freg;
     compute_lo_steps(p);
     p->fresh = true;
+    p->segs.assign(1, pddc_pipeline::WordSeg{ 0, p->freg, 0u });      /* samples before the start are zeros */
     HIP_TRY(hipMemset(p->d_sched, 0, 64));
     for (int i = 0; i < p->nstages; ++i) {
         Stage &s = p->st[i];
@@ -540,9 +555,14 @@ int pddc_pipeline_set_freg(pddc_pipeline *p, uint32_t freg)
         if (p->fresh) {
             /* before the first batch: the stream starts with this word, offset 0 */
             p->freg_applied = freg;
+            p->segs.assign(1, pddc_pipeline::WordSeg{ 0, freg, 0u });
         } else {
             /* takes effect at sample n0 (the next one to be processed), phase-continuous there */
             p->phase_off += (uint32_t)p->n0 * (p->freg - freg);
+            if (!p->segs.empty() && p->segs.back().n_begin == (long long)p->n0)
+                p->segs.back() = pddc_pipeline::WordSeg{ (long long)p->n0, freg, p->phase_off };
+            else
+                p->segs.push_back(pddc_pipeline::WordSeg{ (long long)p->n0, freg, p->phase_off });
         }
         p->freg = freg;
         compute_lo_steps(p);
@@ -826,7 +846,24 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
      * half way leaves the pipeline exactly where it was, and the batch can be retried.       */
     bool flip[PDDC_MAX_STAGES] = { false, false, false, false };
     int first = 0;
-    if (stages01_fusable(p, nsamples)) {
+    /* which tuning words does stage 0's history window [n0 - H, n0) hold?  Drop the segments that
+     * ended before it.  One word, or the old word all through with the new one starting exactly now:
+     * the packed-history kernels handle it (freg_hist).  Anything else: the mixed-history route.  */
+    bool mixed_hist = false;
+    if (mix && (stage0_fused(p) || stage0_packed_generic(p))) {
+        const long long w0 = (long long)p->n0 - (long long)p->st[0].hist;
+        while (p->segs.size() >= 2 && p->segs[1].n_begin <= w0)
+            p->segs.erase(p->segs.begin());
+        const size_t k = p->segs.size();
+        const bool ok = k == 1 || (k == 2 && p->segs[1].n_begin == (long long)p->n0);
+        mixed_hist = !ok;
+        const uint32_t hist_word = p->segs[0].freg;
+        if (ok && hist_word != p->freg_applied) {      /* cannot happen while set_freg keeps both in step */
+            p->freg_applied = hist_word;
+            compute_lo_steps(p);
+        }
+    }
+    if (!mixed_hist && stages01_fusable(p, nsamples)) {
         /* stages 0 and 1 in ONE kernel: the 8 B/sample-at-1/8-rate intermediate
          * (1 B written + 1 B read per input sample) never touches HBM */
         Stage &s0 = p->st[0], &s1 = p->st[1];
@@ -856,7 +893,36 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         void *h_in = st.d_hist[st.cur], *h_out = st.d_hist[st.cur ^ 1];
         const void *x = d_packed;                       /* this stage's input batch */
         bool hist_done = false;
-        if (i == 0 && stage0_fused(p)) {
+        if (i == 0 && mixed_hist) {
+            /* rare: batches shorter than the history with retunes between them.  The packed history
+             * is unpacked and mixed stretch by stretch, each with the word and offset that applied to
+             * it, the batch likewise with the current word, and the generic decimator runs on floats;
+             * the packed history for the next call is carried as usual.                            */
+            const int H = st.hist;
+            if ((rc = ensure_buf(st, nsamples + 8)))
+                return rc;
+            if (!p->d_hist_f32)
+                HIP_TRY(hipMalloc(&p->d_hist_f32, (size_t)PDDC_MAX_TAPS * 8 + 256));
+            const long long w0 = (long long)p->n0 - H;
+            for (size_t k = 0; k < p->segs.size(); ++k) {
+                const long long a0 = std::max(w0, k == 0 ? w0 : p->segs[k].n_begin);
+                const long long a1 = std::min((long long)p->n0, k + 1 < p->segs.size() ? p->segs[k + 1].n_begin
+                                                                                       : (long long)p->n0);
+                if (a1 <= a0)
+                    continue;
+                float lc[8], ls[8];
+                lo_steps(p->segs[k].freg, lc, ls);
+                HIP_TRY(launch_unpack24(static_cast<const uint8_t *>(h_in) + (a0 - w0) * PDDC_PACKED_BYTES, a1 - a0,
+                                        p->d_hist_f32 + 2 * (a0 - w0), false, true, (unsigned long long)a0,
+                                        p->segs[k].freg, p->segs[k].off, lc, ls, s));
+            }
+            HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, st.d_buf, false, true, p->n0, p->freg, p->phase_off,
+                                    p->lo_c, p->lo_s, s));
+            if (n_in[1] > 0)
+                HIP_TRY(launch_fir_generic(st.d_buf, p->d_hist_f32, H, (long long)off[0], (long long)n_in[1], st.decim,
+                                           st.d_taps, st.ntaps, dst, nullptr, (long long)nsamples, s));
+            /* hist_done stays false: the packed history moves on below (x == d_packed) */
+        } else if (i == 0 && stage0_fused(p)) {
             Fir8Args a;
             a.in = d_packed;
             a.hist = h_in;

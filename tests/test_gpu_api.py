@@ -306,3 +306,33 @@ def test_plumbing_client_eight_receivers_on_the_gpu_path(pkg, dev):
     assert int(m.group(5)) == 8
     assert float(m.group(3)) >= 8 * 250.0 * 5           # the eight together well beyond 8 x real time
     print("plumbing -N 8:", m.group(0))
+
+
+def test_retunes_between_batches_shorter_than_the_history(pkg, dev, O):
+    """Batches of a few groups with a new tuning word before each: stage 0's history window then holds samples
+    of several words.  The packed-history kernels mix their history with ONE word; the pipeline notices and
+    routes such a batch through mixed float history (found by tools/stress_gpu.py)."""
+    import torch
+    from conftest import load_taps
+    rng = np.random.default_rng(89)
+    for stages in ([(8, load_taps("d8_255"))], [(8, load_taps("c320_s1_d8_32")), (8, load_taps("c320_s2_d8_64"))],
+                   [(10, load_taps("c320_s3_d5_161")[:77])]):
+        sizes = [8 * int(v) for v in rng.integers(1, 40, size=30)] + [8192, 8, 16, 4096 * 3]
+        words = [int(w) for w in rng.integers(0, 2 ** 32, size=len(sizes))]
+        words[5] = words[4]
+        words[6] = words[4]                                  # also runs of batches without a retune
+        ns = sum(sizes)
+        packed = O.lcg_bytes(6 * ns, 8989)
+        pipe = pkg.Pipeline(stages, mix=True)
+        ys, at, segs = [], 0, []
+        for n, w in zip(sizes, words):
+            pipe.set_freg(w)
+            if not segs or segs[-1][1] != w:
+                segs.append((at, w))
+            ys.append(pipe.process(torch.from_numpy(packed[6 * at:6 * (at + n)].copy()).to(dev)).cpu().numpy().reshape(-1))
+            at += n
+        y = np.concatenate(ys)
+        ref = O.ddc_chain_retuned(packed, stages, segs)
+        assert y.size == ref.size
+        assert O.rel_err(y, ref) <= FIR_TOL, [(s[0], len(s[1])) for s in stages]
+        pipe.close()

@@ -1,5 +1,6 @@
-# one-off randomized stress of the stream state machine against the oracle: random plans, cuts,
-# NCO words, scheduler settings (PDDC_FIR8_BLOCKS / DYN_PCT / CHUNK / R).  Usage: python tools/stress_gpu.py [n]
+# randomized stress of the stream state machine against the oracle: random plans, cuts, NCO words retuned
+# between batches (phase-continuous), scheduler settings (PDDC_FIR8_BLOCKS / DYN_PCT / CHUNK / R).
+# Usage: python tools/stress_gpu.py [n]
 import sys, os, importlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -27,13 +28,19 @@ for it in range(n_iter):
     if rng.integers(0, 2):
         ns = 8192 * int(rng.integers(1, 40))
     packed = O.lcg_bytes(6 * ns, 9000 + it)
-    ref = O.ddc_chain(packed, stages, freg=freg, mix=mix)
     cuts = sorted(set([0, ns] + [8 * int(c) for c in rng.integers(1, max(2, ns // 8), size=4)] +
                       [4096 * int(c) for c in rng.integers(0, max(1, ns // 4096), size=3) if 0 < 4096 * int(c) < ns]))
+    # a new tuning word at some of the batch boundaries (the retune path of the drop-in API)
+    words = [freg]
+    for _ in cuts[1:-1]:
+        words.append(int(rng.integers(0, 2**32)) if (mix and rng.integers(0, 3) == 0) else words[-1])
+    segs = [(a, w) for k, (a, w) in enumerate(zip(cuts[:-1], words)) if k == 0 or w != words[k - 1]]
+    ref = O.ddc_chain_retuned(packed, stages, segs) if mix else O.ddc_chain(packed, stages)
     pipe = pkg.Pipeline(stages, mix=mix)
-    pipe.set_freg(freg)
-    parts = [pipe.process(torch.from_numpy(packed[6 * a:6 * b].copy()).to(dev)).cpu().numpy().reshape(-1)
-             for a, b in zip(cuts[:-1], cuts[1:])]
+    parts = []
+    for (a, b), w in zip(zip(cuts[:-1], cuts[1:]), words):
+        pipe.set_freg(w)
+        parts.append(pipe.process(torch.from_numpy(packed[6 * a:6 * b].copy()).to(dev)).cpu().numpy().reshape(-1))
     y = np.concatenate(parts) if parts else np.zeros(0, np.float32)
     pipe.close()
     ok = y.size == ref.size
@@ -42,7 +49,7 @@ for it in range(n_iter):
     tag = "ok " if ok and err <= 1e-6 else "BAD"
     print(f"{tag} it {it} stages {[(s[0], len(s[1])) for s in stages]} mix {mix} ns {ns} cuts {len(cuts)-1} "
           f"blocks {os.environ['PDDC_FIR8_BLOCKS']} dyn {os.environ['PDDC_FIR8_DYN_PCT']} K {os.environ['PDDC_FIR8_CHUNK']} "
-          f"R {os.environ['PDDC_FIR8_R']} err {err:.2e}", flush=True)
+          f"R {os.environ['PDDC_FIR8_R']} retunes {len(segs) - 1} err {err:.2e}", flush=True)
     if tag == "BAD":
         sys.exit(1)
 print("worst", worst)
