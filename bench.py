@@ -372,7 +372,9 @@ def run_rank(a):
     verified = None
     if not a.no_verify:
         from oracle import oracle as O
-        O.build()
+        if rank == 0:
+            O.build()                                   # one rank (re)builds the checker, the others wait for it
+        grp.barrier()
 
         def fetch(a0, b0):                              # absolute samples of the periodic stream
             idx = (torch.arange(6 * a0, 6 * b0, device=dev, dtype=torch.int64) % (6 * ns))
