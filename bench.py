@@ -366,6 +366,19 @@ def run_rank(a):
         kern_ms = pipe.time_stage0(d_in.data_ptr(), ns, out_k.data_ptr(), max(a.steps, 5), stream)
     else:
         kern_ms = ev_ms / a.steps
+    # measured copy ceiling: a device-to-device copy that moves as many bytes through HBM as
+    # one launch of the dominant kernel does (nbytes read + nbytes written)
+    copy_gbps = None
+    try:
+        nb = int(wl["kernel_bytes_per_sample"] * ns / 2) // 256 * 256
+        src = d_in[:nb] if nb <= d_in.numel() else torch.empty(nb, dtype=torch.uint8, device=dev)
+        dst = torch.empty(nb, dtype=torch.uint8, device=dev)
+        ms = pkg.measure_copy(dst.data_ptr(), src.data_ptr(), nb, 40, stream)
+        copy_gbps = 2.0 * nb / (ms * 1e-3) / 1e9
+        del dst, src
+    except Exception as e:                              # never lose the line over the extra figure
+        print(f"[bench] copy ceiling failed: {e}", file=sys.stderr)
+
     dt_max = grp.max_seconds(dt)
 
     # ---- parity of what was just timed (outside the timed region, every rank its own stream)
@@ -397,19 +410,6 @@ def run_rank(a):
                 bad += int((ref != got).sum())
             verified = {"windows": len(starts), "window_outputs": 4096, "mismatching_words": bad, "ok": bad == 0,
                         "metric": "bit-exact vs the CPU oracle (examples/perseustest.c:466-502)"}
-
-    # measured copy ceiling: a device-to-device copy that moves as many bytes through HBM as
-    # one launch of the dominant kernel does (nbytes read + nbytes written)
-    copy_gbps = None
-    try:
-        nb = int(wl["kernel_bytes_per_sample"] * ns / 2) // 256 * 256
-        src = d_in[:nb] if nb <= d_in.numel() else torch.empty(nb, dtype=torch.uint8, device=dev)
-        dst = torch.empty(nb, dtype=torch.uint8, device=dev)
-        ms = pkg.measure_copy(dst.data_ptr(), src.data_ptr(), nb, 20, stream)
-        copy_gbps = 2.0 * nb / (ms * 1e-3) / 1e9
-        del dst, src
-    except Exception as e:                              # never lose the line over the extra figure
-        print(f"[bench] copy ceiling failed: {e}", file=sys.stderr)
 
     names = grp.all_gather_object(torch.cuda.get_device_name(dev))
     oks = grp.all_gather_object(None if verified is None else bool(verified["ok"]))

@@ -179,6 +179,29 @@ class Group:
         pass
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _c_stdout_to_stderr():
+    """RCCL prints a version banner on C stdout when a communicator is made; a bench line must be
+    the only thing on stdout, so file descriptor 1 points at stderr while that happens."""
+    import ctypes
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class RcclGroup(Group):
     """One process per GPU.  `force_single` builds a 1-rank communicator so that a 1-GPU
     box still runs every RCCL call of the N>1 path."""
@@ -192,10 +215,12 @@ class RcclGroup(Group):
             os.environ.setdefault("MASTER_PORT", "29511")
             dist.init_process_group(pg_backend, rank=rank, world_size=world)
             self._own_pg = True
-        uid = [pkg.Comm.unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(uid, src=0)
-        self.comm = pkg.Comm.init_rank(world, rank, uid[0], local)
+        with _c_stdout_to_stderr():
+            uid = [pkg.Comm.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            self.comm = pkg.Comm.init_rank(world, rank, uid[0], local)
+            self.comm.barrier()                   # first collective: whatever RCCL still wants to say, it says now
 
     def make_pipeline(self, pkg, stages, freg, mix, taps_fp16=False):
         """Rank 0's plan reaches every rank through ncclBroadcast inside the C library."""

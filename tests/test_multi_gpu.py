@@ -126,7 +126,9 @@ def test_bench_gather_leg_on_one_rank():
                         "--settle-ms", "20", "--no-cpu", "--gather"], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, PDDC_BENCH_GATHER_C320="1"))
     assert p.returncode == 0, p.stderr[-2000:]
-    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:5]                    # RCCL's banner went to stderr, not into the contract's stdout
+    d = json.loads(lines[-1])
     assert d["ranks_seen"] == 1 and "RCCL called from the C library" in d["collectives"]
     g = d["gather"]
     assert "error" not in g, g
