@@ -204,6 +204,10 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
  * tiles [b*S, (b+1)*S), the tiles from blocks*S on are handed out in chunks of K.  For
  * tests and bench.py, which place their comparison windows on these seams.           */
 int pddc_pipeline_schedule(const pddc_pipeline *p, size_t nsamples, int out[5]);
+/* Test hook: the next process()/push fails with PDDC_EHIP when it reaches `stage`, after the stages
+ * in front of it have been launched -- to show that a failure half way leaves the stream state
+ * (histories, decimation phases, NCO counter) where it was and the batch can simply be retried.   */
+int pddc_pipeline_inject_failure(pddc_pipeline *p, int stage);
 /* Device-to-device streaming copy of nbytes (16 B per lane, nontemporal stores), `iters`
  * times, timed with HIP events on `stream`: the measured copy ceiling bench.py prints
  * next to the 8 TB/s spec figure (SURVEY.md 8d "Which roofline").  A copy moves

@@ -120,6 +120,8 @@ def ddc_lib() -> C.CDLL:
     L.pddc_host_alloc.argtypes = [C.POINTER(vp), sz]
     L.pddc_host_free.argtypes = [vp]
     L.pddc_pipeline_time_stage0.argtypes = [vp, vp, sz, vp, C.c_int, vp, C.POINTER(C.c_float)]
+    L.pddc_pipeline_inject_failure.argtypes = [vp, C.c_int]
+    L.pddc_pipeline_inject_failure.restype = C.c_int
     L.pddc_pipeline_schedule.argtypes = [vp, sz, C.POINTER(C.c_int)]
     L.pddc_pipeline_schedule.restype = C.c_int
     L.pddc_measure_copy.argtypes = [vp, vp, sz, C.c_int, vp, C.POINTER(C.c_float)]

@@ -107,6 +107,7 @@ struct pddc_pipeline {
     };
     std::vector<WordSeg> segs;
     float *d_hist_f32 = nullptr;  /* stage 0's history as mixed float2, for that route */
+    int fail_at_stage = -1;       /* test hook: the next process() fails when it reaches this stage */
     float lo_c[8], lo_s[8];
     float lo_c_applied[8], lo_s_applied[8];   /* step phasors of freg_applied */
     unsigned long long n0 = 0;    /* absolute sample counter (stage 0 input)    */
@@ -887,6 +888,10 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
     }
     for (int i = first; i < p->nstages; ++i) {
         Stage &st = p->st[i];
+        if (p->fail_at_stage >= 0 && p->fail_at_stage <= i) {
+            p->fail_at_stage = -1;
+            return fail(PDDC_EHIP, "injected failure at stage %d (pddc_pipeline_inject_failure)", i);
+        }
         float *dst;
         if ((rc = stage_dst(i, &dst)))
             return rc;
@@ -1176,6 +1181,14 @@ int pddc_pipeline_push_host(pddc_pipeline *p, const void *h_packed, size_t nsamp
         return rc;
     if (ticket >= 0)
         return pddc_pipeline_wait_ticket(p, ticket);
+    return PDDC_OK;
+}
+
+int pddc_pipeline_inject_failure(pddc_pipeline *p, int stage)
+{
+    if (!p || stage < 0 || stage >= p->nstages)
+        return fail(PDDC_EINVAL, "bad stage");
+    p->fail_at_stage = stage;
     return PDDC_OK;
 }
 

@@ -901,3 +901,51 @@ def test_perseus_api_1600k_plan_is_fused_end_to_end(pkg, dev, O, monkeypatch):
     ref = O.ddc_chain(O.lcg_bytes(6 * need, 12345), [(dec[i], taps[i]) for i in range(n)], freg=O.nco_freg(21.3e6),
                       mix=True)
     assert O.rel_err(y, ref[:y.size]) <= FIR_TOL
+
+
+# ------------------------------------------------------------ failure atomicity
+def test_a_failed_batch_leaves_the_stream_where_it_was(pkg, dev, O):
+    """process() commits its state only after every launch was accepted: a failure half way (injected at
+    each stage in turn) changes nothing, the same batch is simply pushed again, and the stream goes on
+    bit-identically to one that never failed."""
+    import ctypes as C
+    stages = [(8, load_taps("c320_s1_d8_32")), (5, load_taps("c320_s3_d5_161")[:41]), (4, load_taps("c320_s1_d8_32")),
+              (25, (np.random.default_rng(3).standard_normal(120) / 10).astype(np.float32), 12)]
+    ns = 8 * 4000
+    batches = [to_dev(O.lcg_bytes(6 * ns, 100 + k), dev) for k in range(6)]
+    good = pkg.Pipeline(stages, mix=True)
+    good.set_freg(123456789)
+    want = [good.process(b).cpu().numpy() for b in batches]
+    flaky = pkg.Pipeline(stages, mix=True)
+    flaky.set_freg(123456789)
+    L = pkg.ddc_lib()
+    for k, b in enumerate(batches):
+        if k >= 1:
+            stage = (k - 1) % len(stages)
+            assert L.pddc_pipeline_inject_failure(flaky._h, stage) == 0
+            with pytest.raises(pkg.PddcError) as e:
+                flaky.process(b)
+            assert e.value.code == pkg.PDDC_EHIP and b"injected failure" in L.pddc_last_error()
+        got = flaky.process(b).cpu().numpy()                      # the retry
+        assert np.array_equal(got, want[k]), k
+    good.close()
+    flaky.close()
+
+
+def test_too_small_output_buffer_is_refused_before_anything_runs(pkg, dev, O):
+    import ctypes as C
+    h = load_taps("d8_127")
+    ns = 8 * 3000
+    a, b = O.lcg_bytes(6 * ns, 1), O.lcg_bytes(6 * ns, 2)
+    pipe = pkg.Pipeline([(8, h)])
+    ya = pipe.push_host(a)
+    out = np.empty((ns // 8, 2), np.float32)
+    n = C.c_size_t(0)
+    L = pkg.ddc_lib()
+    rc = L.pddc_pipeline_push_host(pipe._h, b.ctypes.data, ns, out.ctypes.data, ns // 8 - 1, C.byref(n))
+    assert rc == pkg.PDDC_ECAPACITY and n.value == 0
+    yb = pipe.push_host(b)                                          # same batch again, with room
+    ref = O.ddc_chain(np.concatenate([a, b]), [(8, h)])
+    assert O.rel_err(np.concatenate([ya, yb]).reshape(-1), ref) <= FIR_TOL
+    assert pipe.next_output(ns) == ns // 8
+    pipe.close()
