@@ -204,6 +204,14 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
  * tiles [b*S, (b+1)*S), the tiles from blocks*S on are handed out in chunks of K.  For
  * tests and bench.py, which place their comparison windows on these seams.           */
 int pddc_pipeline_schedule(const pddc_pipeline *p, size_t nsamples, int out[5]);
+/* Checkpoint / resume.  The stream state the reference never needed (its FPGA kept it): per stage the
+ * FIR history and the decimation phase, the sample counter, the NCO word with its phase offset.  save:
+ * one host blob (pddc_pipeline_state_size bytes), taken after everything pushed so far has completed.
+ * restore: into a pipeline of the SAME plan and flags, on the same or another GPU -- the stream then
+ * continues bit-identically (a receiver can move between GPUs, or survive a restart).             */
+size_t pddc_pipeline_state_size(const pddc_pipeline *p);
+int pddc_pipeline_save_state(pddc_pipeline *p, void *h_buf, size_t capacity, size_t *used);
+int pddc_pipeline_restore_state(pddc_pipeline *p, const void *h_buf, size_t nbytes);
 /* Test hook: the next process()/push fails with PDDC_EHIP when it reaches `stage`, after the stages
  * in front of it have been launched -- to show that a failure half way leaves the stream state
  * (histories, decimation phases, NCO counter) where it was and the batch can simply be retried.   */

@@ -120,6 +120,12 @@ def ddc_lib() -> C.CDLL:
     L.pddc_host_alloc.argtypes = [C.POINTER(vp), sz]
     L.pddc_host_free.argtypes = [vp]
     L.pddc_pipeline_time_stage0.argtypes = [vp, vp, sz, vp, C.c_int, vp, C.POINTER(C.c_float)]
+    L.pddc_pipeline_state_size.argtypes = [vp]
+    L.pddc_pipeline_state_size.restype = sz
+    L.pddc_pipeline_save_state.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.pddc_pipeline_save_state.restype = C.c_int
+    L.pddc_pipeline_restore_state.argtypes = [vp, vp, sz]
+    L.pddc_pipeline_restore_state.restype = C.c_int
     L.pddc_pipeline_inject_failure.argtypes = [vp, C.c_int]
     L.pddc_pipeline_inject_failure.restype = C.c_int
     L.pddc_pipeline_schedule.argtypes = [vp, sz, C.POINTER(C.c_int)]
@@ -299,6 +305,18 @@ class Pipeline:
 
     def wait(self):
         check(ddc_lib().pddc_pipeline_wait(self._h))
+
+    def save_state(self) -> bytes:
+        """The stream state as one blob (histories, decimation phases, sample counter, NCO)."""
+        L = ddc_lib()
+        n = L.pddc_pipeline_state_size(self._h)
+        buf = C.create_string_buffer(n)
+        used = C.c_size_t(0)
+        check(L.pddc_pipeline_save_state(self._h, buf, n, C.byref(used)))
+        return buf.raw[:used.value]
+
+    def restore_state(self, blob: bytes):
+        check(ddc_lib().pddc_pipeline_restore_state(self._h, C.create_string_buffer(blob, len(blob)), len(blob)))
 
     def schedule(self, nsamples: int) -> dict:
         """Tile schedule of the fused stage-0 kernel for a batch of nsamples."""

@@ -1184,6 +1184,133 @@ int pddc_pipeline_push_host(pddc_pipeline *p, const void *h_packed, size_t nsamp
     return PDDC_OK;
 }
 
+/* ---- checkpoint / resume of the stream state ------------------------------------------------
+ * What the reference never had to keep (its FPGA did): per stage the FIR history and the decimation
+ * phase, the 64-bit sample counter, the NCO word with its phase offset and the tuning-word segments
+ * that still reach into stage 0's history.  Saved as one host blob; restored into a pipeline of the
+ * same plan (same or another GPU): the stream then continues bit-identically.                       */
+struct StateHeader {
+    uint32_t magic, version, nstages, flags;
+    int32_t R, NT;
+    uint64_t n0;
+    uint32_t freg, phase_off, freg_applied, fresh, nsegs, pad;
+    struct {
+        int32_t decim, interp, ntaps, hist, hist_elem, pad;
+        uint64_t consumed;
+    } st[PDDC_MAX_STAGES];
+};
+static const uint32_t kStateMagic = 0x53434450u;      /* "PDCS" */
+
+static size_t state_bytes(const pddc_pipeline *p)
+{
+    size_t n = sizeof(StateHeader) + p->segs.size() * (sizeof(long long) + 2 * sizeof(uint32_t));
+    for (int i = 0; i < p->nstages; ++i)
+        n += (size_t)p->st[i].hist * (size_t)p->st[i].hist_elem;
+    return n;
+}
+
+size_t pddc_pipeline_state_size(const pddc_pipeline *p) { return p ? state_bytes(p) : 0; }
+
+int pddc_pipeline_save_state(pddc_pipeline *p, void *h_buf, size_t capacity, size_t *used)
+{
+    if (!p || !h_buf)
+        return fail(PDDC_EINVAL, "null argument");
+    const size_t need = state_bytes(p);
+    if (used)
+        *used = need;
+    if (capacity < need)
+        return fail(PDDC_ECAPACITY, "state needs %zu bytes, buffer has %zu", need, capacity);
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());                  /* every batch pushed so far is part of the state */
+    StateHeader h = {};
+    h.magic = kStateMagic;
+    h.version = 1;
+    h.nstages = (uint32_t)p->nstages;
+    h.flags = p->flags;
+    h.R = p->R;
+    h.NT = p->NT;
+    h.n0 = p->n0;
+    h.freg = p->freg;
+    h.phase_off = p->phase_off;
+    h.freg_applied = p->freg_applied;
+    h.fresh = p->fresh ? 1u : 0u;
+    h.nsegs = (uint32_t)p->segs.size();
+    for (int i = 0; i < p->nstages; ++i) {
+        const Stage &s = p->st[i];
+        h.st[i].decim = s.decim;
+        h.st[i].interp = s.interp;
+        h.st[i].ntaps = s.ntaps;
+        h.st[i].hist = s.hist;
+        h.st[i].hist_elem = s.hist_elem;
+        h.st[i].consumed = s.consumed;
+    }
+    uint8_t *w = static_cast<uint8_t *>(h_buf);
+    memcpy(w, &h, sizeof(h));
+    w += sizeof(h);
+    for (const auto &sg : p->segs) {
+        memcpy(w, &sg.n_begin, sizeof(long long));
+        memcpy(w + 8, &sg.freg, 4);
+        memcpy(w + 12, &sg.off, 4);
+        w += 16;
+    }
+    for (int i = 0; i < p->nstages; ++i) {
+        const Stage &s = p->st[i];
+        const size_t nb = (size_t)s.hist * (size_t)s.hist_elem;
+        HIP_TRY(hipMemcpy(w, s.d_hist[s.cur], nb, hipMemcpyDeviceToHost));
+        w += nb;
+    }
+    return PDDC_OK;
+}
+
+int pddc_pipeline_restore_state(pddc_pipeline *p, const void *h_buf, size_t nbytes)
+{
+    if (!p || !h_buf || nbytes < sizeof(StateHeader))
+        return fail(PDDC_EINVAL, "bad state buffer");
+    StateHeader h;
+    memcpy(&h, h_buf, sizeof(h));
+    if (h.magic != kStateMagic || h.version != 1)
+        return fail(PDDC_EINVAL, "not a pipeline state (magic %08x version %u)", h.magic, h.version);
+    if ((int)h.nstages != p->nstages || h.flags != p->flags || h.R != p->R || h.NT != p->NT)
+        return fail(PDDC_ESTATE, "state was saved from a different plan (stages %u/%d, flags %x/%x, R %d/%d)", h.nstages,
+                    p->nstages, h.flags, p->flags, h.R, p->R);
+    size_t need = sizeof(StateHeader) + (size_t)h.nsegs * 16;
+    for (int i = 0; i < p->nstages; ++i) {
+        const Stage &s = p->st[i];
+        if (h.st[i].decim != s.decim || h.st[i].interp != s.interp || h.st[i].ntaps != s.ntaps ||
+            h.st[i].hist != s.hist || h.st[i].hist_elem != s.hist_elem)
+            return fail(PDDC_ESTATE, "state was saved from a different plan (stage %d)", i);
+        need += (size_t)s.hist * (size_t)s.hist_elem;
+    }
+    if (nbytes < need || h.nsegs < 1 || h.nsegs > 4096)
+        return fail(PDDC_EINVAL, "state buffer truncated (%zu of %zu bytes)", nbytes, need);
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const uint8_t *r = static_cast<const uint8_t *>(h_buf) + sizeof(StateHeader);
+    p->segs.clear();
+    for (uint32_t k = 0; k < h.nsegs; ++k) {
+        pddc_pipeline::WordSeg sg;
+        memcpy(&sg.n_begin, r, sizeof(long long));
+        memcpy(&sg.freg, r + 8, 4);
+        memcpy(&sg.off, r + 12, 4);
+        p->segs.push_back(sg);
+        r += 16;
+    }
+    for (int i = 0; i < p->nstages; ++i) {
+        Stage &s = p->st[i];
+        const size_t nb = (size_t)s.hist * (size_t)s.hist_elem;
+        HIP_TRY(hipMemcpy(s.d_hist[s.cur], r, nb, hipMemcpyHostToDevice));
+        s.consumed = h.st[i].consumed;
+        r += nb;
+    }
+    p->n0 = h.n0;
+    p->freg = h.freg;
+    p->phase_off = h.phase_off;
+    p->freg_applied = h.freg_applied;
+    p->fresh = h.fresh != 0;
+    compute_lo_steps(p);
+    return PDDC_OK;
+}
+
 int pddc_pipeline_inject_failure(pddc_pipeline *p, int stage)
 {
     if (!p || stage < 0 || stage >= p->nstages)

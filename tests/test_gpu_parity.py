@@ -949,3 +949,41 @@ def test_too_small_output_buffer_is_refused_before_anything_runs(pkg, dev, O):
     assert O.rel_err(np.concatenate([ya, yb]).reshape(-1), ref) <= FIR_TOL
     assert pipe.next_output(ns) == ns // 8
     pipe.close()
+
+
+# ------------------------------------------------------------ checkpoint / resume
+@pytest.mark.parametrize("plan", ["d8_255", "c320", "rational", "generic10"])
+def test_checkpoint_and_resume_continue_bit_identically(pkg, dev, O, plan):
+    """The stream state -- FIR histories, decimation phases, sample counter, NCO word and phase offset -- saved
+    after some batches and restored into a fresh pipeline of the same plan: the continuation is bit-identical
+    to the stream that was never interrupted (also right after a retune, and with uneven batches)."""
+    g = (np.random.default_rng(4).standard_normal(120) / 10).astype(np.float32)
+    plans = {"d8_255": [(8, load_taps("d8_255"))],
+             "c320": [(8, load_taps("c320_s1_d8_32")), (8, load_taps("c320_s2_d8_64")), (5, load_taps("c320_s3_d5_161"))],
+             "rational": [(8, load_taps("c320_s1_d8_32")), (5, load_taps("c320_s3_d5_161")[:41]), (25, g, 12)],
+             "generic10": [(10, load_taps("c320_s3_d5_161")[:77]), (5, load_taps("c320_s3_d5_161"))]}
+    stages = plans[plan]
+    sizes = [8192 * 3, 8 * 777, 8192, 8 * 12, 8192 * 2 + 8 * 5, 4096]
+    packed = [to_dev(O.lcg_bytes(6 * n, 700 + k), dev) for k, n in enumerate(sizes)]
+    words = [381178347, 381178347, 99999999, 99999999, 4000000000, 4000000000]
+    a = pkg.Pipeline(stages, mix=True)
+    blobs, outs = [], []
+    for b, w in zip(packed, words):
+        a.set_freg(w)
+        blobs.append(a.save_state())
+        outs.append(a.process(b).cpu().numpy())
+    for cut in (1, 2, 3, 5):                                  # resume from the state saved BEFORE batch `cut`
+        b2 = pkg.Pipeline(stages, mix=True)
+        b2.restore_state(blobs[cut])
+        for k in range(cut, len(sizes)):
+            b2.set_freg(words[k])
+            assert np.array_equal(b2.process(packed[k]).cpu().numpy(), outs[k]), (plan, cut, k)
+        b2.close()
+    other = pkg.Pipeline([(8, load_taps("d8_127"))], mix=True)
+    with pytest.raises(pkg.PddcError) as e:
+        other.restore_state(blobs[2])                         # another plan: refused
+    assert e.value.code == pkg.PDDC_ESTATE
+    with pytest.raises(pkg.PddcError):
+        a.restore_state(blobs[2][:40])
+    other.close()
+    a.close()
