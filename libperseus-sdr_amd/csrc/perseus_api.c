@@ -478,10 +478,11 @@ static int turn(perseus_descr *d, fill_fn fill, size_t avail)
     }
     if (avail == 0)
         return 0;
-    if (fault == FAULT_OOS) {
-        /* two neighbouring transfers complete in the wrong order */
-        if (avail < 2 || QUEUE_SIZE - d->n_dead < 2)
-            return 0;
+    if (fault == FAULT_OOS && QUEUE_SIZE - d->n_dead >= 2) {
+        /* two neighbouring transfers complete in the wrong order (with a single live transfer left
+         * there is no neighbour: the rule is ignored) */
+        if (avail < 2)
+            return 0;                                 /* wait until two buffers of payload exist */
         const int a = next_live_slot(d), b = next_live_slot(d);
         const size_t ga = fill(d, d->ring + (size_t)a * d->buffersize);
         const size_t gb = fill(d, d->ring + (size_t)b * d->buffersize);
@@ -1273,6 +1274,11 @@ int perseus_amd_get_stats(perseus_descr *d, perseus_amd_stats *st)
 {
     if (d == NULL || st == NULL)
         return errorset(PERSEUS_NULLDESCR, "null descriptor");
+    /* the delivery thread updates these under the pump lock while streaming (a client callback runs
+     * ON that thread with the lock held: no second lock then) */
+    const int on_worker = g_thread_on && pthread_equal(pthread_self(), g_thread);
+    if (!on_worker)
+        pthread_mutex_lock(&d->pump_lock);
     st->delivered = d->delivered;
     st->dropped = d->dropped;
     st->timeouts = d->timeouts;
@@ -1284,6 +1290,8 @@ int perseus_amd_get_stats(perseus_descr *d, perseus_amd_stats *st)
     st->gpu_device = d->gpu_dev;
     st->gpu_source = d->gpu_source;
     st->peak_receivers_in_flight = g_peak_inflight;
+    if (!on_worker)
+        pthread_mutex_unlock(&d->pump_lock);
     return errornone(0);
 }
 
@@ -1292,7 +1300,9 @@ int perseus_amd_get_retune_log(perseus_descr *d, uint64_t *first_sample, uint32_
     if (d == NULL)
         return errorset(PERSEUS_NULLDESCR, "null descriptor");
     /* read under the pump lock: the delivery thread appends while streaming */
-    pthread_mutex_lock(&d->pump_lock);
+    const int on_worker = g_thread_on && pthread_equal(pthread_self(), g_thread);
+    if (!on_worker)
+        pthread_mutex_lock(&d->pump_lock);
     const int n = d->n_retunes;
     for (int i = 0; i < n && i < capacity; i++) {
         if (first_sample)
@@ -1300,7 +1310,8 @@ int perseus_amd_get_retune_log(perseus_descr *d, uint64_t *first_sample, uint32_
         if (word)
             word[i] = d->retune_word[i];
     }
-    pthread_mutex_unlock(&d->pump_lock);
+    if (!on_worker)
+        pthread_mutex_unlock(&d->pump_lock);
     return errornone(n);
 }
 

@@ -544,3 +544,29 @@ def test_api_layer_is_threadsanitizer_clean(pkg, tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[-3000:]
     assert p.returncode == 0 and "4 receivers:" in p.stderr
+
+
+def test_introspection_calls_are_safe_inside_the_callback(L, pkg):
+    """perseus_amd_get_stats / _get_retune_log from the client callback (which runs on the delivery thread
+    with the receiver's lock held) must not deadlock."""
+    d = bring_up(L)
+    seen = []
+
+    def on_buf(buf, n, extra):
+        st = pkg.AmdStats()
+        assert L.perseus_amd_get_stats(d, C.byref(st)) == 0
+        assert L.perseus_amd_get_retune_log(d, None, None, 0) >= 0
+        seen.append(int(st.transfers))
+        return 0
+
+    cfg = pkg.AmdConfig()
+    L.perseus_amd_get_config(d, C.byref(cfg))
+    cfg.max_buffers, cfg.pace = 12, 0
+    L.perseus_amd_set_config(d, C.byref(cfg))
+    cb = pkg.PERSEUS_CALLBACK(on_buf)
+    assert L.perseus_start_async_input(d, 6144, cb, None) == 0
+    t0 = time.time()
+    while L.perseus_amd_source_running(d) and time.time() - t0 < 20:
+        time.sleep(0.002)
+    assert L.perseus_stop_async_input(d) == 0
+    assert seen == list(range(1, 13))
