@@ -262,8 +262,11 @@ int pddc_comm_barrier(pddc_comm *c);
 int pddc_comm_gather(pddc_comm *c, const void *d_send, size_t nbytes, void *d_recv, int root, void *stream);
 /* The same on the communicator's own side stream, started once everything queued on
  * `after_stream` so far (the kernels that wrote d_send) is done -- the transfer of
- * batch k then runs under the kernels of batch k+1.  Before d_send is overwritten
- * (or d_recv read) either make a stream wait with _fence, or the host with _wait.  */
+ * batch k then runs under the kernels of batch k+1.  Meant for TWO alternating send
+ * buffers: pddc_comm_gather_fence(c, stream) makes `stream` wait for every transfer
+ * but the most recent one -- call it before the kernels that overwrite the buffer
+ * used two gathers ago; pddc_comm_gather_wait(c) makes the host wait for all of them
+ * (before d_recv is read, or a buffer is freed).                                    */
 int pddc_comm_gather_async(pddc_comm *c, const void *d_send, size_t nbytes, void *d_recv, int root,
                            void *after_stream);
 int pddc_comm_gather_fence(pddc_comm *c, void *stream);

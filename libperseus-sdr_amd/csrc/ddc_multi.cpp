@@ -53,18 +53,26 @@ struct pddc_comm {
     int nranks = 0, rank = 0, device = 0;
     hipStream_t side = nullptr;          /* gathers run here, beside the compute stream      */
     hipEvent_t ev_ready = nullptr;       /* compute stream -> side stream: the batch exists  */
-    hipEvent_t ev_done = nullptr;        /* side stream: the batch has left / has arrived    */
-    bool pending = false;
+    hipEvent_t ev_done[2] = { nullptr, nullptr };   /* side stream: transfer n has left / arrived (n & 1) */
+    unsigned long long n_gathers = 0;    /* side-stream gathers started so far                */
     void *d_scratch = nullptr;           /* bounce buffer of the host-level helpers          */
     size_t scratch_cap = 0;
 };
+
+/* pddc_comm_group_start/_end bracket the per-communicator calls of ONE collective when a single
+ * thread drives several GPUs.  RCCL only enqueues the grouped operations at the outermost
+ * ncclGroupEnd, so the "transfer done" event of a side-stream gather cannot be recorded where the
+ * gather is called: it is recorded here, after the group has ended.                              */
+static thread_local int g_group_depth = 0;
+static thread_local std::vector<pddc_comm *> g_group_pending;
 
 static int comm_finish_init(pddc_comm *c)
 {
     HIP_TRYM(hipSetDevice(c->device));
     HIP_TRYM(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     HIP_TRYM(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-    HIP_TRYM(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    HIP_TRYM(hipEventCreateWithFlags(&c->ev_done[0], hipEventDisableTiming));
+    HIP_TRYM(hipEventCreateWithFlags(&c->ev_done[1], hipEventDisableTiming));
     return PDDC_OK;
 }
 
@@ -185,8 +193,9 @@ int pddc_comm_destroy(pddc_comm *c)
         ncclCommDestroy(c->comm);
     if (c->ev_ready)
         hipEventDestroy(c->ev_ready);
-    if (c->ev_done)
-        hipEventDestroy(c->ev_done);
+    for (int k = 0; k < 2; ++k)
+        if (c->ev_done[k])
+            hipEventDestroy(c->ev_done[k]);
     if (c->side)
         hipStreamDestroy(c->side);
     if (c->d_scratch)
@@ -202,12 +211,24 @@ int pddc_comm_device(const pddc_comm *c) { return c ? c->device : pddc_set_error
 int pddc_comm_group_start(void)
 {
     NCCL_TRY(ncclGroupStart());
+    ++g_group_depth;
     return PDDC_OK;
 }
 
 int pddc_comm_group_end(void)
 {
+    if (g_group_depth > 0)
+        --g_group_depth;
     NCCL_TRY(ncclGroupEnd());
+    if (g_group_depth == 0) {
+        /* the grouped transfers are on their side streams now: mark their completion points */
+        std::vector<pddc_comm *> done;
+        done.swap(g_group_pending);
+        for (pddc_comm *c : done) {
+            HIP_TRYM(hipSetDevice(c->device));
+            HIP_TRYM(hipEventRecord(c->ev_done[(c->n_gathers - 1) & 1], c->side));
+        }
+    }
     return PDDC_OK;
 }
 
@@ -323,8 +344,11 @@ int pddc_comm_gather_async(pddc_comm *c, const void *d_send, size_t nbytes, void
     HIP_TRYM(hipStreamWaitEvent(c->side, c->ev_ready, 0));
     if (nbytes && (rc = gather_on(c, d_send, nbytes, d_recv, root, c->side)))
         return rc;
-    HIP_TRYM(hipEventRecord(c->ev_done, c->side));
-    c->pending = true;
+    c->n_gathers++;
+    if (g_group_depth > 0)
+        g_group_pending.push_back(c);          /* recorded by pddc_comm_group_end, once RCCL has enqueued the group */
+    else
+        HIP_TRYM(hipEventRecord(c->ev_done[(c->n_gathers - 1) & 1], c->side));
     return PDDC_OK;
 }
 
@@ -332,10 +356,12 @@ int pddc_comm_gather_fence(pddc_comm *c, void *stream)
 {
     if (!c)
         return pddc_set_error_(PDDC_EINVAL, "null communicator");
-    if (!c->pending)
+    /* double buffering: the caller alternates two send buffers, so before it writes one again the
+     * transfer BEFORE the most recent one must be done -- the most recent may still be running */
+    if (c->n_gathers < 2)
         return PDDC_OK;
     HIP_TRYM(hipSetDevice(c->device));
-    HIP_TRYM(hipStreamWaitEvent((hipStream_t)stream, c->ev_done, 0));
+    HIP_TRYM(hipStreamWaitEvent((hipStream_t)stream, c->ev_done[(c->n_gathers - 2) & 1], 0));
     return PDDC_OK;
 }
 
@@ -343,11 +369,10 @@ int pddc_comm_gather_wait(pddc_comm *c)
 {
     if (!c)
         return pddc_set_error_(PDDC_EINVAL, "null communicator");
-    if (!c->pending)
+    if (c->n_gathers == 0)
         return PDDC_OK;
     HIP_TRYM(hipSetDevice(c->device));
-    HIP_TRYM(hipEventSynchronize(c->ev_done));
-    c->pending = false;
+    HIP_TRYM(hipEventSynchronize(c->ev_done[(c->n_gathers - 1) & 1]));      /* the latest; the side stream is in order */
     return PDDC_OK;
 }
 

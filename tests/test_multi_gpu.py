@@ -136,3 +136,27 @@ def test_bench_gather_leg_on_one_rank():
     assert g["this_workload"]["out_bytes_per_rank_per_step"] == (1 << 24) // 8 * 8
     assert g["c320"]["root_block_matches_own_output"] is True and g["c320"]["value"] > 0
     assert d["verified"]["ok"] is True
+
+
+def test_c_multi_gpu_bench_needs_a_gpu(pkg):
+    exe = os.path.join(os.path.dirname(pkg.DDC_LIB), "perseus_multi_bench")
+    assert os.path.exists(exe)
+    if pkg.ddc_lib().pddc_device_count() > 0:
+        pytest.skip("GPU present")
+    p = subprocess.run([exe, "-g", "2"], capture_output=True, text=True, timeout=60)
+    assert p.returncode != 0 and "no CPU path" in p.stderr
+
+
+@pytest.mark.gpu
+def test_c_multi_gpu_bench_with_gather(pkg, dev):
+    """BASELINE config 4 from a plain C host (csrc/perseus_multi_bench.c): pddc_comm_init_all, one pipeline per
+    GPU, grouped side-stream gathers -- here with the one GPU the box has (the same code drives eight)."""
+    import re
+    exe = os.path.join(os.path.dirname(pkg.DDC_LIB), "perseus_multi_bench")
+    for extra in ([], ["-c"]):
+        p = subprocess.run([exe, "-n", "24", "-s", "20", "-G"] + extra, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr[-800:]
+        m = re.search(r"(\d+) GPU\(s\).*: ([0-9.]+) MS/s aggregate.*with the gather to GPU 0: ([0-9.]+) MS/s", p.stdout)
+        assert m, p.stdout
+        assert int(m.group(1)) == 1 and float(m.group(2)) > 50000 and float(m.group(3)) > 20000
+        print(p.stdout.strip().splitlines()[-1])
