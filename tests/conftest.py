@@ -19,7 +19,8 @@ def pytest_configure(config):
 def pkg():
     p = importlib.import_module("libperseus-sdr_amd")
     plumbing = os.path.join(os.path.dirname(p.SDR_LIB), "perseus_plumbing")
-    if not all(os.path.exists(f) for f in (p.DDC_LIB, p.SDR_LIB, plumbing)):
+    multi = os.path.join(os.path.dirname(p.SDR_LIB), "perseus_multi_bench")
+    if not all(os.path.exists(f) for f in (p.DDC_LIB, p.SDR_LIB, plumbing, multi)):
         p.build()
     return p
 
