@@ -40,8 +40,12 @@ def _run(O, stages, tones_hz, n_in, amp=0.2):
     return y[0::2] + 1j * y[1::2]
 
 
+NFFT = 1024
+
+
 def _spectrum(z, skip):
-    z = z[skip:]
+    z = z[skip:skip + NFFT]
+    assert z.size == NFFT
     w = np.blackman(z.size)
     return np.abs(np.fft.fft(z * w)) / np.sum(w)
 
@@ -55,7 +59,7 @@ def test_rate_plan_is_a_clean_receiver(pkg, O, rate):
     skip = 512                                                          # filter transients
     amp = 0.2
     # 1. a tone inside the wanted band: unit gain, and nothing else in the output above -75 dBc
-    f0 = 0.23 * rate
+    f0 = round(0.23 * NFFT) / NFFT * rate                               # on an FFT bin: no scalloping loss
     z = _run(O, stages, [f0], n_in, amp)
     sp = _spectrum(z, skip)
     nfft = sp.size
