@@ -489,16 +489,22 @@ def gather_leg(a, pkg, grp, dev, stream, ns, d_in, pipe, out_shape_rows, decim, 
     torch.cuda.synchronize(dev)
     grp.barrier()
     tg = grp.max_seconds(time.perf_counter() - t0)
-    ok = None
+    # every block that reached the root against what its rank sent: checksums of the last batch travel over
+    # the control plane (gloo), the blocks themselves came over xGMI
+    last = outs[(a.steps - 1) & 1][:n_out]
+    sums = grp.all_gather_object(int(last.view(torch.int32).to(torch.int64).sum().item()))
+    ok = blocks_ok = None
     if rank == 0:                               # rank 0's own block is its own last output
-        ok = bool(torch.equal(recv[0], outs[(a.steps - 1) & 1][:n_out]))
+        ok = bool(torch.equal(recv[0], last))
+        blocks_ok = bool(all(int(recv[r].view(torch.int32).to(torch.int64).sum().item()) == sums[r]
+                             for r in range(world)))
     return {"workload": label, "value": round(world * ns * a.steps / tg / 1e6, 1), "unit": "MS/s",
             "ms_per_step": round(tg / a.steps * 1e3, 4),
             "out_bytes_per_rank_per_step": int(nbytes),
             "root_ingest_GBps": round((world - 1) * nbytes * a.steps / tg / 1e9, 2),
             # xGMI is point to point: each peer reaches rank 0 over its own link
             "per_link_GBps": round(nbytes * a.steps / tg / 1e9, 2) if world > 1 else 0.0,
-            "root_block_matches_own_output": ok}
+            "root_block_matches_own_output": ok, "all_blocks_match_their_ranks_checksums": blocks_ok}
 
 
 def guarded_gather_legs(a, pkg, shard, grp, dev, stream, ns, d_in, wl, pipe, out):

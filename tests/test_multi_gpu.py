@@ -133,6 +133,7 @@ def test_bench_gather_leg_on_one_rank():
     g = d["gather"]
     assert "error" not in g, g
     assert g["this_workload"]["root_block_matches_own_output"] is True
+    assert g["this_workload"]["all_blocks_match_their_ranks_checksums"] is True
     assert g["this_workload"]["out_bytes_per_rank_per_step"] == (1 << 24) // 8 * 8
     assert g["c320"]["root_block_matches_own_output"] is True and g["c320"]["value"] > 0
     assert d["verified"]["ok"] is True
