@@ -131,6 +131,16 @@ def launch_ranks(n, argv, timeout_s=3000.0):
 # ----------------------------------------------------------------------------------------
 # CPU leg
 # ----------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(workload, seconds):
     """Oracle float path on the host cores, bounded sample (kind: port)."""
     import numpy as np
@@ -149,12 +159,17 @@ def cpu_baseline(workload, seconds):
         m = re.search(r"Rate: ([0-9.]+) kS/s", p.stderr)
         if m:
             return {"value": round(float(m.group(1)) / 1e3, 2), "unit": "MS/s", "cores": 1, "kind": "reference",
+                    "cpu_model": cpu_model(),
                     "sample": f"examples/perseustest.c user_data_callback_c_f (6144-byte buffers, per-sample fwrite to "
                               f"/dev/null) driven unpaced by libperseus-sdr.so for {t} s"}
     if workload == "unpack":
         run = lambda b: O.unpack24_f32(b)
         label = "24-bit unpack only, 1 thread (reference callback style)"
         threads = 1
+    elif workload == "c320":
+        w = workload_def("c320")
+        run = lambda b: O.ddc_chain(b, w["stages"], w["freg"], True)
+        label = "unpack + NCO 7.1 MHz + cascade /320 (8*8*5), the parity oracle itself: double accumulate, FIR stages OpenMP"
     else:
         h = load_taps("d8_255" if workload == "d8_255" else "d8_127")
         run = lambda b: O.stage1_f32(b, h, 8, threads)
@@ -170,7 +185,7 @@ def cpu_baseline(workload, seconds):
         if dt >= seconds or passes >= 4096:
             break
     n_big = n * passes
-    return {"value": round(n_big / dt / 1e6, 2), "unit": "MS/s", "cores": threads, "kind": "port",
+    return {"value": round(n_big / dt / 1e6, 2), "unit": "MS/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{passes} passes over 2^25 samples of the same LCG stream ({label}), {dt:.1f} s"}
 
 

@@ -31,7 +31,7 @@ def test_defaults_follow_the_contract(monkeypatch):
 def test_cpu_baseline_leg_fields():
     b = _bench()
     r = b.cpu_baseline("d8_127", 0.2)
-    assert set(r) == {"value", "unit", "cores", "kind", "sample"}
+    assert set(r) == {"value", "unit", "cores", "kind", "sample", "cpu_model"} and r["cpu_model"]
     assert r["unit"] == "MS/s" and r["kind"] == "port" and r["cores"] >= 1 and r["value"] > 0
     r1 = b.cpu_baseline("unpack", 0.1)
     assert r1["cores"] == 1 and r1["value"] > 0
