@@ -199,6 +199,12 @@ int pddc_host_free(void *h_ptr);
 int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsamples,
                               void *d_out_f32, int iters, void *stream, float *avg_ms);
 
+/* The same measurement INSIDE the caller's own loop: while enabled, every process() brackets its stage-0
+ * (or fused-pair) kernel with a pair of HIP events on the caller's stream; pddc_pipeline_stage0_time waits for
+ * them and returns the average kernel duration over the process() calls since it was enabled (or last read).
+ * This is how bench.py gets the dominant kernel's duration over exactly its timed region.                  */
+int pddc_pipeline_time_stage0_inline(pddc_pipeline *p, int enable);
+int pddc_pipeline_stage0_time(pddc_pipeline *p, float *avg_ms, int *nlaunches);
 /* The tile schedule a process() of nsamples would launch the fused stage-0 kernel with:
  * out = { inputs per tile, tiles, persistent blocks, S, K } -- block b first owns the S
  * tiles [b*S, (b+1)*S), the tiles from blocks*S on are handed out in chunks of K.  For

@@ -120,6 +120,10 @@ def ddc_lib() -> C.CDLL:
     L.pddc_host_alloc.argtypes = [C.POINTER(vp), sz]
     L.pddc_host_free.argtypes = [vp]
     L.pddc_pipeline_time_stage0.argtypes = [vp, vp, sz, vp, C.c_int, vp, C.POINTER(C.c_float)]
+    L.pddc_pipeline_time_stage0_inline.argtypes = [vp, C.c_int]
+    L.pddc_pipeline_time_stage0_inline.restype = C.c_int
+    L.pddc_pipeline_stage0_time.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.pddc_pipeline_stage0_time.restype = C.c_int
     L.pddc_pipeline_state_size.argtypes = [vp]
     L.pddc_pipeline_state_size.restype = sz
     L.pddc_pipeline_save_state.argtypes = [vp, vp, sz, C.POINTER(sz)]
@@ -323,6 +327,16 @@ class Pipeline:
         o = (C.c_int * 5)()
         check(ddc_lib().pddc_pipeline_schedule(self._h, nsamples, o))
         return {"tile": o[0], "ntiles": o[1], "nblocks": o[2], "S": o[3], "K": o[4]}
+
+    def time_stage0_inline(self, enable: bool):
+        """Bracket the stage-0 kernel of every process() with HIP events (read with stage0_time)."""
+        check(ddc_lib().pddc_pipeline_time_stage0_inline(self._h, 1 if enable else 0))
+
+    def stage0_time(self):
+        """-> (average ms of the stage-0 kernel over the process() calls since enabled, number of calls)."""
+        ms, n = C.c_float(0), C.c_int(0)
+        check(ddc_lib().pddc_pipeline_stage0_time(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
 
     def time_stage0(self, d_in: int, nsamples: int, d_out: int, iters: int, stream: int = 0) -> float:
         ms = C.c_float(0)

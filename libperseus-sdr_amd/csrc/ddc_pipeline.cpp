@@ -108,6 +108,10 @@ struct pddc_pipeline {
     std::vector<WordSeg> segs;
     float *d_hist_f32 = nullptr;  /* stage 0's history as mixed float2, for that route */
     int fail_at_stage = -1;       /* test hook: the next process() fails when it reaches this stage */
+    /* measurement hook: HIP events around the stage-0 (or fused-pair) kernel of every process() */
+    bool time_stage0 = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
     float lo_c[8], lo_s[8];
     float lo_c_applied[8], lo_s_applied[8];   /* step phasors of freg_applied */
     unsigned long long n0 = 0;    /* absolute sample counter (stage 0 input)    */
@@ -517,6 +521,10 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
         hipFree(p->d_fout);
     if (p->d_hist_f32)
         hipFree(p->d_hist_f32);
+    for (auto &e : p->ev_pool) {
+        hipEventDestroy(e.first);
+        hipEventDestroy(e.second);
+    }
     if (p->d_sched)
         hipFree(p->d_sched);
     if (p->own_stream)
@@ -773,6 +781,28 @@ static int ensure_buf(Stage &s, size_t need)
     return PDDC_OK;
 }
 
+/* stage-0 timing: a pair of events per process(), reused from a pool */
+static int stage0_event(pddc_pipeline *p, hipStream_t s, bool start)
+{
+    if (!p->time_stage0)
+        return PDDC_OK;
+    if (start) {
+        if (p->ev_used == p->ev_pool.size()) {
+            if (p->ev_pool.size() >= 8192)
+                return PDDC_OK;                       /* enough samples: stop recording */
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            p->ev_pool.emplace_back(a, b);
+        }
+        HIP_TRY(hipEventRecord(p->ev_pool[p->ev_used].first, s));
+    } else if (p->ev_used < p->ev_pool.size()) {
+        HIP_TRY(hipEventRecord(p->ev_pool[p->ev_used].second, s));
+        p->ev_used++;
+    }
+    return PDDC_OK;
+}
+
 static void fill_fir8_args(const pddc_pipeline *p, Fir8Args &a)
 {
     a.n0 = p->n0;
@@ -882,7 +912,11 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         a.hist2_out = s1.d_hist[s1.cur ^ 1];
         a.n_in = (long long)nsamples;
         fill_fir8_args(p, a);
+        if ((rc = stage0_event(p, s, true)))
+            return rc;
         HIP_TRY(launch_fir8_fused2(s0.ntb, p->R, mix, a, s));
+        if ((rc = stage0_event(p, s, false)))
+            return rc;
         flip[0] = flip[1] = true;
         first = 2;
     }
@@ -936,7 +970,11 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             a.taps_blk = st.d_taps_blk;
             a.n_in = (long long)nsamples;
             fill_fir8_args(p, a);
+            if ((rc = stage0_event(p, s, true)))
+                return rc;
             HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s, p->NT));
+            if ((rc = stage0_event(p, s, false)))
+                return rc;
             hist_done = a.hist_out != nullptr;
         } else if (i == 0 && stage0_packed_generic(p)) {
             if (n_in[1] > 0) {
@@ -1308,6 +1346,34 @@ int pddc_pipeline_restore_state(pddc_pipeline *p, const void *h_buf, size_t nbyt
     p->freg_applied = h.freg_applied;
     p->fresh = h.fresh != 0;
     compute_lo_steps(p);
+    return PDDC_OK;
+}
+
+int pddc_pipeline_time_stage0_inline(pddc_pipeline *p, int enable)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    p->time_stage0 = enable != 0;
+    p->ev_used = 0;
+    return PDDC_OK;
+}
+
+int pddc_pipeline_stage0_time(pddc_pipeline *p, float *avg_ms, int *nlaunches)
+{
+    if (!p || !avg_ms)
+        return fail(PDDC_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    double sum = 0.0;
+    for (size_t k = 0; k < p->ev_used; ++k) {
+        HIP_TRY(hipEventSynchronize(p->ev_pool[k].second));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, p->ev_pool[k].first, p->ev_pool[k].second));
+        sum += ms;
+    }
+    *avg_ms = p->ev_used ? (float)(sum / (double)p->ev_used) : 0.0f;
+    if (nlaunches)
+        *nlaunches = (int)p->ev_used;
+    p->ev_used = 0;
     return PDDC_OK;
 }
 
