@@ -67,6 +67,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle window check of the last output")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--out-candidates", type=int, default=6,
+                    help="output buffers to allocate and try before the run; the fastest one is used (where a buffer\n"
+                         "lies in HBM changes this kernel's speed by up to 8 %% on some boxes, tools/placement_probe.py);\n"
+                         "1 = take the first allocation as it comes")
     ap.add_argument("--gather-timeout", type=float, default=240.0,
                     help="watchdog for the gather leg: past this the line is printed without it")
     return ap.parse_args(argv)
@@ -332,25 +336,78 @@ def run_rank(a):
     ns = 1 << a.log2n
     wl = workload_def(a.workload)
     stages = wl["stages"]
-    d_in = pkg.synth_lcg(6 * ns, shard.stream_seed(rank), 0, dev)   # device resident before timing
+    inbox = [pkg.synth_lcg(6 * ns, shard.stream_seed(rank), 0, dev)]   # device resident before timing
     stream = torch.cuda.current_stream(dev).cuda_stream
     calls = [0]
     if stages is not None:
         # configuration (taps, NCO word, plan) comes from rank 0 over RCCL: a few KB, once
         pipe = grp.make_pipeline(pkg, stages, wl["freg"], wl["mix"], a.taps_fp16)
-        out = torch.empty((pipe.max_output(ns) + 8, 2), dtype=torch.float32, device=dev)
+        out_rows = pipe.max_output(ns) + 8
+        outbox = [torch.empty((out_rows, 2), dtype=torch.float32, device=dev)]
 
         def step():
             calls[0] += 1
-            return pipe.process_ptr(d_in.data_ptr(), ns, out.data_ptr(), out.shape[0], stream)
+            return pipe.process_ptr(inbox[0].data_ptr(), ns, outbox[0].data_ptr(), out_rows, stream)
     else:
         pipe = None
-        out = torch.empty((ns, 2), dtype=torch.float32, device=dev)
+        out_rows = ns
+        outbox = [torch.empty((ns, 2), dtype=torch.float32, device=dev)]
 
         def step():
             calls[0] += 1
-            pkg.check(pkg.ddc_lib().pddc_unpack24_f32(d_in.data_ptr(), ns, out.data_ptr(), stream))
+            pkg.check(pkg.ddc_lib().pddc_unpack24_f32(inbox[0].data_ptr(), ns, outbox[0].data_ptr(), stream))
             return ns
+
+    # Where the buffers lie in HBM matters to this read/write stream: the same kernel runs at 0.340, 0.352 or 0.367 ms
+    # depending on WHICH of several equally sized, equally aligned allocations it reads from and writes to -- a property
+    # of the (input, output) pair, i.e. the two streams colliding or not in the memory system (matrix in
+    # profiles/r02/i_placement_matrix.txt, tools/placement_probe3.py; box and allocation dependent).  A receiver that
+    # runs for hours allocates once, so it can afford to try a few: N output candidates, 30 back-to-back steps into
+    # each, keep the fastest; if none stands out, one more input buffer (same bytes) and the outputs again.
+    placement = None
+    ncand = max(1, a.out_candidates) if out_rows * 8 >= (32 << 20) else 1
+    if ncand > 1:
+        cands = outbox + [torch.empty((out_rows, 2), dtype=torch.float32, device=dev) for _ in range(ncand - 1)]
+
+        def probe():
+            times = []
+            for c in cands:
+                outbox[0] = c
+                for _ in range(8):
+                    step()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(30):
+                    step()
+                e1.record()
+                e1.synchronize()
+                times.append(e0.elapsed_time(e1) / 30)
+            return times
+
+        outbox[0] = cands[0]
+        for _ in range(150):                              # the first candidate is not to be measured on cold clocks
+            step()
+        rounds = [probe()]
+        inputs_tried = 1
+        if min(rounds[0]) > 0.975 * float(np.median(rounds[0])):      # no pair stands out: another input placement
+            d_in2 = pkg.synth_lcg(6 * ns, shard.stream_seed(rank), 0, dev)
+            first_in, inbox[0] = inbox[0], d_in2
+            rounds.append(probe())
+            inputs_tried = 2
+            if min(rounds[1]) >= 0.985 * min(rounds[0]):
+                inbox[0] = first_in                        # no better: stay with the first input
+                rounds.append(None)
+            del first_in, d_in2
+        use = rounds[1] if (len(rounds) == 2) else rounds[0]
+        best = int(np.argmin(use))
+        outbox[0] = cands[best]
+        placement = {"output_candidates": ncand, "inputs_tried": inputs_tried,
+                     "step_ms_each": [[round(t, 4) for t in r] for r in rounds if r is not None], "chosen_output": best,
+                     "note": "buffers picked among equally sized allocations by 30-step probes before the settle phase; "
+                             "the speed is a property of the (input, output) pair"}
+        del cands
+    out = outbox[0]
+    d_in = inbox[0]
 
     # untimed settle: sustained-load clocks, not boost.  Eight calibration steps, then settle_ms worth of
     # launches queued back to back with NO host synchronisation in between (every idle gap, however short,
@@ -470,6 +527,7 @@ def run_rank(a):
                          "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_sample": bps},
             "events_ms_per_step": round(ev_ms / a.steps, 4),
+            "placement": placement,
             "verified": verified,
             "ranks_seen": grp.world, "devices": names,
             "collectives": "RCCL called from the C library (pddc_comm_*); torch.distributed = rendezvous only"
