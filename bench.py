@@ -67,10 +67,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle window check of the last output")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--out-candidates", type=int, default=6,
-                    help="output buffers to allocate and try before the run; the fastest one is used (where a buffer\n"
-                         "lies in HBM changes this kernel's speed by up to 8 %% on some boxes, tools/placement_probe.py);\n"
-                         "1 = take the first allocation as it comes")
+    ap.add_argument("--out-candidates", type=int, default=24,
+                    help="at most this many output buffers, 8 GiB apart, are tried before the run and the fastest is\n"
+                         "kept (input and output in different HBM extent classes: 0.340 instead of 0.367 ms,\n"
+                         "profiles/r02/i_placement_map.txt); 1 = take the first allocation as it comes")
     ap.add_argument("--gather-timeout", type=float, default=240.0,
                     help="watchdog for the gather leg: past this the line is printed without it")
     return ap.parse_args(argv)
@@ -358,54 +358,53 @@ def run_rank(a):
             pkg.check(pkg.ddc_lib().pddc_unpack24_f32(inbox[0].data_ptr(), ns, outbox[0].data_ptr(), stream))
             return ns
 
-    # Where the buffers lie in HBM matters to this read/write stream: the same kernel runs at 0.340, 0.352 or 0.367 ms
-    # depending on WHICH of several equally sized, equally aligned allocations it reads from and writes to -- a property
-    # of the (input, output) pair, i.e. the two streams colliding or not in the memory system (matrix in
-    # profiles/r02/i_placement_matrix.txt, tools/placement_probe3.py; box and allocation dependent).  A receiver that
-    # runs for hours allocates once, so it can afford to try a few: N output candidates, 30 back-to-back steps into
-    # each, keep the fastest; if none stands out, one more input buffer (same bytes) and the outputs again.
+    # Where the buffers lie in HBM matters to this read/write stream.  HBM is laid out in a few classes of large
+    # extents (tens of GiB each; three classes seen -- the stacks are 12 dies high, i.e. three ranks): with the input
+    # and the output in extents of the SAME class the kernel takes 0.367 ms, in DIFFERENT classes 0.340 ms, on every
+    # box, for every pair tried (maps in profiles/r02/i_placement_map.txt, tools/placement_probe5.py / 6.py) -- reads
+    # and writes that share a rank pay the write-to-read turnaround.  Buffers allocated one after the other usually
+    # land in the same extent.  So: allocate the output, time 24 back-to-back steps into it, put an 8 GiB spacer
+    # behind it and try again further on, until a candidate is clearly faster than the slowest seen (another class
+    # has been reached) or 192 GiB have been walked; keep the fastest, free everything else.  A receiver allocates
+    # once and runs for hours; 288 GB of HBM make the walk affordable.
     placement = None
     ncand = max(1, a.out_candidates) if out_rows * 8 >= (32 << 20) else 1
     if ncand > 1:
-        cands = outbox + [torch.empty((out_rows, 2), dtype=torch.float32, device=dev) for _ in range(ncand - 1)]
+        def probe_one(buf):
+            outbox[0] = buf
+            for _ in range(30):                           # the allocation before it left the GPU idle for a while
+                step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(24):
+                step()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / 24
 
-        def probe():
-            times = []
-            for c in cands:
-                outbox[0] = c
-                for _ in range(8):
-                    step()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(30):
-                    step()
-                e1.record()
-                e1.synchronize()
-                times.append(e0.elapsed_time(e1) / 30)
-            return times
-
-        outbox[0] = cands[0]
         for _ in range(150):                              # the first candidate is not to be measured on cold clocks
             step()
-        rounds = [probe()]
-        inputs_tried = 1
-        if min(rounds[0]) > 0.975 * float(np.median(rounds[0])):      # no pair stands out: another input placement
-            d_in2 = pkg.synth_lcg(6 * ns, shard.stream_seed(rank), 0, dev)
-            first_in, inbox[0] = inbox[0], d_in2
-            rounds.append(probe())
-            inputs_tried = 2
-            if min(rounds[1]) >= 0.985 * min(rounds[0]):
-                inbox[0] = first_in                        # no better: stay with the first input
-                rounds.append(None)
-            del first_in, d_in2
-        use = rounds[1] if (len(rounds) == 2) else rounds[0]
-        best = int(np.argmin(use))
+        cands, spacers, times = [outbox[0]], [], [probe_one(outbox[0])]
+        def both_classes_seen():                          # a fast and a slow placement, 4..12 % apart (more: an outlier)
+            lo = min(times)
+            return any(1.04 * lo < t < 1.12 * lo for t in times)
+
+        while len(cands) < ncand and not both_classes_seen():
+            try:
+                spacers.append(torch.empty(8 << 30, dtype=torch.uint8, device=dev))
+                c = torch.empty((out_rows, 2), dtype=torch.float32, device=dev)
+            except RuntimeError:                          # out of memory: stay with what there is
+                break
+            cands.append(c)
+            times.append(probe_one(c))
+        best = int(np.argmin(times))
         outbox[0] = cands[best]
-        placement = {"output_candidates": ncand, "inputs_tried": inputs_tried,
-                     "step_ms_each": [[round(t, 4) for t in r] for r in rounds if r is not None], "chosen_output": best,
-                     "note": "buffers picked among equally sized allocations by 30-step probes before the settle phase; "
-                             "the speed is a property of the (input, output) pair"}
-        del cands
+        placement = {"output_candidates_tried": len(cands), "spacer_GiB_between_candidates": 8,
+                     "step_ms_each": [round(t, 4) for t in times], "chosen": best,
+                     "note": "output buffer placed in another HBM extent class than the input: candidates 8 GiB apart, "
+                             "24-step probes before the settle phase, fastest kept, the rest freed"}
+        del cands, spacers, c
+        torch.cuda.empty_cache()
     out = outbox[0]
     d_in = inbox[0]
 
