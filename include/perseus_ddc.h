@@ -109,6 +109,15 @@ int pddc_synth_lcg(void *d_dst, size_t nbytes, uint32_t seed, uint64_t byte_offs
 int pddc_set_device(int device);
 int pddc_malloc(void **d_ptr, size_t nbytes);
 int pddc_free(void *d_ptr);
+/* Device memory for a buffer that is streamed AGAINST d_partner (one read while the other is written -- the packed
+ * input and the float output of a pipeline): HBM is laid out in a few classes of large extents, and such a pair runs
+ * ~8 % faster (k_fir8 127 taps: 0.340 instead of 0.367 ms) when the two buffers lie in extents of different classes;
+ * allocations made one after the other usually share one.  This allocates candidates 8 GiB apart (spacers, freed
+ * again), times a read+write probe stream between the partner and each, stops when both speeds have been seen or after
+ * max_candidates, and returns the fastest (free it with pddc_free).  *ms_best / *ms_worst: the probe's time per launch
+ * for the kept and for the slowest candidate.  Buffers under 32 MiB, or max_candidates <= 1: a plain allocation.      */
+int pddc_malloc_apart(void **d_ptr, size_t nbytes, const void *d_partner, size_t partner_bytes, int max_candidates,
+                      float *ms_best, float *ms_worst);
 int pddc_memcpy_h2d(void *d_dst, const void *h_src, size_t nbytes, void *stream);
 int pddc_memcpy_d2h(void *h_dst, const void *d_src, size_t nbytes, void *stream);
 int pddc_stream_sync(void *stream);

@@ -118,6 +118,10 @@ hipError_t launch_pack24(const float *in, long long nsamples, void *out, hipStre
 /* plain streaming copy of nbytes (multiple of 16, both pointers 16-byte aligned) */
 hipError_t launch_stream_copy(const void *src, void *dst, size_t nbytes, hipStream_t s);
 
+/* equal read and write streams over two buffers that both wrap (placement probe) */
+hipError_t launch_stream_probe(const void *src, size_t src_bytes, void *dst, size_t dst_bytes, size_t total_bytes,
+                               hipStream_t s);
+
 hipError_t launch_synth_lcg(void *dst, size_t nbytes, uint32_t seed, uint64_t byte_offset,
                             hipStream_t s);
 

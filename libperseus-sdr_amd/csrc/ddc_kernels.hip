@@ -1927,6 +1927,34 @@ __global__ __launch_bounds__(256) void k_stream_copy(const u32x4 *__restrict__ s
     }
 }
 
+/* read stream + write stream of equal size over two buffers of any sizes (both wrap): the probe of
+ * pddc_malloc_apart -- how well do THESE two buffers stream against each other?                    */
+__global__ __launch_bounds__(256) void k_stream_probe(const u32x4 *__restrict__ src, long long src16,
+                                                       u32x4 *__restrict__ dst, long long dst16, long long total16)
+{
+    const long long stride = (long long)gridDim.x * 1024;
+    for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < total16; i += stride) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = src[(i + 256 * u) % src16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            __builtin_nontemporal_store(v[u], dst + (i + 256 * u) % dst16);
+    }
+}
+
+hipError_t launch_stream_probe(const void *src, size_t src_bytes, void *dst, size_t dst_bytes, size_t total_bytes,
+                               hipStream_t s)
+{
+    const long long s16 = (long long)(src_bytes / 16), d16 = (long long)(dst_bytes / 16), t16 = (long long)(total_bytes / 16);
+    if (s16 <= 0 || d16 <= 0 || t16 <= 0)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_stream_probe, dim3(4096), dim3(256), 0, s, static_cast<const u32x4 *>(src), s16,
+                       static_cast<u32x4 *>(dst), d16, t16);
+    return hipGetLastError();
+}
+
 hipError_t launch_stream_copy(const void *src, void *dst, size_t nbytes, hipStream_t s)
 {
     const long long n16 = (long long)(nbytes / 16);

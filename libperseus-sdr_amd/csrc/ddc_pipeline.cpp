@@ -293,6 +293,110 @@ int pddc_malloc(void **d_ptr, size_t nbytes)
     return PDDC_OK;
 }
 
+/* HBM is laid out in a few classes of large extents (tens of GiB; profiles/r02/i_placement_map.txt): a kernel that
+ * streams reads from one buffer and writes to another runs ~8 % faster when the two lie in extents of different
+ * classes -- reads and writes that share a class pay a turnaround.  Two allocations made one after the other usually
+ * share an extent.  This walks: allocate a candidate, time a read+write probe stream between the partner and it, put
+ * an 8 GiB spacer behind it, try again further on, until both speeds have been seen (or max_candidates); the fastest
+ * candidate is returned, everything else freed.                                                                  */
+int pddc_malloc_apart(void **d_ptr, size_t nbytes, const void *d_partner, size_t partner_bytes, int max_candidates,
+                      float *ms_best, float *ms_worst)
+{
+    if (!d_ptr || nbytes == 0)
+        return fail(PDDC_EINVAL, "bad argument");
+    *d_ptr = nullptr;
+    int rc = require_device();
+    if (rc)
+        return rc;
+    if (ms_best)
+        *ms_best = 0.0f;
+    if (ms_worst)
+        *ms_worst = 0.0f;
+    if (!d_partner || partner_bytes < (64u << 20) || nbytes < (32u << 20) || max_candidates <= 1 ||
+        ((uintptr_t)d_partner & 15)) {
+        HIP_TRY(hipMalloc(d_ptr, nbytes));             /* too small to matter (or nothing to stay away from) */
+        return PDDC_OK;
+    }
+    const size_t spacer_bytes = (size_t)8 << 30;
+    const size_t total = (size_t)1 << 30;               /* 1 GiB read + 1 GiB written per probe launch: beyond the L3 */
+    std::vector<void *> cands, spacers;
+    std::vector<float> ms;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    auto cleanup = [&](void *keep) {
+        for (void *c : cands)
+            if (c != keep)
+                hipFree(c);
+        for (void *sp : spacers)
+            hipFree(sp);
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+    };
+    auto both_seen = [&]() {
+        float lo = ms[0];
+        for (float t : ms)
+            lo = t < lo ? t : lo;
+        for (float t : ms)
+            if (t > 1.04f * lo && t < 1.25f * lo)
+                return true;
+        return false;
+    };
+    while ((int)cands.size() < max_candidates) {
+        void *c = nullptr;
+        if (hipMalloc(&c, nbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        cands.push_back(c);
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < 3 && e == hipSuccess; ++k)
+            e = launch_stream_probe(d_partner, partner_bytes, c, nbytes & ~(size_t)15, total, nullptr);
+        if (e == hipSuccess)
+            e = hipEventRecord(e0, nullptr);
+        for (int k = 0; k < 5 && e == hipSuccess; ++k)
+            e = launch_stream_probe(d_partner, partner_bytes, c, nbytes & ~(size_t)15, total, nullptr);
+        if (e == hipSuccess)
+            e = hipEventRecord(e1, nullptr);
+        if (e == hipSuccess)
+            e = hipEventSynchronize(e1);
+        float t = 0.0f;
+        if (e == hipSuccess)
+            e = hipEventElapsedTime(&t, e0, e1);
+        if (e != hipSuccess) {
+            cleanup(nullptr);
+            return fail(PDDC_EHIP, "placement probe: %s", hipGetErrorString(e));
+        }
+        ms.push_back(t / 5.0f);
+        if (ms.size() >= 2 && both_seen())
+            break;
+        void *sp = nullptr;
+        if (hipMalloc(&sp, spacer_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        spacers.push_back(sp);
+    }
+    if (cands.empty()) {
+        cleanup(nullptr);
+        return fail(PDDC_ENOMEM, "hipMalloc(%zu) failed", nbytes);
+    }
+    size_t best = 0, worst = 0;
+    for (size_t k = 1; k < ms.size(); ++k) {
+        if (ms[k] < ms[best])
+            best = k;
+        if (ms[k] > ms[worst])
+            worst = k;
+    }
+    if (ms_best)
+        *ms_best = ms[best];
+    if (ms_worst)
+        *ms_worst = ms[worst];
+    *d_ptr = cands[best];
+    cleanup(cands[best]);
+    return PDDC_OK;
+}
+
 int pddc_free(void *d_ptr)
 {
     if (d_ptr)

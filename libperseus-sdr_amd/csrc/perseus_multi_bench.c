@@ -140,8 +140,12 @@ int main(int argc, char **argv)
         CHECK(pddc_pipeline_set_freg(pipe[g], freg));
         cap = pddc_pipeline_max_output(pipe[g], ns) + 8;
         CHECK(pddc_malloc(&d_in[g], ns * 6));
-        CHECK(pddc_malloc(&d_out[g][0], cap * 8));
-        CHECK(pddc_malloc(&d_out[g][1], cap * 8));
+        /* the output buffers in another HBM extent class than the input (include/perseus_ddc.h) */
+        float fast = 0, slow = 0;
+        CHECK(pddc_malloc_apart(&d_out[g][0], cap * 8, d_in[g], ns * 6, 24, &fast, &slow));
+        CHECK(pddc_malloc_apart(&d_out[g][1], cap * 8, d_in[g], ns * 6, 24, NULL, NULL));
+        if (slow > 0)
+            fprintf(stderr, "GPU %d: output placed apart from the input: probe %.3f ms (slowest candidate %.3f ms)\n", g, fast, slow);
         CHECK(pddc_synth_lcg(d_in[g], ns * 6, 12345u + (uint32_t)g, 0, NULL));     /* stream seed 12345 + g */
         CHECK(pddc_stream_sync(NULL));
     }

@@ -987,3 +987,33 @@ def test_checkpoint_and_resume_continue_bit_identically(pkg, dev, O, plan):
         a.restore_state(blobs[2][:40])
     other.close()
     a.close()
+
+
+def test_malloc_apart_returns_a_usable_buffer(pkg, dev, O):
+    """pddc_malloc_apart (placement of a stream's output away from its input, include/perseus_ddc.h): the pointer
+    works like any other allocation; small requests are plain allocations; the probe times are reported."""
+    import ctypes as C
+    L = pkg.ddc_lib()
+    ns = 1 << 24
+    packed = O.lcg_bytes(6 * ns, 5)
+    d_in = to_dev(packed, dev)
+    h = load_taps("d8_127")
+    pipe = pkg.Pipeline([(8, h)])
+    cap = pipe.max_output(ns) + 8
+    p, fast, slow = C.c_void_p(), C.c_float(-1), C.c_float(-1)
+    assert L.pddc_malloc_apart(C.byref(p), cap * 8, d_in.data_ptr(), 6 * ns, 3, C.byref(fast), C.byref(slow)) == 0
+    assert p.value and fast.value > 0 and slow.value >= fast.value
+    st = _torch().cuda.current_stream(dev).cuda_stream
+    n = pipe.process_ptr(d_in.data_ptr(), ns, p.value, cap, st)
+    y = np.empty((n, 2), np.float32)
+    pkg.check(L.pddc_memcpy_d2h(y.ctypes.data, p.value, n * 8, st))
+    pkg.check(L.pddc_stream_sync(st))
+    ref = O.ddc_chain(packed[:6 * 8192 * 4], [(8, h)])
+    assert O.rel_err(y.reshape(-1)[:ref.size], ref) <= FIR_TOL
+    assert L.pddc_free(p) == 0
+    q = C.c_void_p()
+    assert L.pddc_malloc_apart(C.byref(q), 4096, d_in.data_ptr(), 6 * ns, 8, C.byref(fast), C.byref(slow)) == 0
+    assert q.value and fast.value == 0.0                       # too small to matter: no probing
+    assert L.pddc_free(q) == 0
+    assert L.pddc_malloc_apart(None, 4096, None, 0, 1, None, None) == pkg.PDDC_EINVAL
+    pipe.close()
