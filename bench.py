@@ -453,12 +453,17 @@ def run_rank(a):
     # one launch of the dominant kernel does (nbytes read + nbytes written)
     copy_gbps = None
     try:
+        import ctypes
         nb = int(wl["kernel_bytes_per_sample"] * ns / 2) // 256 * 256
         src = d_in[:nb] if nb <= d_in.numel() else torch.empty(nb, dtype=torch.uint8, device=dev)
-        dst = torch.empty(nb, dtype=torch.uint8, device=dev)
-        ms = pkg.measure_copy(dst.data_ptr(), src.data_ptr(), nb, 40, stream)
+        # a ceiling has to be measured under the same favourable placement as the kernel: destination in another
+        # HBM extent class than the source (pddc_malloc_apart)
+        dst = ctypes.c_void_p()
+        pkg.check(pkg.ddc_lib().pddc_malloc_apart(ctypes.byref(dst), nb, src.data_ptr(), nb, a.out_candidates, None, None))
+        ms = pkg.measure_copy(dst.value, src.data_ptr(), nb, 40, stream)
         copy_gbps = 2.0 * nb / (ms * 1e-3) / 1e9
-        del dst, src
+        pkg.check(pkg.ddc_lib().pddc_free(dst))
+        del src
     except Exception as e:                              # never lose the line over the extra figure
         print(f"[bench] copy ceiling failed: {e}", file=sys.stderr)
 

@@ -994,7 +994,7 @@ def test_malloc_apart_returns_a_usable_buffer(pkg, dev, O):
     works like any other allocation; small requests are plain allocations; the probe times are reported."""
     import ctypes as C
     L = pkg.ddc_lib()
-    ns = 1 << 24
+    ns = 1 << 26                                                # 64 MiB of output: large enough to be probed
     packed = O.lcg_bytes(6 * ns, 5)
     d_in = to_dev(packed, dev)
     h = load_taps("d8_127")
