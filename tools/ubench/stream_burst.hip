@@ -4,6 +4,7 @@
 // writes B*8 KB at once (fewer read/write turnarounds in the memory controllers)?
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -78,6 +79,14 @@ int main()
     const size_t ns = (size_t)1 << 28;
     uint4 *in, *out;
     CHECK(hipMalloc(&in, ns * 6));
+    // SPACER_GIB=n: n GiB of other allocations between the input and the output, so that the two land in
+    // different HBM extent classes; the default, 0, is the first-come placement
+    if (const char *e = getenv("SPACER_GIB")) {
+        for (int k = 0; k < atoi(e); k += 8) {
+            void *sp;
+            CHECK(hipMalloc(&sp, (size_t)8 << 30));
+        }
+    }
     CHECK(hipMalloc(&out, ns));
     CHECK(hipMemset(in, 1, ns * 6));
     for (int blocks : { 512, 1024 })
