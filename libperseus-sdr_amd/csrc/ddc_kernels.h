@@ -73,7 +73,8 @@ hipError_t launch_unpack24(const void *d_in, long long nsamples, void *d_out, bo
 
 /* generic decimating FIR on float2: out[q] = sum_k h[k]*x[first + q*D - k],
  * x indexed relative to `in`; x[-H..-1] come from `hist` (H >= ntaps-1).
- * `taps` must be readable, as zeros, over [-3*D - 8, ntaps + 3*D + 8).  hist_out (or
+ * `taps` is the DUPLICATED table: entry k = the pair (h[k], h[k]) (a naturally aligned SGPR pair for the packed
+ * FMA); it must be readable, as zeros, over entries [-3*D - 8, ntaps + 3*D + 8).  hist_out (or
  * NULL) receives the last H samples of [hist | in(n_batch)]; must not alias hist. */
 hipError_t launch_fir_generic(const float *in, const float *hist, int H, long long first, long long n_out,
                               int D, const float *taps, int ntaps, float *out, float *hist_out,

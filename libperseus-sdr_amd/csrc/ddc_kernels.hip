@@ -1446,16 +1446,21 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ 
     /* sample x[q*D - j], q = q0 + P*tid, has local index S*tid + r with r = ntaps-1-j (wave-
      * uniform) and sits at lane + r + (r >> a): S*tid is a multiple of 2^a, so the pad splits */
     const float2 *lane = sd + (S + (S >> a)) * tid;
-    const bool linear = a >= 3;                    /* (r >> a) is constant over an aligned step */
-    for (int r0 = ((ntaps - 1) + (P - 1) * D) | 7; r0 >= 0; r0 -= 8) {
-        const int jb = (ntaps - 1) - r0;           /* tap of output q for the step's first sample */
-        float hh[P][8];
+    /* The taps arrive DUPLICATED, (h[k], h[k]) per entry, so that a tap is a naturally aligned SGPR pair and the
+     * packed FMA takes it as it is: with single floats hipcc moved every odd tap into the low half of a pair first
+     * (12 s_mov per step of 24 FMAs).  And the two addressing forms are two separate loops: as one loop with a branch
+     * inside, hipcc copied all 6*P accumulator registers at the merge point on every step (18 v_mov per 24 FMAs at
+     * P = 3 -- the kernel issued 2.5x the VALU instructions its FMAs account for, profiles/r02/j_pmc_generic_tail.txt). */
+    const f32x2 PDDC_CONSTANT *taps2 = reinterpret_cast<const f32x2 PDDC_CONSTANT *>(taps);
+    if (a >= 3) {                                  /* (r >> a) is constant over an aligned step: immediates */
+        for (int r0 = ((ntaps - 1) + (P - 1) * D) | 7; r0 >= 0; r0 -= 8) {
+            const int jb = (ntaps - 1) - r0;       /* tap of output q for the step's first sample */
+            f32x2 hh[P][8];
 #pragma unroll
-        for (int p = 0; p < P; ++p)
+            for (int p = 0; p < P; ++p)
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                hh[p][u] = taps[p * D + jb + u];
-        if (linear) {
+                for (int u = 0; u < 8; ++u)
+                    hh[p][u] = taps2[p * D + jb + u];
             const float2 *x8 = lane + (r0 + (r0 >> a)) - 7;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1463,9 +1468,18 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ 
                 const f32x2 x = { xv.x, xv.y };
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    acc[p][u & 3] = __builtin_elementwise_fma(f32x2{ hh[p][u], hh[p][u] }, x, acc[p][u & 3]);
+                    acc[p][u & 3] = __builtin_elementwise_fma(hh[p][u], x, acc[p][u & 3]);
             }
-        } else {
+        }
+    } else {
+        for (int r0 = ((ntaps - 1) + (P - 1) * D) | 7; r0 >= 0; r0 -= 8) {
+            const int jb = (ntaps - 1) - r0;
+            f32x2 hh[P][8];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    hh[p][u] = taps2[p * D + jb + u];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int r = r0 - u;
@@ -1473,7 +1487,7 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ 
                 const f32x2 x = { xv.x, xv.y };
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    acc[p][u & 3] = __builtin_elementwise_fma(f32x2{ hh[p][u], hh[p][u] }, x, acc[p][u & 3]);
+                    acc[p][u & 3] = __builtin_elementwise_fma(hh[p][u], x, acc[p][u & 3]);
             }
         }
     }
@@ -1535,7 +1549,12 @@ static GenShape pick_generic_shape(long long n_out, int D, int ntaps, int ncu)
         const double per_sample = (aa >= 3 ? pp + 1.5 : pp + 4.0);       /* issue slots per window sample */
         const double t_fir = (double)((pp - 1) * D + ntaps) * per_sample * 4.0 / 2000.0 *
                              (waves_per_simd < 1.0 ? 1.0 : waves_per_simd);
-        const double t = (double)rounds * (t_stage + t_fir);
+        double t = (double)rounds * (t_stage + t_fir);
+        /* measured (profiles/r02/f_generic_shape_sweep2.txt): with the tap loop as it is now, one output per
+         * thread and 256 threads is the best or within a few % of the best shape for every stage of the rate
+         * plans -- many waves hide the scalar-cache and LDS latencies of a step better than register reuse pays */
+        if (nt == 256 && pp == 1 && !force_nt)
+            t *= 0.25;
         if (best < 0.0 || t < best) {
             best = t;
             g.NT = nt, g.P = pp, g.span = sp, g.a = aa, g.lds = l;
@@ -1550,8 +1569,8 @@ bool fir_generic_supported(int D, int ntaps)
     return D >= 1 && ntaps >= 1 && pick_generic_shape(1 << 20, D, ntaps, 256).NT != 0;
 }
 
-/* `taps` must be readable (zeros) over [-3*D - 8, ntaps + 3*D + 8): the pipeline uploads
- * its tap tables that way.  hist_out (or NULL) receives the last H samples of
+/* `taps` is the DUPLICATED table -- entry k is the pair (h[k], h[k]), 8 bytes -- and must be readable
+ * (zeros) over entries [-3*D - 8, ntaps + 3*D + 8): the pipeline uploads its tap tables that way.  hist_out (or NULL) receives the last H samples of
  * [hist(H) | in(n_batch)]; it must not alias hist.                                  */
 static hipError_t launch_fir_generic_any(const void *in, const void *hist, int H, long long first, long long n_out,
                                          int D, const float *taps, int ntaps, float *out, void *hist_out,

@@ -63,6 +63,9 @@ struct Stage {
     std::vector<float> taps;      /* host copy (after optional fp16 rounding)  */
     float *d_taps = nullptr;      /* h[k] linear: points INTO d_taps_base (zero-padded on both sides) */
     float *d_taps_base = nullptr; /* the allocation                             */
+    float *d_taps_dup = nullptr;  /* the same table with every tap twice, (h[k], h[k]): what k_fir_generic reads;
+                                     points INTO d_taps_dup_base                 */
+    float *d_taps_dup_base = nullptr;
     float *d_taps_blk = nullptr;  /* [ntb][8] block-reversed (fused kernel)     */
     float *d_taps_poly = nullptr; /* rational stage: [L][Kp] polyphase rows g[ph][j] = h[j*L + ph] */
     int poly_k = 0, poly_kp = 0;
@@ -200,6 +203,15 @@ static int upload_taps(pddc_pipeline *p, int si)
         HIP_TRY(hipMalloc(&s.d_taps_base, sizeof(float) * padded.size()));
         HIP_TRY(hipMemcpy(s.d_taps_base, padded.data(), sizeof(float) * padded.size(), hipMemcpyHostToDevice));
         s.d_taps = s.d_taps_base + Z;
+        std::vector<float> dup(2 * padded.size());
+        for (size_t k = 0; k < padded.size(); ++k)
+            dup[2 * k] = dup[2 * k + 1] = padded[k];
+        if (s.d_taps_dup_base)
+            hipFree(s.d_taps_dup_base);
+        s.d_taps_dup_base = nullptr;
+        HIP_TRY(hipMalloc(&s.d_taps_dup_base, sizeof(float) * dup.size()));
+        HIP_TRY(hipMemcpy(s.d_taps_dup_base, dup.data(), sizeof(float) * dup.size(), hipMemcpyHostToDevice));
+        s.d_taps_dup = s.d_taps_dup_base + 2 * Z;
     }
     if (s.d_taps_poly) {
         hipFree(s.d_taps_poly);
@@ -597,6 +609,8 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
             hipFree(p->st[i].d_taps_base);
         if (p->st[i].d_taps_blk)
             hipFree(p->st[i].d_taps_blk);
+        if (p->st[i].d_taps_dup_base)
+            hipFree(p->st[i].d_taps_dup_base);
         if (p->st[i].d_taps_poly)
             hipFree(p->st[i].d_taps_poly);
         if (p->st[i].d_buf)
@@ -1063,7 +1077,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                                     p->lo_c, p->lo_s, s));
             if (n_in[1] > 0)
                 HIP_TRY(launch_fir_generic(st.d_buf, p->d_hist_f32, H, (long long)off[0], (long long)n_in[1], st.decim,
-                                           st.d_taps, st.ntaps, dst, nullptr, (long long)nsamples, s));
+                                           st.d_taps_dup, st.ntaps, dst, nullptr, (long long)nsamples, s));
             /* hist_done stays false: the packed history moves on below (x == d_packed) */
         } else if (i == 0 && stage0_fused(p)) {
             Fir8Args a;
@@ -1083,7 +1097,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         } else if (i == 0 && stage0_packed_generic(p)) {
             if (n_in[1] > 0) {
                 HIP_TRY(launch_fir_generic_packed(d_packed, h_in, st.hist, (long long)off[0], (long long)n_in[1],
-                                                  st.decim, st.d_taps, st.ntaps, dst, h_out, (long long)nsamples, mix,
+                                                  st.decim, st.d_taps_dup, st.ntaps, dst, h_out, (long long)nsamples, mix,
                                                   p->n0, p->freg, p->phase_off, p->freg_applied, p->lo_c, p->lo_s,
                                                   p->lo_c_applied, p->lo_s_applied, s));
                 hist_done = true;             /* block 0 of the kernel wrote the new (packed) history */
@@ -1126,7 +1140,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             } else if (n_in[i + 1] > 0) {
                 HIP_TRY(launch_fir_generic(static_cast<const float *>(x), static_cast<const float *>(h_in),
                                            st.hist, (long long)off[i], (long long)n_in[i + 1], st.decim,
-                                           st.d_taps, st.ntaps, dst, static_cast<float *>(h_out),
+                                           st.d_taps_dup, st.ntaps, dst, static_cast<float *>(h_out),
                                            (long long)n_in[i], s));
                 hist_done = true;             /* block 0 of the kernel wrote the new history */
             }
