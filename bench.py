@@ -535,7 +535,10 @@ def run_rank(a):
             "verified": verified,
             "ranks_seen": grp.world, "devices": names,
             "collectives": "RCCL called from the C library (pddc_comm_*); torch.distributed = rendezvous only"
-                           if grp.comm is not None else None,
+                           if grp.comm is not None else
+                           ("gloo control plane only (plan broadcast, barrier, MAX of the step time; the data path has "
+                            "no collective): the RCCL communicator could not be made -- " + grp.comm_error)
+                           if grp.comm_error else None,
             "cpu_baseline": None,
         }
         PARTIAL["res"] = res
@@ -545,6 +548,8 @@ def run_rank(a):
         g = guarded_gather_legs(a, pkg, shard, grp, dev, stream, ns, d_in, wl, pipe, out)
         if res is not None:
             res["gather"] = g
+    elif res is not None and grp.comm_error and stages is not None and not a.no_gather:
+        res["gather"] = {"skipped": "the gather is RCCL by definition and no communicator exists: " + grp.comm_error}
     if res is not None and world == 1 and not a.no_cpu:
         res["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_seconds)
     finish(grp, res)
@@ -686,6 +691,9 @@ def finish(grp, res):
     grp.close()
     if res is not None:
         print(json.dumps(res), flush=True)
+    if grp.must_hard_exit:                 # a helper thread is still inside ncclCommInitRank: no normal exit
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def main():

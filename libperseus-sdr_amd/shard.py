@@ -159,6 +159,8 @@ class Group:
     """A single rank (no launcher): every collective is the identity."""
     rank, world, local = 0, 1, 0
     comm = None
+    comm_error = None
+    must_hard_exit = False
 
     def make_pipeline(self, pkg, stages, freg, mix, taps_fp16=False):
         p = pkg.Pipeline(stages, device=self.local, mix=mix, taps_fp16=taps_fp16)
@@ -203,35 +205,100 @@ def _c_stdout_to_stderr():
 
 
 class RcclGroup(Group):
-    """One process per GPU.  `force_single` builds a 1-rank communicator so that a 1-GPU
-    box still runs every RCCL call of the N>1 path."""
+    """One process per GPU.  With world == 1 this builds a 1-rank communicator so that a 1-GPU
+    box still runs every RCCL call of the N>1 path.
 
-    def __init__(self, pkg, rank, world, local, pg_backend="gloo"):
+    The communicator is made under a time limit (`init_timeout` seconds, env PDDC_COMM_INIT_TIMEOUT,
+    default 180): the data path needs no collective, so a node whose RCCL cannot come up (or hangs
+    doing so) must still be measured.  All ranks then agree over gloo whether everyone has a
+    communicator; if any has none, ALL drop to the gloo control plane for the three things that
+    cross ranks (plan broadcast, barrier, MAX of the step time) -- `comm` is None, `comm_error`
+    says why, the gather legs (which are RCCL by definition) are skipped."""
+
+    def __init__(self, pkg, rank, world, local, pg_backend="gloo", init_timeout=None):
         self.rank, self.world, self.local = rank, world, local
         self.pkg = pkg
         self._own_pg = False
+        self.comm = None
+        self.comm_error = None
+        self.must_hard_exit = False               # a thread is stuck inside RCCL: leave through os._exit
+        if init_timeout is None:
+            init_timeout = float(os.environ.get("PDDC_COMM_INIT_TIMEOUT", "180"))
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             dist.init_process_group(pg_backend, rank=rank, world_size=world)
             self._own_pg = True
+        err = None
         with _c_stdout_to_stderr():
-            uid = [pkg.Comm.unique_id() if rank == 0 else None]
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid[0] = pkg.Comm.unique_id()
+                except Exception as e:            # noqa: BLE001 -- whatever it is, the ranks must hear of it
+                    err = f"{type(e).__name__}: {e}"
             if world > 1:
                 dist.broadcast_object_list(uid, src=0)
-            self.comm = pkg.Comm.init_rank(world, rank, uid[0], local)
-            self.comm.barrier()                   # first collective: whatever RCCL still wants to say, it says now
+            if uid[0] is None:
+                err = err or "rank 0 could not make an RCCL id"
+            else:
+                err = self._init_comm(uid[0], init_timeout)
+        if world > 1:
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            bad = [(r, e) for r, e in enumerate(errs) if e]
+            if bad:
+                err = "rank %d: %s" % bad[0]
+        if err:
+            self.comm_error = err
+            self._abandoned = self.comm           # never destroyed: a peer of it may be hung
+            self.comm = None
+
+    def _init_comm(self, uid, timeout):
+        """ncclCommInitRank + the first collective on a helper thread, joined with a time limit."""
+        import threading
+        box = {}
+
+        def work():
+            try:
+                c = self.pkg.Comm.init_rank(self.world, self.rank, uid, self.local)
+                box["comm"] = c
+                c.barrier()                       # first collective: whatever RCCL still wants to say, it says now
+                box["ok"] = True
+            except Exception as e:                # noqa: BLE001
+                box["err"] = f"{type(e).__name__}: {e}"
+
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        t.join(timeout)
+        if t.is_alive():
+            self.must_hard_exit = True
+            self.comm = box.get("comm")
+            return f"RCCL communicator not up after {timeout:.0f} s"
+        self.comm = box.get("comm")
+        return box.get("err")
 
     def make_pipeline(self, pkg, stages, freg, mix, taps_fp16=False):
         """Rank 0's plan reaches every rank through ncclBroadcast inside the C library."""
+        if self.comm is None:                     # gloo control plane (see the class comment)
+            cfg = {"freg": int(freg), "stages": stages} if self.rank == 0 else None
+            if self.world > 1:
+                cfg = broadcast_config(cfg, torch.device("cpu"))
+            return Group.make_pipeline(self, pkg, cfg["stages"], cfg["freg"], mix, taps_fp16)
         flags = (pkg.PDDC_F_MIX if mix else 0) | (pkg.PDDC_F_TAPS_FP16 if taps_fp16 else 0)
         return self.comm.bcast_pipeline(stages if self.rank == 0 else None, freg if self.rank == 0 else 0,
                                         flags if self.rank == 0 else 0, root=0)
 
     def max_seconds(self, t: float) -> float:
+        if self.comm is None:
+            return max_over_ranks(t, torch.device("cpu")) if self.world > 1 else t
         return self.comm.max_f64(t)
 
     def barrier(self):
+        if self.comm is None:
+            if self.world > 1:
+                dist.barrier()
+            return
         self.comm.barrier()
 
     def all_gather_object(self, obj):
@@ -247,7 +314,8 @@ class RcclGroup(Group):
             self.comm = None
         if self._own_pg:
             dist.barrier()
-            dist.destroy_process_group()
+            if not self.must_hard_exit:
+                dist.destroy_process_group()
             self._own_pg = False
 
 

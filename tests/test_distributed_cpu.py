@@ -153,3 +153,86 @@ def test_time_chunk_helpers():
     assert shard.cascade_halo([(8, np.zeros(127, np.float32))]) == 128
     with pytest.raises(ValueError):
         shard.cascade_halo([(25, np.zeros(100, np.float32), 12)])
+
+
+# ---- RcclGroup when RCCL does not come up: every rank drops to the gloo control plane ---------------------------
+class _FakePipe:
+    def __init__(self, stages, device=0, mix=False, taps_fp16=False):
+        self.stages, self.device, self.mix, self.freg = stages, device, mix, None
+
+    def set_freg(self, f):
+        self.freg = f
+
+
+class _FakeComm:
+    """Stands in for the ctypes binding of pddc_comm_* (no GPU here): rank 1 cannot make its
+    communicator, so rank 0's first collective never returns -- what a half-up RCCL looks like."""
+    closed = False
+
+    @staticmethod
+    def unique_id():
+        return b"\x01" * 128
+
+    @classmethod
+    def init_rank(cls, world, rank, uid, local):
+        if rank == 1:
+            raise RuntimeError("ncclCommInitRank: unhandled system error (injected)")
+        return cls()
+
+    def barrier(self):
+        import time
+        time.sleep(3600)
+
+    def close(self):
+        _FakeComm.closed = True
+
+
+class _FakePkg:
+    Comm = _FakeComm
+    Pipeline = _FakePipe
+    PDDC_F_MIX, PDDC_F_TAPS_FP16 = 1, 2
+
+
+def _fallback_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    shard = importlib.import_module("libperseus-sdr_amd.shard")
+    grp = shard.RcclGroup(_FakePkg, rank, world, rank, init_timeout=2.0)
+    h = load_taps("c320_s1_d8_32")
+    pipe = grp.make_pipeline(_FakePkg, [(8, h)] if rank == 0 else None, 381178347 if rank == 0 else 0, True)
+    grp.barrier()
+    res = {"rank": rank, "comm_none": grp.comm is None, "err": grp.comm_error, "hard": grp.must_hard_exit,
+           "tmax": grp.max_seconds(1.0 + rank), "names": grp.all_gather_object(f"r{rank}"),
+           "plan_ok": pipe.freg == 381178347 and pipe.mix and len(pipe.stages) == 1 and pipe.stages[0][0] == 8
+           and np.array_equal(pipe.stages[0][1], h), "device": pipe.device}
+    grp.close()
+    res["abandoned_comm_left_alone"] = not _FakeComm.closed
+    q.put(res)
+    q.close()
+    q.join_thread()
+    if grp.must_hard_exit:
+        os._exit(0)
+
+
+def test_rccl_group_falls_back_to_gloo_when_no_communicator():
+    """bench.py --gpus N on a node whose RCCL cannot come up (or hangs coming up) still measures:
+    the data path has no collective, only the plan / barrier / MAX cross ranks."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r["rank"])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r["comm_none"]
+        assert "injected" in r["err"] or "not up after" in r["err"]       # the first failing rank's reason, the same on all
+        assert r["err"] == res[0]["err"]
+        assert abs(r["tmax"] - 2.0) < 1e-12
+        assert r["names"] == ["r0", "r1"]
+        assert r["plan_ok"] and r["device"] == r["rank"]
+        assert r["abandoned_comm_left_alone"]
+    assert res[0]["hard"] and not res[1]["hard"]          # rank 0's helper thread is still inside the "collective"
