@@ -385,9 +385,9 @@ def run_rank(a):
         for _ in range(150):                              # the first candidate is not to be measured on cold clocks
             step()
         cands, spacers, times = [outbox[0]], [], [probe_one(outbox[0])]
-        def both_classes_seen():                          # a fast and a slow placement, 4..12 % apart (more: an outlier)
+        def both_classes_seen():                          # a fast and a slow placement, 5.5..12 % apart (more: an outlier)
             lo = min(times)
-            return any(1.04 * lo < t < 1.12 * lo for t in times)
+            return any(1.055 * lo < t < 1.12 * lo for t in times)
 
         while len(cands) < ncand and not both_classes_seen():
             try:
