@@ -115,7 +115,11 @@ int pddc_free(void *d_ptr);
  * allocations made one after the other usually share one.  This allocates candidates 8 GiB apart (spacers, freed
  * again), times a read+write probe stream between the partner and each, stops when both speeds have been seen or after
  * max_candidates, and returns the fastest (free it with pddc_free).  *ms_best / *ms_worst: the probe's time per launch
- * for the kept and for the slowest candidate.  Buffers under 32 MiB, or max_candidates <= 1: a plain allocation.      */
+ * for the kept and for the slowest candidate.  Buffers under 1 MiB, a partner under 64 MiB, or max_candidates <= 1: a
+ * plain allocation.  A buffer between 1 MiB and 1 GiB gets a 1 GiB allocation (the probe must write past the 256 MB
+ * last-level cache to see the HBM), because small write streams matter too: the fused first two stages of the /320
+ * cascade write 1/48 of what they read and still run at 0.292 or 0.330 ms depending on where that small buffer lies.
+ * A pipeline places its own inter-stage buffers this way when a batch is >= 64 MiB (PDDC_PLACEMENT=0: never).       */
 int pddc_malloc_apart(void **d_ptr, size_t nbytes, const void *d_partner, size_t partner_bytes, int max_candidates,
                       float *ms_best, float *ms_worst);
 int pddc_memcpy_h2d(void *d_dst, const void *h_src, size_t nbytes, void *stream);

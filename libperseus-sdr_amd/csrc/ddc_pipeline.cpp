@@ -311,8 +311,12 @@ int pddc_malloc(void **d_ptr, size_t nbytes)
  * share an extent.  This walks: allocate a candidate, time a read+write probe stream between the partner and it, put
  * an 8 GiB spacer behind it, try again further on, until both speeds have been seen (or max_candidates); the fastest
  * candidate is returned, everything else freed.                                                                  */
-int pddc_malloc_apart(void **d_ptr, size_t nbytes, const void *d_partner, size_t partner_bytes, int max_candidates,
-                      float *ms_best, float *ms_worst)
+/* min_bytes: buffers smaller than this are not walked.  A candidate smaller than the probe's 1 GiB is ALLOCATED at
+ * 1 GiB (the caller uses its first nbytes): the probe must write past the 256 MB last-level cache to see the HBM, and
+ * a 33 MB buffer written once per launch matters as much as a large one -- the fused pair of the x320 cascade, which
+ * writes 1/48 of what it reads, runs at 0.292 or 0.330 ms depending on it (tools/placement_probe8.py).           */
+static int malloc_apart_impl(void **d_ptr, size_t nbytes, const void *d_partner, size_t partner_bytes, int max_candidates,
+                             float *ms_best, float *ms_worst, size_t min_bytes)
 {
     if (!d_ptr || nbytes == 0)
         return fail(PDDC_EINVAL, "bad argument");
@@ -324,13 +328,15 @@ int pddc_malloc_apart(void **d_ptr, size_t nbytes, const void *d_partner, size_t
         *ms_best = 0.0f;
     if (ms_worst)
         *ms_worst = 0.0f;
-    if (!d_partner || partner_bytes < (64u << 20) || nbytes < (32u << 20) || max_candidates <= 1 ||
+    if (!d_partner || partner_bytes < (64u << 20) || nbytes < min_bytes || max_candidates <= 1 ||
         ((uintptr_t)d_partner & 15)) {
         HIP_TRY(hipMalloc(d_ptr, nbytes));             /* too small to matter (or nothing to stay away from) */
         return PDDC_OK;
     }
     const size_t spacer_bytes = (size_t)8 << 30;
     const size_t total = (size_t)1 << 30;               /* 1 GiB read + 1 GiB written per probe launch: beyond the L3 */
+    if (nbytes < total)
+        nbytes = total;
     std::vector<void *> cands, spacers;
     std::vector<float> ms;
     hipEvent_t e0, e1;
@@ -407,6 +413,12 @@ int pddc_malloc_apart(void **d_ptr, size_t nbytes, const void *d_partner, size_t
     *d_ptr = cands[best];
     cleanup(cands[best]);
     return PDDC_OK;
+}
+
+int pddc_malloc_apart(void **d_ptr, size_t nbytes, const void *d_partner, size_t partner_bytes, int max_candidates,
+                      float *ms_best, float *ms_worst)
+{
+    return malloc_apart_impl(d_ptr, nbytes, d_partner, partner_bytes, max_candidates, ms_best, ms_worst, (size_t)1 << 20);
 }
 
 int pddc_free(void *d_ptr)
@@ -880,7 +892,10 @@ extern "C" int pddc_pipeline_uses_fused_pair(const pddc_pipeline *p, size_t nsam
     return p && stages01_fusable(p, nsamples) ? 1 : 0;
 }
 
-static int ensure_buf(Stage &s, size_t need)
+/* `reader_src` / `reader_bytes`: the buffer that the kernel WRITING this stage buffer streams its input from.  When
+ * that stream is large (>= 64 MiB per batch) the stage buffer is placed in another HBM extent class than it
+ * (malloc_apart_impl; ~1 s, once per pipeline -- PDDC_PLACEMENT=0 turns it off).                              */
+static int ensure_buf(Stage &s, size_t need, const void *reader_src = nullptr, size_t reader_bytes = 0)
 {
     if (s.d_buf && s.buf_cap >= need)
         return PDDC_OK;
@@ -891,7 +906,20 @@ static int ensure_buf(Stage &s, size_t need)
         HIP_TRY(hipFree(s.d_buf));
     s.d_buf = nullptr;
     s.buf_cap = 0;
-    HIP_TRY(hipMalloc(&s.d_buf, sizeof(float) * 2 * cap));
+    static const bool placement = !(getenv("PDDC_PLACEMENT") && atoi(getenv("PDDC_PLACEMENT")) == 0);
+    if (placement && reader_src && reader_bytes >= ((size_t)64 << 20)) {
+        void *ptr = nullptr;
+        float fast = 0.0f, slow = 0.0f;
+        int rc = malloc_apart_impl(&ptr, sizeof(float) * 2 * cap, reader_src, reader_bytes, 24, &fast, &slow, (size_t)1 << 20);
+        if (rc)
+            return rc;
+        s.d_buf = static_cast<float *>(ptr);
+        if (getenv("PDDC_DEBUG"))
+            fprintf(stderr, "[pddc] stage buffer placed apart from its producer's input: probe %.3f ms (slowest %.3f)\n",
+                    fast, slow);
+    } else {
+        HIP_TRY(hipMalloc(&s.d_buf, sizeof(float) * 2 * cap));
+    }
     s.buf_cap = cap;
     if (getenv("PDDC_DEBUG"))
         fprintf(stderr, "[pddc] stage buffer %p (%zu samples) hist %p %p\n", (void *)s.d_buf, cap, s.d_hist[0],
@@ -967,9 +995,11 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
     const bool mix = (p->flags & PDDC_F_MIX) != 0;
     int rc;
     /* destination of stage i: the next stage's input buffer, or the caller's */
-    auto stage_dst = [&](int i, float **dst) -> int {
+    /* (reads_packed: the kernel writing it streams the packed batch -- stage 0, or the fused pair for stage 1) */
+    auto stage_dst = [&](int i, float **dst, bool reads_packed) -> int {
         if (i + 1 < p->nstages) {
-            int r = ensure_buf(p->st[i + 1], n_in[i + 1] + 8);
+            const void *src = reads_packed ? d_packed : static_cast<const void *>(p->st[i].d_buf);
+            int r = ensure_buf(p->st[i + 1], n_in[i + 1] + 8, src, reads_packed ? nsamples * 6 : n_in[i] * 8);
             if (r)
                 return r;
             *dst = p->st[i + 1].d_buf;
@@ -1017,7 +1047,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
          * (1 B written + 1 B read per input sample) never touches HBM */
         Stage &s0 = p->st[0], &s1 = p->st[1];
         float *dst;
-        if ((rc = stage_dst(1, &dst)))
+        if ((rc = stage_dst(1, &dst, true)))
             return rc;
         Fir8Args a;
         a.in = d_packed;
@@ -1045,7 +1075,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             return fail(PDDC_EHIP, "injected failure at stage %d (pddc_pipeline_inject_failure)", i);
         }
         float *dst;
-        if ((rc = stage_dst(i, &dst)))
+        if ((rc = stage_dst(i, &dst, i == 0)))
             return rc;
         void *h_in = st.d_hist[st.cur], *h_out = st.d_hist[st.cur ^ 1];
         const void *x = d_packed;                       /* this stage's input batch */
@@ -1056,7 +1086,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
              * it, the batch likewise with the current word, and the generic decimator runs on floats;
              * the packed history for the next call is carried as usual.                            */
             const int H = st.hist;
-            if ((rc = ensure_buf(st, nsamples + 8)))
+            if ((rc = ensure_buf(st, nsamples + 8, d_packed, nsamples * 6)))
                 return rc;
             if (!p->d_hist_f32)
                 HIP_TRY(hipMalloc(&p->d_hist_f32, (size_t)PDDC_MAX_TAPS * 8 + 256));
@@ -1105,7 +1135,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         } else {
             if (i == 0) {
                 /* generic first stage: unpack(+mix) to float2, then the generic FIR */
-                if ((rc = ensure_buf(st, nsamples + 8)))
+                if ((rc = ensure_buf(st, nsamples + 8, d_packed, nsamples * 6)))
                     return rc;
                 HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, st.d_buf, false, mix, p->n0, p->freg,
                                         p->phase_off, p->lo_c, p->lo_s, s));
@@ -1562,7 +1592,7 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     a.out = static_cast<float *>(d_out);
     const bool fuse2 = stages01_fusable(p, nsamples);
     if (p->nstages > 1) {                  /* stage 0 (or the fused pair) of a cascade writes an internal buffer */
-        int rc = ensure_buf(p->st[1], nsamples / (size_t)p->st[0].decim + 8);
+        int rc = ensure_buf(p->st[1], nsamples / (size_t)p->st[0].decim + 8, d_packed, nsamples * 6);
         if (rc)
             return rc;
         a.out = p->st[1].d_buf;
