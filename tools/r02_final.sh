@@ -15,6 +15,8 @@ python tools/plan_rates.py > $OUT/plan_rates.txt 2>&1
 python tools/pcie_rate.py > $OUT/pcie_rate.txt 2>&1
 python bench.py --no-cpu --gather --steps 20 --warmup 5 > $OUT/bench_gather_1rank.json 2>/dev/null
 PERSEUS_AMD_PACE=0 PERSEUS_AMD_MODE=ddc libperseus-sdr_amd/perseus_plumbing -N 8 -s 250000 -o none -t 2 -d 0 > $OUT/plumbing_N8.txt 2>&1
+PDDC_PLACEMENT=0 python tools/placement_probe8.py c320 18 > $OUT/placement_input_c320.txt 2>&1
+bash tools/trace_gaps.sh c320 $OUT/trace_c320 --steps 200 --warmup 5 > $OUT/trace_c320.txt 2>&1
 cat $OUT/gpu_round.log | tail -25
 cat $OUT/bench_driver_args.json
 cat $OUT/pmc_traffic/pmc_traffic.json
