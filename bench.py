@@ -68,9 +68,11 @@ def parse(argv=None):
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle window check of the last output")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--out-candidates", type=int, default=24,
-                    help="at most this many output buffers, 8 GiB apart, are tried before the run and the fastest is\n"
-                         "kept (input and output in different HBM extent classes: 0.340 instead of 0.367 ms,\n"
-                         "profiles/r02/i_placement_map.txt); 1 = take the first allocation as it comes")
+                    help="1 = no placement search: input and output as hipMalloc hands them out (anything else: search\n"
+                         "for a pair in different HBM extent classes, 0.340 instead of 0.367 ms,\n"
+                         "profiles/r02/i_placement_map.txt)")
+    ap.add_argument("--arena-gib", type=int, default=192,
+                    help="size of the arena the placement search cuts its 8 GiB slots from (less if less is free)")
     ap.add_argument("--gather-timeout", type=float, default=240.0,
                     help="watchdog for the gather leg: past this the line is printed without it")
     return ap.parse_args(argv)
@@ -363,48 +365,74 @@ def run_rank(a):
     # and the output in extents of the SAME class the kernel takes 0.367 ms, in DIFFERENT classes 0.340 ms, on every
     # box, for every pair tried (maps in profiles/r02/i_placement_map.txt, tools/placement_probe5.py / 6.py) -- reads
     # and writes that share a rank pay the write-to-read turnaround.  Buffers allocated one after the other usually
-    # land in the same extent.  So: allocate the output, time 24 back-to-back steps into it, put an 8 GiB spacer
-    # behind it and try again further on, until a candidate is clearly faster than the slowest seen (another class
-    # has been reached) or 192 GiB have been walked; keep the fastest, free everything else.  A receiver allocates
-    # once and runs for hours; 288 GB of HBM make the walk affordable.
+    # land in the same extent, and separate allocations 8 GiB apart do not reliably leave it (some processes saw one
+    # class over 200 GiB of them).  Inside ONE large allocation the classes alternate every 32-64 GiB in every process
+    # tried (tools/placement_probe10.py), so: one arena (--arena-gib, default 192), cut into 8 GiB slots; the input at
+    # three of them, the output at every one, 24 back-to-back steps per pair (about 1.5 s in all), the fastest pair
+    # kept.  A receiver allocates once and runs for hours; 288 GB of HBM make this affordable.
     placement = None
-    ncand = max(1, a.out_candidates) if out_rows * 8 >= (32 << 20) else 1
-    if ncand > 1:
-        def probe_one(buf):
-            outbox[0] = buf
-            for _ in range(30):                           # the allocation before it left the GPU idle for a while
-                step()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(24):
-                step()
-            e1.record()
-            e1.synchronize()
-            return e0.elapsed_time(e1) / 24
-
-        for _ in range(150):                              # the first candidate is not to be measured on cold clocks
-            step()
-        cands, spacers, times = [outbox[0]], [], [probe_one(outbox[0])]
-        def both_classes_seen():                          # a fast and a slow placement, 5.5..12 % apart (more: an outlier)
-            lo = min(times)
-            return any(1.055 * lo < t < 1.12 * lo for t in times)
-
-        while len(cands) < ncand and not both_classes_seen():
-            try:
-                spacers.append(torch.empty(8 << 30, dtype=torch.uint8, device=dev))
-                c = torch.empty((out_rows, 2), dtype=torch.float32, device=dev)
-            except RuntimeError:                          # out of memory: stay with what there is
-                break
-            cands.append(c)
-            times.append(probe_one(c))
-        best = int(np.argmin(times))
-        outbox[0] = cands[best]
-        placement = {"output_candidates_tried": len(cands), "spacer_GiB_between_candidates": 8,
-                     "step_ms_each": [round(t, 4) for t in times], "chosen": best,
-                     "note": "output buffer placed in another HBM extent class than the input: candidates 8 GiB apart, "
-                             "24-step probes before the settle phase, fastest kept, the rest freed"}
-        del cands, spacers, c
+    arena = None
+    in_bytes, out_bytes = 6 * ns, out_rows * 8
+    # a cascade's inter-stage buffers come from the arena too (pddc_pipeline_set_workspace): the fused pair of the
+    # x320 cascade writes 1/48 of what it reads and is as sensitive to where that goes as the single stage is
+    ws_bytes = pipe.workspace_size(ns) if (stages is not None and len(stages) > 1) else 0
+    in_span = -(-in_bytes // (1 << 30)) << 30                     # the input's share of a slot, whole GiB
+    ws_span = -(-ws_bytes // (2 << 20)) * (2 << 20)
+    slot = max(8 << 30, -(-(in_span + ws_span + out_bytes) // (1 << 30)) << 30)
+    if a.out_candidates > 1 and out_bytes + ws_bytes >= (32 << 20):
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        gib = min(a.arena_gib, (free_b + in_bytes + out_bytes - (32 << 30)) >> 30)
+        inbox[0] = outbox[0] = None                               # the first-come pair goes back before the arena is made
         torch.cuda.empty_cache()
+        while gib << 30 >= 3 * slot:
+            try:
+                arena = torch.empty(gib << 30, dtype=torch.uint8, device=dev)
+                break
+            except RuntimeError:
+                gib = gib * 3 // 4
+        if arena is None:                                         # no room: first come, first served
+            inbox[0] = pkg.synth_lcg(in_bytes, shard.stream_seed(rank), 0, dev)
+            outbox[0] = torch.empty((out_rows, 2), dtype=torch.float32, device=dev)
+    if arena is not None:
+        nslot = (gib << 30) // slot
+
+        def in_view(k):
+            return arena[k * slot:k * slot + in_bytes]
+
+        def out_view(k):
+            if ws_bytes:                                          # the workspace goes where the output goes
+                pipe.set_workspace(arena[k * slot + in_span:].data_ptr(), ws_bytes, ns)
+            at = k * slot + in_span + ws_span
+            return arena[at:at + out_bytes].view(torch.float32).view(out_rows, 2)
+
+        in_slots = sorted({0, nslot // 3, 2 * nslot // 3})
+        for k in in_slots:                                        # the same LCG bytes in every input candidate
+            pkg.check(pkg.ddc_lib().pddc_synth_lcg(in_view(k).data_ptr(), in_bytes, shard.stream_seed(rank), 0, stream))
+        inbox[0], outbox[0] = in_view(0), out_view(0)
+        for _ in range(150):                                      # the first pair is not to be measured on cold clocks
+            step()
+        table = {}
+        for i in in_slots:
+            for o in range(nslot):
+                inbox[0], outbox[0] = in_view(i), out_view(o)
+                for _ in range(30):
+                    step()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(24):
+                    step()
+                e1.record()
+                e1.synchronize()
+                table[(i, o)] = e0.elapsed_time(e1) / 24
+        (bi, bo), _ = min(table.items(), key=lambda kv: kv[1])
+        inbox[0], outbox[0] = in_view(bi), out_view(bo)
+        placement = {"arena_GiB": gib, "slot_GiB": slot >> 30, "output_slots": nslot,
+                     "step_ms_by_input_slot": {f"in@{(i * slot) >> 30}GiB": [round(table[(i, o)], 4) for o in range(nslot)]
+                                               for i in in_slots},
+                     "chosen": {"input_at_GiB": (bi * slot) >> 30, "output_slot": bo},
+                     "note": "input and output (with a cascade's inter-stage workspace) placed in different HBM extent "
+                             "classes: one arena, the input tried at three slots (the same LCG bytes in each), the "
+                             "output side at every slot, 24-step probes before the settle phase, fastest pair kept"}
     out = outbox[0]
     d_in = inbox[0]
 
@@ -455,15 +483,23 @@ def run_rank(a):
     try:
         import ctypes
         nb = int(wl["kernel_bytes_per_sample"] * ns / 2) // 256 * 256
-        src = d_in[:nb] if nb <= d_in.numel() else torch.empty(nb, dtype=torch.uint8, device=dev)
-        # a ceiling has to be measured under the same favourable placement as the kernel: destination in another
-        # HBM extent class than the source (pddc_malloc_apart)
-        dst = ctypes.c_void_p()
-        pkg.check(pkg.ddc_lib().pddc_malloc_apart(ctypes.byref(dst), nb, src.data_ptr(), nb, a.out_candidates, None, None))
-        ms = pkg.measure_copy(dst.value, src.data_ptr(), nb, 40, stream)
+        if arena is not None and nb <= slot:
+            # under the same favourable placement as the kernel: source = the chosen input slot, destination = the
+            # fastest of the other slots (never the one that holds the output still to be verified)
+            src_ptr = arena[bi * slot:bi * slot + nb].data_ptr()
+            quick = {o: pkg.measure_copy(arena[o * slot:o * slot + nb].data_ptr(), src_ptr, nb, 6, stream)
+                     for o in range(nslot) if o not in (bi, bo)}
+            od = min(quick, key=quick.get)
+            ms = pkg.measure_copy(arena[od * slot:od * slot + nb].data_ptr(), src_ptr, nb, 40, stream)
+        else:
+            src = d_in[:nb] if nb <= d_in.numel() else torch.empty(nb, dtype=torch.uint8, device=dev)
+            # destination in another HBM extent class than the source (pddc_malloc_apart)
+            dst = ctypes.c_void_p()
+            pkg.check(pkg.ddc_lib().pddc_malloc_apart(ctypes.byref(dst), nb, src.data_ptr(), nb, 24, None, None))
+            ms = pkg.measure_copy(dst.value, src.data_ptr(), nb, 40, stream)
+            pkg.check(pkg.ddc_lib().pddc_free(dst))
+            del src
         copy_gbps = 2.0 * nb / (ms * 1e-3) / 1e9
-        pkg.check(pkg.ddc_lib().pddc_free(dst))
-        del src
     except Exception as e:                              # never lose the line over the extra figure
         print(f"[bench] copy ceiling failed: {e}", file=sys.stderr)
 

@@ -132,6 +132,16 @@ int pddc_pipeline_create(pddc_pipeline **out, int device,
 int pddc_pipeline_destroy(pddc_pipeline *p);
 /* zero FIR histories, decimation phases and the NCO sample counter            */
 int pddc_pipeline_reset(pddc_pipeline *p);
+
+/* Inter-stage buffers of a cascade from CALLER-provided device memory instead of the pipeline's own allocations, so that
+ * the host decides where they lie (the buffer a stage writes should sit in another HBM extent class than the batch the
+ * stage reads -- see pddc_malloc_apart; bench.py cuts input, workspace and output from one arena and keeps the fastest
+ * arrangement).  d_ws: 256-byte aligned, nbytes >= pddc_pipeline_workspace_size(p, max_nsamples); batches of more than
+ * max_nsamples are then refused (PDDC_ECAPACITY).  Synchronises the device; call between batches.  d_ws == NULL
+ * returns to own allocations.  The memory stays the caller's; stream state (histories, phases) is not touched.
+ * (No reference counterpart: libperseus-sdr's buffers are libusb transfers, perseus-in.c:67-110.)               */
+size_t pddc_pipeline_workspace_size(const pddc_pipeline *p, size_t max_nsamples);
+int pddc_pipeline_set_workspace(pddc_pipeline *p, void *d_ws, size_t nbytes, size_t max_nsamples);
 /* reset, then place the stream at absolute input sample `abs_sample` with zero history:
  * the NCO phase and every stage's decimation phase are those of a stream that started at
  * sample 0.  This is what lets ONE stream be cut into time chunks for several GPUs

@@ -132,6 +132,10 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_save_state.restype = C.c_int
     L.pddc_pipeline_restore_state.argtypes = [vp, vp, sz]
     L.pddc_pipeline_restore_state.restype = C.c_int
+    L.pddc_pipeline_workspace_size.argtypes = [vp, sz]
+    L.pddc_pipeline_workspace_size.restype = sz
+    L.pddc_pipeline_set_workspace.argtypes = [vp, vp, sz, sz]
+    L.pddc_pipeline_set_workspace.restype = C.c_int
     L.pddc_pipeline_inject_failure.argtypes = [vp, C.c_int]
     L.pddc_pipeline_inject_failure.restype = C.c_int
     L.pddc_pipeline_schedule.argtypes = [vp, sz, C.POINTER(C.c_int)]
@@ -311,6 +315,14 @@ class Pipeline:
 
     def wait(self):
         check(ddc_lib().pddc_pipeline_wait(self._h))
+
+    def workspace_size(self, max_nsamples: int) -> int:
+        """Bytes of caller-provided device memory the inter-stage buffers need for batches up to max_nsamples."""
+        return int(ddc_lib().pddc_pipeline_workspace_size(self._h, max_nsamples))
+
+    def set_workspace(self, d_ws: int | None, nbytes: int = 0, max_nsamples: int = 0):
+        """Inter-stage buffers from the caller's memory (pddc_pipeline_set_workspace); None: own allocations again."""
+        check(ddc_lib().pddc_pipeline_set_workspace(self._h, d_ws, nbytes, max_nsamples))
 
     def save_state(self) -> bytes:
         """The stream state as one blob (histories, decimation phases, sample counter, NCO)."""

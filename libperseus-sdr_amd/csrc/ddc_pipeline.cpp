@@ -81,6 +81,7 @@ struct Stage {
     /* input data of stages >= 1 (and the unpacked floats of a generic stage 0) */
     float *d_buf = nullptr;
     size_t buf_cap = 0;           /* capacity in samples                        */
+    bool buf_in_ws = false;       /* d_buf lies in the caller's workspace (pddc_pipeline_set_workspace): not ours to free */
     unsigned long long consumed = 0;   /* inputs consumed since reset           */
 };
 
@@ -625,7 +626,7 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
             hipFree(p->st[i].d_taps_dup_base);
         if (p->st[i].d_taps_poly)
             hipFree(p->st[i].d_taps_poly);
-        if (p->st[i].d_buf)
+        if (p->st[i].d_buf && !p->st[i].buf_in_ws)
             hipFree(p->st[i].d_buf);
         for (int b = 0; b < 2; ++b)
             if (p->st[i].d_hist[b])
@@ -899,6 +900,9 @@ static int ensure_buf(Stage &s, size_t need, const void *reader_src = nullptr, s
 {
     if (s.d_buf && s.buf_cap >= need)
         return PDDC_OK;
+    if (s.buf_in_ws)
+        return fail(PDDC_ECAPACITY, "batch needs %zu samples of stage buffer, the workspace was sized for %zu", need,
+                    s.buf_cap);
     /* happens only when a batch is larger than any seen before (synchronising) */
     const size_t cap = need + need / 4 + 64;
     HIP_TRY(hipDeviceSynchronize());
@@ -924,6 +928,54 @@ static int ensure_buf(Stage &s, size_t need, const void *reader_src = nullptr, s
     if (getenv("PDDC_DEBUG"))
         fprintf(stderr, "[pddc] stage buffer %p (%zu samples) hist %p %p\n", (void *)s.d_buf, cap, s.d_hist[0],
                 s.d_hist[1]);
+    return PDDC_OK;
+}
+
+/* samples of stage i's input buffer (i >= 1) for batches of up to max_nsamples: every stage may emit one output more
+ * than the ratio says, depending on where the batch begins in its decimation phase                                  */
+static size_t ws_stage_samples(const pddc_pipeline *p, int i, size_t max_nsamples)
+{
+    size_t n = max_nsamples;
+    for (int k = 0; k < i; ++k)
+        n = (n * (size_t)p->st[k].interp) / (size_t)p->st[k].decim + 2;
+    return n + 8 + 64;
+}
+
+extern "C" size_t pddc_pipeline_workspace_size(const pddc_pipeline *p, size_t max_nsamples)
+{
+    if (!p)
+        return 0;
+    size_t total = 0;
+    for (int i = 1; i < p->nstages; ++i)
+        total += (ws_stage_samples(p, i, max_nsamples) * 8 + 255) & ~(size_t)255;
+    return total;
+}
+
+extern "C" int pddc_pipeline_set_workspace(pddc_pipeline *p, void *d_ws, size_t nbytes, size_t max_nsamples)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    if (d_ws && (((uintptr_t)d_ws & 255) || nbytes < pddc_pipeline_workspace_size(p, max_nsamples)))
+        return fail(PDDC_EINVAL, "workspace must be 256-byte aligned and hold pddc_pipeline_workspace_size() = %zu bytes",
+                    pddc_pipeline_workspace_size(p, max_nsamples));
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());                 /* nothing in flight may still use the old buffers */
+    uint8_t *at = static_cast<uint8_t *>(d_ws);
+    for (int i = 1; i < p->nstages; ++i) {
+        Stage &s = p->st[i];
+        if (s.d_buf && !s.buf_in_ws)
+            HIP_TRY(hipFree(s.d_buf));
+        s.d_buf = nullptr;
+        s.buf_cap = 0;
+        s.buf_in_ws = false;
+        if (d_ws) {
+            const size_t cap = ws_stage_samples(p, i, max_nsamples);
+            s.d_buf = reinterpret_cast<float *>(at);
+            s.buf_cap = cap;
+            s.buf_in_ws = true;
+            at += (cap * 8 + 255) & ~(size_t)255;
+        }
+    }
     return PDDC_OK;
 }
 

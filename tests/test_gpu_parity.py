@@ -1017,3 +1017,61 @@ def test_malloc_apart_returns_a_usable_buffer(pkg, dev, O):
     assert L.pddc_free(q) == 0
     assert L.pddc_malloc_apart(None, 4096, None, 0, 1, None, None) == pkg.PDDC_EINVAL
     pipe.close()
+
+
+@pytest.mark.gpu
+def test_workspace_from_the_caller(pkg, dev, O):
+    """pddc_pipeline_set_workspace: the inter-stage buffers of a cascade live in memory the HOST provides (so the host
+    decides where in HBM they lie).  Same outputs bit for bit as with the pipeline's own buffers, in one shot and in
+    ragged batches, unfused and fused routes; a batch beyond what the workspace was sized for is refused; NULL goes
+    back to own allocations without touching the stream state."""
+    torch = _torch()
+    meta = json.load(open(os.path.join(GOLD, "ddc_golden.json")))
+    stages = [(d, load_taps(n)) for d, n in meta["c320_stages"]]
+    ns = 8 * 8192 * 5 + 8 * 123                                     # fused-pair tiles plus a ragged rest
+    packed = O.lcg_bytes(6 * ns, 77)
+    d_in = to_dev(packed, dev)
+    own = pkg.Pipeline(stages, mix=True)
+    own.set_freg(meta["freg"])
+    ref = own.process(d_in).cpu().numpy()
+    p = pkg.Pipeline(stages, mix=True)
+    p.set_freg(meta["freg"])
+    need = p.workspace_size(ns)
+    assert need >= (ns // 8 + ns // 64) * 8 and need % 256 == 0
+    ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+    base = (ws.data_ptr() + 255) & ~255
+    with pytest.raises(pkg.PddcError) as e:
+        p.set_workspace(base, need - 256, ns)                       # too small
+    assert e.value.code == pkg.PDDC_EINVAL
+    with pytest.raises(pkg.PddcError):
+        p.set_workspace(base + 8, need, ns)                         # misaligned
+    p.set_workspace(base, need, ns)
+    y = p.process(d_in).cpu().numpy()
+    assert np.array_equal(y, ref)
+    assert O.rel_err(y.reshape(-1)[:2 * 64], O.ddc_chain(packed[:6 * 320 * 200], stages, freg=meta["freg"], mix=True)[:2 * 64]) <= FIR_TOL
+    # ragged batches through the same workspace, stream state carried as usual
+    p.reset()
+    cuts = [0, 8 * 8192 * 2, 8 * 8192 * 2 + 8 * 31, ns]
+    own.reset()
+    parts = [p.process(d_in[6 * a:6 * b]).cpu().numpy() for a, b in zip(cuts[:-1], cuts[1:])]
+    own_parts = [own.process(d_in[6 * a:6 * b]).cpu().numpy() for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(parts), np.concatenate(own_parts))     # the same routes: the same bits
+    assert O.rel_err(np.concatenate(parts).reshape(-1), ref.reshape(-1)) <= FIR_TOL
+    # a larger batch than the workspace was sized for: refused, state untouched
+    big = to_dev(O.lcg_bytes(6 * (ns + 8 * 8192 * 8), 78), dev)
+    with pytest.raises(pkg.PddcError) as e:
+        p.process(big)
+    assert e.value.code == pkg.PDDC_ECAPACITY
+    # back to own allocations in the middle of a stream: the state is kept
+    p.reset()
+    own.reset()
+    a1 = p.process(d_in[:6 * cuts[1]]).cpu().numpy()
+    p.set_workspace(None)
+    a2 = p.process(d_in[6 * cuts[1]:]).cpu().numpy()
+    b1 = own.process(d_in[:6 * cuts[1]]).cpu().numpy()
+    b2 = own.process(d_in[6 * cuts[1]:]).cpu().numpy()
+    assert np.array_equal(np.concatenate([a1, a2]), np.concatenate([b1, b2]))
+    p.process(big)                                                  # and large batches are fine again
+    del ws
+    p.close()
+    own.close()

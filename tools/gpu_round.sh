@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 ben
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null; cat $OUT/kernel_stats.csv
 # PMC traffic, separate passes (FETCH_SIZE undercounts 16 B/lane streams by 2x on gfx950: MI355X_MICROARCH.md HBM)
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 bench.py --no-cpu --steps 5 --warmup 1 > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 bench.py --no-cpu --out-candidates 1 --steps 5 --warmup 1 > $OUT/pmc_$C.log 2>&1
 done
 python3 - $OUT <<'PY'
 import csv, glob, sys, json

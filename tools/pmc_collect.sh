@@ -18,7 +18,7 @@ PASSES=(
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$OUT/pass$i" -- python3 bench.py --no-cpu "$@" > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed (see $OUT/pass$i.log)"
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$OUT/pass$i" -- python3 bench.py --no-cpu --out-candidates 1 "$@" > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed (see $OUT/pass$i.log)"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 for W in d8_127 d8_255 c320 unpack; do
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/${W}_$C -- python3 bench.py --no-cpu --workload $W --steps 5 --warmup 1 > $OUT/${W}_$C.log 2>&1
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/${W}_$C -- python3 bench.py --no-cpu --out-candidates 1 --workload $W --steps 5 --warmup 1 > $OUT/${W}_$C.log 2>&1
   done
 done
 python3 - $OUT <<'PY'
