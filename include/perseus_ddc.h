@@ -122,6 +122,17 @@ int pddc_free(void *d_ptr);
  * A pipeline places its own inter-stage buffers this way when a batch is >= 64 MiB (PDDC_PLACEMENT=0: never).       */
 int pddc_malloc_apart(void **d_ptr, size_t nbytes, const void *d_partner, size_t partner_bytes, int max_candidates,
                       float *ms_best, float *ms_worst);
+/* The dependable form of the same search: ONE large allocation of the caller's (tens of GiB up; 288 GB of HBM make it
+ * affordable), cut into slots of slot_bytes; slot k holds an input region [0, in_bytes) and an output side at
+ * [out_offset, out_offset + out_bytes).  Every pair (input in one of n_in_slots evenly spread slots, output side in any
+ * slot) is timed with a read+write probe stream; *in_slot / *out_slot are the fastest pair, ms_table (optional,
+ * n_in_slots x (arena_bytes / slot_bytes) floats) every time.  The arena's contents are overwritten: search first, fill
+ * later.  Separate allocations 8 GiB apart sometimes never leave an extent class; inside one allocation the classes
+ * alternate every 32-64 GiB and about two thirds of all pairs are fast (bench.py does this search with the real
+ * kernel as its probe; tests/test_gpu_parity.py checks that both agree).                                           */
+int pddc_arena_search(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t in_bytes, size_t out_offset,
+                      size_t out_bytes, int n_in_slots, size_t *in_slot, size_t *out_slot, float *ms_table,
+                      float *ms_best, float *ms_worst);
 int pddc_memcpy_h2d(void *d_dst, const void *h_src, size_t nbytes, void *stream);
 int pddc_memcpy_d2h(void *h_dst, const void *d_src, size_t nbytes, void *stream);
 int pddc_stream_sync(void *stream);

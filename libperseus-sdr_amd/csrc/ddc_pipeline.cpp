@@ -422,6 +422,81 @@ int pddc_malloc_apart(void **d_ptr, size_t nbytes, const void *d_partner, size_t
     return malloc_apart_impl(d_ptr, nbytes, d_partner, partner_bytes, max_candidates, ms_best, ms_worst, (size_t)1 << 20);
 }
 
+/* The same question inside ONE large allocation of the caller's: which (input slot, output slot) pair streams fastest?
+ * Separate allocations do not reliably leave an extent class (some processes saw one class over 200 GiB of them); inside
+ * one allocation the classes alternate every 32-64 GiB in every process tried (tools/placement_probe10.py).         */
+int pddc_arena_search(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t in_bytes, size_t out_offset,
+                      size_t out_bytes, int n_in_slots, size_t *in_slot, size_t *out_slot, float *ms_table,
+                      float *ms_best, float *ms_worst)
+{
+    if (!d_arena || !in_slot || !out_slot || slot_bytes == 0 || ((uintptr_t)d_arena & 15) || (slot_bytes & 15) ||
+        (out_offset & 15) || in_bytes < 16 || out_bytes < 16 || out_offset < in_bytes || out_offset + out_bytes > slot_bytes ||
+        n_in_slots < 1)
+        return fail(PDDC_EINVAL, "bad argument");
+    const size_t nslot = arena_bytes / slot_bytes;
+    if (nslot < 2)
+        return fail(PDDC_EINVAL, "the arena holds fewer than two slots");
+    int rc = require_device();
+    if (rc)
+        return rc;
+    if ((size_t)n_in_slots > nslot)
+        n_in_slots = (int)nslot;
+    const size_t total = (size_t)1 << 30;
+    /* the probe writes up to 1 GiB from out_offset on (never into the next slot): past the last-level cache */
+    size_t dst_bytes = slot_bytes - out_offset;
+    if (dst_bytes > total)
+        dst_bytes = total;
+    dst_bytes &= ~(size_t)15;
+    uint8_t *base = static_cast<uint8_t *>(d_arena);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float best = 0.0f, worst = 0.0f;
+    size_t bi = 0, bo = 0;
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < n_in_slots && e == hipSuccess; ++k) {
+        const size_t i = (size_t)k * nslot / (size_t)n_in_slots;
+        for (size_t o = 0; o < nslot && e == hipSuccess; ++o) {
+            const void *src = base + i * slot_bytes;
+            void *dst = base + o * slot_bytes + out_offset;
+            for (int r = 0; r < 2 && e == hipSuccess; ++r)
+                e = launch_stream_probe(src, in_bytes & ~(size_t)15, dst, dst_bytes, total, nullptr);
+            if (e == hipSuccess)
+                e = hipEventRecord(e0, nullptr);
+            for (int r = 0; r < 4 && e == hipSuccess; ++r)
+                e = launch_stream_probe(src, in_bytes & ~(size_t)15, dst, dst_bytes, total, nullptr);
+            if (e == hipSuccess)
+                e = hipEventRecord(e1, nullptr);
+            if (e == hipSuccess)
+                e = hipEventSynchronize(e1);
+            float t = 0.0f;
+            if (e == hipSuccess)
+                e = hipEventElapsedTime(&t, e0, e1);
+            t /= 4.0f;
+            if (ms_table)
+                ms_table[(size_t)k * nslot + o] = t;
+            if ((k == 0 && o == 0) || t < best) {
+                best = t;
+                bi = i;
+                bo = o;
+            }
+            if ((k == 0 && o == 0) || t > worst)
+                worst = t;
+        }
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (e != hipSuccess)
+        return fail(PDDC_EHIP, "placement probe: %s", hipGetErrorString(e));
+    *in_slot = bi;
+    *out_slot = bo;
+    if (ms_best)
+        *ms_best = best;
+    if (ms_worst)
+        *ms_worst = worst;
+    return PDDC_OK;
+}
+
 int pddc_free(void *d_ptr)
 {
     if (d_ptr)

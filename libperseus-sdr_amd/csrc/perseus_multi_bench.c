@@ -13,6 +13,7 @@
  *   -T file   first-stage taps, raw float32 (default ../tests/golden/taps_d8_127.f32 next to the binary)
  *   -c        cascade /320 with NCO (taps c320_* from the same directory) instead of the single /8
  *   -G        gather the outputs on GPU 0
+ *   -A GiB    size of the per-GPU arena that input, workspace and outputs are cut from (160; 0: separate allocations)
  * Prints one line per run: aggregate input MS/s (kernel path only), and with -G the with-gather rate
  * and the bytes per second that reached the root per peer link.
  */
@@ -69,7 +70,7 @@ static float *load_f32(const char *dir, const char *name, int *n)
 
 int main(int argc, char **argv)
 {
-    int ng = 0, log2n = 26, steps = 50, warm = 5, cascade = 0, gather = 0, c;
+    int ng = 0, log2n = 26, steps = 50, warm = 5, cascade = 0, gather = 0, arena_gib = 160, c;
     char tapdir[1024];
     {
         char self[1024];
@@ -77,17 +78,18 @@ int main(int argc, char **argv)
         self[k > 0 ? k : 0] = 0;
         snprintf(tapdir, sizeof(tapdir), "%s/../tests/golden", dirname(self));
     }
-    while ((c = getopt(argc, argv, "g:n:s:w:T:cGh")) != -1) {
+    while ((c = getopt(argc, argv, "g:n:s:w:T:A:cGh")) != -1) {
         switch (c) {
         case 'g': ng = atoi(optarg); break;
         case 'n': log2n = atoi(optarg); break;
         case 's': steps = atoi(optarg); break;
         case 'w': warm = atoi(optarg); break;
         case 'T': snprintf(tapdir, sizeof(tapdir), "%s", optarg); break;
+        case 'A': arena_gib = atoi(optarg); break;
         case 'c': cascade = 1; break;
         case 'G': gather = 1; break;
         default:
-            fprintf(stderr, "usage: %s [-g gpus] [-n log2n] [-s steps] [-w warmup] [-T tapdir] [-c] [-G]\n", argv[0]);
+            fprintf(stderr, "usage: %s [-g gpus] [-n log2n] [-s steps] [-w warmup] [-T tapdir] [-A arena GiB] [-c] [-G]\n", argv[0]);
             return 2;
         }
     }
@@ -127,7 +129,7 @@ int main(int argc, char **argv)
     /* one communicator rank, one pipeline, one input batch and two output buffers per GPU */
     pddc_comm *comm[MAXG] = { 0 };
     pddc_pipeline *pipe[MAXG] = { 0 };
-    void *d_in[MAXG] = { 0 }, *d_out[MAXG][2] = { { 0 } }, *d_all = NULL;
+    void *d_in[MAXG] = { 0 }, *d_out[MAXG][2] = { { 0 } }, *d_all = NULL, *arena[MAXG] = { 0 };
     int devs[MAXG];
     for (int g = 0; g < ng; g++)
         devs[g] = g;
@@ -139,13 +141,39 @@ int main(int argc, char **argv)
         CHECK(pddc_pipeline_create(&pipe[g], g, st, nst, flags));   /* same host memory: nothing to broadcast */
         CHECK(pddc_pipeline_set_freg(pipe[g], freg));
         cap = pddc_pipeline_max_output(pipe[g], ns) + 8;
-        CHECK(pddc_malloc(&d_in[g], ns * 6));
-        /* the output buffers in another HBM extent class than the input (include/perseus_ddc.h) */
-        float fast = 0, slow = 0;
-        CHECK(pddc_malloc_apart(&d_out[g][0], cap * 8, d_in[g], ns * 6, 24, &fast, &slow));
-        CHECK(pddc_malloc_apart(&d_out[g][1], cap * 8, d_in[g], ns * 6, 24, NULL, NULL));
-        if (slow > 0)
-            fprintf(stderr, "GPU %d: output placed apart from the input: probe %.3f ms (slowest candidate %.3f ms)\n", g, fast, slow);
+        /* Input, inter-stage workspace and the two output buffers of a GPU are cut from ONE arena, at the pair of
+         * slots where a read stream and a write stream run fastest against each other (different HBM extent
+         * classes; pddc_arena_search, include/perseus_ddc.h).  Slot layout: [input | workspace | out 0 | out 1]. */
+        const size_t GiB = (size_t)1 << 30, slot = 8 * GiB;
+        const size_t in_span = (ns * 6 + GiB - 1) / GiB * GiB;
+        const size_t ws = (pddc_pipeline_workspace_size(pipe[g], ns) + 255) & ~(size_t)255;
+        const size_t ob = (cap * 8 + 255) & ~(size_t)255;
+        size_t got = 0;
+        if (arena_gib > 0 && in_span + ws + 2 * ob <= slot) {
+            for (size_t gib = (size_t)arena_gib; gib >= 24 && !arena[g]; gib = gib * 3 / 4)
+                if (pddc_malloc(&arena[g], gib * GiB) == PDDC_OK)
+                    got = gib * GiB;
+                else
+                    arena[g] = NULL;
+        }
+        if (arena[g]) {
+            size_t si = 0, so = 0;
+            float fast = 0, slow = 0;
+            CHECK(pddc_arena_search(arena[g], got, slot, ns * 6, in_span, ws + 2 * ob, 3, &si, &so, NULL, &fast, &slow));
+            fprintf(stderr, "GPU %d: %zu GiB arena, input in slot %zu, outputs in slot %zu: probe %.3f ms (slowest pair %.3f ms)\n",
+                    g, got / GiB, si, so, fast, slow);
+            d_in[g] = (char *)arena[g] + si * slot;
+            char *o = (char *)arena[g] + so * slot + in_span;
+            if (ws)
+                CHECK(pddc_pipeline_set_workspace(pipe[g], o, ws, ns));
+            d_out[g][0] = o + ws;
+            d_out[g][1] = o + ws + ob;
+        } else {
+            /* no room for an arena: separate allocations, the outputs walked away from the input */
+            CHECK(pddc_malloc(&d_in[g], ns * 6));
+            CHECK(pddc_malloc_apart(&d_out[g][0], cap * 8, d_in[g], ns * 6, 24, NULL, NULL));
+            CHECK(pddc_malloc_apart(&d_out[g][1], cap * 8, d_in[g], ns * 6, 24, NULL, NULL));
+        }
         CHECK(pddc_synth_lcg(d_in[g], ns * 6, 12345u + (uint32_t)g, 0, NULL));     /* stream seed 12345 + g */
         CHECK(pddc_stream_sync(NULL));
     }
@@ -207,9 +235,13 @@ int main(int argc, char **argv)
     for (int g = 0; g < ng; g++) {
         pddc_set_device(g);
         pddc_pipeline_destroy(pipe[g]);
-        pddc_free(d_in[g]);
-        pddc_free(d_out[g][0]);
-        pddc_free(d_out[g][1]);
+        if (arena[g]) {
+            pddc_free(arena[g]);
+        } else {
+            pddc_free(d_in[g]);
+            pddc_free(d_out[g][0]);
+            pddc_free(d_out[g][1]);
+        }
         if (comm[g])
             pddc_comm_destroy(comm[g]);
     }

@@ -79,3 +79,69 @@ def test_window_check_catches_a_broken_seam(pkg, O, dev):
 
     v, _, _ = _run(pkg, O, dev, "d8_127", corrupt=corrupt_last)
     assert not v["ok"]
+
+
+def test_arena_search_agrees_with_the_kernel(pkg, O, dev):
+    """pddc_arena_search (include/perseus_ddc.h) ranks (input slot, output slot) pairs of one large allocation with a
+    read+write probe stream.  The pair it returns must be a fast one for the real kernel too: k_fir8 (127 taps, 2^28
+    samples) timed on the helper's best pair is within 3 % of the best of a dozen pairs timed directly, and when the
+    kernel sees both speeds (>= 4 % apart) the helper's worst pair is one of the slow ones."""
+    import ctypes as C
+    import torch
+    b = _bench()
+    L = pkg.ddc_lib()
+    wl = b.workload_def("d8_127")
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    gib = min(176, (free_b - (16 << 30)) >> 30)
+    if gib < 32:
+        pytest.skip("less than 32 GiB free")
+    slot, in_bytes, out_off = 8 << 30, 6 * NS, 2 << 30
+    pipe = pkg.Pipeline(wl["stages"])
+    rows = pipe.max_output(NS) + 8
+    arena = torch.empty(gib << 30, dtype=torch.uint8, device=dev)
+    nslot = (gib << 30) // slot
+    i_sl, o_sl, best, worst = C.c_size_t(), C.c_size_t(), C.c_float(), C.c_float()
+    table = (C.c_float * (2 * nslot))()
+    pkg.check(L.pddc_arena_search(arena.data_ptr(), gib << 30, slot, in_bytes, out_off, rows * 8, 2, C.byref(i_sl),
+                                  C.byref(o_sl), table, C.byref(best), C.byref(worst)))
+    tab = np.array(table[:]).reshape(2, nslot)
+    in_slots = [0, nslot // 2]
+    assert i_sl.value in in_slots and o_sl.value < nslot and 0 < best.value <= worst.value
+    assert abs(tab.min() - best.value) < 1e-6 and abs(tab.max() - worst.value) < 1e-6
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for k in in_slots:                                   # search first, fill later
+        pkg.check(L.pddc_synth_lcg(arena.data_ptr() + k * slot, in_bytes, 12345, 0, st))
+
+    def kernel_ms(i, o):
+        a, c = arena.data_ptr() + i * slot, arena.data_ptr() + o * slot + out_off
+        for _ in range(30):
+            pipe.process_ptr(a, NS, c, rows, st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(24):
+            pipe.process_ptr(a, NS, c, rows, st)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / 24
+
+    for _ in range(150):
+        pipe.process_ptr(arena.data_ptr(), NS, arena.data_ptr() + out_off, rows, st)
+    direct = {(i, o): kernel_ms(i, o) for i in in_slots for o in range(0, nslot, max(1, nslot // 6))}
+    t_best = kernel_ms(i_sl.value, o_sl.value)
+    wi, wo = divmod(int(tab.argmax()), nslot)
+    t_worst = kernel_ms(in_slots[wi], wo)
+    lo, hi = min(direct.values()), max(direct.values())
+    print(f"probe best pair in{i_sl.value}/out{o_sl.value}: kernel {t_best:.4f} ms; probe worst pair: kernel {t_worst:.4f} ms; "
+          f"direct {lo:.4f} .. {hi:.4f} ms over {len(direct)} pairs; probe {best.value:.3f} .. {worst.value:.3f} ms")
+    assert t_best <= 1.03 * lo
+    if hi > 1.04 * lo:
+        assert t_worst > 1.03 * t_best
+    # the result is still right at the chosen place
+    n = pipe.process_ptr(arena.data_ptr() + i_sl.value * slot, NS, arena.data_ptr() + o_sl.value * slot + out_off, rows, st)
+    y = np.empty((4096, 2), np.float32)
+    pkg.check(L.pddc_memcpy_d2h(y.ctypes.data, arena.data_ptr() + o_sl.value * slot + out_off + 8 * (n - 4096), y.nbytes, st))
+    pkg.check(L.pddc_stream_sync(st))
+    assert np.isfinite(y).all() and np.abs(y).max() > 0
+    pipe.close()
+    del arena
+    torch.cuda.empty_cache()
