@@ -1,5 +1,6 @@
 # randomized stress of the stream state machine against the oracle: random plans, cuts, NCO words retuned
-# between batches (phase-continuous), scheduler settings (PDDC_FIR8_BLOCKS / DYN_PCT / CHUNK / R).
+# between batches (phase-continuous), scheduler settings (PDDC_FIR8_BLOCKS / DYN_PCT / CHUNK / R), caller-provided
+# workspaces and checkpoint/restore hops to a fresh pipeline in mid-stream.
 # Usage: python tools/stress_gpu.py [n]
 import sys, os, importlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,10 +38,31 @@ for it in range(n_iter):
     segs = [(a, w) for k, (a, w) in enumerate(zip(cuts[:-1], words)) if k == 0 or w != words[k - 1]]
     ref = O.ddc_chain_retuned(packed, stages, segs) if mix else O.ddc_chain(packed, stages)
     pipe = pkg.Pipeline(stages, mix=mix)
+    # caller-provided workspace for the inter-stage buffers (sometimes dropped again in mid-stream), and sometimes a
+    # hop to a fresh pipeline through save_state / restore_state between two batches
+    use_ws = len(stages) > 1 and bool(rng.integers(0, 2))
+    ws = None
+    if use_ws:
+        need = pipe.workspace_size(ns)
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+        pipe.set_workspace((ws.data_ptr() + 255) & ~255, need, ns)
+    hops = 0
     parts = []
-    for (a, b), w in zip(zip(cuts[:-1], cuts[1:]), words):
+    for k, ((a, b), w) in enumerate(zip(zip(cuts[:-1], cuts[1:]), words)):
         pipe.set_freg(w)
         parts.append(pipe.process(torch.from_numpy(packed[6 * a:6 * b].copy()).to(dev)).cpu().numpy().reshape(-1))
+        act = int(rng.integers(0, 6))
+        if act == 0 and use_ws:
+            pipe.set_workspace(None)
+            use_ws = False
+        elif act == 1:
+            blob = pipe.save_state()
+            q = pkg.Pipeline(stages, mix=mix)
+            q.restore_state(blob)
+            pipe.close()
+            pipe = q
+            use_ws = False
+            hops += 1
     y = np.concatenate(parts) if parts else np.zeros(0, np.float32)
     pipe.close()
     ok = y.size == ref.size
@@ -49,7 +71,7 @@ for it in range(n_iter):
     tag = "ok " if ok and err <= 1e-6 else "BAD"
     print(f"{tag} it {it} stages {[(s[0], len(s[1])) for s in stages]} mix {mix} ns {ns} cuts {len(cuts)-1} "
           f"blocks {os.environ['PDDC_FIR8_BLOCKS']} dyn {os.environ['PDDC_FIR8_DYN_PCT']} K {os.environ['PDDC_FIR8_CHUNK']} "
-          f"R {os.environ['PDDC_FIR8_R']} retunes {len(segs) - 1} err {err:.2e}", flush=True)
+          f"R {os.environ['PDDC_FIR8_R']} retunes {len(segs) - 1} ws {ws is not None} hops {hops} err {err:.2e}", flush=True)
     if tag == "BAD":
         sys.exit(1)
 print("worst", worst)
