@@ -112,6 +112,10 @@ struct pddc_pipeline {
     std::vector<WordSeg> segs;
     float *d_hist_f32 = nullptr;  /* stage 0's history as mixed float2, for that route */
     int fail_at_stage = -1;       /* test hook: the next process() fails when it reaches this stage */
+    /* inter-stage buffers are placed in another HBM extent class than the batch they are produced from (ensure_buf).
+     * Not for a pipeline fed through push_host* / push_synth_async: those are bound by PCIe or by real time, their
+     * batches alternate between two staging slots, and the search would only delay the start of the stream.       */
+    bool place_buffers = true;
     /* measurement hook: HIP events around the stage-0 (or fused-pair) kernel of every process() */
     bool time_stage0 = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -1125,7 +1129,9 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
     /* (reads_packed: the kernel writing it streams the packed batch -- stage 0, or the fused pair for stage 1) */
     auto stage_dst = [&](int i, float **dst, bool reads_packed) -> int {
         if (i + 1 < p->nstages) {
-            const void *src = reads_packed ? d_packed : static_cast<const void *>(p->st[i].d_buf);
+            const void *src = !p->place_buffers ? nullptr
+                              : reads_packed    ? d_packed
+                                                : static_cast<const void *>(p->st[i].d_buf);
             int r = ensure_buf(p->st[i + 1], n_in[i + 1] + 8, src, reads_packed ? nsamples * 6 : n_in[i] * 8);
             if (r)
                 return r;
@@ -1213,7 +1219,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
              * it, the batch likewise with the current word, and the generic decimator runs on floats;
              * the packed history for the next call is carried as usual.                            */
             const int H = st.hist;
-            if ((rc = ensure_buf(st, nsamples + 8, d_packed, nsamples * 6)))
+            if ((rc = ensure_buf(st, nsamples + 8, p->place_buffers ? d_packed : nullptr, nsamples * 6)))
                 return rc;
             if (!p->d_hist_f32)
                 HIP_TRY(hipMalloc(&p->d_hist_f32, (size_t)PDDC_MAX_TAPS * 8 + 256));
@@ -1262,7 +1268,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         } else {
             if (i == 0) {
                 /* generic first stage: unpack(+mix) to float2, then the generic FIR */
-                if ((rc = ensure_buf(st, nsamples + 8, d_packed, nsamples * 6)))
+                if ((rc = ensure_buf(st, nsamples + 8, p->place_buffers ? d_packed : nullptr, nsamples * 6)))
                     return rc;
                 HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, st.d_buf, false, mix, p->n0, p->freg,
                                         p->phase_off, p->lo_c, p->lo_s, s));
@@ -1416,6 +1422,7 @@ static int push_async(pddc_pipeline *p, const void *h_packed, bool synth, uint32
     if (sl.used)
         HIP_TRY(hipStreamWaitEvent(p->own_stream, sl.ev_out, 0));
     size_t n_out = 0;
+    p->place_buffers = false;
     int rc = pddc_pipeline_process(p, sl.d_in, nsamples, sl.d_out, sl.out_cap, &n_out, p->own_stream);
     if (rc)
         return rc;

@@ -308,6 +308,28 @@ def test_plumbing_client_eight_receivers_on_the_gpu_path(pkg, dev):
     print("plumbing -N 8:", m.group(0))
 
 
+def test_large_api_batches_start_at_once_and_run_faster(pkg, dev):
+    """A receiver of the drop-in API with 2^24-sample GPU batches (100 MB of packed input each): its pipeline is fed
+    through the staging slots of push_*_async and must NOT run the HBM placement search for its inter-stage buffers
+    (a second per receiver before the first callback; found when eight of them took 9 s to start).  Larger batches
+    amortise the per-batch synchronisation: the eight together are well beyond the 2^22 default's rate."""
+    import re
+    import time
+    exe = os.path.join(os.path.dirname(pkg.SDR_LIB), "perseus_plumbing")
+    env = dict(os.environ, PERSEUS_AMD_PACE="0", PERSEUS_AMD_MODE="ddc", PERSEUS_AMD_BATCH=str(1 << 24))
+    env.pop("PERSEUS_AMD_DEVICES", None)
+    t0 = time.time()
+    p = subprocess.run([exe, "-N", "8", "-s", "250000", "-o", "none", "-t", "2", "-d", "0"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    wall = time.time() - t0
+    assert p.returncode == 0, p.stderr[-1000:]
+    m = re.search(r"8 receivers: (\d+) samples in ([0-9.]+) s = ([0-9.]+) kS/s aggregate", p.stderr)
+    assert m, p.stderr[-600:]
+    print("plumbing -N 8, 2^24-sample batches:", m.group(0), f"wall {wall:.1f} s")
+    assert wall < 8.0                                        # 2 s of streaming + process start, no 9 s of searching
+    assert float(m.group(3)) >= 8 * 250.0 * 20               # >= 20x real time for each of the eight
+
+
 def test_retunes_between_batches_shorter_than_the_history(pkg, dev, O):
     """Batches of a few groups with a new tuning word before each: stage 0's history window then holds samples
     of several words.  The packed-history kernels mix their history with ONE word; the pipeline notices and
