@@ -92,6 +92,16 @@ def test_synth_lcg_matches_oracle(pkg, dev, O):
     off = 6 * 1234 + 3
     got2 = pkg.synth_lcg(1000, 12345, off, dev).cpu().numpy()
     assert np.array_equal(got2, ref[off:off + 1000])
+    # more chunks than the grid has threads (8192 blocks x 256 threads x 16 bytes = 32 MiB): every thread then walks on
+    # by the grid stride with one affine jump; ragged end, odd offset beyond 2^32 steps
+    big = (80 << 20) + 7
+    refb = O.lcg_bytes(big, 777)
+    gotb = pkg.synth_lcg(big, 777, 0, dev).cpu().numpy()
+    assert np.array_equal(gotb, refb)
+    far = (1 << 32) + 12345
+    # the LCG has period 2^32 in its state: byte k + 2^32 equals byte k
+    got3 = pkg.synth_lcg(4096, 777, far, dev).cpu().numpy()
+    assert np.array_equal(got3, refb[12345:12345 + 4096])
 
 
 # ------------------------------------------------------------- fused /8 FIR

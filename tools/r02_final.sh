@@ -5,9 +5,11 @@
 OUT=gpurun_out/r02_final
 mkdir -p $OUT
 export TMPDIR=/tmp
+# traffic first: the bench lines below print roofline.traffic only if profiles/pmc_traffic.json was measured on THIS kernel source
+bash tools/pmc_traffic.sh $OUT/pmc_traffic > $OUT/pmc_traffic.log 2>&1
+cp $OUT/pmc_traffic/pmc_traffic.json profiles/pmc_traffic.json
 bash tools/gpu_round.sh r02_final > $OUT/gpu_round.log 2>&1
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.err
-bash tools/pmc_traffic.sh $OUT/pmc_traffic > $OUT/pmc_traffic.log 2>&1
 bash tools/pmc_collect.sh $OUT/pmc_127 --workload d8_127 --steps 20 --warmup 3 > $OUT/pmc_127.log 2>&1
 bash tools/pmc_collect.sh $OUT/pmc_255 --workload d8_255 --steps 20 --warmup 3 > $OUT/pmc_255.log 2>&1
 python tools/sweep.py > $OUT/sweep.log 2>&1; cp gpurun_out/sweep.json $OUT/sweep.json
