@@ -1082,8 +1082,8 @@ static int g_fir8_blocks = 0;       /* override (development) */
  * chunks of K tiles.  Measured (profiles/r01/v7_schedule_sweep.txt): 127 taps R=4
  * 0.398 -> 0.385 ms with 15-25 % dynamic in 4-tile chunks, 255 taps R=8 0.538 ->
  * 0.511 ms with 25 % in 2-tile chunks; single-tile chunks lose (one atomic per
- * tile on one address).  The fused pair pays a warm-up tile per chunk and gains
- * nothing, so only its remainder (< one tile per block) is dynamic.
+ * tile on one address).  The fused pair pays a warm-up tile per chunk: round 1 saw no
+ * gain and kept it static; with the buffers placed (round 2) 8 % in chunks of 8 is worth 1 %.
  * Development overrides: PDDC_FIR8_DYN_PCT (share of the tiles handed out
  * dynamically), PDDC_FIR8_CHUNK (K).                                              */
 struct Fir8Sched {
@@ -1103,7 +1103,9 @@ static Fir8Sched fir8_schedule(int ntiles, int R, bool fused, int NT = 256)
     const int want = g_fir8_blocks > 0 ? g_fir8_blocks : kFir8DefaultBlocks * (256 / NT);
     sc.nblocks = ntiles < want ? ntiles : want;
     sc.K = chunk > 0 ? chunk : (fused ? 8 : (R == 4 ? 4 : 2) * (256 / NT));
-    const int pct = dyn_pct >= 0 ? dyn_pct : (fused ? 0 : 20);
+    /* fused pair: a dynamic chunk starts with a warm-up tile, so only a small share pays (same-box sweep under the
+     * arena placement, tools/sched_sweep_c320.sh: static 0.2897 ms, 5-10 % in chunks of 8 0.2863-0.2867, 20 % 0.293) */
+    const int pct = dyn_pct >= 0 ? dyn_pct : (fused ? 8 : 20);
     sc.S = (int)((long long)ntiles * (100 - pct) / 100 / sc.nblocks);
     return sc;
 }
