@@ -20,8 +20,13 @@ for it in range(n_iter):
              [(8, h1), (5, h3[:41]), (25, g, 12)], [(10, h3[:77])], [(8, h2), (4, h1)], [(5, h3), (8, h1)]]
     stages = plans[int(rng.integers(0, len(plans)))]
     os.environ["PDDC_FIR8_BLOCKS"] = str(int(rng.choice([1, 2, 3, 5, 16, 512])))
-    os.environ["PDDC_FIR8_DYN_PCT"] = str(int(rng.choice([0, 10, 20, 50, 100])))
-    os.environ["PDDC_FIR8_CHUNK"] = str(int(rng.choice([1, 2, 3, 4, 8])))
+    dyn = int(rng.choice([-1, -1, 0, 10, 20, 50, 100]))          # -1: the library's own default schedule
+    if dyn < 0:
+        os.environ.pop("PDDC_FIR8_DYN_PCT", None)
+        os.environ.pop("PDDC_FIR8_CHUNK", None)
+    else:
+        os.environ["PDDC_FIR8_DYN_PCT"] = str(dyn)
+        os.environ["PDDC_FIR8_CHUNK"] = str(int(rng.choice([1, 2, 3, 4, 8])))
     os.environ["PDDC_FIR8_R"] = str(int(rng.choice([4, 8])))
     mix = bool(rng.integers(0, 2))
     freg = int(rng.integers(0, 2**32))
@@ -70,7 +75,7 @@ for it in range(n_iter):
     worst = max(worst, err)
     tag = "ok " if ok and err <= 1e-6 else "BAD"
     print(f"{tag} it {it} stages {[(s[0], len(s[1])) for s in stages]} mix {mix} ns {ns} cuts {len(cuts)-1} "
-          f"blocks {os.environ['PDDC_FIR8_BLOCKS']} dyn {os.environ['PDDC_FIR8_DYN_PCT']} K {os.environ['PDDC_FIR8_CHUNK']} "
+          f"blocks {os.environ['PDDC_FIR8_BLOCKS']} dyn {os.environ.get('PDDC_FIR8_DYN_PCT', 'default')} K {os.environ.get('PDDC_FIR8_CHUNK', 'default')} "
           f"R {os.environ['PDDC_FIR8_R']} retunes {len(segs) - 1} ws {ws is not None} hops {hops} err {err:.2e}", flush=True)
     if tag == "BAD":
         sys.exit(1)
