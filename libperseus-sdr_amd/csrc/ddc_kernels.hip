@@ -1100,7 +1100,19 @@ static Fir8Sched fir8_schedule(int ntiles, int R, bool fused, int NT = 256)
     const int chunk = e ? atoi(e) : 0;
     Fir8Sched sc;
     /* 128-thread blocks: four per CU, tiles half as long (chunks of twice as many) */
-    const int want = g_fir8_blocks > 0 ? g_fir8_blocks : kFir8DefaultBlocks * (256 / NT);
+    /* small batches (BASELINE config 5's low end): one block per tile up to one block per CU, then about three tiles
+     * per block -- a block with a single tile overlaps nothing, its load, filter and store phases just follow each other
+     * (tools/small_batch.sh, 127 taps: 2^22 samples 19.0 -> 14.4 us with 256 instead of 512 blocks, 2^23 22.4 -> 20.2
+     * with 340; x320 cascade 2^21 31.5 -> 25.4) -- and the full two blocks per CU from 1536 tiles on                */
+    const int full = kFir8DefaultBlocks * (256 / NT);
+    int want = g_fir8_blocks;
+    if (want <= 0) {
+        want = ntiles / 3;
+        if (want < full / 2)
+            want = full / 2;
+        if (want > full)
+            want = full;
+    }
     sc.nblocks = ntiles < want ? ntiles : want;
     sc.K = chunk > 0 ? chunk : (fused ? 8 : (R == 4 ? 4 : 2) * (256 / NT));
     /* fused pair: a dynamic chunk starts with a warm-up tile, so only a small share pays (same-box sweep under the
