@@ -582,11 +582,13 @@ def run_rank(a):
 
     # ---- BASELINE config 4: gather of every rank's output on rank 0's GPU (RCCL, C library)
     if grp.comm is not None and stages is not None and not a.no_gather:
-        out2 = None
+        out2 = spare = None
         if arena is not None and in_span + ws_span + 2 * out_bytes + 256 <= slot:
             at = bo * slot + in_span + ws_span + ((out_bytes + 255) & ~255)      # right behind `out`, same slot
             out2 = arena[at:at + out_bytes].view(torch.float32).view(out_rows, 2)
-        g = guarded_gather_legs(a, pkg, shard, grp, dev, stream, ns, d_in, wl, pipe, out, out2)
+            at2 = (at + out_bytes + 255) & ~255
+            spare = arena[at2:(bo + 1) * slot]                                   # the rest of that slot
+        g = guarded_gather_legs(a, pkg, shard, grp, dev, stream, ns, d_in, wl, pipe, out, out2, spare)
         if res is not None:
             res["gather"] = g
     elif res is not None and grp.comm_error and stages is not None and not a.no_gather:
@@ -614,7 +616,9 @@ def gather_leg(a, pkg, grp, dev, stream, ns, d_in, pipe, out_shape_rows, decim, 
         pipe.process_ptr(d_in.data_ptr(), ns, o.data_ptr(), o.shape[0], stream)
         grp.comm.gather_async(o.data_ptr(), nbytes, rptr, 0, stream)
 
-    for k in range(2):
+    # untimed: both buffers once, then enough back-to-back steps for sustained clocks (the legs before this one end in
+    # verification and host work; the first dozen launches after an idle spell run up to 40 % slow, DESIGN.md 5 DVFS)
+    for k in range(200 + a.warmup):         # the same count on every rank: each step is a collective
         gstep(k)
     grp.comm.gather_wait()
     torch.cuda.synchronize(dev)
@@ -644,9 +648,10 @@ def gather_leg(a, pkg, grp, dev, stream, ns, d_in, pipe, out_shape_rows, decim, 
             "root_block_matches_own_output": ok, "all_blocks_match_their_ranks_checksums": blocks_ok}
 
 
-def guarded_gather_legs(a, pkg, shard, grp, dev, stream, ns, d_in, wl, pipe, out, out2=None):
+def guarded_gather_legs(a, pkg, shard, grp, dev, stream, ns, d_in, wl, pipe, out, out2=None, spare=None):
     """Both gather legs under a watchdog: a collective that never completes must not cost the
     run its line -- the watchdog prints it without the gather and ends the process."""
+    import torch
     res = {"note": "hot path + RCCL gather (grouped ncclSend/ncclRecv from the C library, peer -> rank 0, one xGMI "
                    "link per peer) of the float32 output; batch k's transfer runs under batch k+1's kernels. "
                    "Never part of `value`."}
@@ -670,7 +675,14 @@ def guarded_gather_legs(a, pkg, shard, grp, dev, stream, ns, d_in, wl, pipe, out
         if a.workload != "c320" and (grp.world > 1 or os.environ.get("PDDC_BENCH_GATHER_C320") == "1"):
             w2 = workload_def("c320")
             p2 = grp.make_pipeline(pkg, w2["stages"], w2["freg"], w2["mix"])
-            res["c320"] = gather_leg(a, pkg, grp, dev, stream, ns, d_in, p2, p2.max_output(ns) + 8, 320, w2["label"])
+            rows2, placed2 = p2.max_output(ns) + 8, None
+            ws2 = (p2.workspace_size(ns) + 255) & ~255
+            ob2 = (rows2 * 8 + 255) & ~255
+            if spare is not None and ws2 + 2 * ob2 <= spare.numel():
+                # the cascade's workspace and outputs in the rest of the arena slot that already suits this input
+                p2.set_workspace(spare.data_ptr(), ws2, ns)
+                placed2 = [spare[ws2 + k * ob2:ws2 + k * ob2 + rows2 * 8].view(torch.float32).view(rows2, 2) for k in range(2)]
+            res["c320"] = gather_leg(a, pkg, grp, dev, stream, ns, d_in, p2, rows2, 320, w2["label"], placed=placed2)
             p2.close()
     except Exception as e:
         res["error"] = f"{type(e).__name__}: {e}"
