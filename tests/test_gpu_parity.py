@@ -1085,3 +1085,10 @@ def test_workspace_from_the_caller(pkg, dev, O):
     del ws
     p.close()
     own.close()
+    # a single-stage pipeline has no inter-stage buffer: size 0, and setting an (empty) workspace is a no-op
+    one = pkg.Pipeline([(8, load_taps("d8_127"))])
+    assert one.workspace_size(1 << 20) == 0
+    one.set_workspace(None)
+    y1 = one.process(d_in[:6 * 8192]).cpu().numpy()
+    assert O.rel_err(y1.reshape(-1), O.ddc_chain(packed[:6 * 8192], [(8, load_taps("d8_127"))])) <= FIR_TOL
+    one.close()
