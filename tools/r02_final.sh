@@ -25,6 +25,7 @@ libperseus-sdr_amd/perseus_multi_bench -n 28 -s 200 > $OUT/multi_bench_c_host.tx
 libperseus-sdr_amd/perseus_multi_bench -n 28 -s 200 -c >> $OUT/multi_bench_c_host.txt 2>&1
 libperseus-sdr_amd/perseus_multi_bench -n 28 -s 100 -c -G >> $OUT/multi_bench_c_host.txt 2>&1
 bash tools/small_batch_default.sh > $OUT/small_batches.txt 2>&1
+bash tools/trace_gaps.sh d8_127 $OUT/trace_d8_127 --steps 200 --warmup 5 > $OUT/trace_d8_127.txt 2>&1
 bash tools/trace_gaps.sh c320 $OUT/trace_c320 --steps 200 --warmup 5 > $OUT/trace_c320.txt 2>&1
 cat $OUT/gpu_round.log | tail -25
 cat $OUT/bench_driver_args.json
