@@ -105,7 +105,10 @@ int pddc_pack24_f32(const void *d_in_f32, size_t nsamples, void *d_out_packed, v
  * s=s*1664525+1013904223, byte=s>>24, starting `byte_offset` bytes in.        */
 int pddc_synth_lcg(void *d_dst, size_t nbytes, uint32_t seed, uint64_t byte_offset, void *stream);
 
-/* ---- device memory helpers for C hosts (tests/bench use torch instead) ---- */
+/* ---- device memory helpers for C hosts (tests/bench use torch instead) ----
+ * No reference counterpart: the reference's only buffers are the eight libusb transfer buffers of a queue in host
+ * memory (perseus-in.c:67-110, input_queue_create); everything here exists because the DSP moved from the FPGA
+ * into HBM. */
 int pddc_set_device(int device);
 int pddc_malloc(void **d_ptr, size_t nbytes);
 int pddc_free(void *d_ptr);
