@@ -338,7 +338,9 @@ struct Fir8Geom2 {
     /* plain layout (offset 8 + position): the second stage is ~3 % of the work, a
      * 2-way bank conflict on its reads is cheaper than the LDS a pad would cost  */
     static constexpr int PLANE = NTB2 > 0 ? 8 + 8 * NG2 + 8 : 0;
-    static constexpr int LDS_FLT = NTB2 > 0 ? 2 * PLANE + 2 * TO2 : 0;
+    /* two plane SETS, alternating tile by tile (the history of tile t+1 is carried into the other set while all four
+     * waves may still be reading tile t's), and two staging areas for the two halves of the tap sum */
+    static constexpr int LDS_FLT = NTB2 > 0 ? 4 * PLANE + 4 * TO2 : 0;
 };
 
 size_t fir8_lds_bytes(int ntb, int R)
@@ -584,9 +586,10 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
     float *sI = smem;
     float *sQ = smem + G::PLANE;
     float *ot = smem + 2 * G::PLANE;     /* stage-1 output staging (unfused) ...                            */
-    float *sI2 = ot;                     /* ... or the second stage's input planes + its staging (fused)    */
-    float *sQ2 = ot + G2::PLANE;
-    float *ot2 = ot + 2 * G2::PLANE;
+    /* ... or (fused) the second stage's input planes -- set s: I at ot + 2s*PLANE2, Q behind it -- and its staging */
+    auto pl2_of = [&](int set, int q) { return ot + (2 * set + q) * G2::PLANE; };
+    float *ot2 = ot + 4 * G2::PLANE;
+    int cur2 = 0;                        /* the plane set of the tile in work (uniform)                      */
     /* plane offsets 0..6 (slots 0..6 of "group -1") never hold a sample: offset 0 of the
      * I plane (smem[0], as raw bits) carries the next chunk index from thread 0 to the
      * block.  Accessed as smem[0] so it stays an LDS access (a cast pointer becomes a
@@ -653,8 +656,8 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {            /* position p2 = 8*tid + e - 1, offset 8 + p2 */
-            sI2[7 + 8 * tid + e] = xi[e];
-            sQ2[7 + 8 * tid + e] = xq[e];
+            pl2_of(cur2, 0)[7 + 8 * tid + e] = xi[e];
+            pl2_of(cur2, 1)[7 + 8 * tid + e] = xq[e];
         }
     }
 
@@ -714,6 +717,7 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
         if (tid < NCH2) {
             const long long m = (long long)tile * G2::TO2 + 2LL * tid;     /* no ragged tiles when fused */
             f32x4 v = *reinterpret_cast<const f32x4 *>(ot2 + 4 * tid);
+            v += *reinterpret_cast<const f32x4 *>(ot2 + 2 * G2::TO2 + 4 * tid);      /* the other half of the taps */
             if (MIX)                        /* tile-relative NCO: the tile's phasor goes on at the very end */
                 v = cmul2(v, pc, ps);
             float *dstp = p.out + 2 * m;
@@ -796,11 +800,27 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
     }
     if (MIX)
         nco_lo((uint32_t)G::TI * p.freg, d_c, d_s);
+    /* The tile's phasor is the same for every lane: lane l computes the one of tile ph_base + l, once per 64
+     * consecutive tiles, and each tile fetches its own with v_readlane -- the sin/cos polynomial is ~25 VALU
+     * instructions, a tenth of what a wave of the fused pair issues per tile (same-box A/B -0.4 %).           */
+    /* (R = 4 only: the R = 8 mixing variants sit at 256 VGPRs and the two table registers would spill) */
+    constexpr bool PHTAB = MIX && R == 4;
+    float ph_c = 1.0f, ph_s = 0.0f;
+    int ph_base = -0x40000000;
     auto tile_phasor = [&](int tile, float &c, float &sn) {
         c = 1.0f;
         sn = 0.0f;
-        if (MIX)
+        if (MIX && !PHTAB)
             nco_lo((uint32_t)(p.n0 + (unsigned long long)((long long)tile * G::TI)) * p.freg + p.phase_off, c, sn);
+        if (PHTAB) {
+            if (tile < ph_base || tile >= ph_base + 64) {            /* uniform */
+                ph_base = tile;
+                nco_lo(((uint32_t)p.n0 + (uint32_t)(tile + (tid & 63)) * (uint32_t)G::TI) * p.freg + p.phase_off, ph_c,
+                       ph_s);
+            }
+            c  = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ph_c), tile - ph_base));
+            sn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ph_s), tile - ph_base));
+        }
     };
 
     int  t = (FUSE2 && c_lo > 0) ? c_lo - 1 : c_lo;   /* tile in work (a fused chunk starts one tile early) */
@@ -933,7 +953,7 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
             /* results -> the second stage's input plane, rotated like the first:
              * position p2 = m + 8*NTB2 - 1 for tile-relative output m = R*L + r,
              * float offset 8 + p2                                                  */
-            float *pl2 = plane ? sQ2 : sI2;
+            float *pl2 = pl2_of(cur2, plane);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 pl2[8 + (R * L + r + 8 * NTB2 - 1)] = acc[r].x + acc[r].y;
@@ -979,33 +999,39 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
                 sQ[od + 7] = q1.w;
             }
         }
-        /* ---- F2 / C2 (fused): waves 0 (I) and 1 (Q) run the second decimator on
-         * the TO stage-1 outputs now in LDS, then carry its history.  Ordering
-         * needs no extra barrier: the inputs were written before B, the outputs
-         * (ot2) are read after the next A, and the next writes into these planes
-         * come after the next A as well.                                        */
-        if (FUSE2 && wave < 2) {
-            float *pl2 = wave ? sQ2 : sI2;
+        /* ---- F2 / C2 (fused): the second decimator on the TO stage-1 outputs now in LDS, all four waves: waves
+         * 0 / 1 take the OLDER half of the tap blocks of plane I / Q, waves 2 / 3 the newer half (the two partial
+         * sums meet in store_tile2) -- the 64 taps on two waves left SIMDs 0 and 1 with half as much FIR work again
+         * as SIMDs 2 and 3 (same-box A/B 0.2897 -> 0.2875 ms).  Then waves 0 / 1 carry the history INTO THE OTHER
+         * PLANE SET, which nobody reads before the next barrier B, so waves 2 / 3 may still be reading this one.
+         * Ordering needs no extra barrier: the inputs were written before B, the outputs (ot2) are read after the
+         * next A, and the next stage-1 results go into the other set after the next A as well.                  */
+        if (FUSE2) {
+            const float *pl2r = pl2_of(cur2, wave & 1);
+            const int newer = wave >> 1;
             if (t >= c_lo) {
                 constexpr int R2 = G2::R2 > 0 ? G2::R2 : 1;
-                f32x2 acc2[R2][1];                 /* NTB2 <= 8: one packed accumulator per output */
+                constexpr int HB = NTB2 > 1 ? NTB2 / 2 : 1;
+                static_assert(NTB2 == 0 || NTB2 % 2 == 0, "the split second stage needs an even number of tap blocks");
+                f32x2 acc2[R2][1];                 /* HB <= 4 tap blocks: one packed accumulator per output */
 #pragma unroll
                 for (int r = 0; r < R2; ++r)
                     acc2[r][0] = f32x2{ 0.0f, 0.0f };
-                fir_window<(NTB2 > 0 ? NTB2 : 1), R2, 0, false>(pl2 + 8 + 8 * R2 * lane, hb2, acc2);
+                fir_window<HB, R2, 0, false>(pl2r + 8 + 8 * R2 * lane + (newer ? 8 * HB : 0), hb2 + (newer ? 0 : 8 * HB),
+                                             acc2);
 #pragma unroll
                 for (int r = 0; r < R2; ++r)
-                    ot2[2 * (R2 * lane + r) + wave] = acc2[r][0].x + acc2[r][0].y;
+                    ot2[newer * 2 * G2::TO2 + 2 * (R2 * lane + r) + (wave & 1)] = acc2[r][0].x + acc2[r][0].y;
             }
-            if (!last && lane < NTB2) {
+            if (wave < 2 && !last && lane < NTB2) {
+                float *nx2 = pl2_of(cur2 ^ 1, wave);                /* the next tile's plane of this wave */
                 const int os = 8 + 8 * (G2::GT2 + lane), od = 8 + 8 * lane;
-                float4 a0 = *reinterpret_cast<const float4 *>(pl2 + os);
-                float4 a1 = *reinterpret_cast<const float4 *>(pl2 + os + 4);
+                float4 a0 = *reinterpret_cast<const float4 *>(pl2r + os);
+                float4 a1 = *reinterpret_cast<const float4 *>(pl2r + os + 4);
                 if (MIX) {
                     /* * conj(D), like the first stage's history.  The rotation needs the other
-                     * plane's tail too: read-only here (written before B), and each wave still
-                     * writes only its own plane, so the two waves do not race                 */
-                    const float *ol2 = wave ? sI2 : sQ2;
+                     * plane's tail too: read-only here (written before B)                      */
+                    const float *ol2 = pl2_of(cur2, wave ^ 1);
                     const float4 b0 = *reinterpret_cast<const float4 *>(ol2 + os);
                     const float4 b1 = *reinterpret_cast<const float4 *>(ol2 + os + 4);
                     /* wave 0: I' = I*dc + Q*ds ; wave 1: Q' = Q*dc - I*ds */
@@ -1019,11 +1045,11 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
                     a1.z = a1.z * d_c + b1.z * sg;
                     a1.w = a1.w * d_c + b1.w * sg;
                 }
-                *reinterpret_cast<float4 *>(pl2 + od) = a0;
-                *reinterpret_cast<float2 *>(pl2 + od + 4) = make_float2(a1.x, a1.y);
-                pl2[od + 6] = a1.z;
+                *reinterpret_cast<float4 *>(nx2 + od) = a0;
+                *reinterpret_cast<float2 *>(nx2 + od + 4) = make_float2(a1.x, a1.y);
+                nx2[od + 6] = a1.z;
                 if (lane != NTB2 - 1)
-                    pl2[od + 7] = a1.w;
+                    nx2[od + 7] = a1.w;
             }
         }
         tprev = t;
@@ -1032,6 +1058,8 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
         prev_out2 = FUSE2 && t >= c_lo;
         if (tn < 0)
             break;
+        if (FUSE2)
+            cur2 ^= 1;                    /* the next tile's stage-1 results and history live in the other set */
         first = last;
         t = tn;
         c_lo = n_lo;
@@ -1045,7 +1073,7 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
         /* the last 8*NTB2 stage-1 outputs are the second stage's next history */
         if (p.hist2_out != nullptr && tprev == ntiles - 1 && tid < 8 * NTB2) {
             const int o = 8 + (G::TO + tid - 1);       /* position of stage-1 output TO - 8*NTB2 + tid */
-            float hi = sI2[o], hq = sQ2[o];
+            float hi = pl2_of(cur2, 0)[o], hq = pl2_of(cur2, 1)[o];
             if (MIX)
                 cmul(hi, hq, pp_c, pp_s);              /* stored in final form */
             static_cast<float2 *>(p.hist2_out)[tid] = make_float2(hi, hq);
