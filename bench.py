@@ -21,7 +21,10 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_fir8):
 algorithmic bytes = 7 B per input sample (6 packed in + 8/8 out) over the
 kernel's average duration measured with HIP events on the launch stream;
 `roofline.copy_ceiling_GBps` is a device-to-device copy of the same number of bytes
-measured in this run.  `verified` is a parity check of the LAST timed step's output
+measured in this run.  `placement`: input, a cascade's inter-stage workspace and the output
+are cut from one arena at the pair of 8 GiB slots where they run fastest against each other
+(different HBM extent classes; every pair's probe time is in the line).
+`verified` is a parity check of the LAST timed step's output
 against the CPU oracle on windows placed at the tile scheduler's seams (outside the
 timed region).  `cpu_baseline` times the oracle's float path (oracle/perseus_oracle.c
 orc_stage1_f32, kind "port") on this box's cores over a bounded sample of the same
