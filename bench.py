@@ -459,7 +459,8 @@ def run_rank(a):
     torch.cuda.synchronize(dev)
     # the dominant kernel's duration is taken over THIS region: for a cascade the library brackets its stage-0
     # (fused-pair) kernel with HIP events on this stream; a single-kernel step needs nothing but ev0/ev1
-    multi_kernel = stages is not None and pipe.fused and len(stages) > 1
+    cascade = stages is not None and len(stages) > 2 and pipe.fused_cascade(ns)     # the whole cascade is ONE kernel
+    multi_kernel = stages is not None and pipe.fused and len(stages) > 1 and not cascade
     if multi_kernel:
         pipe.time_stage0_inline(True)
     t0 = time.perf_counter()
@@ -508,6 +509,8 @@ def run_rank(a):
         print(f"[bench] copy ceiling failed: {e}", file=sys.stderr)
 
     dt_max = grp.max_seconds(dt)
+    if pipe is not None:
+        pipe.check(stream)                              # a kernel-side failure flag (fused cascade) fails the run
 
     # ---- parity of what was just timed (outside the timed region, every rank its own stream)
     verified = None
@@ -546,8 +549,9 @@ def run_rank(a):
         total_samples = world * ns * a.steps
         value = total_samples / dt_max / 1e6
         fused = stages is not None and pipe.fused
-        bps = wl["kernel_bytes_per_sample"] if fused else wl["bytes_per_sample"]
+        bps = wl["bytes_per_sample"] if cascade else (wl["kernel_bytes_per_sample"] if fused else wl["bytes_per_sample"])
         achieved = bps * ns / (kern_ms * 1e-3) / 1e9
+        step_achieved = wl["bytes_per_sample"] * ns / (dt_max / a.steps) / 1e9      # the whole step, gaps and tails included
         traffic, traffic_src = traffic_from_profile(a.workload, kernel_source_sig(), a.log2n, a.taps_fp16)
         if verified is not None:
             verified["all_ranks_ok"] = bool(all(o for o in oks))
@@ -567,9 +571,12 @@ def run_rank(a):
                          "traffic": traffic, "traffic_source": traffic_src,
                          "copy_ceiling_GBps": round(copy_gbps, 1) if copy_gbps else None,
                          "frac_of_copy_ceiling": round(achieved / copy_gbps, 4) if copy_gbps else None,
-                         "kernel": "k_fir8" if fused else "pipeline",
+                         "kernel": ("k_fir8 (fused cascade: all stages in one launch)" if cascade else "k_fir8") if fused
+                                   else "pipeline",
                          "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_sample": bps},
+                         "algorithmic_bytes_per_sample": bps,
+                         "step_achieved": round(step_achieved, 1), "step_frac": round(step_achieved / HBM_PEAK_GBS, 4),
+                         "step_algorithmic_bytes_per_sample": wl["bytes_per_sample"]},
             "events_ms_per_step": round(ev_ms / a.steps, 4),
             "placement": placement,
             "verified": verified,

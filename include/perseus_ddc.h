@@ -190,6 +190,14 @@ int pddc_pipeline_stage0_reads_packed(const pddc_pipeline *p);
  * decimate-by-8, stage 1 <= 64 taps, nsamples a multiple of the kernel's tile):
  * the stage-0 output then never reaches HBM                                    */
 int pddc_pipeline_uses_fused_pair(const pddc_pipeline *p, size_t nsamples);
+/* 1 if a process() of nsamples would run stages 0, 1 AND 2 as one kernel (the fused pair followed by a plain
+ * decimator whose group of tiles fits the LDS, e.g. the 8*8*5 and 8*8*10 plans of the 250 and 125 kS/s rates):
+ * the whole cascade is then one streaming pass, 6 + 8/D bytes per input sample                               */
+int pddc_pipeline_uses_fused_cascade(const pddc_pipeline *p, size_t nsamples);
+/* Waits for `stream`, then reports whether a kernel of this pipeline has flagged a failure since the last reset (the
+ * fused cascade's blocks hand each other FIR history inside the launch; their wait is bounded and a block that
+ * gives up says so here: PDDC_EHIP).  PDDC_OK otherwise.  Tests and bench.py call it after their runs.          */
+int pddc_pipeline_check(pddc_pipeline *p, void *stream);
 
 /* Device-resident batch: d_packed (16-byte aligned, nsamples % 8 == 0) ->
  * d_out_f32 (16-byte aligned, capacity in complex samples; with

@@ -110,6 +110,10 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_stage0_reads_packed.restype = C.c_int
     L.pddc_pipeline_uses_fused_pair.argtypes = [vp, sz]
     L.pddc_pipeline_uses_fused_pair.restype = C.c_int
+    L.pddc_pipeline_uses_fused_cascade.argtypes = [vp, sz]
+    L.pddc_pipeline_uses_fused_cascade.restype = C.c_int
+    L.pddc_pipeline_check.argtypes = [vp, vp]
+    L.pddc_pipeline_check.restype = C.c_int
     L.pddc_pipeline_process.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp]
     L.pddc_pipeline_push_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     L.pddc_pipeline_push_host_async.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(C.c_int)]
@@ -263,6 +267,14 @@ class Pipeline:
 
     def fused_pair(self, nsamples: int) -> bool:
         return bool(ddc_lib().pddc_pipeline_uses_fused_pair(self._h, nsamples))
+
+    def fused_cascade(self, nsamples: int) -> bool:
+        """stages 0, 1 and 2 as one kernel for a batch of this size"""
+        return bool(ddc_lib().pddc_pipeline_uses_fused_cascade(self._h, nsamples))
+
+    def check(self, stream: int = 0):
+        """wait for `stream`; raises if a kernel of this pipeline flagged a failure"""
+        check(ddc_lib().pddc_pipeline_check(self._h, stream))
 
     def max_output(self, n: int) -> int:
         return int(ddc_lib().pddc_pipeline_max_output(self._h, n))

@@ -13,6 +13,34 @@ namespace pddc {
 
 enum InFmt { IN_PACKED24 = 0, IN_F32C = 1 };
 
+/* A THIRD stage fused behind the decimate-by-8 pair (launch_fir8_fused3): a plain decimate-by-d FIR on the second
+ * stage's outputs, which then never reach HBM either -- the whole cascade is ONE streaming pass (x320 = 8*8*5:
+ * 6 B read + 8/320 B written per input sample).  The stage runs at 1/64 of the input rate, so it is written for
+ * simplicity, not for issue slots: the block keeps the second stage's outputs of a GROUP of g tiles (g*TO2 samples, a
+ * multiple of d, so every group has the same output phase) in an LDS ring behind the h samples of history, and a
+ * lane computes one output from 1/spl of the taps (both rails as one packed FMA; partial sums meet by lane shuffles).
+ * A chunk of tiles starts with an unknown history: the outputs of its first group are held back, and when the chunk
+ * ends the block takes the last h samples of the chunk in front of it -- published by that chunk's block through
+ * `seam` with write-through (sc1) stores and a flag, MI355X_MICROARCH.md "inter-workgroup visibility" -- and adds
+ * what they contribute.  Waiting only ever goes back in tile order, to a chunk that was taken earlier by a block
+ * that is running, so it cannot deadlock; the spin is bounded all the same (sched[2] != 0 afterwards: timed out). */
+struct Fir8Stage3 {
+    const float *taps = nullptr;      /* [spl*seglen] h[k], zero beyond ntaps: segment s starts at s*seglen        */
+    const void  *hist = nullptr;      /* the h second-stage outputs (float2) that precede this batch               */
+    void        *hist_out = nullptr;  /* receives the batch's last h of them (or NULL)                             */
+    float       *out = nullptr;       /* float2 outputs of the third stage                                         */
+    void        *seam = nullptr;      /* [chunks][seam_stride bytes]: each chunk's last h second-stage outputs     */
+    unsigned    *flags = nullptr;     /* one word per chunk, zero between launches (the last block out clears them) */
+    long long    n_out = 0;           /* outputs this batch produces                                               */
+    int d = 0, ntaps = 0, h = 0;      /* decimation, taps, history (multiple of 8, >= ntaps - 1)                   */
+    int off = 0;                      /* batch-relative index of the second-stage output that completes this
+                                         batch's first third-stage output, 0 .. d-1                               */
+    int g = 0, ng = 0;                /* tiles per group; outputs per group (g*TO2/d, a power of two >= 4)         */
+    int njw = 0, spl = 0, seglen = 0; /* outputs per wave (ng/4), tap segments (64/njw), taps per segment (% 8 == 0) */
+    int padf = 0;                     /* zero samples in front of the ring's history: max(0, spl*seglen - h), even */
+    int seam_stride = 0;              /* bytes, multiple of 16, >= 8*h                                             */
+};
+
 /* arguments of the fused decimate-by-8 kernel (k_fir8) */
 struct Fir8Args {
     const void *in;          /* batch start: packed bytes or float2            */
@@ -26,9 +54,11 @@ struct Fir8Args {
     const void  *hist2 = nullptr;      /* its history: the 64 stage-1 outputs (float2) that
                                 precede this batch                               */
     void        *hist2_out = nullptr;  /* receives the batch's last 64 stage-1 outputs    */
-    unsigned    *sched = nullptr;      /* 2 zero-initialised words of device memory: the tile
+    unsigned    *sched = nullptr;      /* 3 zero-initialised words of device memory: the tile
                                 scheduler's chunk counter and exit counter (the kernel
-                                leaves them zero again); one pair per stream      */
+                                leaves them zero again) and a sticky error word (fused third
+                                stage: a bounded wait gave up); one set per stream  */
+    Fir8Stage3   s3;                   /* launch_fir8_fused3 only                          */
     long long   n_in;        /* samples in the batch, multiple of 8            */
     unsigned long long n0;   /* absolute index of batch sample 0 (NCO phase)   */
     uint32_t    freg;        /* NCO tuning word                                */
@@ -54,7 +84,8 @@ size_t fir8_lds_bytes(int ntb, int R);
 bool   fir8_supported(int ntb, int R);
 /* the two-level tile schedule a launch over n_in samples would use (tests place their
  * comparison windows on its seams) */
-void   fir8_schedule_query(long long n_in, int R, bool fused, int NT, int *ntiles, int *nblocks, int *S, int *K);
+void   fir8_schedule_query(long long n_in, int R, bool fused, int NT, int *ntiles, int *nblocks, int *S, int *K,
+                           int group = 0 /* fused third stage: tiles per group; S and K are multiples of it */);
 /* block sizes of k_fir8: 256 threads always; 128 (four independent blocks per CU) for R = 8 packed first stages */
 bool   fir8_nt_supported(int ntb, int R, int NT);
 void   fir8_set_grid_blocks(int nblocks);   /* persistent grid override (0 = resident blocks x CUs) */
@@ -63,6 +94,14 @@ void   fir8_set_grid_blocks(int nblocks);   /* persistent grid override (0 = res
  * outputs (n_in/64); n_in must be a multiple of the tile (1024*R samples) */
 bool fir8_fused2_supported(int ntb, int ntb2, int R);
 hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipStream_t s);
+
+/* packed -> [mix] -> /8 -> /8 -> /d3 in one kernel (a.s3 filled in, a.out unused): `a.s3.out` receives the THIRD
+ * stage's outputs.  fir8_fused3_geometry fills the derived fields of s3 (g, ng, njw, spl, seglen, padf, seam_stride)
+ * from d, ntaps, h and R and says whether the kernel can run the stage at all; fir8_fused3_max_chunks: how many
+ * seam slots / flag words a launch may use at most.                                                           */
+bool fir8_fused3_geometry(int ntb, int ntb2, int R, Fir8Stage3 *s3);
+int  fir8_fused3_max_chunks();
+hipError_t launch_fir8_fused3(int ntb, int R, bool mix, const Fir8Args &a, hipStream_t s);
 
 /* returns hipSuccess or the launch error */
 hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, hipStream_t s, int NT = 256);

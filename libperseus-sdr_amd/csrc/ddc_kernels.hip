@@ -564,10 +564,12 @@ __device__ __forceinline__ void fir_window_tap_outer(const float *base, const fl
  * tools/ablate.sh; their outputs are garbage.)                                              */
 /* NT = threads per block.  256 (4 waves: two per plane) is the default; 128 (R = 8 only: one wave per
  * plane, half the tile, half the LDS) lets four independent blocks share a CU instead of two.       */
-template <int NTB, int R, int INFMT, bool MIX, int NTB2, int NT = 256>
+/* FUSE3: a third stage (plain decimate-by-d3 FIR, struct Fir8Stage3) runs on the second stage's outputs in LDS as well. */
+template <int NTB, int R, int INFMT, bool MIX, int NTB2, int NT = 256, bool FUSE3 = false>
 __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, int K)
 {
     static_assert(NT == 256 || (NT == 128 && R == 8 && NTB2 == 0), "128-thread blocks: R = 8, no fused second stage");
+    static_assert(!FUSE3 || (NTB2 > 0 && NT == 256), "the third stage sits behind the fused pair");
 #ifdef PDDC_CLOCK_PROBE
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
         g_probe[blockIdx.x].c0 = clock64();
@@ -590,6 +592,14 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
     auto pl2_of = [&](int set, int q) { return ot + (2 * set + q) * G2::PLANE; };
     float *ot2 = ot + 4 * G2::PLANE;
     int cur2 = 0;                        /* the plane set of the tile in work (uniform)                      */
+    /* third stage (FUSE3), all in (I, Q) pairs: the duplicated taps (h, h), two ring sets -- [padf zeros | h3 history |
+     * g3 tiles of second-stage outputs] each, alternating group by group like the second stage's planes -- and the
+     * held-back outputs of a chunk's first group                                                                  */
+    const int T3   = FUSE3 ? p.s3.spl * p.s3.seglen : 0;
+    const int RING = FUSE3 ? p.s3.padf + p.s3.h + p.s3.g * G2::TO2 : 0;
+    f32x2 *t3     = reinterpret_cast<f32x2 *>(ot2 + 4 * G2::TO2);
+    f32x2 *ring3  = t3 + T3;
+    f32x2 *first3 = ring3 + 2 * RING;
     /* plane offsets 0..6 (slots 0..6 of "group -1") never hold a sample: offset 0 of the
      * I plane (smem[0], as raw bits) carries the next chunk index from thread 0 to the
      * block.  Accessed as smem[0] so it stays an LDS access (a cast pointer becomes a
@@ -607,11 +617,25 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
     const int dyn0 = nblk * S;                           /* first tile of the dynamic part */
     const int ND   = (ntiles - dyn0 + K - 1) / K;        /* number of dynamic chunks       */
 
-    /* leaving: the last block out resets the schedule for the next launch */
+    /* leaving: the last block out resets the schedule for the next launch (and, FUSE3, the chunks' flags: every
+     * other block has made its last poll by then) */
     auto leave = [&]() {
+        bool last_out = false;
         if (tid == 0 && atomicAdd(p.sched + 1, 1u) == (unsigned)(nblk - 1)) {
             atomicExch(p.sched, 0u);
             atomicExch(p.sched + 1, 0u);
+            last_out = true;
+        }
+        if (FUSE3) {
+            __syncthreads();                              /* nobody still reads smem[0] as a chunk index */
+            if (tid == 0)
+                smem[0] = last_out ? 1.0f : 0.0f;
+            __syncthreads();
+            if (smem[0] != 0.0f) {
+                const int nchunks = (S > 0 ? nblk : 0) + ND;
+                for (int i = tid; i < nchunks; i += NT)
+                    __hip_atomic_store(p.s3.flags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
 #ifdef PDDC_CLOCK_PROBE
         if (threadIdx.x == 0 && blockIdx.x < 4096) {
@@ -726,6 +750,165 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
     };
     const float PDDC_CONSTANT *hb2 = (const float PDDC_CONSTANT *)p.taps2_blk;
 
+    /* ---- third stage (FUSE3) ------------------------------------------------------------------------------------
+     * State of the APPEND stream, which runs one tile behind the tile loop (a tile's second-stage outputs are summed
+     * and leave the staging area after the next barrier A, where store_tile2 would have written them to HBM).  Per
+     * tile that is one 16-byte LDS write for 32 threads and a countdown; everything else happens once per group or
+     * once per chunk and takes its parameters from the kernel-argument segment when it runs (kept out of the tile
+     * loop's registers: as locals they cost 50 SGPR spills)                                                      */
+    int rs3 = 0;                         /* ring set of the group being filled                                       */
+    int g_left = FUSE3 ? p.s3.g : 0;     /* tiles the group still takes                                              */
+    int first_nnew = 0;                  /* held-back first group of the chunk: its samples, its first output        */
+    long long first_m0 = 0;
+    const Fir8Args PDDC_CONSTANT *kp = (const Fir8Args PDDC_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr();
+    auto ring_of = [&](int set) { return ring3 + set * RING; };
+    f32x2 *ap3 = FUSE3 ? ring_of(0) + p.s3.padf + p.s3.h + 2 * tid : nullptr;   /* where this thread's next pair goes */
+    /* chunk [lo, ..) in tile order: the static runs first, then the dynamic chunks */
+    auto chunk_id = [&](int lo) { return lo < dyn0 ? lo / S : (S > 0 ? nblk : 0) + (lo - dyn0) / K; };
+    /* output j3 of the group whose samples lie in ring set `rb`: a lane takes seglen of the taps (segment seg3), four
+     * partial sums, then the segments' sums meet in every lane of the output (xor shuffles over lanes njw apart)   */
+    auto stage3_sum = [&](const Fir8Stage3 PDDC_CONSTANT &q, const f32x2 *rb, int &j3, int &seg3) {
+        seg3 = lane / q.njw;
+        j3 = wave * q.njw + (lane - seg3 * q.njw);
+        const int seglen = q.seglen;
+        const f32x2 *xr = rb + q.padf + q.h + q.off + j3 * q.d - seg3 * seglen;
+        const f32x2 *hr = t3 + seg3 * seglen;
+        f32x2 a0 = { 0.0f, 0.0f }, a1 = a0, a2 = a0, a3 = a0;
+        for (int kk = 0; kk < seglen; kk += 4) {
+            a0 = __builtin_elementwise_fma(hr[kk], xr[-kk], a0);
+            a1 = __builtin_elementwise_fma(hr[kk + 1], xr[-kk - 1], a1);
+            a2 = __builtin_elementwise_fma(hr[kk + 2], xr[-kk - 2], a2);
+            a3 = __builtin_elementwise_fma(hr[kk + 3], xr[-kk - 3], a3);
+        }
+        f32x2 sum = (a0 + a1) + (a2 + a3);
+        for (int m = q.njw; m < 64; m <<= 1) {
+            sum.x += __shfl_xor(sum.x, m, 64);
+            sum.y += __shfl_xor(sum.y, m, 64);
+        }
+        return sum;
+    };
+    auto store_out3 = [&](float *out3, long long m, f32x2 v) {
+        float *dstp = out3 + 2 * m;
+        asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dstp), "v"(v) : "memory");   /* see store_tile */
+    };
+    /* S (FUSE3): the tile's TO2 second-stage outputs go into the ring instead of HBM */
+    auto append3 = [&](float pc, float ps) {
+        if (tid < G2::TO2 / 2) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(ot2 + 4 * tid);
+            v += *reinterpret_cast<const f32x4 *>(ot2 + 2 * G2::TO2 + 4 * tid);
+            if (MIX)
+                v = cmul2(v, pc, ps);
+            *reinterpret_cast<f32x4 *>(ap3) = v;
+        }
+        ap3 += G2::TO2;
+        --g_left;
+    };
+    /* a group is complete (g tiles, or the chunk [a_lo, ..) ends with tile t_last): its outputs; unless the chunk ends,
+     * its last h samples become the history of the next group in the other ring set                               */
+    auto group_done3 = [&](int a_lo, int t_last, bool chunk_ends) {
+        asm volatile("" : "+s"(kp));
+        const Fir8Stage3 PDDC_CONSTANT &q = kp->s3;
+        const int g_cnt = q.g - g_left;
+        const int g_t0 = t_last + 1 - g_cnt;
+        const int n_new = g_cnt * G2::TO2;
+        const long long m0 = (long long)(g_t0 / q.g) * q.ng;
+        int j3, seg3;
+        const f32x2 y = stage3_sum(q, ring_of(rs3), j3, seg3);
+        if (g_t0 == a_lo) {                   /* the chunk's first group: no history yet, held back (chunk_end3) */
+            if (seg3 == 0)
+                first3[j3] = y;
+            first_nnew = n_new;
+            first_m0 = m0;
+        } else if (seg3 == 0 && q.off + j3 * q.d < n_new && m0 + j3 < q.n_out) {
+            store_out3(q.out, m0 + j3, y);
+        }
+        if (!chunk_ends) {
+            const int h3 = q.h, padf = q.padf;
+            for (int i = tid; i < h3; i += NT)
+                ring_of(rs3 ^ 1)[padf + i] = ring_of(rs3)[padf + n_new + i];
+            rs3 ^= 1;
+            g_left = q.g;
+            ap3 = ring_of(rs3) + padf + h3 + 2 * tid;
+        }
+    };
+    /* the chunk [a_lo, a_hi) has ended: publish its last h second-stage outputs for the chunk behind it, take those
+     * of the chunk in front of it (the previous call's for the batch's first chunk), add what they contribute to the
+     * held-back outputs, and -- the batch's last chunk -- leave the next call's history                           */
+    auto chunk_end3 = [&](int a_lo, int a_hi, bool at_exit) {
+        asm volatile("" : "+s"(kp));
+        const Fir8Stage3 PDDC_CONSTANT &q = kp->s3;
+        const int h3 = q.h, padf = q.padf;
+        const int g_cnt = q.g - g_left;
+        const int n_new = g_cnt * G2::TO2;
+        const bool single = a_hi - g_cnt == a_lo;            /* the chunk's last group is also its first */
+        const int id = chunk_id(a_lo);
+        const bool batch_last = a_hi == ntiles;
+        if (!batch_last) {
+            if (tid < h3 / 2) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(ring_of(rs3) + padf + n_new + 2 * tid);
+                uint8_t *dstp = static_cast<uint8_t *>(q.seam) + (size_t)id * q.seam_stride + 16 * tid;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dstp), "v"(v) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          /* every storing wave drains ...          */
+            __syncthreads();                                          /* ... before ONE lane raises the flag    */
+            if (tid == 0)
+                __hip_atomic_store(q.flags + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a_lo > 0) {
+            if (tid == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(q.flags + id - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 20)) {                       /* ~0.3 s: something is badly wrong */
+                        atomicOr(p.sched + 2, 1u);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        f32x2 *fx = ring_of(rs3 ^ 1);        /* free now: [padf zeros | the predecessor's tail | zeros] */
+        if (tid < h3 / 2) {
+            f32x4 v;
+            if (a_lo == 0) {
+                v = *(reinterpret_cast<const f32x4 *>(q.hist) + tid);
+            } else {
+                const uint8_t *srcp = static_cast<const uint8_t *>(q.seam) + (size_t)(id - 1) * q.seam_stride + 16 * tid;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(srcp) : "memory");
+            }
+            *reinterpret_cast<f32x4 *>(fx + padf + 2 * tid) = v;
+        }
+        for (int i = tid; i < q.g * G2::TO2 / 2; i += NT)
+            *reinterpret_cast<f32x4 *>(fx + padf + h3 + 2 * i) = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+        __syncthreads();
+        int j3, seg3;
+        const f32x2 c = stage3_sum(q, fx, j3, seg3);
+        if (seg3 == 0 && q.off + j3 * q.d < first_nnew && first_m0 + j3 < q.n_out)
+            store_out3(q.out, first_m0 + j3, first3[j3] + c);
+        if (at_exit && batch_last && q.hist_out != nullptr) {
+            for (int i = tid; i < h3; i += NT) {
+                const int rel = n_new - h3 + i;              /* relative to the first new sample of set rs3 */
+                const f32x2 v = (rel >= 0 || !single) ? ring_of(rs3)[padf + h3 + rel] : fx[padf + h3 + rel];
+                static_cast<float2 *>(q.hist_out)[i] = make_float2(v.x, v.y);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < h3; i += NT)                   /* the next chunk starts in set rs3 from a zero history */
+            ring_of(rs3)[padf + i] = f32x2{ 0.0f, 0.0f };
+        g_left = q.g;
+        ap3 = ring_of(rs3) + padf + h3 + 2 * tid;
+    };
+    if (FUSE3) {
+        for (int i = tid; i < T3; i += NT) {
+            const float h = p.s3.taps[i];
+            t3[i] = f32x2{ h, h };
+        }
+        for (int i = tid; i < 2 * RING; i += NT)
+            ring3[i] = f32x2{ 0.0f, 0.0f };
+    }
+
     /* S: coalesced stores of one finished tile from the staging area */
     auto store_tile = [&](int tile, float pc, float ps) {
         const long long tile_o0 = (long long)tile * G::TO;
@@ -827,6 +1010,7 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
     bool first = true;                                /* t opens a chunk: history comes from rawH            */
     int  tprev = -1;                                  /* tile whose outputs are staged, not yet stored        */
     bool prev_out2 = false;                           /* ... and (fused) whether it produced stage-2 outputs  */
+    int  pv_lo = 0, pv_hi = 0;                        /* ... and (FUSE3) the chunk it belongs to              */
     unsigned grabv = 0;                               /* thread 0: the chunk taken for after this one         */
     float pp_c = 1.0f, pp_s = 0.0f;                   /* NCO phasor of tile tprev                             */
     prefetch(t, true);
@@ -892,7 +1076,11 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
         if (!FUSE2 && tprev >= 0)
             store_tile(tprev, pp_c, pp_s);
         __syncthreads();                                           /* A */
-        if (FUSE2 && prev_out2)        /* written by waves 0/1 after the previous barrier B */
+        const bool appended = FUSE3 && prev_out2;
+        if (FUSE3) {
+            if (prev_out2)             /* into the third stage's ring */
+                append3(pp_c, pp_s);
+        } else if (FUSE2 && prev_out2) /* written by waves 0/1 after the previous barrier B */
             store_tile2(tprev, pp_c, pp_s);
 
         /* ---- P: next tile's loads (and, one tile before a chunk ends, the next chunk) ---- */
@@ -1052,10 +1240,22 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
                     nx2[od + 7] = a1.w;
             }
         }
+        /* ---- F3 (FUSE3): the ring holds tprev's outputs since before barrier B.  A full group, or the end of tprev's
+         * chunk: the third stage runs on it; a chunk's end also settles the seam with the chunk in front of it     */
+        if (appended) {
+            const bool a_last = tprev + 1 == pv_hi;
+            if (g_left == 0 || a_last) {
+                group_done3(pv_lo, tprev, a_last);
+                if (a_last)
+                    chunk_end3(pv_lo, pv_hi, false);
+            }
+        }
         tprev = t;
         pp_c = pt_c;
         pp_s = pt_s;
         prev_out2 = FUSE2 && t >= c_lo;
+        pv_lo = c_lo;
+        pv_hi = c_hi;
         if (tn < 0)
             break;
         if (FUSE2)
@@ -1068,7 +1268,14 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
 
     if (FUSE2) {
         __syncthreads();                 /* ot2 and the stage-2 planes of the last tile are complete */
-        if (prev_out2)
+        if (FUSE3) {
+            if (prev_out2) {
+                append3(pp_c, pp_s);
+                __syncthreads();
+                group_done3(pv_lo, tprev, true);
+                chunk_end3(pv_lo, pv_hi, true);
+            }
+        } else if (prev_out2)
             store_tile2(tprev, pp_c, pp_s);
         /* the last 8*NTB2 stage-1 outputs are the second stage's next history */
         if (p.hist2_out != nullptr && tprev == ntiles - 1 && tid < 8 * NTB2) {
@@ -1117,7 +1324,8 @@ static int g_fir8_blocks = 0;       /* override (development) */
 struct Fir8Sched {
     int nblocks, S, K;
 };
-static Fir8Sched fir8_schedule(int ntiles, int R, bool fused, int NT = 256)
+static constexpr int kFused3MaxChunks = 2048;      /* seam slots / flag words of a fused-cascade launch */
+static Fir8Sched fir8_schedule(int ntiles, int R, bool fused, int NT = 256, int group = 0)
 {
     /* read per launch (two getenv calls against a launch of several microseconds), so a
      * test can switch schedules inside one process */
@@ -1142,19 +1350,37 @@ static Fir8Sched fir8_schedule(int ntiles, int R, bool fused, int NT = 256)
             want = full;
     }
     sc.nblocks = ntiles < want ? ntiles : want;
+    if (group > 0) {              /* fused third stage: every chunk but the batch's last is whole groups of tiles */
+        const int cap = ntiles / group > 0 ? ntiles / group : 1;
+        if (sc.nblocks > cap)
+            sc.nblocks = cap;
+    }
     sc.K = chunk > 0 ? chunk : (fused ? 8 : (R == 4 ? 4 : 2) * (256 / NT));
+    if (group > 0)
+        sc.K = chunk > 0 ? (chunk + group - 1) / group * group : 2 * group;
     /* fused pair: a dynamic chunk starts with a warm-up tile, so only a small share pays (same-box sweep under the
      * arena placement, tools/sched_sweep_c320.sh: static 0.2897 ms, 5-10 % in chunks of 8 0.2863-0.2867, 20 % 0.293) */
     const int pct = dyn_pct >= 0 ? dyn_pct : (fused ? 8 : 20);
     sc.S = (int)((long long)ntiles * (100 - pct) / 100 / sc.nblocks);
+    if (group > 0) {
+        sc.S -= sc.S % group;
+        if (sc.S == 0 && chunk <= 0)
+            sc.K = group;         /* small batch: one group per block, all of them handed out dynamically */
+        for (;;) {                /* a bounded number of chunks: each has a seam slot and a flag */
+            const long long nd = ((long long)ntiles - (long long)sc.nblocks * sc.S + sc.K - 1) / sc.K;
+            if ((sc.S > 0 ? sc.nblocks : 0) + nd <= kFused3MaxChunks)
+                break;
+            sc.K += group;
+        }
+    }
     return sc;
 }
 
-void fir8_schedule_query(long long n_in, int R, bool fused, int NT, int *ntiles, int *nblocks, int *S, int *K)
+void fir8_schedule_query(long long n_in, int R, bool fused, int NT, int *ntiles, int *nblocks, int *S, int *K, int group)
 {
     const long long TI = 4LL * NT * R;
     const int nt = (int)((n_in + TI - 1) / TI);
-    const Fir8Sched sc = fir8_schedule(nt, R, fused, NT);
+    const Fir8Sched sc = fir8_schedule(nt, R, fused, NT, group);
     *ntiles = nt;
     *nblocks = sc.nblocks;
     *S = sc.S;
@@ -1249,6 +1475,89 @@ static hipError_t launch_fir8_fused2_t(bool mix, const Fir8Args &a, hipStream_t 
 bool fir8_fused2_supported(int ntb, int ntb2, int R)
 {
     return (R == 4 || R == 8) && (ntb == 4 || ntb == 8) && ntb2 > 0 && ntb2 <= 8;
+}
+
+/* ---- fused cascade: packed input -> [mix] -> /8 -> /8 -> /d3, one kernel ---------------------------------------- */
+int fir8_fused3_max_chunks() { return kFused3MaxChunks; }
+
+static size_t fir8_fused3_lds3(const Fir8Stage3 &q, int TO2)
+{
+    return (size_t)(q.spl * q.seglen + 2 * (q.padf + q.h + q.g * TO2) + q.ng) * sizeof(f32x2);
+}
+
+bool fir8_fused3_geometry(int ntb, int ntb2, int R, Fir8Stage3 *q)
+{
+    if (!q || R != 4 || ntb2 != 8 || !fir8_fused2_supported(ntb, ntb2, R))
+        return false;                          /* instantiated for R = 4 (the fused pair's own default) */
+    const int TO2 = 16 * R;
+    if (q->d < 2 || q->ntaps < 1 || q->h < q->ntaps - 1 || (q->h & 7) || q->h > 512)
+        return false;
+    int a = TO2, b = q->d;
+    while (b) {
+        const int t = a % b;
+        a = b;
+        b = t;
+    }
+    q->g = q->d / a;                           /* g*TO2 is the smallest whole number of tiles that is a multiple of d */
+    q->ng = TO2 / a;
+    if (q->ng < 4 || q->g * TO2 < q->h)        /* a one-group chunk must hold a whole history */
+        return false;
+    q->njw = q->ng / 4;
+    q->spl = 64 / q->njw;
+    q->seglen = ((q->ntaps + q->spl - 1) / q->spl + 7) & ~7;
+    q->padf = q->spl * q->seglen > q->h ? (q->spl * q->seglen - q->h + 1) & ~1 : 0;
+    q->seam_stride = (8 * q->h + 255) & ~255;
+    return fir8_fused3_lds3(*q, TO2) <= 40u * 1024u;
+}
+
+template <int NTB, int R>
+static hipError_t launch_fir8_fused3_t(bool mix, const Fir8Args &a, hipStream_t s)
+{
+    using G = Fir8Geom<NTB, R>;
+    using G2 = Fir8Geom2<8, R>;
+    const Fir8Stage3 &q = a.s3;
+    const size_t lds = (size_t)(2 * G::PLANE + G2::LDS_FLT) * sizeof(float) + fir8_fused3_lds3(q, G2::TO2);
+    constexpr size_t lds_cap = 96u * 1024u;
+    if (a.n_in <= 0 || a.n_in % G::TI || lds > lds_cap)
+        return hipErrorInvalidValue;             /* whole tiles only */
+    const long long ntiles_ll = a.n_in / G::TI;
+    if (ntiles_ll > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+    const int ntiles = (int)ntiles_ll;
+    if (a.sched == nullptr || q.taps == nullptr || q.hist == nullptr || q.out == nullptr || q.seam == nullptr ||
+        q.flags == nullptr || q.g < 1 || q.off < 0 || q.off >= q.d)
+        return hipErrorInvalidValue;
+    const Fir8Sched sc = fir8_schedule(ntiles, R, true, 256, q.g);
+    const dim3 grid((unsigned)sc.nblocks), blk(256);
+#define PDDC_LAUNCH3(MIXV)                                                                        \
+    do {                                                                                          \
+        static unsigned long long attr_done = 0;                                                  \
+        int dev__ = 0;                                                                            \
+        (void)hipGetDevice(&dev__);                                                               \
+        if (!(attr_done >> (dev__ & 63) & 1ull)) {                                                \
+            hipError_t e = hipFuncSetAttribute(                                                   \
+                reinterpret_cast<const void *>(&k_fir8<NTB, R, IN_PACKED24, MIXV, 8, 256, true>), \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);                        \
+            if (e != hipSuccess)                                                                  \
+                return e;                                                                         \
+            attr_done |= 1ull << (dev__ & 63);                                                    \
+        }                                                                                         \
+        hipLaunchKernelGGL((k_fir8<NTB, R, IN_PACKED24, MIXV, 8, 256, true>), grid, blk, lds, s, a, ntiles, \
+                           sc.S, sc.K);                                                           \
+    } while (0)
+    if (mix)
+        PDDC_LAUNCH3(true);
+    else
+        PDDC_LAUNCH3(false);
+#undef PDDC_LAUNCH3
+    return hipGetLastError();
+}
+
+hipError_t launch_fir8_fused3(int ntb, int R, bool mix, const Fir8Args &a, hipStream_t s)
+{
+    if (ntb == 4 && R == 4) return launch_fir8_fused3_t<4, 4>(mix, a, s);
+    if (ntb == 8 && R == 4) return launch_fir8_fused3_t<8, 4>(mix, a, s);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipStream_t s)

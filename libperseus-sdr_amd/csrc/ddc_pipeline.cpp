@@ -68,6 +68,7 @@ struct Stage {
     float *d_taps_dup_base = nullptr;
     float *d_taps_blk = nullptr;  /* [ntb][8] block-reversed (fused kernel)     */
     float *d_taps_poly = nullptr; /* rational stage: [L][Kp] polyphase rows g[ph][j] = h[j*L + ph] */
+    float *d_taps_seg = nullptr;  /* stage 2 as the fused cascade's third stage: h[k] zero padded to spl*seglen */
     int poly_k = 0, poly_kp = 0;
     int ntb = 0;                  /* tap blocks if fused-capable, else 0        */
     int hist = 0;                 /* history length in samples (mult. of 8)     */
@@ -141,11 +142,18 @@ struct pddc_pipeline {
     float *d_fout = nullptr;      /* float output of the last stage when the caller wants packed */
     size_t d_fout_cap = 0;
     hipStream_t own_stream = nullptr;
-    unsigned *d_sched = nullptr;  /* k_fir8's tile scheduler words (zero between launches) */
+    unsigned *d_sched = nullptr;  /* k_fir8's tile scheduler words (zero between launches) + its sticky error word */
+    /* fused cascade (stages 0+1+2 in one kernel, launch_fir8_fused3): geometry of the third stage, the seam slots
+     * through which a chunk of tiles hands its last outputs to the chunk behind it, one flag per chunk            */
+    bool s3_ok = false;
+    Fir8Stage3 s3;
+    void *d_seam = nullptr;
+    unsigned *d_flags = nullptr;
 };
 
 static bool stage0_fused(const pddc_pipeline *p);
 static bool stage0_packed_generic(const pddc_pipeline *p);
+static int setup_stage3(pddc_pipeline *p);
 
 static float round_to_half(float v)
 {
@@ -679,6 +687,10 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
         pddc_pipeline_destroy(p);
         return fail(PDDC_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    if ((rc = setup_stage3(p))) {
+        pddc_pipeline_destroy(p);
+        return rc;
+    }
     if ((rc = pddc_pipeline_reset(p))) {
         pddc_pipeline_destroy(p);
         return rc;
@@ -705,6 +717,8 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
             hipFree(p->st[i].d_taps_dup_base);
         if (p->st[i].d_taps_poly)
             hipFree(p->st[i].d_taps_poly);
+        if (p->st[i].d_taps_seg)
+            hipFree(p->st[i].d_taps_seg);
         if (p->st[i].d_buf && !p->st[i].buf_in_ws)
             hipFree(p->st[i].d_buf);
         for (int b = 0; b < 2; ++b)
@@ -737,6 +751,10 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
     }
     if (p->d_sched)
         hipFree(p->d_sched);
+    if (p->d_seam)
+        hipFree(p->d_seam);
+    if (p->d_flags)
+        hipFree(p->d_flags);
     if (p->own_stream)
         hipStreamDestroy(p->own_stream);
     delete p;
@@ -756,6 +774,8 @@ int pddc_pipeline_reset(pddc_pipeline *p)
     p->fresh = true;
     p->segs.assign(1, pddc_pipeline::WordSeg{ 0, p->freg, 0u });      /* samples before the start are zeros */
     HIP_TRY(hipMemset(p->d_sched, 0, 64));
+    if (p->d_flags)
+        HIP_TRY(hipMemset(p->d_flags, 0, sizeof(unsigned) * (size_t)fir8_fused3_max_chunks()));
     for (int i = 0; i < p->nstages; ++i) {
         Stage &s = p->st[i];
         s.consumed = 0;
@@ -881,6 +901,8 @@ int pddc_pipeline_set_taps(pddc_pipeline *p, int stage, const float *taps, int n
         HIP_TRY(hipMalloc(&s.d_taps_blk, sizeof(float) * blk.size()));
         HIP_TRY(hipMemcpy(s.d_taps_blk, blk.data(), sizeof(float) * blk.size(), hipMemcpyHostToDevice));
     }
+    if (stage <= 2)
+        return setup_stage3(p);
     return PDDC_OK;
 }
 
@@ -970,6 +992,71 @@ static bool stages01_fusable(const pddc_pipeline *p, size_t nsamples)
 extern "C" int pddc_pipeline_uses_fused_pair(const pddc_pipeline *p, size_t nsamples)
 {
     return p && stages01_fusable(p, nsamples) ? 1 : 0;
+}
+
+/* The whole cascade in one kernel: behind the fused pair, stage 2 -- a plain decimator at 1/64 of the input rate --
+ * runs on the pair's outputs while they are still in LDS (k_fir8<.., FUSE3>): the 1/8 B per input sample that the
+ * pair wrote and the tail kernel read back, the tail's launch and the two launch gaps all go (x320: one streaming
+ * pass of 6 + 8/320 bytes per input sample).  Geometry and seam buffers are prepared at create time.            */
+static int setup_stage3(pddc_pipeline *p)
+{
+    p->s3_ok = false;
+    if (p->nstages < 3 || !stage0_fused(p))
+        return PDDC_OK;
+    const Stage &s0 = p->st[0], &s1 = p->st[1];
+    Stage &s2 = p->st[2];
+    if (s1.decim != 8 || s1.interp != 1 || s1.ntb != 8 || s1.hist != 64 || s2.interp != 1 || s2.hist_elem != 8)
+        return PDDC_OK;
+    Fir8Stage3 q;
+    q.d = s2.decim;
+    q.ntaps = s2.ntaps;
+    q.h = s2.hist;
+    if (!fir8_fused3_geometry(s0.ntb, s1.ntb, p->R, &q))
+        return PDDC_OK;
+    std::vector<float> seg((size_t)q.spl * q.seglen, 0.0f);
+    std::copy(s2.taps.begin(), s2.taps.begin() + s2.ntaps, seg.begin());
+    if (s2.d_taps_seg)
+        HIP_TRY(hipFree(s2.d_taps_seg));
+    s2.d_taps_seg = nullptr;
+    HIP_TRY(hipMalloc(&s2.d_taps_seg, sizeof(float) * seg.size()));
+    HIP_TRY(hipMemcpy(s2.d_taps_seg, seg.data(), sizeof(float) * seg.size(), hipMemcpyHostToDevice));
+    const size_t nch = (size_t)fir8_fused3_max_chunks();
+    if (p->d_seam)
+        HIP_TRY(hipFree(p->d_seam));
+    p->d_seam = nullptr;
+    HIP_TRY(hipMalloc(&p->d_seam, nch * (size_t)q.seam_stride));
+    if (!p->d_flags) {
+        HIP_TRY(hipMalloc((void **)&p->d_flags, sizeof(unsigned) * nch));
+        HIP_TRY(hipMemset(p->d_flags, 0, sizeof(unsigned) * nch));
+    }
+    p->s3 = q;
+    p->s3_ok = true;
+    return PDDC_OK;
+}
+
+static bool stages012_fusable(const pddc_pipeline *p, size_t nsamples)
+{
+    return p->s3_ok && p->nstages >= 3 && !getenv("PDDC_NO_FUSE3") && stages01_fusable(p, nsamples);
+}
+
+extern "C" int pddc_pipeline_uses_fused_cascade(const pddc_pipeline *p, size_t nsamples)
+{
+    return p && stages012_fusable(p, nsamples) ? 1 : 0;
+}
+
+/* Waits for everything queued on `stream` and reports a kernel-side failure (the fused cascade's bounded wait for a
+ * neighbouring chunk gave up: PDDC_EHIP, sticky until reset).  Tests and bench.py call it after their runs.        */
+extern "C" int pddc_pipeline_check(pddc_pipeline *p, void *stream)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    unsigned w[4] = { 0, 0, 0, 0 };
+    HIP_TRY(hipMemcpy(w, p->d_sched, sizeof(w), hipMemcpyDeviceToHost));
+    if (w[2] != 0)
+        return fail(PDDC_EHIP, "fused cascade: a block gave up waiting for the chunk in front of it (code %u)", w[2]);
+    return PDDC_OK;
 }
 
 /* `reader_src` / `reader_bytes`: the buffer that the kernel WRITING this stage buffer streams its input from.  When
@@ -1095,6 +1182,20 @@ static void fill_fir8_args(const pddc_pipeline *p, Fir8Args &a)
     }
 }
 
+static void fill_stage3_args(const pddc_pipeline *p, Fir8Args &a, float *dst, size_t off, size_t n_out, bool advance)
+{
+    const Stage &s2 = p->st[2];
+    a.s3 = p->s3;
+    a.s3.taps = s2.d_taps_seg;
+    a.s3.hist = s2.d_hist[s2.cur];
+    a.s3.hist_out = advance ? s2.d_hist[s2.cur ^ 1] : nullptr;
+    a.s3.out = dst;
+    a.s3.seam = p->d_seam;
+    a.s3.flags = p->d_flags;
+    a.s3.n_out = (long long)n_out;
+    a.s3.off = (int)off;
+}
+
 int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsamples, void *d_out,
                           size_t out_capacity, size_t *n_out_ret, void *stream_v)
 {
@@ -1175,7 +1276,32 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             compute_lo_steps(p);
         }
     }
-    if (!mixed_hist && stages01_fusable(p, nsamples)) {
+    if (!mixed_hist && stages012_fusable(p, nsamples)) {
+        /* stages 0, 1 and 2 in ONE kernel: neither intermediate touches HBM */
+        Stage &s0 = p->st[0], &s1 = p->st[1];
+        float *dst;
+        if ((rc = stage_dst(2, &dst, true)))
+            return rc;
+        Fir8Args a;
+        a.in = d_packed;
+        a.hist = s0.d_hist[s0.cur];
+        a.hist_out = s0.d_hist[s0.cur ^ 1];
+        a.out = nullptr;
+        a.taps_blk = s0.d_taps_blk;
+        a.taps2_blk = s1.d_taps_blk;
+        a.hist2 = s1.d_hist[s1.cur];
+        a.hist2_out = s1.d_hist[s1.cur ^ 1];
+        a.n_in = (long long)nsamples;
+        fill_fir8_args(p, a);
+        fill_stage3_args(p, a, dst, off[2], n_in[3], true);
+        if ((rc = stage0_event(p, s, true)))
+            return rc;
+        HIP_TRY(launch_fir8_fused3(s0.ntb, p->R, mix, a, s));
+        if ((rc = stage0_event(p, s, false)))
+            return rc;
+        flip[0] = flip[1] = flip[2] = true;
+        first = 3;
+    } else if (!mixed_hist && stages01_fusable(p, nsamples)) {
         /* stages 0 and 1 in ONE kernel: the 8 B/sample-at-1/8-rate intermediate
          * (1 B written + 1 B read per input sample) never touches HBM */
         Stage &s0 = p->st[0], &s1 = p->st[1];
@@ -1676,7 +1802,8 @@ int pddc_pipeline_schedule(const pddc_pipeline *p, size_t nsamples, int out[5])
     const bool fuse2 = stages01_fusable(p, nsamples);
     const int nt = fuse2 ? 256 : p->NT;
     out[0] = fir8_tile_inputs(p->R, nt);
-    fir8_schedule_query((long long)nsamples, p->R, fuse2, nt, &out[1], &out[2], &out[3], &out[4]);
+    fir8_schedule_query((long long)nsamples, p->R, fuse2, nt, &out[1], &out[2], &out[3], &out[4],
+                        stages012_fusable(p, nsamples) ? p->s3.g : 0);
     return PDDC_OK;
 }
 
@@ -1725,11 +1852,18 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     a.hist_out = nullptr;                  /* state is not advanced */
     a.out = static_cast<float *>(d_out);
     const bool fuse2 = stages01_fusable(p, nsamples);
+    const bool fuse3 = stages012_fusable(p, nsamples);
     if (p->nstages > 1) {                  /* stage 0 (or the fused pair) of a cascade writes an internal buffer */
         int rc = ensure_buf(p->st[1], nsamples / (size_t)p->st[0].decim + 8, d_packed, nsamples * 6);
         if (rc)
             return rc;
         a.out = p->st[1].d_buf;
+    }
+    if (fuse3) {                           /* the fused cascade: third-stage outputs into that buffer, state untouched */
+        size_t off3, n3;
+        unsigned long long m3;
+        stage_outputs(p->st[2].consumed, nsamples / 64, p->st[2].decim, 1, &off3, &m3, &n3);
+        fill_stage3_args(p, a, a.out, off3, n3, false);
     }
     if (fuse2) {
         a.taps2_blk = p->st[1].d_taps_blk;
@@ -1745,7 +1879,9 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i) {
-        if (fuse2)
+        if (fuse3)
+            HIP_TRY(launch_fir8_fused3(p->st[0].ntb, p->R, mix, a, s));
+        else if (fuse2)
             HIP_TRY(launch_fir8_fused2(p->st[0].ntb, p->R, mix, a, s));
         else
             HIP_TRY(launch_fir8(p->st[0].ntb, p->R, IN_PACKED24, mix, a, s, p->NT));

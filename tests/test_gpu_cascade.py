@@ -1,0 +1,140 @@
+"""GPU tests (-m gpu) of the fused cascade: stages 0, 1 and 2 (packed -> [NCO] -> /8 -> /8 -> /D3) as ONE kernel
+(k_fir8<.., FUSE3>).  What is new in that kernel is exchanged between thread blocks INSIDE the launch:
+a chunk of tiles starts without the third stage's history, holds its first outputs back and completes them from the
+last outputs of the chunk in front of it, published by another block.  So the tests put many chunk seams into small
+batches (few blocks, several static / dynamic splits), cut the stream at whole-tile and odd places (the path falls
+back to the unfused kernels and returns, on one shared state), run it under a competing load, and compare with the
+CPU oracle (the FIR chain is authored here, tolerance 1e-6 of full scale) and with the unfused path."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_taps
+
+pytestmark = pytest.mark.gpu
+FIR_TOL = 1e-6
+TILE = 4096                     # inputs per tile of the fused pair at R = 4
+
+
+def to_dev(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def lowpass(ntaps, cutoff):
+    k = np.arange(ntaps) - (ntaps - 1) / 2.0
+    h = np.sinc(2 * cutoff * k) * np.hamming(ntaps)
+    return (h / h.sum()).astype(np.float32)
+
+
+def plans():
+    h1, h2, h3 = load_taps("c320_s1_d8_32"), load_taps("c320_s2_d8_64"), load_taps("c320_s3_d5_161")
+    return {
+        "8*8*5": [(8, h1), (8, h2), (5, h3)],                               # BASELINE config 3 (250 kS/s)
+        "8*8*10": [(8, lowpass(48, 0.05)), (8, lowpass(51, 0.05)), (10, lowpass(287, 0.04))],   # the 125 kS/s plan's shape
+        "8*8*4": [(8, h1), (8, h2), (4, lowpass(33, 0.1))],                 # one tile per group
+    }
+
+
+@pytest.mark.parametrize("plan", ["8*8*5", "8*8*10", "8*8*4"])
+@pytest.mark.parametrize("mix", [False, True])
+@pytest.mark.parametrize("sched", ["3,-1,0", "7,0,0", "5,100,0", "4,50,5", "512,-1,0"])
+def test_fused_cascade_vs_oracle(pkg, dev, O, monkeypatch, plan, mix, sched):
+    blocks, dyn, chunk = sched.split(",")
+    monkeypatch.setenv("PDDC_FIR8_BLOCKS", blocks)
+    if int(dyn) >= 0:
+        monkeypatch.setenv("PDDC_FIR8_DYN_PCT", dyn)
+    if int(chunk) > 0:
+        monkeypatch.setenv("PDDC_FIR8_CHUNK", chunk)
+    stages = plans()[plan]
+    # batches in tiles; 0.25 = a batch that is not whole tiles (unfused path on the same state)
+    sizes = [3, 37, 5, 0.25, 1, 64, 12, 0.5, 23]
+    cuts = [0]
+    for t in sizes:
+        cuts.append(cuts[-1] + int(t * TILE))
+    ns = cuts[-1]
+    packed = O.lcg_bytes(6 * ns, 4242)
+    ref = O.ddc_chain(packed, stages, freg=381178347, mix=mix)
+    pipe = pkg.Pipeline(stages, mix=mix)
+    pipe.set_freg(381178347)
+    parts, used = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        used.append(pipe.fused_cascade(b - a))
+        parts.append(pipe.process(to_dev(packed[6 * a:6 * b], dev)).cpu().numpy().reshape(-1))
+    pipe.check()
+    assert used == [float(t).is_integer() for t in sizes]
+    y = np.concatenate(parts)
+    assert y.size == ref.size
+    assert O.rel_err(y, ref) <= FIR_TOL, (plan, mix, sched, O.rel_err(y, ref))
+    pipe.close()
+
+
+def test_fused_cascade_equals_unfused_and_is_deterministic_under_load(pkg, dev, O, monkeypatch):
+    """2^24 samples on the full grid: the fused cascade agrees with the unfused path to 1e-6 of full scale, and its
+    own output does not depend on how the blocks are timed -- which chunk a block draws changes who computes an
+    output, never its arithmetic -- also while another stream keeps the chip busy (uneven load on the seams)."""
+    import torch
+    stages = plans()["8*8*5"]
+    ns = 1 << 24
+    d_in = pkg.synth_lcg(6 * ns, 5150, 0, dev)
+    fused = pkg.Pipeline(stages, mix=True)
+    fused.set_center_freq(7.1e6)
+    assert fused.fused_cascade(ns)
+    a1 = fused.process(d_in).clone()
+    a2 = fused.process(d_in).clone()
+    fused.check()
+    monkeypatch.setenv("PDDC_NO_FUSE3", "1")
+    plain = pkg.Pipeline(stages, mix=True)
+    plain.set_center_freq(7.1e6)
+    assert plain.fused_pair(ns) and not plain.fused_cascade(ns)
+    b1 = plain.process(d_in).clone()
+    b2 = plain.process(d_in).clone()
+    monkeypatch.delenv("PDDC_NO_FUSE3")
+    scale = float(b2.abs().max())
+    assert a1.shape == b1.shape
+    assert float((a1 - b1).abs().max()) / scale <= FIR_TOL
+    assert float((a2 - b2).abs().max()) / scale <= FIR_TOL
+    # the same two batches again, with a competing stream of unpack kernels on the chip
+    side = torch.cuda.Stream(device=dev)
+    junk_in = pkg.synth_lcg(6 * (1 << 22), 1, 0, dev)
+    for rep in range(6):
+        fused.reset()
+        with torch.cuda.stream(side):
+            for _ in range(4 + 3 * rep):
+                pkg.unpack24_f32(junk_in, stream=side.cuda_stream)
+        c1 = fused.process(d_in).clone()
+        c2 = fused.process(d_in).clone()
+        fused.check()
+        side.synchronize()
+        assert torch.equal(c1, a1) and torch.equal(c2, a2), rep
+    fused.close()
+    plain.close()
+
+
+def test_fused_cascade_checkpoint_and_retune(pkg, dev, O):
+    """The fused cascade shares its stream state with the unfused kernels: a checkpoint taken behind a fused batch
+    restores into a fresh pipeline, and a retune between two fused batches is phase-continuous (oracle's retuned NCO)."""
+    stages = plans()["8*8*5"]
+    nb = 20 * TILE
+    packed = O.lcg_bytes(6 * 3 * nb, 99)
+    f1, f2 = 381178347, 123456789
+    ref = O.ddc_chain_retuned(packed, stages, [(0, f1), (2 * nb, f2)])
+    pipe = pkg.Pipeline(stages, mix=True)
+    pipe.set_freg(f1)
+    y0 = pipe.process(to_dev(packed[:6 * nb], dev)).cpu().numpy().reshape(-1)
+    blob = pipe.save_state()
+    pipe.close()
+    pipe = pkg.Pipeline(stages, mix=True)
+    pipe.set_freg(f1)
+    pipe.restore_state(blob)
+    assert pipe.fused_cascade(nb)
+    y1 = pipe.process(to_dev(packed[6 * nb:12 * nb], dev)).cpu().numpy().reshape(-1)
+    pipe.set_freg(f2)
+    y2 = pipe.process(to_dev(packed[12 * nb:], dev)).cpu().numpy().reshape(-1)
+    pipe.check()
+    y = np.concatenate([y0, y1, y2])
+    assert y.size == ref.size
+    assert O.rel_err(y, ref) <= FIR_TOL
+    pipe.close()
