@@ -17,15 +17,17 @@ enum InFmt { IN_PACKED24 = 0, IN_F32C = 1 };
  * stage's outputs, which then never reach HBM either -- the whole cascade is ONE streaming pass (x320 = 8*8*5:
  * 6 B read + 8/320 B written per input sample).  The stage runs at 1/64 of the input rate, so it is written for
  * simplicity, not for issue slots: the block keeps the second stage's outputs of a GROUP of g tiles (g*TO2 samples, a
- * multiple of d, so every group has the same output phase) in an LDS ring behind the h samples of history, and a
- * lane computes one output from 1/spl of the taps (both rails as one packed FMA; partial sums meet by lane shuffles).
+ * multiple of d, so every group has the same output phase) in an LDS ring behind the h samples of history; lane j
+ * computes output j of the group and each of the four waves a quarter of the taps (kept in two VGPRs, one tap per
+ * lane, and read with v_readlane; one packed FMA for both rails per tap; the four partial sums meet in LDS) -- sliced
+ * over the g tiles of the next group, `sl` taps per wave and tile, their LDS reads hidden behind the first-stage FIR.
  * A chunk of tiles starts with an unknown history: the outputs of its first group are held back, and when the chunk
  * ends the block takes the last h samples of the chunk in front of it -- published by that chunk's block through
  * `seam` with write-through (sc1) stores and a flag, MI355X_MICROARCH.md "inter-workgroup visibility" -- and adds
  * what they contribute.  Waiting only ever goes back in tile order, to a chunk that was taken earlier by a block
  * that is running, so it cannot deadlock; the spin is bounded all the same (sched[2] != 0 afterwards: timed out). */
 struct Fir8Stage3 {
-    const float *taps = nullptr;      /* [spl*seglen] h[k], zero beyond ntaps: segment s starts at s*seglen        */
+    const float *taps = nullptr;      /* [spl*seglen] h[k], zero beyond ntaps: wave w's segment starts at w*seglen  */
     const void  *hist = nullptr;      /* the h second-stage outputs (float2) that precede this batch               */
     void        *hist_out = nullptr;  /* receives the batch's last h of them (or NULL)                             */
     float       *out = nullptr;       /* float2 outputs of the third stage                                         */
@@ -35,8 +37,9 @@ struct Fir8Stage3 {
     int d = 0, ntaps = 0, h = 0;      /* decimation, taps, history (multiple of 8, >= ntaps - 1)                   */
     int off = 0;                      /* batch-relative index of the second-stage output that completes this
                                          batch's first third-stage output, 0 .. d-1                               */
-    int g = 0, ng = 0;                /* tiles per group; outputs per group (g*TO2/d, a power of two >= 4)         */
-    int njw = 0, spl = 0, seglen = 0; /* outputs per wave (ng/4), tap segments (64/njw), taps per segment (% 8 == 0) */
+    int g = 0, ng = 0;                /* tiles per group; outputs per group (g*TO2/d, a power of two <= 64)        */
+    int spl = 0, seglen = 0, sl = 0;  /* tap segments (4: one per wave), taps per segment = g*sl, sl = taps a wave
+                                         takes per tile (its slice; one of the instantiated lengths)             */
     int padf = 0;                     /* zero samples in front of the ring's history: max(0, spl*seglen - h), even */
     int seam_stride = 0;              /* bytes, multiple of 16, >= 8*h                                             */
 };
@@ -96,7 +99,7 @@ bool fir8_fused2_supported(int ntb, int ntb2, int R);
 hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipStream_t s);
 
 /* packed -> [mix] -> /8 -> /8 -> /d3 in one kernel (a.s3 filled in, a.out unused): `a.s3.out` receives the THIRD
- * stage's outputs.  fir8_fused3_geometry fills the derived fields of s3 (g, ng, njw, spl, seglen, padf, seam_stride)
+ * stage's outputs.  fir8_fused3_geometry fills the derived fields of s3 (g, ng, spl, seglen, sl, padf, seam_stride)
  * from d, ntaps, h and R and says whether the kernel can run the stage at all; fir8_fused3_max_chunks: how many
  * seam slots / flag words a launch may use at most.                                                           */
 bool fir8_fused3_geometry(int ntb, int ntb2, int R, Fir8Stage3 *s3);

@@ -62,6 +62,9 @@
 
 namespace pddc {
 
+static constexpr int kFused3MaxChunks = 2048;      /* seam slots / flag words of a fused-cascade launch */
+static constexpr int kPend3 = 4;                   /* open seams a block of the fused cascade may carry along */
+
 /* float = (float)(v24*256) * RN(1/2147483392): the int->float convert is exact
  * (24 significant bits) and the product is bit-identical to the reference's
  * (float)int32 / (float)(INT_MAX-256) for all 2^24 codes (tests). */
@@ -564,10 +567,13 @@ __device__ __forceinline__ void fir_window_tap_outer(const float *base, const fl
  * tools/ablate.sh; their outputs are garbage.)                                              */
 /* NT = threads per block.  256 (4 waves: two per plane) is the default; 128 (R = 8 only: one wave per
  * plane, half the tile, half the LDS) lets four independent blocks share a CU instead of two.       */
-/* FUSE3: a third stage (plain decimate-by-d3 FIR, struct Fir8Stage3) runs on the second stage's outputs in LDS as well. */
-template <int NTB, int R, int INFMT, bool MIX, int NTB2, int NT = 256, bool FUSE3 = false>
+/* SL3 > 0 (FUSE3): a third stage (plain decimate-by-d3 FIR, struct Fir8Stage3) runs on the second stage's outputs in LDS
+ * as well, SL3 taps per wave and tile (its work is sliced into the tile loop, see "third stage" below).          */
+template <int NTB, int R, int INFMT, bool MIX, int NTB2, int NT = 256, int SL3 = 0>
 __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, int K)
 {
+    constexpr bool FUSE3 = SL3 > 0;
+    constexpr int SLN = SL3 > 0 ? SL3 : 1;
     static_assert(NT == 256 || (NT == 128 && R == 8 && NTB2 == 0), "128-thread blocks: R = 8, no fused second stage");
     static_assert(!FUSE3 || (NTB2 > 0 && NT == 256), "the third stage sits behind the fused pair");
 #ifdef PDDC_CLOCK_PROBE
@@ -592,14 +598,15 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
     auto pl2_of = [&](int set, int q) { return ot + (2 * set + q) * G2::PLANE; };
     float *ot2 = ot + 4 * G2::PLANE;
     int cur2 = 0;                        /* the plane set of the tile in work (uniform)                      */
-    /* third stage (FUSE3), all in (I, Q) pairs: the duplicated taps (h, h), two ring sets -- [padf zeros | h3 history |
+    /* third stage (FUSE3), all in (I, Q) pairs: the four waves' partial sums, two ring sets -- [padf zeros | h3 history |
      * g3 tiles of second-stage outputs] each, alternating group by group like the second stage's planes -- and the
-     * held-back outputs of a chunk's first group                                                                  */
-    const int T3   = FUSE3 ? p.s3.spl * p.s3.seglen : 0;
+     * held-back outputs of the first groups of up to kPend3 chunks                                                */
     const int RING = FUSE3 ? p.s3.padf + p.s3.h + p.s3.g * G2::TO2 : 0;
-    f32x2 *t3     = reinterpret_cast<f32x2 *>(ot2 + 4 * G2::TO2);
-    f32x2 *ring3  = t3 + T3;
-    f32x2 *first3 = ring3 + 2 * RING;
+    f32x2 *part3  = reinterpret_cast<f32x2 *>(ot2 + 4 * G2::TO2);      /* [4 waves][64]: partial sums of a group */
+    f32x2 *ring3  = part3 + 4 * 64;                   /* sets 0 and 1; set 2 is the scratch of the seam fix-ups */
+    f32x2 *pend3  = ring3 + 3 * RING;                 /* [kPend3][64] held-back outputs of chunks whose seam is open */
+    int   *pendh  = reinterpret_cast<int *>(pend3 + kPend3 * 64);   /* [kPend3][4] chunk id, samples, first output */
+    int   *poll3  = pendh + 4 * kPend3;               /* one word: thread 0's poll result for the block          */
     /* plane offsets 0..6 (slots 0..6 of "group -1") never hold a sample: offset 0 of the
      * I plane (smem[0], as raw bits) carries the next chunk index from thread 0 to the
      * block.  Accessed as smem[0] so it stays an LDS access (a cast pointer becomes a
@@ -751,45 +758,211 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
     const float PDDC_CONSTANT *hb2 = (const float PDDC_CONSTANT *)p.taps2_blk;
 
     /* ---- third stage (FUSE3) ------------------------------------------------------------------------------------
-     * State of the APPEND stream, which runs one tile behind the tile loop (a tile's second-stage outputs are summed
-     * and leave the staging area after the next barrier A, where store_tile2 would have written them to HBM).  Per
-     * tile that is one 16-byte LDS write for 32 threads and a countdown; everything else happens once per group or
-     * once per chunk and takes its parameters from the kernel-argument segment when it runs (kept out of the tile
-     * loop's registers: as locals they cost 50 SGPR spills)                                                      */
+     * APPEND: a tile's second-stage outputs are summed and leave the staging area after the next barrier A, where
+     * store_tile2 would have written them to HBM; they go into the ring set of the GROUP being filled (g tiles).
+     * JOB: when a group is complete its outputs are due -- lane j output j, wave w the taps [w*seglen, (w+1)*seglen),
+     * seglen = g*SL3.  Doing that on the spot stalls the whole block on a chain of latencies (LDS round trips, a
+     * barrier for the partial sums, parameters from the argument segment): measured 0.8 us per group, 26 groups per
+     * block, +27 us on a 0.29 ms launch, although the arithmetic is a tenth of the first stage's.  So the job is SLICED
+     * into the next g tiles: each F phase issues SL3 LDS reads before the first-stage FIR and takes SL3 taps -- two
+     * VGPRs hold the wave's taps, one per lane, read with v_readlane, so a tap has no memory latency -- into two packed
+     * accumulators after it; the last slice leaves the wave's partial sums in LDS and they are combined behind the
+     * tile's barrier B.  The group's ring set stays untouched meanwhile (the next group fills the other set).
+     * SEAMS: a chunk of tiles starts with an unknown history: the outputs of its first group are held back (pending
+     * list), its last h second-stage outputs are published for the chunk behind it (write-through stores, then a flag:
+     * MI355X_MICROARCH.md, inter-workgroup visibility), and at later chunk ends -- at the exit at the latest -- the
+     * block looks whether the chunk in front has published, and completes the held-back outputs (resolve3).     */
     int rs3 = 0;                         /* ring set of the group being filled                                       */
     int g_left = FUSE3 ? p.s3.g : 0;     /* tiles the group still takes                                              */
-    int first_nnew = 0;                  /* held-back first group of the chunk: its samples, its first output        */
-    long long first_m0 = 0;
+    int npend = 0;                       /* chunks of this block whose seam with the chunk in front is still open    */
     const Fir8Args PDDC_CONSTANT *kp = (const Fir8Args PDDC_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr();
     auto ring_of = [&](int set) { return ring3 + set * RING; };
     f32x2 *ap3 = FUSE3 ? ring_of(0) + p.s3.padf + p.s3.h + 2 * tid : nullptr;   /* where this thread's next pair goes */
     /* chunk [lo, ..) in tile order: the static runs first, then the dynamic chunks */
     auto chunk_id = [&](int lo) { return lo < dyn0 ? lo / S : (S > 0 ? nblk : 0) + (lo - dyn0) / K; };
-    /* output j3 of the group whose samples lie in ring set `rb`: a lane takes seglen of the taps (segment seg3), four
-     * partial sums, then the segments' sums meet in every lane of the output (xor shuffles over lanes njw apart)   */
-    auto stage3_sum = [&](const Fir8Stage3 PDDC_CONSTANT &q, const f32x2 *rb, int &j3, int &seg3) {
-        seg3 = lane / q.njw;
-        j3 = wave * q.njw + (lane - seg3 * q.njw);
-        const int seglen = q.seglen;
-        const f32x2 *xr = rb + q.padf + q.h + q.off + j3 * q.d - seg3 * seglen;
-        const f32x2 *hr = t3 + seg3 * seglen;
-        f32x2 a0 = { 0.0f, 0.0f }, a1 = a0, a2 = a0, a3 = a0;
-        for (int kk = 0; kk < seglen; kk += 4) {
-            a0 = __builtin_elementwise_fma(hr[kk], xr[-kk], a0);
-            a1 = __builtin_elementwise_fma(hr[kk + 1], xr[-kk - 1], a1);
-            a2 = __builtin_elementwise_fma(hr[kk + 2], xr[-kk - 2], a2);
-            a3 = __builtin_elementwise_fma(hr[kk + 3], xr[-kk - 3], a3);
+    float tapv0 = 0.0f, tapv1 = 0.0f;    /* the wave's taps: lane k holds taps k and 64 + k of its segment           */
+    if (FUSE3) {
+        const int seglen = p.s3.seglen;
+        const float *tp = p.s3.taps + wave * seglen;
+        if (lane < seglen)
+            tapv0 = tp[lane];
+        if (64 + lane < seglen)
+            tapv1 = tp[64 + lane];
+    }
+    /* the job in work */
+    const f32x2 *xr3 = ring3 + RING;     /* this lane's newest sample of the next slice (reads xr3[0 .. -(SL3-1)])   */
+    int sl_k = 0, sl_left = 0;           /* the next slice's first tap; slices to go (0: no job, the slices idle)    */
+    f32x2 acc3a = { 0.0f, 0.0f }, acc3b = { 0.0f, 0.0f };
+    bool sum_ready = false;              /* the waves' partial sums are in part3, to be combined behind a barrier    */
+    int job_nnew = 0, job_cid = -1;      /* the group's samples; >= 0: its outputs are held back for chunk job_cid   */
+    long long job_m0 = 0;                /* its first output                                                         */
+    /* SL3 plain ds_read_b64 (2 LDS cycles each; hipcc pairs neighbouring loads into ds_read2_b64, which runs at half
+     * that rate: MI355X_MICROARCH.md, LDS table), issued from inline asm: the compiler's own counted lgkmcnt waits stay
+     * correct because these reads are OLDER than anything it waits for (LDS returns in order); slice_taps waits.   */
+    auto slice_load = [&](f32x2 (&xs)[SLN], const f32x2 *xr) {
+        const unsigned lo = (unsigned)(size_t)(xr - (SLN - 1));       /* the LDS offset: low half of a flat LDS address */
+#pragma unroll
+        for (int u = 0; u < SLN; ++u)
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xs[u]) : "v"(lo), "n"(8 * (SLN - 1 - u)));
+    };
+    /* taps k0 .. k0+SL3-1 of the wave's segment (a slice never straddles lane 64: fir8_fused3_geometry) */
+    auto slice_taps = [&](f32x2 (&xs)[SLN], int k0, f32x2 &a, f32x2 &b) {
+        const int tv = __float_as_int(k0 < 64 ? tapv0 : tapv1);          /* uniform */
+        float hh[SLN];
+#pragma unroll
+        for (int u = 0; u < SLN; ++u)
+            hh[u] = __int_as_float(__builtin_amdgcn_readlane(tv, (k0 + u) & 63));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xs[0]) : : "memory");
+#pragma unroll
+        for (int u = 1; u < SLN; ++u)
+            asm volatile("" : "+v"(xs[u]));                              /* not before the wait */
+#pragma unroll
+        for (int u = 0; u < SLN; ++u) {
+            if (u & 1)
+                b = __builtin_elementwise_fma(f32x2{ hh[u], hh[u] }, xs[u], b);
+            else
+                a = __builtin_elementwise_fma(f32x2{ hh[u], hh[u] }, xs[u], a);
         }
-        f32x2 sum = (a0 + a1) + (a2 + a3);
-        for (int m = q.njw; m < 64; m <<= 1) {
-            sum.x += __shfl_xor(sum.x, m, 64);
-            sum.y += __shfl_xor(sum.y, m, 64);
+    };
+    /* second half of a slice (the first is slice_load); with no job in work it accumulates nothing anybody reads */
+    auto slice_fma = [&](f32x2 (&xs)[SLN]) {
+        slice_taps(xs, sl_k, acc3a, acc3b);
+        if (sl_left > 0) {
+            xr3 -= SL3;
+            sl_k += SL3;
+            if (--sl_left == 0) {
+                part3[64 * wave + lane] = acc3a + acc3b;
+                sum_ready = true;
+            }
         }
-        return sum;
     };
     auto store_out3 = [&](float *out3, long long m, f32x2 v) {
         float *dstp = out3 + 2 * m;
         asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dstp), "v"(v) : "memory");   /* see store_tile */
+    };
+    /* all outputs of the group in ring set `rb` at once (the seam fix-ups; a handful per block and launch):
+     * returns output `tid` to the threads tid < 64, behind a barrier                                              */
+    auto visit3 = [&](const Fir8Stage3 PDDC_CONSTANT &q, const f32x2 *rb) {
+        const int seglen = q.seglen, ng = q.ng;
+        const int j = lane < ng ? lane : ng - 1;
+        const f32x2 *xr = rb + q.padf + q.h + q.off + j * q.d - wave * seglen;
+        f32x2 a = { 0.0f, 0.0f }, b = a;
+        for (int k0 = 0; k0 < seglen; k0 += SLN) {
+            f32x2 xs[SLN];
+            slice_load(xs, xr - k0);
+            slice_taps(xs, k0, a, b);
+        }
+        part3[64 * wave + lane] = a + b;
+        __syncthreads();
+        f32x2 sum = { 0.0f, 0.0f };
+        if (tid < 64)
+            sum = (part3[tid] + part3[64 + tid]) + (part3[128 + tid] + part3[192 + tid]);
+        return sum;
+    };
+    /* Settle open seams.  Entry i of the pending list is a chunk of this block whose first outputs wait for the last
+     * h second-stage outputs of the chunk in front of it (the previous call's for the batch's first chunk).  Thread 0
+     * looks at that chunk's flag -- once; or, `blocking`, until it is up (bounded) -- and when it is, the block loads
+     * the tail into the scratch ring set ([zeros | tail | zeros]), runs the third stage on it and adds the result to
+     * the held-back outputs.  Never waiting at a chunk's end matters: the two blocks of a CU run 15-25 % apart, a
+     * block that waited for its neighbour's static run would idle through exactly the time the dynamic tail is there
+     * to fill.  What is still open when the block runs out of work is waited for at the exit.                     */
+    auto resolve3 = [&](bool blocking) {
+        asm volatile("" : "+s"(kp));
+        const Fir8Stage3 PDDC_CONSTANT &q = kp->s3;
+        const int h3 = q.h, padf = q.padf;
+        f32x2 *fx = ring_of(2);
+        int keep = 0;
+        __syncthreads();                            /* the list as the last push left it */
+        for (int i = 0; i < npend; ++i) {
+            const int id = __builtin_amdgcn_readfirstlane(pendh[4 * i]);
+            if (tid == 0) {
+                int ok = 1;
+                if (id > 0) {
+                    unsigned spins = 0;
+                    while ((ok = __hip_atomic_load(q.flags + id - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) == 0 &&
+                           blocking) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > (1u << 20)) {                   /* ~0.3 s: something is badly wrong */
+                            atomicOr(p.sched + 2, 1u);
+                            ok = 1;
+                            break;
+                        }
+                    }
+                    if (ok)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                *poll3 = ok;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int ok = __builtin_amdgcn_readfirstlane(*poll3);
+            if (ok) {
+                if (tid < h3 / 2) {
+                    f32x4 v;
+                    if (id == 0) {
+                        v = *(reinterpret_cast<const f32x4 *>(q.hist) + tid);
+                    } else {
+                        const uint8_t *srcp = static_cast<const uint8_t *>(q.seam) + (size_t)(id - 1) * q.seam_stride + 16 * tid;
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(srcp) : "memory");
+                    }
+                    *reinterpret_cast<f32x4 *>(fx + padf + 2 * tid) = v;
+                }
+                __syncthreads();
+                const f32x2 c = visit3(q, fx);
+                const int nnew = pendh[4 * i + 1];
+                const long long m0 = ((long long)pendh[4 * i + 3] << 32) | (unsigned)pendh[4 * i + 2];
+                if (tid < q.ng && q.off + tid * q.d < nnew && m0 + tid < q.n_out)
+                    store_out3(q.out, m0 + tid, pend3[64 * i + tid] + c);
+            } else {
+                if (keep != i) {                    /* stays open: move it down */
+                    if (tid < 64)
+                        pend3[64 * keep + tid] = pend3[64 * i + tid];
+                    if (tid < 4)
+                        pendh[4 * keep + tid] = pendh[4 * i + tid];
+                }
+                ++keep;
+            }
+            __syncthreads();                        /* poll3, the scratch ring set and the list are reused */
+        }
+        npend = keep;
+    };
+    /* the waves' partial sums of the finished job (in part3 since before the last barrier) -> its outputs: to HBM,
+     * or, for a chunk's first group, onto the pending list                                                         */
+    auto combine3 = [&]() {
+        asm volatile("" : "+s"(kp));
+        const Fir8Stage3 PDDC_CONSTANT &q = kp->s3;
+        f32x2 y = { 0.0f, 0.0f };
+        if (tid < 64)
+            y = (part3[tid] + part3[64 + tid]) + (part3[128 + tid] + part3[192 + tid]);
+        sum_ready = false;
+        if (job_cid >= 0) {
+            if (npend == kPend3)
+                resolve3(true);                     /* the list is full: wait for its oldest seams */
+            if (tid < 64)
+                pend3[64 * npend + tid] = y;
+            if (tid == 0) {
+                pendh[4 * npend] = job_cid;
+                pendh[4 * npend + 1] = job_nnew;
+                pendh[4 * npend + 2] = (int)(unsigned)(job_m0 & 0xffffffffLL);
+                pendh[4 * npend + 3] = (int)(job_m0 >> 32);
+            }
+            ++npend;
+        } else if (tid < q.ng && q.off + tid * q.d < job_nnew && job_m0 + tid < q.n_out) {
+            store_out3(q.out, job_m0 + tid, y);
+        }
+    };
+    /* finish the job in work on the spot (the block is about to leave, or groups follow each other faster than g tiles:
+     * a short last chunk) */
+    auto flush3 = [&]() {
+        while (sl_left > 0) {
+            f32x2 xs[SLN];
+            slice_load(xs, xr3);
+            slice_fma(xs);
+        }
+        if (sum_ready) {
+            __syncthreads();
+            combine3();
+        }
     };
     /* S (FUSE3): the tile's TO2 second-stage outputs go into the ring instead of HBM */
     auto append3 = [&](float pc, float ps) {
@@ -803,27 +976,24 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
         ap3 += G2::TO2;
         --g_left;
     };
-    /* a group is complete (g tiles, or the chunk [a_lo, ..) ends with tile t_last): its outputs; unless the chunk ends,
-     * its last h samples become the history of the next group in the other ring set                               */
+    /* a group is complete (g tiles, or the chunk [a_lo, ..) ends with tile t_last): its job starts; unless the chunk
+     * ends, its last h samples become the history of the next group in the other ring set                         */
     auto group_done3 = [&](int a_lo, int t_last, bool chunk_ends) {
+        flush3();                             /* normally long finished */
         asm volatile("" : "+s"(kp));
         const Fir8Stage3 PDDC_CONSTANT &q = kp->s3;
         const int g_cnt = q.g - g_left;
         const int g_t0 = t_last + 1 - g_cnt;
         const int n_new = g_cnt * G2::TO2;
-        const long long m0 = (long long)(g_t0 / q.g) * q.ng;
-        int j3, seg3;
-        const f32x2 y = stage3_sum(q, ring_of(rs3), j3, seg3);
-        if (g_t0 == a_lo) {                   /* the chunk's first group: no history yet, held back (chunk_end3) */
-            if (seg3 == 0)
-                first3[j3] = y;
-            first_nnew = n_new;
-            first_m0 = m0;
-        } else if (seg3 == 0 && q.off + j3 * q.d < n_new && m0 + j3 < q.n_out) {
-            store_out3(q.out, m0 + j3, y);
-        }
+        const int h3 = q.h, padf = q.padf;
+        acc3a = acc3b = f32x2{ 0.0f, 0.0f };
+        sl_k = 0;
+        sl_left = q.g;
+        xr3 = ring_of(rs3) + padf + h3 + q.off + (lane < q.ng ? lane : q.ng - 1) * q.d - wave * q.seglen;
+        job_nnew = n_new;
+        job_m0 = (long long)(g_t0 / q.g) * q.ng;
+        job_cid = g_t0 == a_lo ? chunk_id(a_lo) : -1;       /* a chunk's first group has no history yet: held back */
         if (!chunk_ends) {
-            const int h3 = q.h, padf = q.padf;
             for (int i = tid; i < h3; i += NT)
                 ring_of(rs3 ^ 1)[padf + i] = ring_of(rs3)[padf + n_new + i];
             rs3 ^= 1;
@@ -831,9 +1001,9 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
             ap3 = ring_of(rs3) + padf + h3 + 2 * tid;
         }
     };
-    /* the chunk [a_lo, a_hi) has ended: publish its last h second-stage outputs for the chunk behind it, take those
-     * of the chunk in front of it (the previous call's for the batch's first chunk), add what they contribute to the
-     * held-back outputs, and -- the batch's last chunk -- leave the next call's history                           */
+    /* the chunk [a_lo, a_hi) has ended (its last group's job has just started in ring set rs3): publish its last h
+     * second-stage outputs for the chunk behind it, settle whatever seams can be settled, and -- the batch's last chunk
+     * -- leave the next call's history.  The next chunk fills the other ring set, from a zero history.            */
     auto chunk_end3 = [&](int a_lo, int a_hi, bool at_exit) {
         asm volatile("" : "+s"(kp));
         const Fir8Stage3 PDDC_CONSTANT &q = kp->s3;
@@ -854,58 +1024,36 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
             if (tid == 0)
                 __hip_atomic_store(q.flags + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (a_lo > 0) {
-            if (tid == 0) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(q.flags + id - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 20)) {                       /* ~0.3 s: something is badly wrong */
-                        atomicOr(p.sched + 2, 1u);
-                        break;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        f32x2 *fx = ring_of(rs3 ^ 1);        /* free now: [padf zeros | the predecessor's tail | zeros] */
-        if (tid < h3 / 2) {
-            f32x4 v;
-            if (a_lo == 0) {
-                v = *(reinterpret_cast<const f32x4 *>(q.hist) + tid);
-            } else {
-                const uint8_t *srcp = static_cast<const uint8_t *>(q.seam) + (size_t)(id - 1) * q.seam_stride + 16 * tid;
-                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(srcp) : "memory");
-            }
-            *reinterpret_cast<f32x4 *>(fx + padf + 2 * tid) = v;
-        }
-        for (int i = tid; i < q.g * G2::TO2 / 2; i += NT)
-            *reinterpret_cast<f32x4 *>(fx + padf + h3 + 2 * i) = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-        __syncthreads();
-        int j3, seg3;
-        const f32x2 c = stage3_sum(q, fx, j3, seg3);
-        if (seg3 == 0 && q.off + j3 * q.d < first_nnew && first_m0 + j3 < q.n_out)
-            store_out3(q.out, first_m0 + j3, first3[j3] + c);
+        if (at_exit)
+            flush3();                                /* nothing left to hide the last job behind */
+        resolve3(at_exit);
         if (at_exit && batch_last && q.hist_out != nullptr) {
+            /* the stream's last h3 second-stage outputs: from the last group's ring set; where that group is the chunk's
+             * first and shorter than h3 (a tiny batch), from the tail of the chunk in front (settled just above)       */
+            const float2 *pred = id == 0 ? static_cast<const float2 *>(q.hist)
+                                         : reinterpret_cast<const float2 *>(static_cast<const uint8_t *>(q.seam) +
+                                                                            (size_t)(id - 1) * q.seam_stride);
             for (int i = tid; i < h3; i += NT) {
                 const int rel = n_new - h3 + i;              /* relative to the first new sample of set rs3 */
-                const f32x2 v = (rel >= 0 || !single) ? ring_of(rs3)[padf + h3 + rel] : fx[padf + h3 + rel];
-                static_cast<float2 *>(q.hist_out)[i] = make_float2(v.x, v.y);
+                float2 v;
+                if (rel >= 0 || !single) {
+                    const f32x2 r = ring_of(rs3)[padf + h3 + rel];
+                    v = make_float2(r.x, r.y);
+                } else {
+                    const float2 *srcp = pred + (h3 + rel);
+                    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(srcp) : "memory");
+                }
+                static_cast<float2 *>(q.hist_out)[i] = v;
             }
         }
-        __syncthreads();
-        for (int i = tid; i < h3; i += NT)                   /* the next chunk starts in set rs3 from a zero history */
+        rs3 ^= 1;                                            /* the job keeps reading the old set */
+        for (int i = tid; i < h3; i += NT)
             ring_of(rs3)[padf + i] = f32x2{ 0.0f, 0.0f };
         g_left = q.g;
         ap3 = ring_of(rs3) + padf + h3 + 2 * tid;
     };
     if (FUSE3) {
-        for (int i = tid; i < T3; i += NT) {
-            const float h = p.s3.taps[i];
-            t3[i] = f32x2{ h, h };
-        }
-        for (int i = tid; i < 2 * RING; i += NT)
+        for (int i = tid; i < 3 * RING; i += NT)
             ring3[i] = f32x2{ 0.0f, 0.0f };
     }
 
@@ -1114,6 +1262,9 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
         asm volatile("" : "+s"(hb));      /* keep the tap s_loads inside the tile loop (no SGPR spills) */
         if (FUSE2)
             asm volatile("" : "+s"(hb2));
+        f32x2 xs3[SLN];
+        if (FUSE3)                        /* third stage: this tile's slice of the job in work, loads first ... */
+            slice_load(xs3, xr3);
         constexpr int NA = FirAcc<NTB>::N;
         f32x2 accp[R][NA];
 #pragma unroll
@@ -1137,6 +1288,8 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
 #pragma unroll
         for (int r = 0; r < R; ++r)
             acc[r] = NA == 2 ? accp[r][0] + accp[r][NA - 1] : accp[r][0];
+        if (FUSE3)                        /* ... taps behind the first-stage FIR, which hid the loads' latency */
+            slice_fma(xs3);
         if (FUSE2) {
             /* results -> the second stage's input plane, rotated like the first:
              * position p2 = m + 8*NTB2 - 1 for tile-relative output m = R*L + r,
@@ -1242,6 +1395,8 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
         }
         /* ---- F3 (FUSE3): the ring holds tprev's outputs since before barrier B.  A full group, or the end of tprev's
          * chunk: the third stage runs on it; a chunk's end also settles the seam with the chunk in front of it     */
+        if (FUSE3 && sum_ready)
+            combine3();
         if (appended) {
             const bool a_last = tprev + 1 == pv_hi;
             if (g_left == 0 || a_last) {
@@ -1324,7 +1479,7 @@ static int g_fir8_blocks = 0;       /* override (development) */
 struct Fir8Sched {
     int nblocks, S, K;
 };
-static constexpr int kFused3MaxChunks = 2048;      /* seam slots / flag words of a fused-cascade launch */
+
 static Fir8Sched fir8_schedule(int ntiles, int R, bool fused, int NT = 256, int group = 0)
 {
     /* read per launch (two getenv calls against a launch of several microseconds), so a
@@ -1482,7 +1637,7 @@ int fir8_fused3_max_chunks() { return kFused3MaxChunks; }
 
 static size_t fir8_fused3_lds3(const Fir8Stage3 &q, int TO2)
 {
-    return (size_t)(q.spl * q.seglen + 2 * (q.padf + q.h + q.g * TO2) + q.ng) * sizeof(f32x2);
+    return (size_t)(4 * 64 + 3 * (q.padf + q.h + q.g * TO2) + kPend3 * 64) * sizeof(f32x2) + (4 * kPend3 + 4) * sizeof(int);
 }
 
 bool fir8_fused3_geometry(int ntb, int ntb2, int R, Fir8Stage3 *q)
@@ -1500,17 +1655,31 @@ bool fir8_fused3_geometry(int ntb, int ntb2, int R, Fir8Stage3 *q)
     }
     q->g = q->d / a;                           /* g*TO2 is the smallest whole number of tiles that is a multiple of d */
     q->ng = TO2 / a;
-    if (q->ng < 4 || q->g * TO2 < q->h)        /* a one-group chunk must hold a whole history */
+    if (q->ng < 1 || q->ng > 64 || q->g * TO2 < q->h)        /* a one-group chunk must hold a whole history */
         return false;
-    q->njw = q->ng / 4;
-    q->spl = 64 / q->njw;
-    q->seglen = ((q->ntaps + q->spl - 1) / q->spl + 7) & ~7;
+    q->spl = 4;                                /* one tap segment per wave, one slice of it per tile of a group */
+    {
+        static const int slices[] = { 9, 16 };                    /* the instantiated slice lengths */
+        const int need = ((q->ntaps + 3) / 4 + q->g - 1) / q->g;
+        q->sl = 0;
+        for (int v : slices)
+            if (v >= need) {
+                q->sl = v;
+                break;
+            }
+        if (q->sl == 0)
+            return false;
+    }
+    q->seglen = q->g * q->sl;
+    if (q->seglen > 128 || (q->seglen > 64 && 64 % q->sl != 0))
+        return false;                          /* a wave keeps its taps in two VGPRs, one tap per lane each; a slice
+                                                  takes its taps from one of them                                  */
     q->padf = q->spl * q->seglen > q->h ? (q->spl * q->seglen - q->h + 1) & ~1 : 0;
     q->seam_stride = (8 * q->h + 255) & ~255;
     return fir8_fused3_lds3(*q, TO2) <= 40u * 1024u;
 }
 
-template <int NTB, int R>
+template <int NTB, int R, int SL3>
 static hipError_t launch_fir8_fused3_t(bool mix, const Fir8Args &a, hipStream_t s)
 {
     using G = Fir8Geom<NTB, R>;
@@ -1525,7 +1694,7 @@ static hipError_t launch_fir8_fused3_t(bool mix, const Fir8Args &a, hipStream_t 
         return hipErrorInvalidValue;
     const int ntiles = (int)ntiles_ll;
     if (a.sched == nullptr || q.taps == nullptr || q.hist == nullptr || q.out == nullptr || q.seam == nullptr ||
-        q.flags == nullptr || q.g < 1 || q.off < 0 || q.off >= q.d)
+        q.flags == nullptr || q.g < 1 || q.off < 0 || q.off >= q.d || q.sl != SL3 || q.seglen != q.g * SL3)
         return hipErrorInvalidValue;
     const Fir8Sched sc = fir8_schedule(ntiles, R, true, 256, q.g);
     const dim3 grid((unsigned)sc.nblocks), blk(256);
@@ -1536,13 +1705,13 @@ static hipError_t launch_fir8_fused3_t(bool mix, const Fir8Args &a, hipStream_t 
         (void)hipGetDevice(&dev__);                                                               \
         if (!(attr_done >> (dev__ & 63) & 1ull)) {                                                \
             hipError_t e = hipFuncSetAttribute(                                                   \
-                reinterpret_cast<const void *>(&k_fir8<NTB, R, IN_PACKED24, MIXV, 8, 256, true>), \
+                reinterpret_cast<const void *>(&k_fir8<NTB, R, IN_PACKED24, MIXV, 8, 256, SL3>), \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);                        \
             if (e != hipSuccess)                                                                  \
                 return e;                                                                         \
             attr_done |= 1ull << (dev__ & 63);                                                    \
         }                                                                                         \
-        hipLaunchKernelGGL((k_fir8<NTB, R, IN_PACKED24, MIXV, 8, 256, true>), grid, blk, lds, s, a, ntiles, \
+        hipLaunchKernelGGL((k_fir8<NTB, R, IN_PACKED24, MIXV, 8, 256, SL3>), grid, blk, lds, s, a, ntiles, \
                            sc.S, sc.K);                                                           \
     } while (0)
     if (mix)
@@ -1555,8 +1724,14 @@ static hipError_t launch_fir8_fused3_t(bool mix, const Fir8Args &a, hipStream_t 
 
 hipError_t launch_fir8_fused3(int ntb, int R, bool mix, const Fir8Args &a, hipStream_t s)
 {
-    if (ntb == 4 && R == 4) return launch_fir8_fused3_t<4, 4>(mix, a, s);
-    if (ntb == 8 && R == 4) return launch_fir8_fused3_t<8, 4>(mix, a, s);
+#define PDDC_CASE3(N, SL)                                                                          \
+    if (ntb == N && R == 4 && a.s3.sl == SL)                                                       \
+        return launch_fir8_fused3_t<N, 4, SL>(mix, a, s)
+    PDDC_CASE3(4, 9);
+    PDDC_CASE3(4, 16);
+    PDDC_CASE3(8, 9);
+    PDDC_CASE3(8, 16);
+#undef PDDC_CASE3
     return hipErrorInvalidValue;
 }
 

@@ -1034,9 +1034,14 @@ static int setup_stage3(pddc_pipeline *p)
     return PDDC_OK;
 }
 
+/* Opt-in (PDDC_FUSE3=1): measured on MI355X the one-kernel cascade is SLOWER than the fused pair followed by the tail
+ * kernel -- x320 at 2^28 samples 0.323 against 0.287 + 0.027 ms, no gain at 2^20..2^22 either (profiles/r03/
+ * c_fused_cascade_*.txt) -- because k_fir8 is bound by each block's own dependency chain, and work added to the same
+ * waves lengthens it one for one; the tail costs less on OTHER waves (pddc_pipeline_set_overlap).                  */
 static bool stages012_fusable(const pddc_pipeline *p, size_t nsamples)
 {
-    return p->s3_ok && p->nstages >= 3 && !getenv("PDDC_NO_FUSE3") && stages01_fusable(p, nsamples);
+    const char *e = getenv("PDDC_FUSE3");
+    return p->s3_ok && p->nstages >= 3 && e && atoi(e) == 1 && stages01_fusable(p, nsamples);
 }
 
 extern "C" int pddc_pipeline_uses_fused_cascade(const pddc_pipeline *p, size_t nsamples)

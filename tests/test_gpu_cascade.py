@@ -43,6 +43,7 @@ def plans():
 @pytest.mark.parametrize("sched", ["3,-1,0", "7,0,0", "5,100,0", "4,50,5", "512,-1,0"])
 def test_fused_cascade_vs_oracle(pkg, dev, O, monkeypatch, plan, mix, sched):
     blocks, dyn, chunk = sched.split(",")
+    monkeypatch.setenv("PDDC_FUSE3", "1")                # the one-kernel cascade is opt-in (slower than pair + tail)
     monkeypatch.setenv("PDDC_FIR8_BLOCKS", blocks)
     if int(dyn) >= 0:
         monkeypatch.setenv("PDDC_FIR8_DYN_PCT", dyn)
@@ -79,19 +80,20 @@ def test_fused_cascade_equals_unfused_and_is_deterministic_under_load(pkg, dev, 
     stages = plans()["8*8*5"]
     ns = 1 << 24
     d_in = pkg.synth_lcg(6 * ns, 5150, 0, dev)
+    monkeypatch.setenv("PDDC_FUSE3", "1")
     fused = pkg.Pipeline(stages, mix=True)
     fused.set_center_freq(7.1e6)
     assert fused.fused_cascade(ns)
     a1 = fused.process(d_in).clone()
     a2 = fused.process(d_in).clone()
     fused.check()
-    monkeypatch.setenv("PDDC_NO_FUSE3", "1")
+    monkeypatch.delenv("PDDC_FUSE3")
     plain = pkg.Pipeline(stages, mix=True)
     plain.set_center_freq(7.1e6)
     assert plain.fused_pair(ns) and not plain.fused_cascade(ns)
     b1 = plain.process(d_in).clone()
     b2 = plain.process(d_in).clone()
-    monkeypatch.delenv("PDDC_NO_FUSE3")
+    monkeypatch.setenv("PDDC_FUSE3", "1")
     scale = float(b2.abs().max())
     assert a1.shape == b1.shape
     assert float((a1 - b1).abs().max()) / scale <= FIR_TOL
@@ -113,9 +115,10 @@ def test_fused_cascade_equals_unfused_and_is_deterministic_under_load(pkg, dev, 
     plain.close()
 
 
-def test_fused_cascade_checkpoint_and_retune(pkg, dev, O):
+def test_fused_cascade_checkpoint_and_retune(pkg, dev, O, monkeypatch):
     """The fused cascade shares its stream state with the unfused kernels: a checkpoint taken behind a fused batch
     restores into a fresh pipeline, and a retune between two fused batches is phase-continuous (oracle's retuned NCO)."""
+    monkeypatch.setenv("PDDC_FUSE3", "1")
     stages = plans()["8*8*5"]
     nb = 20 * TILE
     packed = O.lcg_bytes(6 * 3 * nb, 99)
