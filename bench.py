@@ -76,6 +76,9 @@ def parse(argv=None):
                          "profiles/r02/i_placement_map.txt)")
     ap.add_argument("--arena-gib", type=int, default=192,
                     help="size of the arena the placement search cuts its 8 GiB slots from (less if less is free)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="cascades: keep the stages behind the fused pair in line on the one stream instead of running them on\n"
+                         "the pipeline's side stream under the next batch's pair (pddc_pipeline_set_overlap)")
     ap.add_argument("--gather-timeout", type=float, default=240.0,
                     help="watchdog for the gather leg: past this the line is printed without it")
     return ap.parse_args(argv)
@@ -347,6 +350,11 @@ def run_rank(a):
     if stages is not None:
         # configuration (taps, NCO word, plan) comes from rank 0 over RCCL: a few KB, once
         pipe = grp.make_pipeline(pkg, stages, wl["freg"], wl["mix"], a.taps_fp16)
+        # a cascade behind the fused pair: its tail (1/64 of the samples) runs on the pipeline's side stream under the
+        # NEXT step's pair; the K timed steps end with a fence, so all K tails are inside the timed region
+        overlap = len(stages) > 2 and pipe.fused_pair(ns) and not a.no_overlap
+        if overlap:
+            pipe.set_overlap(True)
         out_rows = pipe.max_output(ns) + 8
         outbox = [torch.empty((out_rows, 2), dtype=torch.float32, device=dev)]
 
@@ -355,6 +363,7 @@ def run_rank(a):
             return pipe.process_ptr(inbox[0].data_ptr(), ns, outbox[0].data_ptr(), out_rows, stream)
     else:
         pipe = None
+        overlap = False
         out_rows = ns
         outbox = [torch.empty((ns, 2), dtype=torch.float32, device=dev)]
 
@@ -460,7 +469,8 @@ def run_rank(a):
     # the dominant kernel's duration is taken over THIS region: for a cascade the library brackets its stage-0
     # (fused-pair) kernel with HIP events on this stream; a single-kernel step needs nothing but ev0/ev1
     cascade = stages is not None and len(stages) > 2 and pipe.fused_cascade(ns)     # the whole cascade is ONE kernel
-    multi_kernel = stages is not None and pipe.fused and len(stages) > 1 and not cascade
+    # (overlap mode: the step is ONE launch -- the pair with the previous step's tail as extra blocks -- so ev0/ev1 do)
+    multi_kernel = stages is not None and pipe.fused and len(stages) > 1 and not cascade and not overlap
     if multi_kernel:
         pipe.time_stage0_inline(True)
     t0 = time.perf_counter()
@@ -468,6 +478,8 @@ def run_rank(a):
     n_last = 0
     for _ in range(a.steps):
         n_last = step()
+    if overlap:
+        pipe.fence(stream)                              # the last steps' tails belong to the timed region
     ev1.record()
     torch.cuda.synchronize(dev)
     grp.barrier()
@@ -549,7 +561,10 @@ def run_rank(a):
         total_samples = world * ns * a.steps
         value = total_samples / dt_max / 1e6
         fused = stages is not None and pipe.fused
-        bps = wl["bytes_per_sample"] if cascade else (wl["kernel_bytes_per_sample"] if fused else wl["bytes_per_sample"])
+        # overlap mode: a launch is the pair of this batch plus the tail of the one before, i.e. one batch's worth of the
+        # whole cascade: priced with the cascade's figure, not with the larger traffic it really moves
+        bps = wl["bytes_per_sample"] if (cascade or overlap) else (wl["kernel_bytes_per_sample"] if fused
+                                                                   else wl["bytes_per_sample"])
         achieved = bps * ns / (kern_ms * 1e-3) / 1e9
         step_achieved = wl["bytes_per_sample"] * ns / (dt_max / a.steps) / 1e9      # the whole step, gaps and tails included
         traffic, traffic_src = traffic_from_profile(a.workload, kernel_source_sig(), a.log2n, a.taps_fp16)
@@ -565,14 +580,17 @@ def run_rank(a):
             "config": {"workload": wl["label"], "samples_per_gpu_per_step": ns,
                        "input": "LCG bytes seed 12345+rank, device resident",
                        "sharding": "independent stream per GPU, no data-path collective",
-                       "taps_storage": "fp32 (values rounded to binary16)" if a.taps_fp16 else "fp32"},
+                       "taps_storage": "fp32 (values rounded to binary16)" if a.taps_fp16 else "fp32",
+                       "overlap": ("stages behind the fused pair run on the pipeline's side stream under the next step's "
+                                   "pair (pddc_pipeline_set_overlap); the timed region ends with a fence") if overlap else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "copy_ceiling_GBps": round(copy_gbps, 1) if copy_gbps else None,
                          "frac_of_copy_ceiling": round(achieved / copy_gbps, 4) if copy_gbps else None,
-                         "kernel": ("k_fir8 (fused cascade: all stages in one launch)" if cascade else "k_fir8") if fused
-                                   else "pipeline",
+                         "kernel": ("k_fir8 (fused cascade: all stages in one launch)" if cascade else
+                                    "k_fir8 (fused pair + the previous batch's tail as extra blocks of the launch)" if overlap
+                                    else "k_fir8") if fused else "pipeline",
                          "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_sample": bps,
                          "step_achieved": round(step_achieved, 1), "step_frac": round(step_achieved / HBM_PEAK_GBS, 4),
@@ -624,6 +642,7 @@ def gather_leg(a, pkg, grp, dev, stream, ns, d_in, pipe, out_shape_rows, decim, 
         o = outs[k & 1]
         grp.comm.gather_fence(stream)          # the transfer that last read this buffer pair is done
         pipe.process_ptr(d_in.data_ptr(), ns, o.data_ptr(), o.shape[0], stream)
+        pipe.fence(stream)                     # (overlap mode) the gather reads this batch's output
         grp.comm.gather_async(o.data_ptr(), nbytes, rptr, 0, stream)
 
     # untimed: both buffers once, then enough back-to-back steps for sustained clocks (the legs before this one end in

@@ -209,6 +209,19 @@ int pddc_pipeline_check(pddc_pipeline *p, void *stream);
  * without a synchronisation in between.                                        */
 int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsamples,
                           void *d_out_f32, size_t out_capacity, size_t *n_out, void *stream);
+/* Overlap mode for three-stage cascades whose first two stages run as the fused pair (pddc_pipeline_uses_fused_pair):
+ * the third stage -- 1/64 of the samples, a tenth of the arithmetic, but one more kernel in the row with its launch
+ * gaps, 11 % of the /320 step -- is NOT launched with its batch.  The NEXT process() makes it part of its own launch:
+ * extra thread blocks behind the pair's persistent ones, on waves the pair leaves idle (the pair writes the other half
+ * of a double-buffered workspace meanwhile).  One stream, no events.  The price is one batch of latency in what
+ * `stream` holds: behind process() k, the outputs up to batch k-1 are complete; pddc_pipeline_fence(p, stream) launches
+ * the tail that is still held back -- call it before the last output is read, and before save_state / set_taps /
+ * set_overlap.  The output buffer given to process() k must stay valid until the launch of k+1 (or the fence).
+ * Batches that do not take the fused pair (not whole tiles) fence by themselves and run in line; push_host* fence every
+ * batch (they are PCIe-bound).  Call set_overlap BEFORE pddc_pipeline_workspace_size / _set_workspace: the workspace
+ * then holds stage 2's input twice.  No reference counterpart (the FPGA's stages all run at once).              */
+int pddc_pipeline_set_overlap(pddc_pipeline *p, int enable);
+int pddc_pipeline_fence(pddc_pipeline *p, void *stream);
 /* Host batch: H2D copy, process, D2H copy, synchronous.                        */
 int pddc_pipeline_push_host(pddc_pipeline *p, const void *h_packed, size_t nsamples,
                             void *h_out_f32, size_t out_capacity, size_t *n_out);

@@ -114,6 +114,10 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_uses_fused_cascade.restype = C.c_int
     L.pddc_pipeline_check.argtypes = [vp, vp]
     L.pddc_pipeline_check.restype = C.c_int
+    L.pddc_pipeline_set_overlap.argtypes = [vp, C.c_int]
+    L.pddc_pipeline_set_overlap.restype = C.c_int
+    L.pddc_pipeline_fence.argtypes = [vp, vp]
+    L.pddc_pipeline_fence.restype = C.c_int
     L.pddc_pipeline_process.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp]
     L.pddc_pipeline_push_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     L.pddc_pipeline_push_host_async.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(C.c_int)]
@@ -276,6 +280,14 @@ class Pipeline:
         """wait for `stream`; raises if a kernel of this pipeline flagged a failure"""
         check(ddc_lib().pddc_pipeline_check(self._h, stream))
 
+    def set_overlap(self, enable: bool = True):
+        """stages behind the fused pair on a side stream, under the next batch's pair (see perseus_ddc.h)"""
+        check(ddc_lib().pddc_pipeline_set_overlap(self._h, 1 if enable else 0))
+
+    def fence(self, stream: int = 0):
+        """`stream` waits for every tail the overlap mode has queued"""
+        check(ddc_lib().pddc_pipeline_fence(self._h, stream))
+
     def max_output(self, n: int) -> int:
         return int(ddc_lib().pddc_pipeline_max_output(self._h, n))
 
@@ -293,10 +305,12 @@ class Pipeline:
         if self.out_packed:                       # 6 bytes per output sample
             out_u8 = torch.empty(6 * cap + 16, dtype=torch.uint8, device=packed_u8.device)
             n = self.process_ptr(packed_u8.data_ptr(), ns, out_u8.data_ptr(), cap, st)
+            self.fence(st)
             return out_u8[:6 * n]
         if out_f32 is None:
             out_f32 = torch.empty((cap, 2), dtype=torch.float32, device=packed_u8.device)
         n = self.process_ptr(packed_u8.data_ptr(), ns, out_f32.data_ptr(), out_f32.numel() // 2, st)
+        self.fence(st)                            # overlap mode: the caller is about to read this output
         return out_f32[:n]
 
     def push_host(self, packed_np):

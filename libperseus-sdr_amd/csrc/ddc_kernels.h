@@ -44,6 +44,26 @@ struct Fir8Stage3 {
     int seam_stride = 0;              /* bytes, multiple of 16, >= 8*h                                             */
 };
 
+/* One launch of the generic decimator on float2 -- 256 threads a block, one output a thread (k_fir_generic<1>) -- as a
+ * plain record.  A launch of the fused pair can carry one along: the TAIL of the batch before (overlap mode of the
+ * pipeline): `nblocks` extra thread blocks behind the pair's persistent ones run it on waves that would idle.   */
+struct GenTail {
+    const float *in = nullptr;        /* float2 input batch (the workspace half the previous pair wrote)           */
+    const float *hist = nullptr;      /* the H samples in front of it                                              */
+    float       *hist_out = nullptr;  /* receives the last H samples of [hist | in]                                */
+    float       *out = nullptr;       /* float2 outputs                                                            */
+    const float *taps = nullptr;      /* duplicated table (h[k], h[k]), see launch_fir_generic                     */
+    long long    first = 0, n_out = 0, n_batch = 0;
+    int          H = 0, D = 0, ntaps = 0;
+    int          span = 0, a = 31;    /* block shape (gen_tail_shape)                                              */
+    int          nblocks = 0;         /* 0: nothing carried                                                        */
+    unsigned     lds = 0;             /* bytes of LDS a block needs                                                */
+};
+/* fills span / a / nblocks / lds for D, ntaps, n_out; false if a block's span does not fit `lds_cap` bytes */
+bool gen_tail_shape(GenTail *t, size_t lds_cap);
+/* the record as a launch of its own (what pddc_pipeline_fence queues for the last batch) */
+hipError_t launch_gen_tail(const GenTail &t, hipStream_t s);
+
 /* arguments of the fused decimate-by-8 kernel (k_fir8) */
 struct Fir8Args {
     const void *in;          /* batch start: packed bytes or float2            */
@@ -62,6 +82,7 @@ struct Fir8Args {
                                 leaves them zero again) and a sticky error word (fused third
                                 stage: a bounded wait gave up); one set per stream  */
     Fir8Stage3   s3;                   /* launch_fir8_fused3 only                          */
+    GenTail      tail;                 /* launch_fir8_fused2 only: the previous batch's tail, carried along */
     long long   n_in;        /* samples in the batch, multiple of 8            */
     unsigned long long n0;   /* absolute index of batch sample 0 (NCO phase)   */
     uint32_t    freg;        /* NCO tuning word                                */
@@ -96,6 +117,7 @@ void   fir8_set_grid_blocks(int nblocks);   /* persistent grid override (0 = res
 /* packed -> [mix] -> /8 -> /8 in one kernel: `out` receives the SECOND stage's
  * outputs (n_in/64); n_in must be a multiple of the tile (1024*R samples) */
 bool fir8_fused2_supported(int ntb, int ntb2, int R);
+size_t fir8_fused2_lds_bytes(int ntb, int R);        /* dynamic LDS of a fused-pair block (a carried tail block must fit) */
 hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipStream_t s);
 
 /* packed -> [mix] -> /8 -> /8 -> /d3 in one kernel (a.s3 filled in, a.out unused): `a.s3.out` receives the THIRD
@@ -167,6 +189,7 @@ hipError_t launch_stream_probe(const void *src, size_t src_bytes, void *dst, siz
 
 hipError_t launch_synth_lcg(void *dst, size_t nbytes, uint32_t seed, uint64_t byte_offset,
                             hipStream_t s);
+
 
 #ifdef PDDC_CLOCK_PROBE
 void fir8_probe_dump();

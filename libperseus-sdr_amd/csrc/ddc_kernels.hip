@@ -300,6 +300,234 @@ hipError_t launch_unpack24(const void *d_in, long long ns, void *d_out, bool to_
 }
 
 /* ======================================================================== */
+/* k_fir_generic, the kernel body (its description and launchers: further down) */
+/* ======================================================================== */
+struct GenMixArgs {
+    unsigned long long n0;      /* absolute index of batch sample 0                            */
+    uint32_t freg, phase_off;   /* phase(n) = n*freg + phase_off                               */
+    uint32_t freg_hist;         /* word the history samples were mixed with (first batch after a retune) */
+    float lo_c[8], lo_s[8];     /* step phasors of freg                                        */
+    float lo_c_hist[8], lo_s_hist[8];
+};
+
+/* the body of one block: `bid` its index, `sd` its LDS, NT its threads -- also run by the extra blocks k_fir8 carries
+ * along for the PREVIOUS batch's tail (Fir8Args::tail)                                                          */
+template <int P, bool PACKED, bool MIX>
+__device__ __forceinline__ void fir_generic_body(const float2 *__restrict__ in, const float2 *__restrict__ hist,
+                                                 int H, long long first, long long n_out, int D,
+                                                 const float PDDC_CONSTANT *taps, int ntaps,
+                                                 float2 *__restrict__ out, int span, int a,
+                                                 float2 *__restrict__ hist_out, long long n_batch,
+                                                 const GenMixArgs &mx, const int bid, float2 *sd, const int NT)
+{
+    /* layout: span samples | 8 zero samples (the first, aligned step of the tap loop may
+     * look up to 7 samples past a thread's windows, with zero taps); sample i at i + (i >> a) */
+    const int tid = threadIdx.x;
+    const int S = P * D;
+    const long long q0 = (long long)bid * (NT * P);
+    /* inputs needed: x[first + q0*D - (ntaps-1)  ..  first + (q0+NT*P-1)*D] */
+    const long long x0 = first + q0 * D - (ntaps - 1);
+    const long long last_needed = first + (n_out - 1) * (long long)D;    /* last valid input index */
+    if (tid < 8) {
+        const int i = span + tid;
+        sd[i + (i >> a)] = make_float2(0.0f, 0.0f);
+    }
+    if (PACKED) {
+        /* whole groups of 8 samples (48 bytes, 16-byte aligned both in the batch and in the
+         * history, whose length is a multiple of 8), four groups in flight per thread */
+        const uint8_t *inb = reinterpret_cast<const uint8_t *>(in);
+        const uint8_t *hb8 = reinterpret_cast<const uint8_t *>(hist);
+        const long long xa = (x0 >= 0 ? x0 : x0 - 7) / 8 * 8;     /* floor to a multiple of 8 */
+        const int shift = (int)(x0 - xa);
+        const int ngroups = (span + shift + 7) >> 3;
+        /* the word and offset the samples in front of the batch were mixed with: the phase is
+         * continuous at n0, so off_old = phase_off + n0*(freg - freg_hist)                    */
+        const uint32_t off_old = mx.phase_off + (uint32_t)mx.n0 * (mx.freg - mx.freg_hist);
+        for (int g0 = tid; g0 < ngroups; g0 += 4 * NT) {
+            u32x4 raw[4][3];
+            long long s0[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + NT * u;
+                s0[u] = xa + 8LL * g;
+                const uint8_t *src = nullptr;
+                if (g < ngroups) {
+                    if (s0[u] < 0) {
+                        if (s0[u] >= -(long long)H)
+                            src = hb8 + (s0[u] + H) * 6;
+                    } else if (s0[u] < n_batch) {
+                        src = inb + s0[u] * 6;
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+                    raw[u][w] = src ? reinterpret_cast<const u32x4 *>(src)[w] : u32x4{ 0u, 0u, 0u, 0u };
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + NT * u;
+                if (g >= ngroups)
+                    continue;
+                const uint32_t w[12] = { raw[u][0].x, raw[u][0].y, raw[u][0].z, raw[u][0].w, raw[u][1].x, raw[u][1].y,
+                                         raw[u][1].z, raw[u][1].w, raw[u][2].x, raw[u][2].y, raw[u][2].z, raw[u][2].w };
+                int32_t I[8], Q[8];
+                unpack8_msb(w, I, Q);
+                float xi[8], xq[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xi[e] = (float)I[e] * kUnpackScale;
+                    xq[e] = (float)Q[e] * kUnpackScale;
+                }
+                if (MIX) {
+                    const bool old = s0[u] < 0;
+                    float cb, sb;
+                    nco_lo((uint32_t)(mx.n0 + (unsigned long long)s0[u]) * (old ? mx.freg_hist : mx.freg) +
+                               (old ? off_old : mx.phase_off), cb, sb);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float sc = old ? mx.lo_c_hist[e] : mx.lo_c[e];
+                        const float ss = old ? mx.lo_s_hist[e] : mx.lo_s[e];
+                        cmul(xi[e], xq[e], cb * sc - sb * ss, cb * ss + sb * sc);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = 8 * g - shift + e;               /* LDS index of sample xa + 8g + e */
+                    if (i >= 0 && i < span)
+                        sd[i + (i >> a)] = make_float2(xi[e], xq[e]);
+                }
+            }
+        }
+    } else if (x0 >= 0 && x0 + span - 1 <= last_needed) {
+        /* interior block: branch-free, so the loads of 8 rounds are in flight together
+         * (with the guarded form below every round waits for its own load: 21 serial
+         * round trips made this kernel 36 us for the x320 cascade's last stage)       */
+        const float2 *src = in + x0;
+        for (int i = tid; i < span; i += 8 * NT) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {          /* clamped, not branched: all 8 loads go out together */
+                const int ii = i + NT * u;
+                v[u] = src[ii < span ? ii : span - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ii = i + NT * u;
+                if (ii < span)
+                    sd[ii + (ii >> a)] = v[u];
+            }
+        }
+    } else {
+        for (int i = tid; i < span; i += NT) {
+            const long long xi = x0 + i;
+            float2 v = make_float2(0.0f, 0.0f);
+            if (xi < 0) {
+                if (xi >= -(long long)H)          /* history: the H samples that precede the batch */
+                    v = hist[xi + H];
+            } else if (xi <= last_needed) {
+                v = in[xi];
+            }
+            sd[i + (i >> a)] = v;
+        }
+    }
+    if (hist_out != nullptr && bid == 0) {
+        if (PACKED) {                                   /* 6 bytes per sample, moved as dwords */
+            const int Hw = H * 6 / 4;
+            const long long nw = n_batch * 6 / 4;
+            const uint32_t *hw = reinterpret_cast<const uint32_t *>(hist), *bw = reinterpret_cast<const uint32_t *>(in);
+            uint32_t *ow = reinterpret_cast<uint32_t *>(hist_out);
+            for (int i = tid; i < Hw; i += NT) {
+                const long long j = (long long)i + nw;
+                ow[i] = j < Hw ? hw[j] : bw[j - Hw];
+            }
+        } else {
+            for (int i = tid; i < H; i += NT) {
+                const long long j = (long long)i + n_batch;
+                hist_out[i] = j < H ? hist[j] : in[j - H];
+            }
+        }
+    }
+    __syncthreads();
+    /* four partial sums per output (window sample index mod 4): the rounding error of a long
+     * fp32 accumulation grows with the length of the chain, and the 1e-6 budget is shared by
+     * all stages of a cascade                                                               */
+    f32x2 acc[P][4];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4)
+            acc[p][a4] = f32x2{ 0.0f, 0.0f };
+    /* sample x[q*D - j], q = q0 + P*tid, has local index S*tid + r with r = ntaps-1-j (wave-
+     * uniform) and sits at lane + r + (r >> a): S*tid is a multiple of 2^a, so the pad splits */
+    const float2 *lane = sd + (S + (S >> a)) * tid;
+    /* The taps arrive DUPLICATED, (h[k], h[k]) per entry, so that a tap is a naturally aligned SGPR pair and the
+     * packed FMA takes it as it is: with single floats hipcc moved every odd tap into the low half of a pair first
+     * (12 s_mov per step of 24 FMAs).  And the two addressing forms are two separate loops: as one loop with a branch
+     * inside, hipcc copied all 6*P accumulator registers at the merge point on every step (18 v_mov per 24 FMAs at
+     * P = 3 -- the kernel issued 2.5x the VALU instructions its FMAs account for, profiles/r02/j_pmc_generic_tail.txt). */
+    const f32x2 PDDC_CONSTANT *taps2 = reinterpret_cast<const f32x2 PDDC_CONSTANT *>(taps);
+    if (a >= 3) {                                  /* (r >> a) is constant over an aligned step: immediates */
+        for (int r0 = ((ntaps - 1) + (P - 1) * D) | 7; r0 >= 0; r0 -= 8) {
+            const int jb = (ntaps - 1) - r0;       /* tap of output q for the step's first sample */
+            f32x2 hh[P][8];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    hh[p][u] = taps2[p * D + jb + u];
+            const float2 *x8 = lane + (r0 + (r0 >> a)) - 7;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float2 xv = x8[7 - u];
+                const f32x2 x = { xv.x, xv.y };
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc[p][u & 3] = __builtin_elementwise_fma(hh[p][u], x, acc[p][u & 3]);
+            }
+        }
+    } else {
+        for (int r0 = ((ntaps - 1) + (P - 1) * D) | 7; r0 >= 0; r0 -= 8) {
+            const int jb = (ntaps - 1) - r0;
+            f32x2 hh[P][8];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    hh[p][u] = taps2[p * D + jb + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 - u;
+                const float2 xv = lane[r + (r >> a)];
+                const f32x2 x = { xv.x, xv.y };
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc[p][u & 3] = __builtin_elementwise_fma(hh[p][u], x, acc[p][u & 3]);
+            }
+        }
+    }
+    const long long q = q0 + (long long)P * tid;
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+        if (q + p < n_out) {
+            const f32x2 sum = (acc[p][0] + acc[p][1]) + (acc[p][2] + acc[p][3]);
+            out[q + p] = make_float2(sum.x, sum.y);
+        }
+}
+
+template <int P, bool PACKED, bool MIX>
+__global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ in, const float2 *__restrict__ hist,
+                                                      int H, long long first, long long n_out, int D,
+                                                      const float PDDC_CONSTANT *taps, int ntaps,
+                                                      float2 *__restrict__ out, int span, int a,
+                                                      float2 *__restrict__ hist_out, long long n_batch,
+                                                      GenMixArgs mx)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 sd[];
+    fir_generic_body<P, PACKED, MIX>(in, hist, H, first, n_out, D, taps, ntaps, out, span, a, hist_out, n_batch, mx,
+                                     (int)blockIdx.x, sd, (int)blockDim.x);
+}
+
+/* ======================================================================== */
 /* k_fir8 : fused unpack + mix + polyphase decimate-by-8                    */
 /* ======================================================================== */
 /* LDS plane layout: group G (8 samples) lives at float offset
@@ -574,6 +802,22 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
 {
     constexpr bool FUSE3 = SL3 > 0;
     constexpr int SLN = SL3 > 0 ? SL3 : 1;
+    /* CARRY (the fused pair): the grid's last p.tail.nblocks blocks are not part of the pair -- they run the generic
+     * decimator on the PREVIOUS batch's second-stage outputs (its tail, Fir8Args::tail).  They are dealt out behind the
+     * pair's persistent blocks and live on the waves those leave idle (the pair issues vector instructions 38 % of the
+     * time and holds two of a SIMD's three possible waves).                                                     */
+    constexpr bool CARRY = NTB2 > 0 && SL3 == 0 && NT == 256;
+    if (CARRY && (int)blockIdx.x >= (int)gridDim.x - p.tail.nblocks) {
+        extern __shared__ __attribute__((aligned(16))) float2 sd_tail[];
+        const GenTail &t = p.tail;
+        const GenMixArgs nomix = {};
+        fir_generic_body<1, false, false>(reinterpret_cast<const float2 *>(t.in), reinterpret_cast<const float2 *>(t.hist), t.H,
+                                          t.first, t.n_out, t.D, (const float PDDC_CONSTANT *)t.taps, t.ntaps,
+                                          reinterpret_cast<float2 *>(t.out), t.span, t.a,
+                                          reinterpret_cast<float2 *>(t.hist_out), t.n_batch, nomix,
+                                          (int)blockIdx.x - ((int)gridDim.x - t.nblocks), sd_tail, 256);
+        return;
+    }
     static_assert(NT == 256 || (NT == 128 && R == 8 && NTB2 == 0), "128-thread blocks: R = 8, no fused second stage");
     static_assert(!FUSE3 || (NTB2 > 0 && NT == 256), "the third stage sits behind the fused pair");
 #ifdef PDDC_CLOCK_PROBE
@@ -620,7 +864,7 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
      * swapped, so that the 8-lane groups of ds_write_b128/_b96 hit 8 distinct
      * 4-bank sets (32-byte group stride + the 16-byte pad every R groups)      */
     const int gtid = (tid & ~12) | ((tid & 4) << 1) | ((tid & 8) >> 1);
-    const int nblk = (int)gridDim.x;
+    const int nblk = (int)gridDim.x - (CARRY ? p.tail.nblocks : 0);      /* the persistent blocks */
     const int dyn0 = nblk * S;                           /* first tile of the dynamic part */
     const int ND   = (ntiles - dyn0 + K - 1) / K;        /* number of dynamic chunks       */
 
@@ -1602,7 +1846,9 @@ static hipError_t launch_fir8_fused2_t(bool mix, const Fir8Args &a, hipStream_t 
     if (a.sched == nullptr)
         return hipErrorInvalidValue;
     const Fir8Sched sc = fir8_schedule(ntiles, R, true);
-    const dim3 grid((unsigned)sc.nblocks), blk(256);
+    if (a.tail.nblocks < 0 || (a.tail.nblocks > 0 && a.tail.lds > lds))
+        return hipErrorInvalidValue;             /* a carried tail block must fit the pair's LDS */
+    const dim3 grid((unsigned)(sc.nblocks + a.tail.nblocks)), blk(256);
 #define PDDC_LAUNCH2(MIXV)                                                                        \
     do {                                                                                          \
         static unsigned long long attr_done = 0;                                                  \
@@ -1625,6 +1871,14 @@ static hipError_t launch_fir8_fused2_t(bool mix, const Fir8Args &a, hipStream_t 
         PDDC_LAUNCH2(false);
 #undef PDDC_LAUNCH2
     return hipGetLastError();
+}
+
+size_t fir8_fused2_lds_bytes(int ntb, int R)
+{
+    const int NG = 1024 * R / 8 + ntb;
+    const int plane = 8 + 8 * NG + 4 * (NG / 8) + 8;
+    const int plane2 = 8 + 8 * (16 * R + 8) + 8;
+    return (size_t)(2 * plane + 4 * plane2 + 4 * 16 * R) * sizeof(float);
 }
 
 bool fir8_fused2_supported(int ntb, int ntb2, int R)
@@ -1815,217 +2069,6 @@ hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, h
  * and, MIX, mixes with the NCO -- while it stages its span, so the float2 intermediate of an
  * unpack kernel (8 B written + 8 B read per input sample) never exists: 6 + 8/D bytes per input
  * sample for ANY decimation, not only the fused decimate-by-8 (the 1.6 MS/s plan is 10*5).    */
-struct GenMixArgs {
-    unsigned long long n0;      /* absolute index of batch sample 0                            */
-    uint32_t freg, phase_off;   /* phase(n) = n*freg + phase_off                               */
-    uint32_t freg_hist;         /* word the history samples were mixed with (first batch after a retune) */
-    float lo_c[8], lo_s[8];     /* step phasors of freg                                        */
-    float lo_c_hist[8], lo_s_hist[8];
-};
-
-template <int P, bool PACKED, bool MIX>
-__global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ in, const float2 *__restrict__ hist,
-                                                      int H, long long first, long long n_out, int D,
-                                                      const float PDDC_CONSTANT *taps, int ntaps,
-                                                      float2 *__restrict__ out, int span, int a,
-                                                      float2 *__restrict__ hist_out, long long n_batch,
-                                                      GenMixArgs mx)
-{
-    extern __shared__ __attribute__((aligned(16))) float2 sd[];
-    /* layout: span samples | 8 zero samples (the first, aligned step of the tap loop may
-     * look up to 7 samples past a thread's windows, with zero taps); sample i at i + (i >> a) */
-    const int tid = threadIdx.x, NT = blockDim.x;
-    const int S = P * D;
-    const long long q0 = (long long)blockIdx.x * (NT * P);
-    /* inputs needed: x[first + q0*D - (ntaps-1)  ..  first + (q0+NT*P-1)*D] */
-    const long long x0 = first + q0 * D - (ntaps - 1);
-    const long long last_needed = first + (n_out - 1) * (long long)D;    /* last valid input index */
-    if (tid < 8) {
-        const int i = span + tid;
-        sd[i + (i >> a)] = make_float2(0.0f, 0.0f);
-    }
-    if (PACKED) {
-        /* whole groups of 8 samples (48 bytes, 16-byte aligned both in the batch and in the
-         * history, whose length is a multiple of 8), four groups in flight per thread */
-        const uint8_t *inb = reinterpret_cast<const uint8_t *>(in);
-        const uint8_t *hb8 = reinterpret_cast<const uint8_t *>(hist);
-        const long long xa = (x0 >= 0 ? x0 : x0 - 7) / 8 * 8;     /* floor to a multiple of 8 */
-        const int shift = (int)(x0 - xa);
-        const int ngroups = (span + shift + 7) >> 3;
-        /* the word and offset the samples in front of the batch were mixed with: the phase is
-         * continuous at n0, so off_old = phase_off + n0*(freg - freg_hist)                    */
-        const uint32_t off_old = mx.phase_off + (uint32_t)mx.n0 * (mx.freg - mx.freg_hist);
-        for (int g0 = tid; g0 < ngroups; g0 += 4 * NT) {
-            u32x4 raw[4][3];
-            long long s0[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int g = g0 + NT * u;
-                s0[u] = xa + 8LL * g;
-                const uint8_t *src = nullptr;
-                if (g < ngroups) {
-                    if (s0[u] < 0) {
-                        if (s0[u] >= -(long long)H)
-                            src = hb8 + (s0[u] + H) * 6;
-                    } else if (s0[u] < n_batch) {
-                        src = inb + s0[u] * 6;
-                    }
-                }
-#pragma unroll
-                for (int w = 0; w < 3; ++w)
-                    raw[u][w] = src ? reinterpret_cast<const u32x4 *>(src)[w] : u32x4{ 0u, 0u, 0u, 0u };
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int g = g0 + NT * u;
-                if (g >= ngroups)
-                    continue;
-                const uint32_t w[12] = { raw[u][0].x, raw[u][0].y, raw[u][0].z, raw[u][0].w, raw[u][1].x, raw[u][1].y,
-                                         raw[u][1].z, raw[u][1].w, raw[u][2].x, raw[u][2].y, raw[u][2].z, raw[u][2].w };
-                int32_t I[8], Q[8];
-                unpack8_msb(w, I, Q);
-                float xi[8], xq[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    xi[e] = (float)I[e] * kUnpackScale;
-                    xq[e] = (float)Q[e] * kUnpackScale;
-                }
-                if (MIX) {
-                    const bool old = s0[u] < 0;
-                    float cb, sb;
-                    nco_lo((uint32_t)(mx.n0 + (unsigned long long)s0[u]) * (old ? mx.freg_hist : mx.freg) +
-                               (old ? off_old : mx.phase_off), cb, sb);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float sc = old ? mx.lo_c_hist[e] : mx.lo_c[e];
-                        const float ss = old ? mx.lo_s_hist[e] : mx.lo_s[e];
-                        cmul(xi[e], xq[e], cb * sc - sb * ss, cb * ss + sb * sc);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int i = 8 * g - shift + e;               /* LDS index of sample xa + 8g + e */
-                    if (i >= 0 && i < span)
-                        sd[i + (i >> a)] = make_float2(xi[e], xq[e]);
-                }
-            }
-        }
-    } else if (x0 >= 0 && x0 + span - 1 <= last_needed) {
-        /* interior block: branch-free, so the loads of 8 rounds are in flight together
-         * (with the guarded form below every round waits for its own load: 21 serial
-         * round trips made this kernel 36 us for the x320 cascade's last stage)       */
-        const float2 *src = in + x0;
-        for (int i = tid; i < span; i += 8 * NT) {
-            float2 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {          /* clamped, not branched: all 8 loads go out together */
-                const int ii = i + NT * u;
-                v[u] = src[ii < span ? ii : span - 1];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int ii = i + NT * u;
-                if (ii < span)
-                    sd[ii + (ii >> a)] = v[u];
-            }
-        }
-    } else {
-        for (int i = tid; i < span; i += NT) {
-            const long long xi = x0 + i;
-            float2 v = make_float2(0.0f, 0.0f);
-            if (xi < 0) {
-                if (xi >= -(long long)H)          /* history: the H samples that precede the batch */
-                    v = hist[xi + H];
-            } else if (xi <= last_needed) {
-                v = in[xi];
-            }
-            sd[i + (i >> a)] = v;
-        }
-    }
-    if (hist_out != nullptr && blockIdx.x == 0) {
-        if (PACKED) {                                   /* 6 bytes per sample, moved as dwords */
-            const int Hw = H * 6 / 4;
-            const long long nw = n_batch * 6 / 4;
-            const uint32_t *hw = reinterpret_cast<const uint32_t *>(hist), *bw = reinterpret_cast<const uint32_t *>(in);
-            uint32_t *ow = reinterpret_cast<uint32_t *>(hist_out);
-            for (int i = tid; i < Hw; i += NT) {
-                const long long j = (long long)i + nw;
-                ow[i] = j < Hw ? hw[j] : bw[j - Hw];
-            }
-        } else {
-            for (int i = tid; i < H; i += NT) {
-                const long long j = (long long)i + n_batch;
-                hist_out[i] = j < H ? hist[j] : in[j - H];
-            }
-        }
-    }
-    __syncthreads();
-    /* four partial sums per output (window sample index mod 4): the rounding error of a long
-     * fp32 accumulation grows with the length of the chain, and the 1e-6 budget is shared by
-     * all stages of a cascade                                                               */
-    f32x2 acc[P][4];
-#pragma unroll
-    for (int p = 0; p < P; ++p)
-#pragma unroll
-        for (int a4 = 0; a4 < 4; ++a4)
-            acc[p][a4] = f32x2{ 0.0f, 0.0f };
-    /* sample x[q*D - j], q = q0 + P*tid, has local index S*tid + r with r = ntaps-1-j (wave-
-     * uniform) and sits at lane + r + (r >> a): S*tid is a multiple of 2^a, so the pad splits */
-    const float2 *lane = sd + (S + (S >> a)) * tid;
-    /* The taps arrive DUPLICATED, (h[k], h[k]) per entry, so that a tap is a naturally aligned SGPR pair and the
-     * packed FMA takes it as it is: with single floats hipcc moved every odd tap into the low half of a pair first
-     * (12 s_mov per step of 24 FMAs).  And the two addressing forms are two separate loops: as one loop with a branch
-     * inside, hipcc copied all 6*P accumulator registers at the merge point on every step (18 v_mov per 24 FMAs at
-     * P = 3 -- the kernel issued 2.5x the VALU instructions its FMAs account for, profiles/r02/j_pmc_generic_tail.txt). */
-    const f32x2 PDDC_CONSTANT *taps2 = reinterpret_cast<const f32x2 PDDC_CONSTANT *>(taps);
-    if (a >= 3) {                                  /* (r >> a) is constant over an aligned step: immediates */
-        for (int r0 = ((ntaps - 1) + (P - 1) * D) | 7; r0 >= 0; r0 -= 8) {
-            const int jb = (ntaps - 1) - r0;       /* tap of output q for the step's first sample */
-            f32x2 hh[P][8];
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    hh[p][u] = taps2[p * D + jb + u];
-            const float2 *x8 = lane + (r0 + (r0 >> a)) - 7;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float2 xv = x8[7 - u];
-                const f32x2 x = { xv.x, xv.y };
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    acc[p][u & 3] = __builtin_elementwise_fma(hh[p][u], x, acc[p][u & 3]);
-            }
-        }
-    } else {
-        for (int r0 = ((ntaps - 1) + (P - 1) * D) | 7; r0 >= 0; r0 -= 8) {
-            const int jb = (ntaps - 1) - r0;
-            f32x2 hh[P][8];
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    hh[p][u] = taps2[p * D + jb + u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = r0 - u;
-                const float2 xv = lane[r + (r >> a)];
-                const f32x2 x = { xv.x, xv.y };
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    acc[p][u & 3] = __builtin_elementwise_fma(hh[p][u], x, acc[p][u & 3]);
-            }
-        }
-    }
-    const long long q = q0 + (long long)P * tid;
-#pragma unroll
-    for (int p = 0; p < P; ++p)
-        if (q + p < n_out) {
-            const f32x2 sum = (acc[p][0] + acc[p][1]) + (acc[p][2] + acc[p][3]);
-            out[q + p] = make_float2(sum.x, sum.y);
-        }
-}
-
 struct GenShape {
     int NT = 0, P = 0, span = 0, a = 31;
     size_t lds = 0;
@@ -2160,11 +2203,12 @@ static hipError_t launch_fir_generic_any(const void *in, const void *hist, int H
     do {                                                                                          \
         static int attr_lds[64] = { 0 };            /* per device */                             \
         if ((int)lds > attr_lds[dev & 63]) {                                                      \
+            /* the whole LDS once (launch_gen_tail sets the same attribute of the same function) */   \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_generic<PP, PK, MX>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             if (e != hipSuccess)                                                                  \
                 return e;                                                                         \
-            attr_lds[dev & 63] = (int)lds;                                                        \
+            attr_lds[dev & 63] = 160 * 1024;                                                      \
         }                                                                                         \
         hipLaunchKernelGGL((k_fir_generic<PP, PK, MX>), grid, blk, lds, s, reinterpret_cast<const float2 *>(in), \
                            reinterpret_cast<const float2 *>(hist), H, first, n_out, D,            \
@@ -2190,6 +2234,45 @@ static hipError_t launch_fir_generic_any(const void *in, const void *hist, int H
         PDDC_GEN(1);
 #undef PDDC_GEN
 #undef PDDC_GEN3
+    return hipGetLastError();
+}
+
+bool gen_tail_shape(GenTail *t, size_t lds_cap)
+{
+    if (!t || t->D < 1 || t->ntaps < 1 || t->n_out < 1)
+        return false;
+    const long long sp = 255LL * t->D + t->ntaps;                 /* 256 threads, one output each */
+    if (sp > (1 << 20))
+        return false;
+    t->span = (int)sp;
+    t->a = (t->D & 1) ? 31 : __builtin_ctz((unsigned)t->D);
+    const size_t l = (size_t)(t->span + 8 + ((t->span + 8) >> t->a) + 2) * sizeof(float2);
+    if (l > lds_cap)
+        return false;
+    t->lds = (unsigned)l;
+    t->nblocks = (int)((t->n_out + 255) / 256);
+    return true;
+}
+
+hipError_t launch_gen_tail(const GenTail &t, hipStream_t s)
+{
+    if (t.nblocks <= 0)
+        return hipSuccess;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static bool attr_done[64] = { false };
+    if (!attr_done[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_generic<1, false, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess)
+            return e;
+        attr_done[dev & 63] = true;
+    }
+    const GenMixArgs mx = {};
+    hipLaunchKernelGGL((k_fir_generic<1, false, false>), dim3((unsigned)t.nblocks), dim3(256), t.lds, s,
+                       reinterpret_cast<const float2 *>(t.in), reinterpret_cast<const float2 *>(t.hist), t.H, t.first,
+                       t.n_out, t.D, (const float PDDC_CONSTANT *)t.taps, t.ntaps, reinterpret_cast<float2 *>(t.out),
+                       t.span, t.a, reinterpret_cast<float2 *>(t.hist_out), t.n_batch, mx);
     return hipGetLastError();
 }
 

@@ -83,6 +83,8 @@ struct Stage {
     float *d_buf = nullptr;
     size_t buf_cap = 0;           /* capacity in samples                        */
     bool buf_in_ws = false;       /* d_buf lies in the caller's workspace (pddc_pipeline_set_workspace): not ours to free */
+    float *d_buf_alt = nullptr;   /* overlap mode, stage 2 only: the second half of the double buffer the fused pair writes */
+    size_t buf_alt_cap = 0;
     unsigned long long consumed = 0;   /* inputs consumed since reset           */
 };
 
@@ -145,6 +147,13 @@ struct pddc_pipeline {
     unsigned *d_sched = nullptr;  /* k_fir8's tile scheduler words (zero between launches) + its sticky error word */
     /* fused cascade (stages 0+1+2 in one kernel, launch_fir8_fused3): geometry of the third stage, the seam slots
      * through which a chunk of tiles hands its last outputs to the chunk behind it, one flag per chunk            */
+    /* overlap mode (pddc_pipeline_set_overlap): the stage behind the fused pair is not launched with its batch; the NEXT
+     * batch's pair carries it along as extra thread blocks (Fir8Args::tail), pddc_pipeline_fence launches what is
+     * left.  The pair writes two alternating workspace halves.                                                  */
+    bool overlap = false;
+    int ov_parity = 0;
+    bool carry_pending = false;   /* carry_tail has not been launched yet */
+    GenTail carry_tail;
     bool s3_ok = false;
     Fir8Stage3 s3;
     void *d_seam = nullptr;
@@ -721,6 +730,8 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
             hipFree(p->st[i].d_taps_seg);
         if (p->st[i].d_buf && !p->st[i].buf_in_ws)
             hipFree(p->st[i].d_buf);
+        if (p->st[i].d_buf_alt && !p->st[i].buf_in_ws)
+            hipFree(p->st[i].d_buf_alt);
         for (int b = 0; b < 2; ++b)
             if (p->st[i].d_hist[b])
                 hipFree(p->st[i].d_hist[b]);
@@ -772,6 +783,8 @@ int pddc_pipeline_reset(pddc_pipeline *p)
     p->freg_applied = p->freg;
     compute_lo_steps(p);
     p->fresh = true;
+    p->carry_pending = false;                         /* a reset stream has no tail to finish */
+    p->ov_parity = 0;
     p->segs.assign(1, pddc_pipeline::WordSeg{ 0, p->freg, 0u });      /* samples before the start are zeros */
     HIP_TRY(hipMemset(p->d_sched, 0, 64));
     if (p->d_flags)
@@ -866,6 +879,8 @@ int pddc_pipeline_set_taps(pddc_pipeline *p, int stage, const float *taps, int n
         return fail(PDDC_EINVAL, "null argument");
     if (stage < 0 || stage >= p->nstages)
         return fail(PDDC_EINVAL, "stage %d out of range", stage);
+    if (p->carry_pending)
+        return fail(PDDC_ESTATE, "overlap mode holds a tail back: pddc_pipeline_fence(p, stream) first");
     Stage &s = p->st[stage];
     /* the history length is fixed at create time; a new tap set must fit it */
     const int need_hist = s.interp > 1 ? (ntaps + s.interp - 1) / s.interp : ntaps - 1;
@@ -1118,7 +1133,7 @@ extern "C" size_t pddc_pipeline_workspace_size(const pddc_pipeline *p, size_t ma
         return 0;
     size_t total = 0;
     for (int i = 1; i < p->nstages; ++i)
-        total += (ws_stage_samples(p, i, max_nsamples) * 8 + 255) & ~(size_t)255;
+        total += ((ws_stage_samples(p, i, max_nsamples) * 8 + 255) & ~(size_t)255) * ((p->overlap && i == 2) ? 2 : 1);
     return total;
 }
 
@@ -1136,8 +1151,10 @@ extern "C" int pddc_pipeline_set_workspace(pddc_pipeline *p, void *d_ws, size_t 
         Stage &s = p->st[i];
         if (s.d_buf && !s.buf_in_ws)
             HIP_TRY(hipFree(s.d_buf));
-        s.d_buf = nullptr;
-        s.buf_cap = 0;
+        if (s.d_buf_alt && !s.buf_in_ws)
+            HIP_TRY(hipFree(s.d_buf_alt));
+        s.d_buf = s.d_buf_alt = nullptr;
+        s.buf_cap = s.buf_alt_cap = 0;
         s.buf_in_ws = false;
         if (d_ws) {
             const size_t cap = ws_stage_samples(p, i, max_nsamples);
@@ -1145,7 +1162,46 @@ extern "C" int pddc_pipeline_set_workspace(pddc_pipeline *p, void *d_ws, size_t 
             s.buf_cap = cap;
             s.buf_in_ws = true;
             at += (cap * 8 + 255) & ~(size_t)255;
+            if (p->overlap && i == 2) {
+                s.d_buf_alt = reinterpret_cast<float *>(at);
+                s.buf_alt_cap = cap;
+                at += (cap * 8 + 255) & ~(size_t)255;
+            }
         }
+    }
+    return PDDC_OK;
+}
+
+/* Overlap mode.  A cascade behind the fused pair is kernels in a row, each waiting for the one before: the pair (0.29 ms
+ * at 2^28 samples), a launch gap, the tail (23 us at a fifth of the HBM rate: it has 1/64 of the samples and a tenth
+ * of the arithmetic), another gap -- 11 % of the x320 step (profiles/r02/k_trace_c320.txt).  What was tried first
+ * (profiles/r03/): the tail INSIDE the pair's kernel (stages012_fusable above: slower, that kernel is bound by every
+ * block's own dependency chain); the tail on a side stream behind an event (every cross-stream event put 18 us between
+ * two pairs on the main stream, and the two grids, ready at the same instant, were dealt out interleaved: the pair took
+ * 0.338 instead of 0.287 ms).  What works needs neither stream nor event: the tail of batch k becomes part of the
+ * LAUNCH of batch k+1 -- extra thread blocks behind the pair's persistent ones in the same grid (Fir8Args::tail), on
+ * waves the pair leaves idle -- and pddc_pipeline_fence launches the one tail that is left at the end.          */
+int pddc_pipeline_set_overlap(pddc_pipeline *p, int enable)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    if (p->carry_pending)
+        return fail(PDDC_ESTATE, "a tail is still to be launched: pddc_pipeline_fence first");
+    p->overlap = enable != 0;
+    p->ov_parity = 0;
+    return PDDC_OK;
+}
+
+/* launches, on `stream`, the tail that overlap mode still holds back (nothing to do otherwise): behind it every output
+ * of every process() so far is complete in stream order                                                        */
+int pddc_pipeline_fence(pddc_pipeline *p, void *stream)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    if (p->carry_pending) {
+        HIP_TRY(hipSetDevice(p->device));
+        HIP_TRY(launch_gen_tail(p->carry_tail, (hipStream_t)stream));
+        p->carry_pending = false;
     }
     return PDDC_OK;
 }
@@ -1264,6 +1320,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
      * half way leaves the pipeline exactly where it was, and the batch can be retried.       */
     bool flip[PDDC_MAX_STAGES] = { false, false, false, false };
     int first = 0;
+    bool carried = false;                   /* overlap mode: this batch's last stage is not launched here          */
     /* which tuning words does stage 0's history window [n0 - H, n0) hold?  Drop the segments that
      * ended before it.  One word, or the old word all through with the new one starting exactly now:
      * the packed-history kernels handle it (freg_hist).  Anything else: the mixed-history route.  */
@@ -1285,6 +1342,8 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         /* stages 0, 1 and 2 in ONE kernel: neither intermediate touches HBM */
         Stage &s0 = p->st[0], &s1 = p->st[1];
         float *dst;
+        if ((rc = pddc_pipeline_fence(p, s)))
+            return rc;
         if ((rc = stage_dst(2, &dst, true)))
             return rc;
         Fir8Args a;
@@ -1313,6 +1372,50 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         float *dst;
         if ((rc = stage_dst(1, &dst, true)))
             return rc;
+        /* overlap mode: the one stage behind the pair is held back and rides along with the NEXT batch's pair */
+        GenTail mine;
+        bool ov = p->overlap && p->nstages == 3 && p->st[2].interp == 1 && !(p->flags & (PDDC_F_OUT_PACKED24 | PDDC_F_NO_FAST)) &&
+                  n_in[3] > 0;
+        if (ov) {
+            Stage &s2 = p->st[2];
+            mine.H = s2.hist;
+            mine.D = s2.decim;
+            mine.ntaps = s2.ntaps;
+            mine.n_out = (long long)n_in[3];
+            ov = gen_tail_shape(&mine, fir8_fused2_lds_bytes(s0.ntb, p->R));
+        }
+        if (ov) {
+            /* the other half of the double buffer: the tail of the batch before this one reads the first during this launch */
+            Stage &s2 = p->st[2];
+            if (p->ov_parity == 1) {
+                if (s2.buf_in_ws) {
+                    if (s2.d_buf_alt == nullptr || s2.buf_alt_cap < n_in[2] + 8)
+                        return fail(PDDC_ECAPACITY, "overlap mode: the workspace was set before pddc_pipeline_set_overlap, "
+                                                    "or for smaller batches (it needs two halves for stage 2)");
+                } else if (s2.buf_alt_cap < n_in[2] + 8) {
+                    HIP_TRY(hipDeviceSynchronize());
+                    if (s2.d_buf_alt)
+                        HIP_TRY(hipFree(s2.d_buf_alt));
+                    s2.d_buf_alt = nullptr;
+                    s2.buf_alt_cap = 0;
+                    HIP_TRY(hipMalloc(&s2.d_buf_alt, sizeof(float) * 2 * s2.buf_cap));
+                    s2.buf_alt_cap = s2.buf_cap;
+                }
+                dst = s2.d_buf_alt;
+            }
+            float *dst3;
+            if ((rc = stage_dst(2, &dst3, false)))
+                return rc;
+            mine.in = dst;
+            mine.hist = static_cast<const float *>(s2.d_hist[s2.cur]);
+            mine.hist_out = static_cast<float *>(s2.d_hist[s2.cur ^ 1]);
+            mine.out = dst3;
+            mine.taps = s2.d_taps_dup;
+            mine.first = (long long)off[2];
+            mine.n_batch = (long long)n_in[2];
+        } else if ((rc = pddc_pipeline_fence(p, s))) {      /* in line: what is held back goes first */
+            return rc;
+        }
         Fir8Args a;
         a.in = d_packed;
         a.hist = s0.d_hist[s0.cur];
@@ -1324,13 +1427,27 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         a.hist2_out = s1.d_hist[s1.cur ^ 1];
         a.n_in = (long long)nsamples;
         fill_fir8_args(p, a);
+        if (ov && p->carry_pending)
+            a.tail = p->carry_tail;
         if ((rc = stage0_event(p, s, true)))
             return rc;
         HIP_TRY(launch_fir8_fused2(s0.ntb, p->R, mix, a, s));
+        if (ov)
+            p->carry_pending = false;       /* (failure atomicity: only once the launch was accepted) */
         if ((rc = stage0_event(p, s, false)))
             return rc;
         flip[0] = flip[1] = true;
         first = 2;
+        if (ov) {                           /* the previous tail went out with this launch; this batch's is held back */
+            p->carry_tail = mine;
+            p->carry_pending = true;
+            p->ov_parity ^= 1;
+            carried = true;
+            flip[2] = true;
+            first = 3;
+        }
+    } else if ((rc = pddc_pipeline_fence(p, s))) {          /* any other route runs the later stages in line */
+        return rc;
     }
     for (int i = first; i < p->nstages; ++i) {
         Stage &st = p->st[i];
@@ -1445,6 +1562,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             flip[i] = true;
         }
     }
+    (void)carried;
     if (p->flags & PDDC_F_OUT_PACKED24)
         HIP_TRY(launch_pack24(p->d_fout, (long long)n_final, d_out, s));
     for (int i = 0; i < p->nstages; ++i) {          /* commit */
@@ -1556,6 +1674,8 @@ static int push_async(pddc_pipeline *p, const void *h_packed, bool synth, uint32
     p->place_buffers = false;
     int rc = pddc_pipeline_process(p, sl.d_in, nsamples, sl.d_out, sl.out_cap, &n_out, p->own_stream);
     if (rc)
+        return rc;
+    if ((rc = pddc_pipeline_fence(p, p->own_stream)))     /* overlap mode: the D2H copy needs the tail's output */
         return rc;
     HIP_TRY(hipEventRecord(sl.ev_comp, p->own_stream));
     sl.used = true;
@@ -1671,6 +1791,8 @@ int pddc_pipeline_save_state(pddc_pipeline *p, void *h_buf, size_t capacity, siz
         *used = need;
     if (capacity < need)
         return fail(PDDC_ECAPACITY, "state needs %zu bytes, buffer has %zu", need, capacity);
+    if (p->carry_pending)
+        return fail(PDDC_ESTATE, "overlap mode holds a tail back: pddc_pipeline_fence(p, stream) first");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipDeviceSynchronize());                  /* every batch pushed so far is part of the state */
     StateHeader h = {};

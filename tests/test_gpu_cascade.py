@@ -141,3 +141,86 @@ def test_fused_cascade_checkpoint_and_retune(pkg, dev, O, monkeypatch):
     assert y.size == ref.size
     assert O.rel_err(y, ref) <= FIR_TOL
     pipe.close()
+
+
+# ------------------------------------------------------------------ overlap mode (the tail under the next batch's pair)
+@pytest.mark.parametrize("plan", ["8*8*5", "8*8*10", "8*8*4*5"])
+def test_overlap_mode_is_bit_identical_and_fenced(pkg, dev, O, plan):
+    """pddc_pipeline_set_overlap: the stage behind the fused pair rides along with the NEXT batch's launch (extra thread
+    blocks of the pair's grid).  Same arithmetic, same order per stage -- so the outputs are bit-identical to the
+    in-line pipeline, whatever mix of whole-tile batches (carried) and odd ones (in line, fenced by the library) the
+    stream is cut into; a retune in between; outputs read only behind pddc_pipeline_fence.  (The four-stage plan is
+    not carried: it must simply still be right with the mode switched on.)"""
+    import torch
+    pl = plans()
+    pl["8*8*4*5"] = pl["8*8*4"] + [(5, lowpass(41, 0.08))]
+    stages = pl[plan]
+    sizes = [8, 8, 3, 0.25, 16, 1, 1, 1, 0.5, 40, 8]
+    cuts = [0]
+    for t in sizes:
+        cuts.append(cuts[-1] + int(t * TILE))
+    d_in = pkg.synth_lcg(6 * cuts[-1], 777, 0, dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    outs = {}
+    for mode in ("inline", "overlap"):
+        pipe = pkg.Pipeline(stages, mix=True)
+        pipe.set_freg(381178347)
+        if mode == "overlap":
+            pipe.set_overlap(True)
+        bufs = []
+        for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            if k == 5:
+                pipe.set_freg(123456789)
+            o = torch.zeros((pipe.max_output(b - a) + 1, 2), dtype=torch.float32, device=dev)
+            n = pipe.process_ptr(d_in[6 * a:6 * b].data_ptr(), b - a, o.data_ptr(), o.shape[0], st)
+            bufs.append((o, n))
+        pipe.fence(st)
+        torch.cuda.synchronize()
+        outs[mode] = torch.cat([o[:n] for o, n in bufs])
+        pipe.close()
+    assert outs["inline"].shape == outs["overlap"].shape and outs["inline"].shape[0] > 0
+    assert torch.equal(outs["inline"], outs["overlap"])
+    packed = d_in.cpu().numpy()
+    ref = O.ddc_chain_retuned(packed, stages, [(0, 381178347), (cuts[5], 123456789)])
+    assert O.rel_err(outs["overlap"].cpu().numpy().reshape(-1), ref) <= FIR_TOL
+
+
+def test_overlap_mode_with_a_caller_workspace_and_checkpoint(pkg, dev, O):
+    """the double-buffered workspace half comes from the caller's workspace too (set_overlap before set_workspace), and a
+    checkpoint taken in overlap mode (save_state synchronises) resumes in an in-line pipeline bit-identically"""
+    import torch
+    stages = plans()["8*8*5"]
+    nb = 32 * TILE
+    d_in = pkg.synth_lcg(6 * 4 * nb, 31, 0, dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ref_pipe = pkg.Pipeline(stages, mix=True)
+    ref_pipe.set_freg(381178347)
+    want = torch.cat([ref_pipe.process(d_in[6 * k * nb:6 * (k + 1) * nb]).clone() for k in range(4)])
+    ref_pipe.close()
+    pipe = pkg.Pipeline(stages, mix=True)
+    pipe.set_freg(381178347)
+    small = pipe.workspace_size(nb)
+    pipe.set_overlap(True)
+    need = pipe.workspace_size(nb)
+    assert need > small
+    ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    pipe.set_workspace(base, need, nb)
+    outs = []
+    for k in range(2):
+        o = torch.zeros((pipe.max_output(nb) + 1, 2), dtype=torch.float32, device=dev)
+        n = pipe.process_ptr(d_in[6 * k * nb:].data_ptr(), nb, o.data_ptr(), o.shape[0], st)
+        outs.append((o, n))
+    with pytest.raises(Exception):
+        pipe.save_state()                      # a tail is still held back: the state would miss it
+    pipe.fence(st)
+    blob = pipe.save_state()
+    pipe.close()
+    torch.cuda.synchronize()
+    got = [o[:n] for o, n in outs]
+    pipe = pkg.Pipeline(stages, mix=True)
+    pipe.set_freg(381178347)
+    pipe.restore_state(blob)
+    got += [pipe.process(d_in[6 * k * nb:6 * (k + 1) * nb]).clone() for k in (2, 3)]
+    pipe.close()
+    assert torch.equal(torch.cat(got), want)
