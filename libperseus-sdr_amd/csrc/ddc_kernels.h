@@ -58,9 +58,13 @@ struct GenTail {
     int          span = 0, a = 31;    /* block shape (gen_tail_shape)                                              */
     int          nblocks = 0;         /* 0: nothing carried                                                        */
     unsigned     lds = 0;             /* bytes of LDS a block needs                                                */
+    int          kind = 0;            /* 0: k_fir_generic<1>'s body; 1: k_firp's (decimation 4, 5, 10), which wants: */
+    const float *taps2 = nullptr;     /*    its own table, (h, h) pairs zero padded to firp_taps_len(D, ntaps)      */
+    int          nbq = 0;
 };
-/* fills span / a / nblocks / lds for D, ntaps, n_out; false if a block's span does not fit `lds_cap` bytes */
-bool gen_tail_shape(GenTail *t, size_t lds_cap);
+/* fills kind / span / a / nbq / nblocks / lds for D, ntaps, n_out (kind 1 where firp_supported and `have_taps2`);
+ * false if a block's span does not fit `lds_cap` bytes */
+bool gen_tail_shape(GenTail *t, size_t lds_cap, bool have_taps2);
 /* the record as a launch of its own (what pddc_pipeline_fence queues for the last batch) */
 hipError_t launch_gen_tail(const GenTail &t, hipStream_t s);
 
@@ -117,7 +121,9 @@ void   fir8_set_grid_blocks(int nblocks);   /* persistent grid override (0 = res
 /* packed -> [mix] -> /8 -> /8 in one kernel: `out` receives the SECOND stage's
  * outputs (n_in/64); n_in must be a multiple of the tile (1024*R samples) */
 bool fir8_fused2_supported(int ntb, int ntb2, int R);
-size_t fir8_fused2_lds_bytes(int ntb, int R);        /* dynamic LDS of a fused-pair block (a carried tail block must fit) */
+size_t fir8_fused2_lds_bytes(int ntb, int R);        /* dynamic LDS of a fused-pair block                              */
+constexpr size_t kCarryLdsCap = 50u * 1024u;        /* a carried tail block may ask for this much: three blocks of that
+                                                       size (two of the first stage's, one of the tail's) share a CU */
 hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipStream_t s);
 
 /* packed -> [mix] -> /8 -> /8 -> /d3 in one kernel (a.s3 filled in, a.out unused): `a.s3.out` receives the THIRD
@@ -153,6 +159,25 @@ hipError_t launch_fir_generic_packed(const void *in_packed, const void *hist_pac
                                      void *hist_out_packed, long long n_batch, bool mix, unsigned long long n0,
                                      uint32_t freg, uint32_t phase_off, uint32_t freg_hist, const float *lo_c,
                                      const float *lo_s, const float *lo_c_hist, const float *lo_s_hist, hipStream_t s);
+
+/* k_firp: the register-blocked decimator for the decimations the rate plans use besides 8 (4, 5, 10), float2 or packed
+ * (+ NCO) input: same contract as launch_fir_generic / launch_fir_generic_packed except for the tap table -- (h[k], h[k])
+ * pairs zero padded to firp_taps_len(D, ntaps) taps, nothing in front -- and that `mx` may be NULL for float2 input.
+ * The history a stage keeps (H >= ntaps - 1, any length) is the same, so a stage can go back and forth between the
+ * two kernels from batch to batch.                                                                               */
+struct GenMixArgs;
+bool firp_supported(int D, int ntaps);
+int  firp_taps_len(int D, int ntaps);
+int  firp_nbq(int D, int ntaps);
+size_t firp_lds_bytes(int D, int ntaps);
+hipError_t launch_firp(int infmt, bool mix, const void *in, const void *hist, int H, long long first, long long n_out,
+                       int D, const float *taps2, int ntaps, float *out, void *hist_out, long long n_batch,
+                       const GenMixArgs *mx, hipStream_t s);
+hipError_t launch_firp_packed(const void *in_packed, const void *hist_packed, int H, long long first, long long n_out,
+                              int D, const float *taps2, int ntaps, float *out, void *hist_out_packed, long long n_batch,
+                              bool mix, unsigned long long n0, uint32_t freg, uint32_t phase_off, uint32_t freg_hist,
+                              const float *lo_c, const float *lo_s, const float *lo_c_hist, const float *lo_s_hist,
+                              hipStream_t s);
 
 /* false when even the smallest block shape of the generic kernel cannot stage its input span
  * ((63*D + ntaps + 10) samples) in the 160 KiB of LDS: such a stage is refused at create time */

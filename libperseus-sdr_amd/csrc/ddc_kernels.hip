@@ -528,6 +528,307 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float2 *__restrict__ 
 }
 
 /* ======================================================================== */
+/* k_firp : register-blocked decimator for any D (tails, first stages that are not /8) */
+/* ======================================================================== */
+/* out[q] = sum_k h[k] * x[first + q*D - k], like k_fir_generic, with k_fir8's arithmetic shape carried over to any D:
+ * a lane owns P CONSECUTIVE outputs, and the TAP BLOCK j (taps jD .. jD+D-1) is the outer loop -- output m meets tap
+ * block j on the sample block b = m - j (block b = inputs bD .. bD+D-1 of the tile), so at step j the lane's P outputs
+ * need the P blocks m0-j .. m0-j+P-1: one NEW block of D LDS reads per step, kept with the P-1 before it in a ring of
+ * registers whose slot numbers are static once the loop is unrolled by P, feeds P*D packed FMAs.  One block of D
+ * taps is live at a time, wave-uniform, from the scalar cache as (h, h) pairs.  LDS reads per output: ntaps/P + D
+ * (the generic kernel: ntaps, and the LDS, not the FMAs, bounded it: D = 10 / 287 taps 200 us at 2^25 samples where
+ * the FMAs need 30).  Samples lie in LDS as interleaved (I, Q) pairs -- a packed FMA does both rails, so odd D needs
+ * no parity tricks -- in SEGMENTS of P*D (one lane's own blocks) with one pad pair behind a segment of even length:
+ * lane stride odd in pairs, conflict-free ds_read_b64.  The window walks backwards one segment per loop iteration,
+ * so every address of the loop body is the iteration's base pointer plus a constant.
+ * A block of 256 threads makes 256*P outputs from its own copy of the span (tile + NB*D samples of history: 2-4 %
+ * re-read); the blocks resident on a CU overlap each other's load and filter phases.  (A persistent variant with the
+ * next tile prefetched into registers measured SLOWER -- packed /10 first stage 0.63 against 0.55 ms at 2^28 samples:
+ * the filter phase of a tile is too short to cover a load -- and was dropped, profiles/r03/e_firp_persistent.txt.)
+ * INFMT = IN_PACKED24: the batch and its history are 24-bit packed (stage 0): unpack -- and MIX: NCO -- while staging,
+ * exactly as k_fir_generic<.., PACKED, MIX> does.
+ * The body is a device function: k_fir8 runs it in the extra blocks that carry the previous batch's tail.        */
+struct FirpArgs {
+    const void *in;          /* batch: float2 or packed                                                   */
+    const void *hist;        /* the H samples in front of it, same format                                  */
+    void       *hist_out;    /* receives the last H samples of [hist | batch] (or NULL)                    */
+    float      *out;         /* float2 outputs                                                             */
+    const float *taps2;      /* (h[k], h[k]) pairs, zero padded to nbq*P*D taps                            */
+    long long   first, n_out, n_batch;
+    int         H, nbq;      /* history samples; loop iterations = tap blocks / P                          */
+    GenMixArgs  mx;
+};
+
+template <int D, int P>
+struct FirpGeom {
+    static constexpr int PD   = P * D;
+    static constexpr int SEGW = PD + ((PD & 1) ? 0 : 1);      /* pairs per segment incl. pad */
+    static constexpr int TO   = 256 * P;                      /* outputs per block           */
+};
+
+constexpr int firp_p_of(int D) { return D >= 8 ? 2 : 4; }     /* outputs per lane (LDS: 256 segments of P*D pairs) */
+
+template <int D, int P, int INFMT, bool MIX>
+__device__ __forceinline__ void firp_block(const FirpArgs &a, const int bid, float2 *sdp)
+{
+    using G = FirpGeom<D, P>;
+    f32x2 *sd = reinterpret_cast<f32x2 *>(sdp) + G::SEGW;     /* one spare segment in front, one behind the span */
+    const int tid = threadIdx.x;
+    const int GH = a.nbq;                                     /* history segments in front of the tile          */
+    const int span = (GH + 256) * G::PD;                      /* samples staged: NB*D of history + the tile     */
+    const long long t0 = (long long)bid * G::TO;              /* first output of the block                      */
+    /* tile input i (0 .. TI-1; history i < 0) is staged sample GH*PD + i; output m of the tile = sum_k h[k]*in[mD+D-1-k] */
+    const long long s0 = a.first + t0 * D - (D - 1) - (long long)GH * G::PD;     /* batch index of staged sample 0 */
+    auto slot_of = [&](int i) {                               /* staged sample i -> LDS pair index              */
+        const int seg = i / G::PD;
+        return seg * G::SEGW + (i - seg * G::PD);
+    };
+    if (INFMT == IN_PACKED24) {
+        /* Staging is most of this kernel's work at the full input rate (the /10 first stage has 7 FMAs per sample).  A
+         * lane takes PAIRS of samples -- 12 bytes, one global_load_dwordx3 -- and consecutive lanes consecutive pairs, so
+         * its two LDS writes land 16 bytes from its neighbours' (2-way on ds_write_b64).  With a whole group of 8 samples
+         * per lane, as k_fir_generic stages them, the lanes of a write are 64 bytes apart: an 8-way bank conflict on every
+         * one, 0.3 ms of LDS-array time per 2^28 samples -- what held this kernel (and holds that one) at 3.3 TB/s.
+         * The samples stay the integers the unpack yields (the host folds RN(1/8388607)/256 into this stage's taps, like
+         * k_fir8); the NCO takes ONE sin/cos per thread -- a thread's pairs lie 512 samples apart, the next one's phasor
+         * is the last one's times LO(512); only the batch's first block can meet samples of the previous batch, mixed
+         * with the previous tuning word (exact phase per pair there).                                             */
+        const uint8_t *inb = static_cast<const uint8_t *>(a.in);
+        const uint8_t *hb8 = static_cast<const uint8_t *>(a.hist);
+        const GenMixArgs &mx = a.mx;
+        const long long xa = s0 & ~1LL;                        /* pairs start at even sample indices (4-byte aligned) */
+        const int shift = (int)(s0 - xa);                      /* 0 or 1 */
+        const int npairs = (span + shift + 1) >> 1;
+        constexpr int NPF = (G::PD * (256 + 16) / 2 + 1 + 255) / 256;       /* pairs per thread */
+        struct W3 { uint32_t a, b, c; };
+        if (xa >= 0 && xa + 2LL * 256 * NPF <= a.n_batch) {
+            /* interior block (uniform): no history, nothing beyond the batch, and every staged index a pair can
+             * touch (-1 .. span) has a slot thanks to the spare segments: straight-line code                  */
+            const uint8_t *src0 = inb + xa * 6 + 12 * tid;
+            W3 rw[NPF];
+#pragma unroll
+            for (int u = 0; u < NPF; ++u)
+                rw[u] = *reinterpret_cast<const W3 *>(src0 + 12 * 256 * u);
+            float gc = 1.0f, gs = 0.0f, kc = 1.0f, ks = 0.0f;
+            if (MIX) {
+                nco_lo((uint32_t)(mx.n0 + (unsigned long long)(xa + 2LL * tid)) * mx.freg + mx.phase_off, gc, gs);
+                nco_lo(512u * mx.freg, kc, ks);
+            }
+            const float stc = mx.lo_c[1], sts = mx.lo_s[1];
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                float x0i = (float)(int32_t)__builtin_amdgcn_perm(rw[u].a, rw[u].a, 0x0201000cu);
+                float x0q = (float)(int32_t)__builtin_amdgcn_perm(rw[u].b, rw[u].a, 0x0504030cu);
+                float x1i = (float)(int32_t)__builtin_amdgcn_perm(rw[u].c, rw[u].b, 0x0403020cu);
+                float x1q = (float)(int32_t)(rw[u].c & 0xffffff00u);
+                if (MIX) {
+                    if (u > 0)
+                        cmul(gc, gs, kc, ks);
+                    const float c1 = gc * stc - gs * sts, s1 = gc * sts + gs * stc;
+                    cmul(x0i, x0q, gc, gs);
+                    cmul(x1i, x1q, c1, s1);
+                }
+                /* staged index of the pair's first sample, plus one segment: -1 .. span+ lands in the spare segments */
+                const unsigned i0 = (unsigned)(2 * (tid + 256 * u) - shift + G::PD);
+                const unsigned seg = i0 / G::PD;
+                const unsigned within = i0 - seg * G::PD;
+                f32x2 *dstp = sd + (int)(seg * G::SEGW + within) - G::SEGW;
+                dstp[0] = f32x2{ x0i, x0q };
+                dstp[within == G::PD - 1 ? 1 + G::SEGW - G::PD : 1] = f32x2{ x1i, x1q };
+            }
+        } else {
+        W3 raw[NPF];
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int j = tid + 256 * u;
+            const long long sp = xa + 2LL * j;
+            const uint8_t *src = nullptr;
+            if (j < npairs) {
+                if (sp < 0) {
+                    if (sp >= -(long long)a.H)
+                        src = hb8 + (sp + a.H) * 6;
+                } else if (sp < a.n_batch) {
+                    src = inb + sp * 6;
+                }
+            }
+            raw[u] = src ? *reinterpret_cast<const W3 *>(src) : W3{ 0u, 0u, 0u };
+        }
+        float gc = 1.0f, gs = 0.0f, kc = 1.0f, ks = 0.0f;
+        const bool has_old = MIX && xa < 0;                    /* uniform: the batch's first block only */
+        const uint32_t off_old = mx.phase_off + (uint32_t)mx.n0 * (mx.freg - mx.freg_hist);
+        if (MIX) {
+            nco_lo((uint32_t)(mx.n0 + (unsigned long long)(xa + 2LL * tid)) * mx.freg + mx.phase_off, gc, gs);
+            nco_lo(512u * mx.freg, kc, ks);
+        }
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int j = tid + 256 * u;
+            if (u > 0 && MIX)
+                cmul(gc, gs, kc, ks);
+            if (j >= npairs)
+                continue;
+            /* 3 dwords = 2 samples -> MSB-aligned integers (the iq_sample placement, cf. unpack8_msb) */
+            float x0i = (float)(int32_t)__builtin_amdgcn_perm(raw[u].a, raw[u].a, 0x0201000cu);
+            float x0q = (float)(int32_t)__builtin_amdgcn_perm(raw[u].b, raw[u].a, 0x0504030cu);
+            float x1i = (float)(int32_t)__builtin_amdgcn_perm(raw[u].c, raw[u].b, 0x0403020cu);
+            float x1q = (float)(int32_t)(raw[u].c & 0xffffff00u);
+            if (MIX) {
+                float c0 = gc, s0p = gs, c1, s1;
+                float stc = mx.lo_c[1], sts = mx.lo_s[1];
+                if (has_old) {                                 /* uniform branch */
+                    const long long sp = xa + 2LL * j;
+                    if (sp < 0) {
+                        nco_lo((uint32_t)(mx.n0 + (unsigned long long)sp) * mx.freg_hist + off_old, c0, s0p);
+                        stc = mx.lo_c_hist[1];
+                        sts = mx.lo_s_hist[1];
+                    }
+                }
+                c1 = c0 * stc - s0p * sts;
+                s1 = c0 * sts + s0p * stc;
+                cmul(x0i, x0q, c0, s0p);
+                cmul(x1i, x1q, c1, s1);
+            }
+            const int i0 = 2 * j - shift;                      /* staged index of the pair's first sample */
+            if (i0 >= 0 && i0 + 1 < span) {
+                const int seg = i0 / G::PD;
+                const int within = i0 - seg * G::PD;
+                f32x2 *dstp = sd + seg * G::SEGW + within;
+                dstp[0] = f32x2{ x0i, x0q };
+                dstp[within == G::PD - 1 ? 1 + G::SEGW - G::PD : 1] = f32x2{ x1i, x1q };
+            } else {
+                if (i0 >= 0 && i0 < span)
+                    sd[slot_of(i0)] = f32x2{ x0i, x0q };
+                if (i0 + 1 >= 0 && i0 + 1 < span)
+                    sd[slot_of(i0 + 1)] = f32x2{ x1i, x1q };
+            }
+        }
+        }
+    } else {
+        const float2 *in = static_cast<const float2 *>(a.in);
+        const float2 *hist = static_cast<const float2 *>(a.hist);
+        if (s0 >= 0 && s0 + span + 1 <= a.n_batch) {
+            /* interior block: the whole span in ONE round trip -- up to 12 loads of 16 bytes (two samples) per thread, all
+             * in flight before the first LDS write.  (In batches of 8 eight-byte loads a tile took three dependent round
+             * trips, 6 of its 13 us: a carried tail, one block per CU, then outlasted the first stage it rides with.)  */
+            const float2 *src = in + s0;
+            u32x4 v[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int ii = 2 * (tid + 256 * u);
+                v[u] = ii < span ? *reinterpret_cast<const u32x4 *>(src + ii) : u32x4{ 0u, 0u, 0u, 0u };
+            }
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int ii = 2 * (tid + 256 * u);
+                if (ii < span)
+                    sd[slot_of(ii)] = f32x2{ __uint_as_float(v[u].x), __uint_as_float(v[u].y) };
+                if (ii + 1 < span)
+                    sd[slot_of(ii + 1)] = f32x2{ __uint_as_float(v[u].z), __uint_as_float(v[u].w) };
+            }
+        } else {
+            for (int i = tid; i < span; i += 256) {
+                const long long sx = s0 + i;
+                float2 v = make_float2(0.0f, 0.0f);
+                if (sx < 0) {
+                    if (sx >= -(long long)a.H)
+                        v = hist[sx + a.H];
+                } else if (sx < a.n_batch) {
+                    v = in[sx];
+                }
+                sd[slot_of(i)] = f32x2{ v.x, v.y };
+            }
+        }
+    }
+    if (a.hist_out != nullptr && bid == 0) {                   /* the next call's history */
+        if (INFMT == IN_PACKED24) {
+            const int Hw = a.H * 6 / 4;
+            const long long nw = a.n_batch * 6 / 4;
+            const uint32_t *hw = static_cast<const uint32_t *>(a.hist), *bw = static_cast<const uint32_t *>(a.in);
+            uint32_t *ow = static_cast<uint32_t *>(a.hist_out);
+            for (int i = tid; i < Hw; i += 256) {
+                const long long j = (long long)i + nw;
+                ow[i] = j < Hw ? hw[j] : bw[j - Hw];
+            }
+        } else {
+            const float2 *in = static_cast<const float2 *>(a.in), *hist = static_cast<const float2 *>(a.hist);
+            float2 *ho = static_cast<float2 *>(a.hist_out);
+            for (int i = tid; i < a.H; i += 256) {
+                const long long j = (long long)i + a.n_batch;
+                ho[i] = j < a.H ? hist[j] : in[j - a.H];
+            }
+        }
+    }
+    __syncthreads();
+    /* the lane's own segment: tile segment `tid`, i.e. staged segment GH + tid */
+    const f32x2 *seg = sd + (GH + tid) * G::SEGW;
+    f32x2 blk[P][D];
+#pragma unroll
+    for (int pb = 1; pb < P; ++pb)
+#pragma unroll
+        for (int e = 0; e < D; ++e)
+            blk[pb][e] = seg[pb * D + e];
+    f32x2 acc[P][2];
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+        acc[r][0] = acc[r][1] = f32x2{ 0.0f, 0.0f };
+    const f32x2 PDDC_CONSTANT *tp = (const f32x2 PDDC_CONSTANT *)a.taps2;
+    for (int q = 0; q < a.nbq; ++q) {
+#pragma unroll
+        for (int jj = 0; jj < P; ++jj) {
+            const int slot = (P - jj) % P;
+#pragma unroll
+            for (int e = 0; e < D; ++e)
+                blk[slot][e] = jj == 0 ? seg[e] : seg[-G::SEGW + (P - jj) * D + e];
+#pragma unroll
+            for (int e = 0; e < D; ++e) {
+                const f32x2 h = tp[jj * D + e];
+#pragma unroll
+                for (int r = 0; r < P; ++r)
+                    acc[r][e & 1] = __builtin_elementwise_fma(h, blk[(r - jj + P) % P][D - 1 - e], acc[r][e & 1]);
+            }
+        }
+        seg -= G::SEGW;
+        tp += P * D;
+    }
+    const long long m = t0 + (long long)P * tid;
+    f32x2 *op = reinterpret_cast<f32x2 *>(a.out) + m;
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+        if (m + r < a.n_out)
+            op[r] = acc[r][0] + acc[r][1];
+}
+
+/* one block of a carried tail (GenTail): the generic decimator's body, or k_firp's for decimations 4, 5, 10 */
+__device__ __forceinline__ void run_tail_block(const GenTail &t, const int bid, float2 *sd_tail)
+{
+    if (t.kind == 1) {
+        FirpArgs fa;
+        fa.in = t.in;
+        fa.hist = t.hist;
+        fa.hist_out = t.hist_out;
+        fa.out = t.out;
+        fa.taps2 = t.taps2;
+        fa.first = t.first;
+        fa.n_out = t.n_out;
+        fa.n_batch = t.n_batch;
+        fa.H = t.H;
+        fa.nbq = t.nbq;
+        if (t.D == 4)
+            firp_block<4, firp_p_of(4), IN_F32C, false>(fa, bid, sd_tail);
+        else if (t.D == 5)
+            firp_block<5, firp_p_of(5), IN_F32C, false>(fa, bid, sd_tail);
+        else
+            firp_block<10, firp_p_of(10), IN_F32C, false>(fa, bid, sd_tail);
+    } else {
+        const GenMixArgs nomix = {};
+        fir_generic_body<1, false, false>(reinterpret_cast<const float2 *>(t.in), reinterpret_cast<const float2 *>(t.hist),
+                                          t.H, t.first, t.n_out, t.D, (const float PDDC_CONSTANT *)t.taps, t.ntaps,
+                                          reinterpret_cast<float2 *>(t.out), t.span, t.a,
+                                          reinterpret_cast<float2 *>(t.hist_out), t.n_batch, nomix, bid, sd_tail, 256);
+    }
+}
+
+/* ======================================================================== */
 /* k_fir8 : fused unpack + mix + polyphase decimate-by-8                    */
 /* ======================================================================== */
 /* LDS plane layout: group G (8 samples) lives at float offset
@@ -806,16 +1107,10 @@ __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, i
      * decimator on the PREVIOUS batch's second-stage outputs (its tail, Fir8Args::tail).  They are dealt out behind the
      * pair's persistent blocks and live on the waves those leave idle (the pair issues vector instructions 38 % of the
      * time and holds two of a SIMD's three possible waves).                                                     */
-    constexpr bool CARRY = NTB2 > 0 && SL3 == 0 && NT == 256;
+    constexpr bool CARRY = SL3 == 0 && NT == 256 && R == 4 && INFMT == IN_PACKED24;
     if (CARRY && (int)blockIdx.x >= (int)gridDim.x - p.tail.nblocks) {
         extern __shared__ __attribute__((aligned(16))) float2 sd_tail[];
-        const GenTail &t = p.tail;
-        const GenMixArgs nomix = {};
-        fir_generic_body<1, false, false>(reinterpret_cast<const float2 *>(t.in), reinterpret_cast<const float2 *>(t.hist), t.H,
-                                          t.first, t.n_out, t.D, (const float PDDC_CONSTANT *)t.taps, t.ntaps,
-                                          reinterpret_cast<float2 *>(t.out), t.span, t.a,
-                                          reinterpret_cast<float2 *>(t.hist_out), t.n_batch, nomix,
-                                          (int)blockIdx.x - ((int)gridDim.x - t.nblocks), sd_tail, 256);
+        run_tail_block(p.tail, (int)blockIdx.x - ((int)gridDim.x - p.tail.nblocks), sd_tail);
         return;
     }
     static_assert(NT == 256 || (NT == 128 && R == 8 && NTB2 == 0), "128-thread blocks: R = 8, no fused second stage");
@@ -1800,7 +2095,13 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
     if (a.sched == nullptr)
         return hipErrorInvalidValue;
     const Fir8Sched sc = fir8_schedule(ntiles, R, false, NT);
-    const dim3 grid((unsigned)sc.nblocks), blk(NT);
+    /* a carried tail (packed R = 4 first stages only): its blocks behind the persistent ones, LDS for the larger of the two */
+    const bool carry_ok = R == 4 && NT == 256 && fmt == IN_PACKED24;
+    if (a.tail.nblocks < 0 || (a.tail.nblocks > 0 && (!carry_ok || a.tail.lds > kCarryLdsCap)))
+        return hipErrorInvalidValue;
+    const size_t lds_launch = a.tail.nblocks > 0 && a.tail.lds > lds ? a.tail.lds : lds;
+    const size_t lds_attr = lds > kCarryLdsCap ? lds : kCarryLdsCap;
+    const dim3 grid((unsigned)(sc.nblocks + a.tail.nblocks)), blk(NT);
 #define PDDC_LAUNCH(FMT, MIXV)                                                                    \
     do {                                                                                          \
         static unsigned long long attr_done = 0;   /* one bit per device: the attribute is per device */ \
@@ -1809,12 +2110,12 @@ static hipError_t launch_fir8_t(InFmt fmt, bool mix, const Fir8Args &a, hipStrea
         if (!(attr_done >> (dev__ & 63) & 1ull)) {                                                \
             hipError_t e = hipFuncSetAttribute(                                                   \
                 reinterpret_cast<const void *>(&k_fir8<NTB, R, FMT, MIXV, 0, NT>),                \
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr);                       \
             if (e != hipSuccess)                                                                  \
                 return e;                                                                         \
             attr_done |= 1ull << (dev__ & 63);                                                    \
         }                                                                                         \
-        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV, 0, NT>), grid, blk, lds, s, a, ntiles, sc.S, sc.K); \
+        hipLaunchKernelGGL((k_fir8<NTB, R, FMT, MIXV, 0, NT>), grid, blk, lds_launch, s, a, ntiles, sc.S, sc.K); \
     } while (0)
     if (fmt == IN_PACKED24) {
         if (mix)
@@ -1846,8 +2147,10 @@ static hipError_t launch_fir8_fused2_t(bool mix, const Fir8Args &a, hipStream_t 
     if (a.sched == nullptr)
         return hipErrorInvalidValue;
     const Fir8Sched sc = fir8_schedule(ntiles, R, true);
-    if (a.tail.nblocks < 0 || (a.tail.nblocks > 0 && a.tail.lds > lds))
-        return hipErrorInvalidValue;             /* a carried tail block must fit the pair's LDS */
+    if (a.tail.nblocks < 0 || (a.tail.nblocks > 0 && (R != 4 || a.tail.lds > kCarryLdsCap)))
+        return hipErrorInvalidValue;
+    const size_t lds_launch = a.tail.nblocks > 0 && a.tail.lds > lds ? a.tail.lds : lds;
+    const size_t lds_attr = lds > kCarryLdsCap ? lds : kCarryLdsCap;
     const dim3 grid((unsigned)(sc.nblocks + a.tail.nblocks)), blk(256);
 #define PDDC_LAUNCH2(MIXV)                                                                        \
     do {                                                                                          \
@@ -1857,12 +2160,12 @@ static hipError_t launch_fir8_fused2_t(bool mix, const Fir8Args &a, hipStream_t 
         if (!(attr_done >> (dev__ & 63) & 1ull)) {                                                \
             hipError_t e = hipFuncSetAttribute(                                                   \
                 reinterpret_cast<const void *>(&k_fir8<NTB, R, IN_PACKED24, MIXV, 8>),            \
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr);                       \
             if (e != hipSuccess)                                                                  \
                 return e;                                                                         \
             attr_done |= 1ull << (dev__ & 63);                                                    \
         }                                                                                         \
-        hipLaunchKernelGGL((k_fir8<NTB, R, IN_PACKED24, MIXV, 8>), grid, blk, lds, s, a, ntiles,  \
+        hipLaunchKernelGGL((k_fir8<NTB, R, IN_PACKED24, MIXV, 8>), grid, blk, lds_launch, s, a, ntiles, \
                            sc.S, sc.K);                                                           \
     } while (0)
     if (mix)
@@ -2237,10 +2540,149 @@ static hipError_t launch_fir_generic_any(const void *in, const void *hist, int H
     return hipGetLastError();
 }
 
-bool gen_tail_shape(GenTail *t, size_t lds_cap)
+template <int D, int P, int INFMT, bool MIX>
+__global__ __launch_bounds__(256) void k_firp(FirpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 sdp[];
+    /* (Carrying the previous batch's tail in this grid, as k_fir8 does, was tried for the packed first stage -- tail
+     * blocks behind the grid start too late to overlap anything, spread through it they cost the first stage more
+     * than they save: 10*5 plan 0.507 -> 0.536 ms -- and is not done.)                                           */
+    const int bid = (int)blockIdx.x;
+    firp_block<D, P, INFMT, MIX>(a, bid, sdp);
+}
+
+/* which D are built: first stages /10 and /5, tails /4 /5 /10 (the reference's rate plans) */
+int firp_nbq(int D, int ntaps)
+{
+    const int P = firp_p_of(D);
+    return ((ntaps + D - 1) / D + P - 1) / P;
+}
+
+size_t firp_lds_bytes(int D, int ntaps)
+{
+    const int P = firp_p_of(D), pd = P * D, segw = pd + ((pd & 1) ? 0 : 1);
+    return (size_t)(firp_nbq(D, ntaps) + 256 + 2) * segw * sizeof(float2);
+}
+
+bool firp_supported(int D, int ntaps)
+{
+    if (getenv("PDDC_NO_FIRP"))
+        return false;
+    if (!(D == 4 || D == 5 || D == 10) || ntaps < 1)
+        return false;
+    if ((long long)(firp_nbq(D, ntaps) + 256) * firp_p_of(D) * D > 6144)       /* a tile's span: 12 x 2 samples per thread */
+        return false;
+    return firp_lds_bytes(D, ntaps) <= 96u * 1024u;
+}
+
+int firp_taps_len(int D, int ntaps)            /* taps the duplicated table must hold (zero padded) */
+{
+    return firp_nbq(D, ntaps) * firp_p_of(D) * D;
+}
+
+template <int D, int P = firp_p_of(D)>
+static hipError_t launch_firp_t(int infmt, bool mix, const FirpArgs &a, int ntaps, hipStream_t s)
+{
+    using G = FirpGeom<D, P>;
+    const size_t lds = (size_t)(a.nbq + 256 + 2) * G::SEGW * sizeof(float2);
+    const long long ntiles = (a.n_out + G::TO - 1) / G::TO;
+    if (ntiles > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+    const size_t lds_launch = lds;
+    const dim3 grid((unsigned)ntiles), blk(256);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+#define PDDC_FIRP(FMT, MX)                                                                         \
+    do {                                                                                          \
+        static bool attr_done[64] = { false };                                                    \
+        if (!attr_done[dev & 63]) {                                                               \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_firp<D, P, FMT, MX>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            if (e != hipSuccess)                                                                  \
+                return e;                                                                         \
+            attr_done[dev & 63] = true;                                                           \
+        }                                                                                         \
+        hipLaunchKernelGGL((k_firp<D, P, FMT, MX>), grid, blk, lds_launch, s, a);                 \
+    } while (0)
+    if (infmt == IN_PACKED24) {
+        if (mix)
+            PDDC_FIRP(IN_PACKED24, true);
+        else
+            PDDC_FIRP(IN_PACKED24, false);
+    } else {
+        PDDC_FIRP(IN_F32C, false);
+    }
+#undef PDDC_FIRP
+    return hipGetLastError();
+}
+
+/* same contract as launch_fir_generic / launch_fir_generic_packed; `taps2` = (h, h) pairs zero padded to
+ * firp_taps_len(D, ntaps) taps                                                                                 */
+hipError_t launch_firp(int infmt, bool mix, const void *in, const void *hist, int H, long long first, long long n_out,
+                       int D, const float *taps2, int ntaps, float *out, void *hist_out, long long n_batch,
+                       const GenMixArgs *mx, hipStream_t s)
+{
+    if (n_out <= 0)
+        return hipSuccess;
+    if (!firp_supported(D, ntaps) || (infmt == IN_PACKED24 && ((H & 7) || (n_batch & 7))))
+        return hipErrorInvalidValue;
+    FirpArgs a;
+    a.in = in;
+    a.hist = hist;
+    a.hist_out = hist_out;
+    a.out = out;
+    a.taps2 = taps2;
+    a.first = first;
+    a.n_out = n_out;
+    a.n_batch = n_batch;
+    a.H = H;
+    a.nbq = firp_nbq(D, ntaps);
+    a.mx = mx ? *mx : GenMixArgs{};
+    /* development: PDDC_FIRP_PACKED_P=1 gives the packed /10 first stage tiles of 256 outputs (one per lane) */
+    static const int pp = getenv("PDDC_FIRP_PACKED_P") ? atoi(getenv("PDDC_FIRP_PACKED_P")) : 0;
+    if (D == 10 && infmt == IN_PACKED24 && pp == 1) {
+        a.nbq = (ntaps + D - 1) / D;
+        return launch_firp_t<10, 1>(infmt, mix, a, ntaps, s);
+    }
+    if (D == 4) return launch_firp_t<4>(infmt, mix, a, ntaps, s);
+    if (D == 5) return launch_firp_t<5>(infmt, mix, a, ntaps, s);
+    if (D == 10) return launch_firp_t<10>(infmt, mix, a, ntaps, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_firp_packed(const void *in_packed, const void *hist_packed, int H, long long first, long long n_out,
+                              int D, const float *taps2, int ntaps, float *out, void *hist_out_packed, long long n_batch,
+                              bool mix, unsigned long long n0, uint32_t freg, uint32_t phase_off, uint32_t freg_hist,
+                              const float *lo_c, const float *lo_s, const float *lo_c_hist, const float *lo_s_hist,
+                              hipStream_t s)
+{
+    GenMixArgs mx = {};
+    mx.n0 = n0;
+    mx.freg = freg;
+    mx.phase_off = phase_off;
+    mx.freg_hist = freg_hist;
+    for (int e = 0; e < 8; ++e) {
+        mx.lo_c[e] = lo_c ? lo_c[e] : 1.0f;
+        mx.lo_s[e] = lo_s ? lo_s[e] : 0.0f;
+        mx.lo_c_hist[e] = lo_c_hist ? lo_c_hist[e] : 1.0f;
+        mx.lo_s_hist[e] = lo_s_hist ? lo_s_hist[e] : 0.0f;
+    }
+    return launch_firp(IN_PACKED24, mix, in_packed, hist_packed, H, first, n_out, D, taps2, ntaps, out, hist_out_packed,
+                       n_batch, &mx, s);
+}
+
+bool gen_tail_shape(GenTail *t, size_t lds_cap, bool have_taps2)
 {
     if (!t || t->D < 1 || t->ntaps < 1 || t->n_out < 1)
         return false;
+    if (have_taps2 && firp_supported(t->D, t->ntaps) && firp_lds_bytes(t->D, t->ntaps) <= lds_cap) {
+        t->kind = 1;
+        t->nbq = firp_nbq(t->D, t->ntaps);
+        t->lds = (unsigned)firp_lds_bytes(t->D, t->ntaps);
+        t->nblocks = (int)((t->n_out + 256 * firp_p_of(t->D) - 1) / (256 * firp_p_of(t->D)));
+        return true;
+    }
+    t->kind = 0;
     const long long sp = 255LL * t->D + t->ntaps;                 /* 256 threads, one output each */
     if (sp > (1 << 20))
         return false;
@@ -2258,6 +2700,9 @@ hipError_t launch_gen_tail(const GenTail &t, hipStream_t s)
 {
     if (t.nblocks <= 0)
         return hipSuccess;
+    if (t.kind == 1)
+        return launch_firp(IN_F32C, false, t.in, t.hist, t.H, t.first, t.n_out, t.D, t.taps2, t.ntaps, t.out, t.hist_out,
+                           t.n_batch, nullptr, s);
     int dev = 0;
     (void)hipGetDevice(&dev);
     static bool attr_done[64] = { false };

@@ -69,6 +69,7 @@ struct Stage {
     float *d_taps_blk = nullptr;  /* [ntb][8] block-reversed (fused kernel)     */
     float *d_taps_poly = nullptr; /* rational stage: [L][Kp] polyphase rows g[ph][j] = h[j*L + ph] */
     float *d_taps_seg = nullptr;  /* stage 2 as the fused cascade's third stage: h[k] zero padded to spl*seglen */
+    float *d_taps_firp = nullptr; /* k_firp (plain decimators by 4, 5, 10): (h[k], h[k]) zero padded to firp_taps_len */
     int poly_k = 0, poly_kp = 0;
     int ntb = 0;                  /* tap blocks if fused-capable, else 0        */
     int hist = 0;                 /* history length in samples (mult. of 8)     */
@@ -238,6 +239,19 @@ static int upload_taps(pddc_pipeline *p, int si)
     if (s.d_taps_poly) {
         hipFree(s.d_taps_poly);
         s.d_taps_poly = nullptr;
+    }
+    if (s.d_taps_firp) {
+        hipFree(s.d_taps_firp);
+        s.d_taps_firp = nullptr;
+    }
+    if (s.interp == 1 && !(p->flags & PDDC_F_NO_FAST) && firp_supported(s.decim, s.ntaps)) {
+        /* stage 0 runs k_firp on the packed samples, which leaves the unpack scale to the taps (like k_fir8) */
+        const float tap_scale = si == 0 ? kFir8PackedTapScale : 1.0f;
+        std::vector<float> t2(2 * (size_t)firp_taps_len(s.decim, s.ntaps), 0.0f);
+        for (int k = 0; k < s.ntaps; ++k)
+            t2[2 * (size_t)k] = t2[2 * (size_t)k + 1] = s.taps[k] * tap_scale;
+        HIP_TRY(hipMalloc(&s.d_taps_firp, sizeof(float) * t2.size()));
+        HIP_TRY(hipMemcpy(s.d_taps_firp, t2.data(), sizeof(float) * t2.size(), hipMemcpyHostToDevice));
     }
     if (s.interp > 1 && resample_lds_supported(s.interp, s.decim, s.ntaps)) {
         s.poly_k = (s.ntaps + s.interp - 1) / s.interp;
@@ -728,6 +742,8 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
             hipFree(p->st[i].d_taps_poly);
         if (p->st[i].d_taps_seg)
             hipFree(p->st[i].d_taps_seg);
+        if (p->st[i].d_taps_firp)
+            hipFree(p->st[i].d_taps_firp);
         if (p->st[i].d_buf && !p->st[i].buf_in_ws)
             hipFree(p->st[i].d_buf);
         if (p->st[i].d_buf_alt && !p->st[i].buf_in_ws)
@@ -1133,7 +1149,8 @@ extern "C" size_t pddc_pipeline_workspace_size(const pddc_pipeline *p, size_t ma
         return 0;
     size_t total = 0;
     for (int i = 1; i < p->nstages; ++i)
-        total += ((ws_stage_samples(p, i, max_nsamples) * 8 + 255) & ~(size_t)255) * ((p->overlap && i == 2) ? 2 : 1);
+        total += ((ws_stage_samples(p, i, max_nsamples) * 8 + 255) & ~(size_t)255) *
+                 ((p->overlap && i == p->nstages - 1) ? 2 : 1);
     return total;
 }
 
@@ -1162,7 +1179,7 @@ extern "C" int pddc_pipeline_set_workspace(pddc_pipeline *p, void *d_ws, size_t 
             s.buf_cap = cap;
             s.buf_in_ws = true;
             at += (cap * 8 + 255) & ~(size_t)255;
-            if (p->overlap && i == 2) {
+            if (p->overlap && i == p->nstages - 1) {
                 s.d_buf_alt = reinterpret_cast<float *>(at);
                 s.buf_alt_cap = cap;
                 at += (cap * 8 + 255) & ~(size_t)255;
@@ -1315,12 +1332,58 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         return PDDC_OK;
     };
 
+    /* Overlap mode: the plan's LAST stage `ti` (a plain decimator behind one first-stage kernel: the fused pair, or the
+     * unfused fused-/8 stage 0) is held back and rides along with the next batch's first-stage launch.  Prepares its
+     * record: shape, the half of the double-buffered input the first stage writes this time, history, output.   */
+    auto carry_setup = [&](int ti, float **dst_first, GenTail *mine) -> int {
+        Stage &sl = p->st[ti];
+        mine->H = sl.hist;
+        mine->D = sl.decim;
+        mine->ntaps = sl.ntaps;
+        mine->n_out = (long long)n_in[ti + 1];
+        if (!gen_tail_shape(mine, kCarryLdsCap, sl.d_taps_firp != nullptr))
+            return 1;                                    /* does not fit: in line */
+        if (p->ov_parity == 1) {
+            if (sl.buf_in_ws) {
+                if (sl.d_buf_alt == nullptr || sl.buf_alt_cap < n_in[ti] + 8)
+                    return fail(PDDC_ECAPACITY, "overlap mode: the workspace was set before pddc_pipeline_set_overlap, "
+                                                "or for smaller batches (it needs two halves for the last stage)");
+            } else if (sl.buf_alt_cap < n_in[ti] + 8) {
+                HIP_TRY(hipDeviceSynchronize());
+                if (sl.d_buf_alt)
+                    HIP_TRY(hipFree(sl.d_buf_alt));
+                sl.d_buf_alt = nullptr;
+                sl.buf_alt_cap = 0;
+                HIP_TRY(hipMalloc(&sl.d_buf_alt, sizeof(float) * 2 * sl.buf_cap));
+                sl.buf_alt_cap = sl.buf_cap;
+            }
+            *dst_first = sl.d_buf_alt;
+        }
+        float *dst_last;
+        int r = stage_dst(ti, &dst_last, false);
+        if (r)
+            return r;
+        mine->in = *dst_first;
+        mine->hist = static_cast<const float *>(sl.d_hist[sl.cur]);
+        mine->hist_out = static_cast<float *>(sl.d_hist[sl.cur ^ 1]);
+        mine->out = dst_last;
+        mine->taps = sl.d_taps_dup;
+        mine->taps2 = sl.d_taps_firp;
+        mine->first = (long long)off[ti];
+        mine->n_batch = (long long)n_in[ti];
+        return PDDC_OK;
+    };
+    auto carry_wanted = [&](int ti) {
+        return p->overlap && p->nstages == ti + 1 && p->R == 4 && stage0_fused(p) && p->st[ti].interp == 1 &&
+               !(p->flags & (PDDC_F_OUT_PACKED24 | PDDC_F_NO_FAST)) && n_in[ti + 1] > 0;
+    };
+
     /* Stream state (which history buffer is current, inputs consumed per stage, the sample
      * counter) is committed only after every launch of the batch has been accepted: a failure
      * half way leaves the pipeline exactly where it was, and the batch can be retried.       */
     bool flip[PDDC_MAX_STAGES] = { false, false, false, false };
     int first = 0;
-    bool carried = false;                   /* overlap mode: this batch's last stage is not launched here          */
+    int skip_from = PDDC_MAX_STAGES;        /* overlap mode: stages from here on are held back, not launched here   */
     /* which tuning words does stage 0's history window [n0 - H, n0) hold?  Drop the segments that
      * ended before it.  One word, or the old word all through with the new one starting exactly now:
      * the packed-history kernels handle it (freg_hist).  Anything else: the mixed-history route.  */
@@ -1374,48 +1437,15 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             return rc;
         /* overlap mode: the one stage behind the pair is held back and rides along with the NEXT batch's pair */
         GenTail mine;
-        bool ov = p->overlap && p->nstages == 3 && p->st[2].interp == 1 && !(p->flags & (PDDC_F_OUT_PACKED24 | PDDC_F_NO_FAST)) &&
-                  n_in[3] > 0;
+        bool ov = carry_wanted(2);
         if (ov) {
-            Stage &s2 = p->st[2];
-            mine.H = s2.hist;
-            mine.D = s2.decim;
-            mine.ntaps = s2.ntaps;
-            mine.n_out = (long long)n_in[3];
-            ov = gen_tail_shape(&mine, fir8_fused2_lds_bytes(s0.ntb, p->R));
-        }
-        if (ov) {
-            /* the other half of the double buffer: the tail of the batch before this one reads the first during this launch */
-            Stage &s2 = p->st[2];
-            if (p->ov_parity == 1) {
-                if (s2.buf_in_ws) {
-                    if (s2.d_buf_alt == nullptr || s2.buf_alt_cap < n_in[2] + 8)
-                        return fail(PDDC_ECAPACITY, "overlap mode: the workspace was set before pddc_pipeline_set_overlap, "
-                                                    "or for smaller batches (it needs two halves for stage 2)");
-                } else if (s2.buf_alt_cap < n_in[2] + 8) {
-                    HIP_TRY(hipDeviceSynchronize());
-                    if (s2.d_buf_alt)
-                        HIP_TRY(hipFree(s2.d_buf_alt));
-                    s2.d_buf_alt = nullptr;
-                    s2.buf_alt_cap = 0;
-                    HIP_TRY(hipMalloc(&s2.d_buf_alt, sizeof(float) * 2 * s2.buf_cap));
-                    s2.buf_alt_cap = s2.buf_cap;
-                }
-                dst = s2.d_buf_alt;
-            }
-            float *dst3;
-            if ((rc = stage_dst(2, &dst3, false)))
+            rc = carry_setup(2, &dst, &mine);
+            if (rc < 0)
                 return rc;
-            mine.in = dst;
-            mine.hist = static_cast<const float *>(s2.d_hist[s2.cur]);
-            mine.hist_out = static_cast<float *>(s2.d_hist[s2.cur ^ 1]);
-            mine.out = dst3;
-            mine.taps = s2.d_taps_dup;
-            mine.first = (long long)off[2];
-            mine.n_batch = (long long)n_in[2];
-        } else if ((rc = pddc_pipeline_fence(p, s))) {      /* in line: what is held back goes first */
-            return rc;
+            ov = rc == PDDC_OK;
         }
+        if (!ov && (rc = pddc_pipeline_fence(p, s)))        /* in line: what is held back goes first */
+            return rc;
         Fir8Args a;
         a.in = d_packed;
         a.hist = s0.d_hist[s0.cur];
@@ -1442,14 +1472,13 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             p->carry_tail = mine;
             p->carry_pending = true;
             p->ov_parity ^= 1;
-            carried = true;
             flip[2] = true;
             first = 3;
         }
-    } else if ((rc = pddc_pipeline_fence(p, s))) {          /* any other route runs the later stages in line */
-        return rc;
+    } else if (!(!mixed_hist && carry_wanted(1)) && (rc = pddc_pipeline_fence(p, s))) {
+        return rc;                                          /* any other route runs the later stages in line */
     }
-    for (int i = first; i < p->nstages; ++i) {
+    for (int i = first; i < p->nstages && i < skip_from; ++i) {
         Stage &st = p->st[i];
         if (p->fail_at_stage >= 0 && p->fail_at_stage <= i) {
             p->fail_at_stage = -1;
@@ -1491,6 +1520,17 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                                            st.d_taps_dup, st.ntaps, dst, nullptr, (long long)nsamples, s));
             /* hist_done stays false: the packed history moves on below (x == d_packed) */
         } else if (i == 0 && stage0_fused(p)) {
+            /* overlap mode, two-stage plan: stage 1 is held back and rides along with the next batch's stage 0 */
+            GenTail mine;
+            bool ov = carry_wanted(1) && p->NT == 256;
+            if (ov) {
+                rc = carry_setup(1, &dst, &mine);
+                if (rc < 0)
+                    return rc;
+                ov = rc == PDDC_OK;
+            }
+            if (!ov && (rc = pddc_pipeline_fence(p, s)))
+                return rc;
             Fir8Args a;
             a.in = d_packed;
             a.hist = h_in;
@@ -1499,18 +1539,33 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             a.taps_blk = st.d_taps_blk;
             a.n_in = (long long)nsamples;
             fill_fir8_args(p, a);
+            if (ov && p->carry_pending)
+                a.tail = p->carry_tail;
             if ((rc = stage0_event(p, s, true)))
                 return rc;
             HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s, p->NT));
             if ((rc = stage0_event(p, s, false)))
                 return rc;
             hist_done = a.hist_out != nullptr;
+            if (ov) {
+                p->carry_tail = mine;
+                p->carry_pending = true;
+                p->ov_parity ^= 1;
+                flip[1] = true;
+                skip_from = 1;
+            }
         } else if (i == 0 && stage0_packed_generic(p)) {
             if (n_in[1] > 0) {
-                HIP_TRY(launch_fir_generic_packed(d_packed, h_in, st.hist, (long long)off[0], (long long)n_in[1],
-                                                  st.decim, st.d_taps_dup, st.ntaps, dst, h_out, (long long)nsamples, mix,
-                                                  p->n0, p->freg, p->phase_off, p->freg_applied, p->lo_c, p->lo_s,
-                                                  p->lo_c_applied, p->lo_s_applied, s));
+                if (st.d_taps_firp)           /* register-blocked kernel for /4 /5 /10 */
+                    HIP_TRY(launch_firp_packed(d_packed, h_in, st.hist, (long long)off[0], (long long)n_in[1], st.decim,
+                                               st.d_taps_firp, st.ntaps, dst, h_out, (long long)nsamples, mix, p->n0,
+                                               p->freg, p->phase_off, p->freg_applied, p->lo_c, p->lo_s, p->lo_c_applied,
+                                               p->lo_s_applied, s));
+                else
+                    HIP_TRY(launch_fir_generic_packed(d_packed, h_in, st.hist, (long long)off[0], (long long)n_in[1],
+                                                      st.decim, st.d_taps_dup, st.ntaps, dst, h_out, (long long)nsamples,
+                                                      mix, p->n0, p->freg, p->phase_off, p->freg_applied, p->lo_c, p->lo_s,
+                                                      p->lo_c_applied, p->lo_s_applied, s));
                 hist_done = true;             /* block 0 of the kernel wrote the new (packed) history */
             }
         } else {
@@ -1549,10 +1604,14 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                                             st.d_taps, st.ntaps, dst, s));
                 }
             } else if (n_in[i + 1] > 0) {
-                HIP_TRY(launch_fir_generic(static_cast<const float *>(x), static_cast<const float *>(h_in),
-                                           st.hist, (long long)off[i], (long long)n_in[i + 1], st.decim,
-                                           st.d_taps_dup, st.ntaps, dst, static_cast<float *>(h_out),
-                                           (long long)n_in[i], s));
+                if (st.d_taps_firp)
+                    HIP_TRY(launch_firp(IN_F32C, false, x, h_in, st.hist, (long long)off[i], (long long)n_in[i + 1], st.decim,
+                                        st.d_taps_firp, st.ntaps, dst, h_out, (long long)n_in[i], nullptr, s));
+                else
+                    HIP_TRY(launch_fir_generic(static_cast<const float *>(x), static_cast<const float *>(h_in),
+                                               st.hist, (long long)off[i], (long long)n_in[i + 1], st.decim,
+                                               st.d_taps_dup, st.ntaps, dst, static_cast<float *>(h_out),
+                                               (long long)n_in[i], s));
                 hist_done = true;             /* block 0 of the kernel wrote the new history */
             }
         }
@@ -1562,7 +1621,6 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             flip[i] = true;
         }
     }
-    (void)carried;
     if (p->flags & PDDC_F_OUT_PACKED24)
         HIP_TRY(launch_pack24(p->d_fout, (long long)n_final, d_out, s));
     for (int i = 0; i < p->nstages; ++i) {          /* commit */

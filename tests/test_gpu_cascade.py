@@ -144,16 +144,21 @@ def test_fused_cascade_checkpoint_and_retune(pkg, dev, O, monkeypatch):
 
 
 # ------------------------------------------------------------------ overlap mode (the tail under the next batch's pair)
-@pytest.mark.parametrize("plan", ["8*8*5", "8*8*10", "8*8*4*5"])
+@pytest.mark.parametrize("plan", ["8*8*5", "8*8*10", "8*8*4*5", "8*10", "8*5", "8*7", "10*5", "5*4"])
 def test_overlap_mode_is_bit_identical_and_fenced(pkg, dev, O, plan):
-    """pddc_pipeline_set_overlap: the stage behind the fused pair rides along with the NEXT batch's launch (extra thread
-    blocks of the pair's grid).  Same arithmetic, same order per stage -- so the outputs are bit-identical to the
+    """pddc_pipeline_set_overlap: the last stage -- behind the fused pair, or behind an unfused /8 first stage -- rides
+    along with the NEXT batch's launch (extra thread blocks of the first stage's grid).  Same arithmetic, same order per stage -- so the outputs are bit-identical to the
     in-line pipeline, whatever mix of whole-tile batches (carried) and odd ones (in line, fenced by the library) the
     stream is cut into; a retune in between; outputs read only behind pddc_pipeline_fence.  (The four-stage plan is
     not carried: it must simply still be right with the mode switched on.)"""
     import torch
     pl = plans()
     pl["8*8*4*5"] = pl["8*8*4"] + [(5, lowpass(41, 0.08))]
+    pl["8*10"] = [(8, lowpass(56, 0.05)), (10, lowpass(287, 0.04))]          # the 1 MS/s plan's shape: k_firp's body rides along
+    pl["8*5"] = [(8, lowpass(56, 0.05)), (5, lowpass(144, 0.08))]            # 2 MS/s
+    pl["8*7"] = [(8, lowpass(56, 0.05)), (7, lowpass(99, 0.06))]             # a decimation k_firp is not built for: generic body
+    pl["10*5"] = [(10, lowpass(69, 0.04)), (5, lowpass(144, 0.08))]          # 1.6 MS/s: k_firp reads the packed samples and carries
+    pl["5*4"] = [(5, lowpass(41, 0.08)), (4, lowpass(33, 0.1))]
     stages = pl[plan]
     sizes = [8, 8, 3, 0.25, 16, 1, 1, 1, 0.5, 40, 8]
     cuts = [0]

@@ -22,6 +22,7 @@ ap.add_argument("--log2n", type=int, default=26)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rates", default="")
 ap.add_argument("--no-fast", action="store_true")
+ap.add_argument("--overlap", action="store_true", help="pddc_pipeline_set_overlap: the last stage rides along with the next batch's launch")
 a = ap.parse_args()
 
 L = pkg.sdr_lib()
@@ -49,6 +50,8 @@ for rate in want:
     stages = [(dec[i], taps[i], it[i]) for i in range(n)]
     pipe = pkg.Pipeline(stages, mix=True, no_fast=a.no_fast)
     pipe.set_freg(381178347)
+    if a.overlap:
+        pipe.set_overlap(True)
     out = torch.empty((pipe.max_output(ns) + 8, 2), dtype=torch.float32, device=dev)
     for _ in range(3):
         pipe.process_ptr(d_in.data_ptr(), ns, out.data_ptr(), out.shape[0], st)
@@ -56,11 +59,13 @@ for rate in want:
     t0 = time.perf_counter()
     for _ in range(a.iters):
         pipe.process_ptr(d_in.data_ptr(), ns, out.data_ptr(), out.shape[0], st)
+    pipe.fence(st)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.iters * 1e3
     r = {"rate": rate, "plan": "*".join(f"{dec[i]}" + (f"(x{it[i]})" if it[i] > 1 else "") for i in range(n)),
          "ntaps": [nt[i] for i in range(n)], "ms_per_2^%d" % a.log2n: round(ms, 4), "GS_per_s": round(ns / ms / 1e6, 1),
-         "stage0_reads_packed": pipe.stage0_reads_packed, "fused8": pipe.fused, "fused_pair": pipe.fused_pair(ns)}
+         "stage0_reads_packed": pipe.stage0_reads_packed, "fused8": pipe.fused, "fused_pair": pipe.fused_pair(ns),
+         "overlap": a.overlap}
     res.append(r)
     print(json.dumps(r), flush=True)
     pipe.close()
