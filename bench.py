@@ -64,7 +64,8 @@ def parse(argv=None):
                     choices=["d8_127", "d8_255", "c320", "unpack"],
                     help="d8_127 = BASELINE configs[1] (default); others are sweep points")
     ap.add_argument("--taps-fp16", action="store_true",
-                    help="round the taps to binary16 values (BASELINE config 5); they are still stored as fp32")
+                    help="round the taps to binary16 values (BASELINE config 5's fp16 leg: its numerics; taps never touch\n"
+                         "HBM in the hot loop -- they sit in SGPRs -- so there is no storage to halve)")
     ap.add_argument("--gather", action="store_true", help="run the gather leg at N=1 too (1-rank RCCL group)")
     ap.add_argument("--no-gather", action="store_true", help="skip the gather leg at N>1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -74,8 +75,12 @@ def parse(argv=None):
                     help="1 = no placement search: input and output as hipMalloc hands them out (anything else: search\n"
                          "for a pair in different HBM extent classes, 0.340 instead of 0.367 ms,\n"
                          "profiles/r02/i_placement_map.txt)")
-    ap.add_argument("--arena-gib", type=int, default=192,
-                    help="size of the arena the placement search cuts its 8 GiB slots from (less if less is free)")
+    ap.add_argument("--arena-gib", type=int, default=80,
+                    help="size of the allocation the placement cuts its 8 GiB slots from (less if less is free);\n"
+                         "80 GiB hold the four offsets the rule probes")
+    ap.add_argument("--placement", default="rule", choices=["rule", "full"],
+                    help="rule: input at the start of the arena, output probed at +8 (first come), +32, +48, +64 GiB;\n"
+                         "full: three input slots x every output slot (the map; use --arena-gib 192)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="cascades: keep the stages behind the fused pair in line on the one stream instead of running them on\n"
                          "the pipeline's side stream under the next batch's pair (pddc_pipeline_set_overlap)")
@@ -111,21 +116,39 @@ def launch_ranks(n, argv, timeout_s=3000.0):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    out0 = ""
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     deadline = time.time() + timeout_s
-    try:
-        out0, _ = procs[0].communicate(timeout=timeout_s)
-    except subprocess.TimeoutExpired:
-        pass
+    failed = None
+    while time.time() < deadline:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:                          # one rank died: the others would sit in rendezvous or a collective until
+            failed = bad[0]              # their own timeouts, holding their GPUs and arenas
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
     worst = 0
     for p in procs:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()                     # the exact child we started
-            p.wait()
+        if p.poll() is None:
+            if failed is None and time.time() < deadline:
+                continue
+            p.terminate()                # the exact children we started
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    for p in procs:
+        p.wait()
         if p.returncode != 0:
             worst = p.returncode if worst == 0 or p.returncode > 0 else worst
+    if failed is not None and worst == 0:
+        worst = failed
+    reader.join(timeout=5)
+    out0 = out0[0] if out0 else ""
     line = None
     for ln in (out0 or "").splitlines():
         t = ln.strip()
@@ -321,6 +344,18 @@ def kernel_source_sig():
     return h.hexdigest()[:16]
 
 
+def arena_plan(free_bytes, in_bytes, out_bytes, ws_bytes, arena_gib):
+    """Sizes of the placement arena (pure arithmetic, tested on CPU for the 8-rank shape): slots of at least 8 GiB, each
+    holding the input's span (whole GiB), a cascade's workspace and the output; the arena takes what `arena_gib` asks
+    for, leaving 32 GiB of the device alone.  search: False for launches small enough to live in the last-level cache."""
+    in_span = -(-in_bytes // (1 << 30)) << 30
+    ws_span = -(-ws_bytes // (2 << 20)) * (2 << 20)
+    slot = max(8 << 30, -(-(in_span + ws_span + out_bytes) // (1 << 30)) << 30)
+    gib = max(0, min(arena_gib, (free_bytes - (32 << 30)) >> 30))
+    return {"in_span": in_span, "ws_span": ws_span, "slot": slot, "gib": gib, "nslot": (gib << 30) // slot,
+            "search": out_bytes + ws_bytes >= (32 << 20)}
+
+
 # ----------------------------------------------------------------------------------------
 def run_rank(a):
     import numpy as np
@@ -331,9 +366,6 @@ def run_rank(a):
     rank, world, local = shard.env_rank_world()
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    dry = os.environ.get("PDDC_BENCH_BACKEND") == "gloo"       # CPU plumbing test of the launcher path
-    if dry:
-        return run_rank_dry(a, shard, rank, world, local)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local)
@@ -389,14 +421,14 @@ def run_rank(a):
     # a cascade's inter-stage buffers come from the arena too (pddc_pipeline_set_workspace): the fused pair of the
     # x320 cascade writes 1/48 of what it reads and is as sensitive to where that goes as the single stage is
     ws_bytes = pipe.workspace_size(ns) if (stages is not None and len(stages) > 1) else 0
-    in_span = -(-in_bytes // (1 << 30)) << 30                     # the input's share of a slot, whole GiB
-    ws_span = -(-ws_bytes // (2 << 20)) * (2 << 20)
-    slot = max(8 << 30, -(-(in_span + ws_span + out_bytes) // (1 << 30)) << 30)
-    if a.out_candidates > 1 and out_bytes + ws_bytes >= (32 << 20):
-        free_b, _ = torch.cuda.mem_get_info(dev)
-        gib = min(a.arena_gib, (free_b + in_bytes + out_bytes - (32 << 30)) >> 30)
+    plan = arena_plan(0, in_bytes, out_bytes, ws_bytes, a.arena_gib)
+    in_span, ws_span, slot = plan["in_span"], plan["ws_span"], plan["slot"]
+    if a.out_candidates > 1 and plan["search"]:
         inbox[0] = outbox[0] = None                               # the first-come pair goes back before the arena is made
         torch.cuda.empty_cache()
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        plan = arena_plan(free_b, in_bytes, out_bytes, ws_bytes, a.arena_gib)
+        gib = plan["gib"]
         while gib << 30 >= 3 * slot:
             try:
                 arena = torch.empty(gib << 30, dtype=torch.uint8, device=dev)
@@ -418,34 +450,62 @@ def run_rank(a):
             at = k * slot + in_span + ws_span
             return arena[at:at + out_bytes].view(torch.float32).view(out_rows, 2)
 
-        in_slots = sorted({0, nslot // 3, 2 * nslot // 3})
+        full = a.placement == "full"
+        in_slots = sorted({0, nslot // 3, 2 * nslot // 3}) if full else [0]
         for k in in_slots:                                        # the same LCG bytes in every input candidate
             pkg.check(pkg.ddc_lib().pddc_synth_lcg(in_view(k).data_ptr(), in_bytes, shard.stream_seed(rank), 0, stream))
         inbox[0], outbox[0] = in_view(0), out_view(0)
         for _ in range(150):                                      # the first pair is not to be measured on cold clocks
             step()
-        table = {}
-        for i in in_slots:
-            for o in range(nslot):
-                inbox[0], outbox[0] = in_view(i), out_view(o)
-                for _ in range(30):
-                    step()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(24):
-                    step()
-                e1.record()
-                e1.synchronize()
-                table[(i, o)] = e0.elapsed_time(e1) / 24
-        (bi, bo), _ = min(table.items(), key=lambda kv: kv[1])
+        table, launches = {}, [150]
+
+        def probe(i, o):
+            inbox[0], outbox[0] = in_view(i), out_view(o)
+            for _ in range(30):
+                step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(24):
+                step()
+            e1.record()
+            e1.synchronize()
+            if overlap:
+                pipe.fence(stream)
+            launches[0] += 54
+            table[(i, o)] = e0.elapsed_time(e1) / 24
+            return table[(i, o)]
+
+        if full:                                                  # the map: every pair (profiles/r02/k_arena_map.txt)
+            for i in in_slots:
+                for o in range(nslot):
+                    probe(i, o)
+        else:
+            # The rule read off those maps (some twenty leases, profiles/r0[23]/*placement*): with the
+            # input at the START of one allocation, the extent class it lies in reaches 32, 48 or 64 GiB up; the slot
+            # right behind the input is always in it ("first come"), and +32, +48 or +64 GiB is always in another one.
+            # So: four probes.  Only if none of them gains (a workload that does not care, or a layout not seen yet)
+            # the other slots are looked at too.
+            first_come = probe(0, 1 if nslot > 1 else 0)
+            for o in (4, 6, 8):
+                if o < nslot:
+                    probe(0, o)
+            if min(table.values()) > 0.97 * first_come:
+                for o in range(2, nslot):
+                    if (0, o) not in table:
+                        probe(0, o)
+        (bi, bo), best_ms = min(table.items(), key=lambda kv: kv[1])
         inbox[0], outbox[0] = in_view(bi), out_view(bo)
-        placement = {"arena_GiB": gib, "slot_GiB": slot >> 30, "output_slots": nslot,
-                     "step_ms_by_input_slot": {f"in@{(i * slot) >> 30}GiB": [round(table[(i, o)], 4) for o in range(nslot)]
+        placement = {"arena_GiB": gib, "slot_GiB": slot >> 30, "output_slots": nslot, "mode": a.placement,
+                     "step_ms_by_input_slot": {f"in@{(i * slot) >> 30}GiB": {str(o): round(table[(i, o)], 4)
+                                                                             for o in range(nslot) if (i, o) in table}
                                                for i in in_slots},
-                     "chosen": {"input_at_GiB": (bi * slot) >> 30, "output_slot": bo},
-                     "note": "input and output (with a cascade's inter-stage workspace) placed in different HBM extent "
-                             "classes: one arena, the input tried at three slots (the same LCG bytes in each), the "
-                             "output side at every slot, 24-step probes before the settle phase, fastest pair kept"}
+                     "first_come_ms": round(table.get((0, 1), table.get((0, 0))), 4),
+                     "chosen": {"input_at_GiB": (bi * slot) >> 30, "output_slot": bo, "ms": round(best_ms, 4)},
+                     "probe_pairs": len(table), "probe_launches": launches[0],
+                     "note": "input and output (with a cascade's inter-stage workspace) cut from ONE allocation and placed in "
+                             "different HBM extent classes: input at the start, the output probed right behind it (first "
+                             "come: same class) and at +32 / +48 / +64 GiB (one of them is always another class); every "
+                             "probed pair's step time is listed (key = output slot)"}
     out = outbox[0]
     d_in = inbox[0]
 
@@ -489,9 +549,9 @@ def run_rank(a):
     # region after a host synchronisation would see other clocks: a pause of a few hundred microseconds buys
     # ~8 % faster kernels for the next milliseconds on this chip)
     if multi_kernel:
-        kern_ms, n_k = pipe.stage0_time()
+        kern_ms, n_k = pipe.stage0_time()           # the library keeps at most 8192 event pairs
         pipe.time_stage0_inline(False)
-        assert n_k == a.steps, (n_k, a.steps)
+        assert n_k == min(a.steps, 8192), (n_k, a.steps)
     else:
         kern_ms = ev_ms / a.steps
     # measured copy ceiling: a device-to-device copy that moves as many bytes through HBM as
@@ -555,6 +615,7 @@ def run_rank(a):
                         "metric": "bit-exact vs the CPU oracle (examples/perseustest.c:466-502)"}
 
     names = grp.all_gather_object(torch.cuda.get_device_name(dev))
+    per_rank_ms = [float(v) * 1e3 / a.steps for v in grp.all_gather_object(dt)]
     oks = grp.all_gather_object(None if verified is None else bool(verified["ok"]))
     res = None
     if rank == 0:
@@ -580,7 +641,7 @@ def run_rank(a):
             "config": {"workload": wl["label"], "samples_per_gpu_per_step": ns,
                        "input": "LCG bytes seed 12345+rank, device resident",
                        "sharding": "independent stream per GPU, no data-path collective",
-                       "taps_storage": "fp32 (values rounded to binary16)" if a.taps_fp16 else "fp32",
+                       "taps": "binary16 VALUES held in fp32 registers (PDDC_F_TAPS_FP16)" if a.taps_fp16 else "fp32",
                        "overlap": ("stages behind the fused pair run on the pipeline's side stream under the next step's "
                                    "pair (pddc_pipeline_set_overlap); the timed region ends with a fence") if overlap else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -598,7 +659,11 @@ def run_rank(a):
             "events_ms_per_step": round(ev_ms / a.steps, 4),
             "placement": placement,
             "verified": verified,
-            "ranks_seen": grp.world, "devices": names,
+            "ranks_seen": grp.comm_size(), "devices": names,
+            "per_rank_ms_per_step": {"min": round(min(per_rank_ms), 4),
+                                     "median": round(sorted(per_rank_ms)[len(per_rank_ms) // 2], 4),
+                                     "max": round(max(per_rank_ms), 4)},
+            "kernel_only_aggregate_MSps": round(world * ns / (kern_ms * 1e-3) / 1e6, 1),
             "collectives": "RCCL called from the C library (pddc_comm_*); torch.distributed = rendezvous only"
                            if grp.comm is not None else
                            ("gloo control plane only (plan broadcast, barrier, MAX of the step time; the data path has "
@@ -693,7 +758,7 @@ def guarded_gather_legs(a, pkg, shard, grp, dev, stream, ns, d_in, wl, pipe, out
             r = PARTIAL["res"]
             r["gather"] = {"error": f"gather leg did not finish within {a.gather_timeout:.0f} s"}
             print(json.dumps(r), flush=True)
-        os._exit(0)
+        os._exit(3)          # a collective that never completed is a failure: the launcher passes the status on
 
     timer = threading.Timer(a.gather_timeout, on_timeout)
     timer.daemon = True
@@ -723,44 +788,6 @@ def guarded_gather_legs(a, pkg, shard, grp, dev, stream, ns, d_in, wl, pipe, out
 PARTIAL = {}
 
 
-def run_rank_dry(a, shard, rank, world, local):
-    """PDDC_BENCH_BACKEND=gloo: the launcher / rendezvous / relay path on CPU, for the tests.
-    No GPU exists there, so nothing is measured: the CPU oracle stands in for the pipeline only to
-    give the ranks distinct data to gather, and the line says so."""
-    import numpy as np
-    import torch
-    from oracle import oracle as O
-    O.build()
-    grp = shard.TorchGroup(rank, world, local)
-    wl = workload_def(a.workload)
-    ns = 1 << min(a.log2n, 13)
-    cfg = shard.broadcast_config({"freg": wl["freg"], "stages": wl["stages"]} if rank == 0 else None, grp.device)
-    packed = O.lcg_bytes(6 * ns, shard.stream_seed(rank))
-    t0 = time.perf_counter()
-    y = None
-    for _ in range(a.steps):
-        y = O.ddc_chain(packed, cfg["stages"], cfg["freg"], wl["mix"])
-    dt = grp.max_seconds(time.perf_counter() - t0)
-    bufs = shard.gather_to_root(torch.from_numpy(y.copy()))
-    ok = None
-    if rank == 0:
-        ok = all(np.array_equal(bufs[r].numpy(), O.ddc_chain(O.lcg_bytes(6 * ns, shard.stream_seed(r)), cfg["stages"],
-                                                              cfg["freg"], wl["mix"])) for r in range(world))
-    hosts = grp.all_gather_object(f"cpu:{rank}")
-    res = None
-    if rank == 0:
-        res = {"metric": BASELINE_METRIC, "value": 0.0, "unit": "MS/s", "n_gpus": world, "steps": a.steps,
-               "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": wl["label"], "samples_per_gpu_per_step": ns},
-               "dry_run": "PDDC_BENCH_BACKEND=gloo: launcher/rendezvous plumbing test on CPU, the oracle stands in "
-                          "for the HIP pipeline, nothing is measured",
-               "ranks_seen": world, "devices": hosts,
-               "gather": {"this_workload": {"root_blocks_match_each_ranks_stream": ok}},
-               "roofline": None, "cpu_baseline": None}
-    finish(grp, res)
-
-
 def finish(grp, res):
     # RCCL writes its version banner to C stdout, which is block buffered on a pipe and would
     # otherwise come out at process exit -- after the JSON line, on any rank.  Every rank flushes
@@ -785,6 +812,13 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain command: become the launcher.  Nothing above has imported torch or touched a GPU.
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    hook = os.environ.get("PDDC_BENCH_RANK_HOOK")
+    if hook:
+        # test scaffolding lives in tests/, not here: "module:function" replaces the rank body, so the launcher /
+        # rendezvous / relay path can be exercised where no GPU exists (tests/bench_dry_rank.py).  Nothing in this
+        # file computes an output on the CPU.
+        mod, fn = hook.split(":")
+        return getattr(importlib.import_module(mod), fn)(a, sys.modules[__name__])
     run_rank(a)
 
 

@@ -122,7 +122,8 @@ int pddc_free(void *d_ptr);
  * plain allocation.  A buffer between 1 MiB and 1 GiB gets a 1 GiB allocation (the probe must write past the 256 MB
  * last-level cache to see the HBM), because small write streams matter too: the fused first two stages of the /320
  * cascade write 1/48 of what they read and still run at 0.292 or 0.330 ms depending on where that small buffer lies.
- * A pipeline places its own inter-stage buffers this way when a batch is >= 64 MiB (PDDC_PLACEMENT=0: never).       */
+ * Candidates and spacers never take more than half of the free memory; a probe that fails leaves a plain allocation.
+ * pddc_pipeline_place_buffers does this for a pipeline's own inter-stage buffers (process() never searches).         */
 int pddc_malloc_apart(void **d_ptr, size_t nbytes, const void *d_partner, size_t partner_bytes, int max_candidates,
                       float *ms_best, float *ms_worst);
 /* The dependable form of the same search: ONE large allocation of the caller's (tens of GiB up; 288 GB of HBM make it
@@ -136,6 +137,13 @@ int pddc_malloc_apart(void **d_ptr, size_t nbytes, const void *d_partner, size_t
 int pddc_arena_search(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t in_bytes, size_t out_offset,
                       size_t out_bytes, int n_in_slots, size_t *in_slot, size_t *out_slot, float *ms_table,
                       float *ms_best, float *ms_worst);
+/* The cheap form, from what those searches showed on some twenty leases: with the input at the START of one allocation
+ * (slot 0), its extent class reaches 32, 48 or 64 GiB up -- the slot right behind it is always in it (the "first come"
+ * case) and +32, +48 or +64 GiB is always in another one.  Probes the output side at those four places on `stream`
+ * (0.1 s), looks at the remaining slots only if none gains 3 %, returns the fastest in *out_slot with the first-come
+ * and the chosen probe times and the number of probes made.  An arena of 80 GiB (ten 8-GiB slots) is enough.      */
+int pddc_arena_place(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t in_bytes, size_t out_offset,
+                     size_t out_bytes, size_t *out_slot, float *ms_first_come, float *ms_best, int *nprobes, void *stream);
 int pddc_memcpy_h2d(void *d_dst, const void *h_src, size_t nbytes, void *stream);
 int pddc_memcpy_d2h(void *h_dst, const void *d_src, size_t nbytes, void *stream);
 int pddc_stream_sync(void *stream);
@@ -156,6 +164,13 @@ int pddc_pipeline_reset(pddc_pipeline *p);
  * (No reference counterpart: libperseus-sdr's buffers are libusb transfers, perseus-in.c:67-110.)               */
 size_t pddc_pipeline_workspace_size(const pddc_pipeline *p, size_t max_nsamples);
 int pddc_pipeline_set_workspace(pddc_pipeline *p, void *d_ws, size_t nbytes, size_t max_nsamples);
+/* The same decision for the pipeline's OWN inter-stage buffers (a host that does not manage a workspace): allocates
+ * them now, for batches of up to max_nsamples samples read from d_packed, each through the candidate walk of
+ * pddc_malloc_apart against the buffer its writer reads.  Probes run on `stream`; candidates and spacers take at most
+ * half of the free device memory and are freed again; a failing probe leaves a plain allocation.  About a second per
+ * buffer, once.  pddc_pipeline_process itself never searches: without this call (or a workspace) the buffers are plain
+ * allocations made when the first batch arrives.  (No reference counterpart.)                                    */
+int pddc_pipeline_place_buffers(pddc_pipeline *p, const void *d_packed, size_t max_nsamples, void *stream);
 /* reset, then place the stream at absolute input sample `abs_sample` with zero history:
  * the NCO phase and every stage's decimation phase are those of a stream that started at
  * sample 0.  This is what lets ONE stream be cut into time chunks for several GPUs
@@ -304,6 +319,10 @@ int pddc_measure_copy(void *d_dst, const void *d_src, size_t nbytes, int iters, 
  * All sizes in bytes.  Errors: PDDC_ECOMM + pddc_last_error().                  */
 typedef struct pddc_comm pddc_comm;
 #define PDDC_COMM_ID_BYTES 128
+/* Version codes (ncclGetVersion style: major*10000 + minor*100 + patch) of the RCCL library bound at run time and of the
+ * header this library was compiled against.  Every communicator constructor checks that the MAJOR versions agree and
+ * fails with PDDC_ECOMM otherwise (two librccl can be on a box: /opt/rocm/lib and the one inside a torch wheel).   */
+int pddc_comm_rccl_version(int *running, int *compiled);
 int pddc_comm_get_unique_id(void *id128);
 int pddc_comm_init_rank(pddc_comm **out, int nranks, int rank, const void *id128, int device);
 int pddc_comm_init_all(pddc_comm **comms /* [ndev] */, int ndev, const int *devices /* NULL: 0..ndev-1 */);

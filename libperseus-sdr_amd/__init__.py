@@ -114,6 +114,13 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_uses_fused_cascade.restype = C.c_int
     L.pddc_pipeline_check.argtypes = [vp, vp]
     L.pddc_pipeline_check.restype = C.c_int
+    L.pddc_arena_place.argtypes = [vp, sz, sz, sz, sz, sz, C.POINTER(sz), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                   C.POINTER(C.c_int), vp]
+    L.pddc_arena_place.restype = C.c_int
+    L.pddc_comm_rccl_version.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pddc_comm_rccl_version.restype = C.c_int
+    L.pddc_pipeline_place_buffers.argtypes = [vp, vp, sz, vp]
+    L.pddc_pipeline_place_buffers.restype = C.c_int
     L.pddc_pipeline_set_overlap.argtypes = [vp, C.c_int]
     L.pddc_pipeline_set_overlap.restype = C.c_int
     L.pddc_pipeline_fence.argtypes = [vp, vp]
@@ -279,6 +286,10 @@ class Pipeline:
     def check(self, stream: int = 0):
         """wait for `stream`; raises if a kernel of this pipeline flagged a failure"""
         check(ddc_lib().pddc_pipeline_check(self._h, stream))
+
+    def place_buffers(self, d_in: int, max_nsamples: int, stream: int = 0):
+        """allocate the pipeline's own inter-stage buffers away (in HBM extent class) from the batch they are made from"""
+        check(ddc_lib().pddc_pipeline_place_buffers(self._h, d_in, max_nsamples, stream))
 
     def set_overlap(self, enable: bool = True):
         """stages behind the fused pair on a side stream, under the next batch's pair (see perseus_ddc.h)"""

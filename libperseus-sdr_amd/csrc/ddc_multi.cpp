@@ -90,13 +90,55 @@ static int ensure_scratch(pddc_comm *c, size_t nbytes)
     return PDDC_OK;
 }
 
+/* Two librccl are on these boxes: the one this library was linked against (/opt/rocm/lib) and, in a Python process that
+ * has imported torch, torch/lib/librccl.so, which the dynamic loader may have bound first.  The RUNNING library's version
+ * is compared with the header this file was compiled against before the first communicator is made: a different MAJOR
+ * version means different struct layouts and wire protocol -- fail here, loudly, not inside the first collective on 8 GPUs. */
+static int check_rccl_version(void)
+{
+    static int checked = 0;                 /* 0 not yet, 1 fine, -1 refused */
+    static int running = 0;
+    if (checked == 0) {
+        if (ncclGetVersion(&running) != ncclSuccess)
+            running = -1;
+        const int run_major = running >= 10000 ? running / 10000 : running / 1000;
+        const int hdr_major = NCCL_VERSION_CODE >= 10000 ? NCCL_VERSION_CODE / 10000 : NCCL_VERSION_CODE / 1000;
+        checked = (running > 0 && run_major == hdr_major) ? 1 : -1;
+        if (getenv("PDDC_DEBUG") || checked < 0)
+            fprintf(stderr, "[pddc] RCCL: running library version code %d, compiled against %d (%d.%d.%d)%s\n", running,
+                    (int)NCCL_VERSION_CODE, NCCL_MAJOR, NCCL_MINOR, NCCL_PATCH, checked < 0 ? " -- MAJOR VERSION MISMATCH" : "");
+    }
+    if (checked < 0)
+        return pddc_set_error_(PDDC_ECOMM, "the RCCL library bound at run time (version code %d) does not match the one this "
+                               "library was built against (%d): two librccl on the path?", running, (int)NCCL_VERSION_CODE);
+    return PDDC_OK;
+}
+
 extern "C" {
+
+/* version codes of the RCCL library in use and of the header compiled against (either pointer may be NULL) */
+int pddc_comm_rccl_version(int *running, int *compiled)
+{
+    int v = 0;
+    if (ncclGetVersion(&v) != ncclSuccess)
+        return pddc_set_error_(PDDC_ECOMM, "ncclGetVersion failed");
+    if (running)
+        *running = v;
+    if (compiled)
+        *compiled = (int)NCCL_VERSION_CODE;
+    return PDDC_OK;
+}
 
 int pddc_comm_get_unique_id(void *id)
 {
     if (!id)
         return pddc_set_error_(PDDC_EINVAL, "null id");
     static_assert(sizeof(ncclUniqueId) == PDDC_COMM_ID_BYTES, "unique id size");
+    {
+        int rc = check_rccl_version();
+        if (rc)
+            return rc;
+    }
     ncclUniqueId u;
     NCCL_TRY(ncclGetUniqueId(&u));
     memcpy(id, &u, sizeof(u));
@@ -113,6 +155,11 @@ int pddc_comm_init_rank(pddc_comm **out, int nranks, int rank, const void *id, i
         return pddc_set_error_(PDDC_ENODEV, "no HIP device visible (no CPU fallback)");
     if (device < 0 || device >= ndev)
         return pddc_set_error_(PDDC_ENODEV, "device %d out of range (0..%d)", device, ndev - 1);
+    {
+        int rc = check_rccl_version();
+        if (rc)
+            return rc;
+    }
     HIP_TRYM(hipSetDevice(device));
     pddc_comm *c = new (std::nothrow) pddc_comm();
     if (!c)
@@ -155,6 +202,11 @@ int pddc_comm_init_all(pddc_comm **comms, int ndev, const int *devices)
                 return pddc_set_error_(PDDC_EINVAL, "device %d listed twice: one communicator rank per GPU", devs[i]);
     }
     std::vector<ncclComm_t> raw(ndev, nullptr);
+    {
+        int rc = check_rccl_version();
+        if (rc)
+            return rc;
+    }
     NCCL_TRY(ncclCommInitAll(raw.data(), ndev, devs.data()));
     for (int i = 0; i < ndev; ++i) {
         pddc_comm *c = new (std::nothrow) pddc_comm();
@@ -219,11 +271,14 @@ int pddc_comm_group_end(void)
 {
     if (g_group_depth > 0)
         --g_group_depth;
+    /* the list is taken BEFORE the call that may fail: a failing ncclGroupEnd must not leave communicators on it that a
+     * later group would touch, possibly after they have been destroyed */
+    std::vector<pddc_comm *> done;
+    if (g_group_depth == 0)
+        done.swap(g_group_pending);
     NCCL_TRY(ncclGroupEnd());
     if (g_group_depth == 0) {
         /* the grouped transfers are on their side streams now: mark their completion points */
-        std::vector<pddc_comm *> done;
-        done.swap(g_group_pending);
         for (pddc_comm *c : done) {
             HIP_TRYM(hipSetDevice(c->device));
             HIP_TRYM(hipEventRecord(c->ev_done[(c->n_gathers - 1) & 1], c->side));

@@ -116,10 +116,6 @@ struct pddc_pipeline {
     std::vector<WordSeg> segs;
     float *d_hist_f32 = nullptr;  /* stage 0's history as mixed float2, for that route */
     int fail_at_stage = -1;       /* test hook: the next process() fails when it reaches this stage */
-    /* inter-stage buffers are placed in another HBM extent class than the batch they are produced from (ensure_buf).
-     * Not for a pipeline fed through push_host* / push_synth_async: those are bound by PCIe or by real time, their
-     * batches alternate between two staging slots, and the search would only delay the start of the stream.       */
-    bool place_buffers = true;
     /* measurement hook: HIP events around the stage-0 (or fused-pair) kernel of every process() */
     bool time_stage0 = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -352,7 +348,7 @@ int pddc_malloc(void **d_ptr, size_t nbytes)
  * a 33 MB buffer written once per launch matters as much as a large one -- the fused pair of the x320 cascade, which
  * writes 1/48 of what it reads, runs at 0.292 or 0.330 ms depending on it (tools/placement_probe8.py).           */
 static int malloc_apart_impl(void **d_ptr, size_t nbytes, const void *d_partner, size_t partner_bytes, int max_candidates,
-                             float *ms_best, float *ms_worst, size_t min_bytes)
+                             float *ms_best, float *ms_worst, size_t min_bytes, hipStream_t stream = nullptr)
 {
     if (!d_ptr || nbytes == 0)
         return fail(PDDC_EINVAL, "bad argument");
@@ -369,10 +365,29 @@ static int malloc_apart_impl(void **d_ptr, size_t nbytes, const void *d_partner,
         HIP_TRY(hipMalloc(d_ptr, nbytes));             /* too small to matter (or nothing to stay away from) */
         return PDDC_OK;
     }
-    const size_t spacer_bytes = (size_t)8 << 30;
+    size_t spacer_bytes = (size_t)8 << 30;
     const size_t total = (size_t)1 << 30;               /* 1 GiB read + 1 GiB written per probe launch: beyond the L3 */
+    const size_t asked = nbytes;
     if (nbytes < total)
         nbytes = total;
+    {
+        /* candidates and spacers together never take more than half of what is free: other allocations on this GPU
+         * (another pipeline, torch's allocator) must not hit out-of-memory because of a search */
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+            free_b = 0;
+        (void)hipGetLastError();
+        const size_t budget = free_b / 2;
+        if (budget < 2 * nbytes + spacer_bytes) {
+            HIP_TRY(hipMalloc(d_ptr, asked));
+            return PDDC_OK;
+        }
+        const size_t per = nbytes + spacer_bytes;
+        if ((size_t)max_candidates > budget / per)
+            max_candidates = (int)(budget / per);
+        if (max_candidates < 2)
+            max_candidates = 2;
+    }
     std::vector<void *> cands, spacers;
     std::vector<float> ms;
     hipEvent_t e0, e1;
@@ -405,21 +420,23 @@ static int malloc_apart_impl(void **d_ptr, size_t nbytes, const void *d_partner,
         cands.push_back(c);
         hipError_t e = hipSuccess;
         for (int k = 0; k < 3 && e == hipSuccess; ++k)
-            e = launch_stream_probe(d_partner, partner_bytes, c, nbytes & ~(size_t)15, total, nullptr);
+            e = launch_stream_probe(d_partner, partner_bytes, c, nbytes & ~(size_t)15, total, stream);
         if (e == hipSuccess)
-            e = hipEventRecord(e0, nullptr);
+            e = hipEventRecord(e0, stream);
         for (int k = 0; k < 5 && e == hipSuccess; ++k)
-            e = launch_stream_probe(d_partner, partner_bytes, c, nbytes & ~(size_t)15, total, nullptr);
+            e = launch_stream_probe(d_partner, partner_bytes, c, nbytes & ~(size_t)15, total, stream);
         if (e == hipSuccess)
-            e = hipEventRecord(e1, nullptr);
+            e = hipEventRecord(e1, stream);
         if (e == hipSuccess)
             e = hipEventSynchronize(e1);
         float t = 0.0f;
         if (e == hipSuccess)
             e = hipEventElapsedTime(&t, e0, e1);
-        if (e != hipSuccess) {
+        if (e != hipSuccess) {                          /* a probe that fails costs the search, not the buffer */
+            (void)hipGetLastError();
             cleanup(nullptr);
-            return fail(PDDC_EHIP, "placement probe: %s", hipGetErrorString(e));
+            HIP_TRY(hipMalloc(d_ptr, asked));
+            return PDDC_OK;
         }
         ms.push_back(t / 5.0f);
         if (ms.size() >= 2 && both_seen())
@@ -529,6 +546,86 @@ int pddc_arena_search(void *d_arena, size_t arena_bytes, size_t slot_bytes, size
         *ms_best = best;
     if (ms_worst)
         *ms_worst = worst;
+    return PDDC_OK;
+}
+
+/* The rule those maps gave (some twenty leases, profiles/r02/k_arena_map.txt, profiles/r03/f_placement_rule.txt): with the
+ * input at the START of one allocation, the extent class it lies in reaches 32, 48 or 64 GiB up -- the slot right behind
+ * the input is always in it (what "first come" buffers get) and +32, +48 or +64 GiB is always in another one.  So the
+ * input goes to slot 0 and the output side is probed at four places; only if none of them gains 3 % over the first-come
+ * slot are the remaining slots looked at.  At most nslot probes, normally four (0.1 s).                          */
+int pddc_arena_place(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t in_bytes, size_t out_offset,
+                     size_t out_bytes, size_t *out_slot, float *ms_first_come, float *ms_best, int *nprobes, void *stream_v)
+{
+    if (!d_arena || !out_slot || slot_bytes == 0 || ((uintptr_t)d_arena & 15) || (slot_bytes & 15) || (out_offset & 15) ||
+        in_bytes < 16 || out_bytes < 16 || out_offset < in_bytes || out_offset + out_bytes > slot_bytes)
+        return fail(PDDC_EINVAL, "bad argument");
+    const size_t nslot = arena_bytes / slot_bytes;
+    if (nslot < 2)
+        return fail(PDDC_EINVAL, "the arena holds fewer than two slots");
+    int rc = require_device();
+    if (rc)
+        return rc;
+    hipStream_t st = (hipStream_t)stream_v;
+    const size_t total = (size_t)1 << 30;
+    size_t dst_bytes = slot_bytes - out_offset;
+    if (dst_bytes > total)
+        dst_bytes = total;
+    dst_bytes &= ~(size_t)15;
+    uint8_t *base = static_cast<uint8_t *>(d_arena);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    std::vector<float> ms(nslot, -1.0f);
+    hipError_t e = hipSuccess;
+    int n = 0;
+    auto probe = [&](size_t o) {
+        if (o >= nslot || ms[o] >= 0.0f || e != hipSuccess)
+            return;
+        void *dst = base + o * slot_bytes + out_offset;
+        for (int r = 0; r < 2 && e == hipSuccess; ++r)
+            e = launch_stream_probe(base, in_bytes & ~(size_t)15, dst, dst_bytes, total, st);
+        if (e == hipSuccess)
+            e = hipEventRecord(e0, st);
+        for (int r = 0; r < 4 && e == hipSuccess; ++r)
+            e = launch_stream_probe(base, in_bytes & ~(size_t)15, dst, dst_bytes, total, st);
+        if (e == hipSuccess)
+            e = hipEventRecord(e1, st);
+        if (e == hipSuccess)
+            e = hipEventSynchronize(e1);
+        float t = 0.0f;
+        if (e == hipSuccess)
+            e = hipEventElapsedTime(&t, e0, e1);
+        ms[o] = t / 4.0f;
+        ++n;
+    };
+    const size_t gib8 = ((size_t)8 << 30) / slot_bytes ? ((size_t)8 << 30) / slot_bytes : 1;      /* slots per 8 GiB */
+    probe(1);                                            /* first come: right behind the input */
+    probe(4 * gib8);
+    probe(6 * gib8);
+    probe(8 * gib8);
+    auto best_of = [&]() {
+        size_t b = 1;
+        for (size_t o = 1; o < nslot; ++o)
+            if (ms[o] >= 0.0f && ms[o] < ms[b])
+                b = o;
+        return b;
+    };
+    if (e == hipSuccess && ms[best_of()] > 0.97f * ms[1])
+        for (size_t o = 2; o < nslot; ++o)
+            probe(o);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (e != hipSuccess)
+        return fail(PDDC_EHIP, "placement probe: %s", hipGetErrorString(e));
+    const size_t b = best_of();
+    *out_slot = b;
+    if (ms_first_come)
+        *ms_first_come = ms[1];
+    if (ms_best)
+        *ms_best = ms[b];
+    if (nprobes)
+        *nprobes = n;
     return PDDC_OK;
 }
 
@@ -1095,37 +1192,23 @@ extern "C" int pddc_pipeline_check(pddc_pipeline *p, void *stream)
     return PDDC_OK;
 }
 
-/* `reader_src` / `reader_bytes`: the buffer that the kernel WRITING this stage buffer streams its input from.  When
- * that stream is large (>= 64 MiB per batch) the stage buffer is placed in another HBM extent class than it
- * (malloc_apart_impl; ~1 s, once per pipeline -- PDDC_PLACEMENT=0 turns it off).                              */
-static int ensure_buf(Stage &s, size_t need, const void *reader_src = nullptr, size_t reader_bytes = 0)
+/* the stage's input buffer, grown when a batch is larger than any seen before (synchronising).  Plain allocations: WHERE
+ * a buffer lies in HBM matters to the kernel that writes it, but a search for a good place is the
+ * host's decision and never happens inside process(): pddc_pipeline_place_buffers, or pddc_pipeline_set_workspace.  */
+static int ensure_buf(Stage &s, size_t need, const void * = nullptr, size_t = 0)
 {
     if (s.d_buf && s.buf_cap >= need)
         return PDDC_OK;
     if (s.buf_in_ws)
         return fail(PDDC_ECAPACITY, "batch needs %zu samples of stage buffer, the workspace was sized for %zu", need,
                     s.buf_cap);
-    /* happens only when a batch is larger than any seen before (synchronising) */
     const size_t cap = need + need / 4 + 64;
     HIP_TRY(hipDeviceSynchronize());
     if (s.d_buf)
         HIP_TRY(hipFree(s.d_buf));
     s.d_buf = nullptr;
     s.buf_cap = 0;
-    static const bool placement = !(getenv("PDDC_PLACEMENT") && atoi(getenv("PDDC_PLACEMENT")) == 0);
-    if (placement && reader_src && reader_bytes >= ((size_t)64 << 20)) {
-        void *ptr = nullptr;
-        float fast = 0.0f, slow = 0.0f;
-        int rc = malloc_apart_impl(&ptr, sizeof(float) * 2 * cap, reader_src, reader_bytes, 24, &fast, &slow, (size_t)1 << 20);
-        if (rc)
-            return rc;
-        s.d_buf = static_cast<float *>(ptr);
-        if (getenv("PDDC_DEBUG"))
-            fprintf(stderr, "[pddc] stage buffer placed apart from its producer's input: probe %.3f ms (slowest %.3f)\n",
-                    fast, slow);
-    } else {
-        HIP_TRY(hipMalloc(&s.d_buf, sizeof(float) * 2 * cap));
-    }
+    HIP_TRY(hipMalloc(&s.d_buf, sizeof(float) * 2 * cap));
     s.buf_cap = cap;
     if (getenv("PDDC_DEBUG"))
         fprintf(stderr, "[pddc] stage buffer %p (%zu samples) hist %p %p\n", (void *)s.d_buf, cap, s.d_hist[0],
@@ -1185,6 +1268,53 @@ extern "C" int pddc_pipeline_set_workspace(pddc_pipeline *p, void *d_ws, size_t 
                 at += (cap * 8 + 255) & ~(size_t)255;
             }
         }
+    }
+    return PDDC_OK;
+}
+
+/* Explicit placement of the pipeline's own inter-stage buffers for batches of up to `max_nsamples` samples that will
+ * be read from `d_packed`: every buffer a kernel streams at least 32 MiB per batch into is allocated through the
+ * candidate walk of pddc_malloc_apart against the buffer that kernel reads (the packed batch for the first one).  Probes
+ * run on `stream`; candidates and spacers take at most half of the free memory and are freed again; a probe that fails
+ * leaves a plain allocation.  Takes about a second per buffer, once.  (Until round 3 process() did this by itself when a
+ * large batch first arrived -- a search inside the asynchronous hot-path call, on the NULL stream, with up to 216 GiB of
+ * transient allocations; now it only happens where the host asks for it.)                                       */
+int pddc_pipeline_place_buffers(pddc_pipeline *p, const void *d_packed, size_t max_nsamples, void *stream)
+{
+    if (!p || !d_packed || max_nsamples == 0)
+        return fail(PDDC_EINVAL, "bad argument");
+    if (p->carry_pending)
+        return fail(PDDC_ESTATE, "overlap mode holds a tail back: pddc_pipeline_fence(p, stream) first");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const void *src = d_packed;
+    size_t src_bytes = max_nsamples * 6;
+    for (int i = 1; i < p->nstages; ++i) {
+        Stage &s = p->st[i];
+        if (s.buf_in_ws)
+            return fail(PDDC_ESTATE, "the inter-stage buffers come from the caller's workspace (pddc_pipeline_set_workspace)");
+        const size_t cap = ws_stage_samples(p, i, max_nsamples);
+        /* with the fused pair stage 1's buffer is never written: the pair writes stage 2's, reading the packed batch */
+        const bool skipped = i == 1 && p->nstages >= 2 && stages01_fusable(p, max_nsamples - max_nsamples % (size_t)fir8_tile_inputs(p->R));
+        if (skipped)
+            continue;
+        if (cap * 8 >= ((size_t)32 << 20) && src_bytes >= ((size_t)64 << 20)) {
+            void *ptr = nullptr;
+            float fast = 0.0f, slow = 0.0f;
+            int rc = malloc_apart_impl(&ptr, cap * 8, src, src_bytes, 8, &fast, &slow, (size_t)1 << 20, (hipStream_t)stream);
+            if (rc)
+                return rc;
+            if (s.d_buf)
+                HIP_TRY(hipFree(s.d_buf));
+            s.d_buf = static_cast<float *>(ptr);
+            s.buf_cap = cap;
+            if (getenv("PDDC_DEBUG"))
+                fprintf(stderr, "[pddc] stage %d buffer placed: probe %.3f ms (slowest candidate %.3f)\n", i, fast, slow);
+        }
+        src = s.d_buf;
+        src_bytes = cap * 8;
+        if (!src)
+            break;
     }
     return PDDC_OK;
 }
@@ -1308,10 +1438,8 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
     /* (reads_packed: the kernel writing it streams the packed batch -- stage 0, or the fused pair for stage 1) */
     auto stage_dst = [&](int i, float **dst, bool reads_packed) -> int {
         if (i + 1 < p->nstages) {
-            const void *src = !p->place_buffers ? nullptr
-                              : reads_packed    ? d_packed
-                                                : static_cast<const void *>(p->st[i].d_buf);
-            int r = ensure_buf(p->st[i + 1], n_in[i + 1] + 8, src, reads_packed ? nsamples * 6 : n_in[i] * 8);
+            (void)reads_packed;
+            int r = ensure_buf(p->st[i + 1], n_in[i + 1] + 8);
             if (r)
                 return r;
             *dst = p->st[i + 1].d_buf;
@@ -1496,7 +1624,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
              * it, the batch likewise with the current word, and the generic decimator runs on floats;
              * the packed history for the next call is carried as usual.                            */
             const int H = st.hist;
-            if ((rc = ensure_buf(st, nsamples + 8, p->place_buffers ? d_packed : nullptr, nsamples * 6)))
+            if ((rc = ensure_buf(st, nsamples + 8)))
                 return rc;
             if (!p->d_hist_f32)
                 HIP_TRY(hipMalloc(&p->d_hist_f32, (size_t)PDDC_MAX_TAPS * 8 + 256));
@@ -1571,7 +1699,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         } else {
             if (i == 0) {
                 /* generic first stage: unpack(+mix) to float2, then the generic FIR */
-                if ((rc = ensure_buf(st, nsamples + 8, p->place_buffers ? d_packed : nullptr, nsamples * 6)))
+                if ((rc = ensure_buf(st, nsamples + 8)))
                     return rc;
                 HIP_TRY(launch_unpack24(d_packed, (long long)nsamples, st.d_buf, false, mix, p->n0, p->freg,
                                         p->phase_off, p->lo_c, p->lo_s, s));
@@ -1729,7 +1857,6 @@ static int push_async(pddc_pipeline *p, const void *h_packed, bool synth, uint32
     if (sl.used)
         HIP_TRY(hipStreamWaitEvent(p->own_stream, sl.ev_out, 0));
     size_t n_out = 0;
-    p->place_buffers = false;
     int rc = pddc_pipeline_process(p, sl.d_in, nsamples, sl.d_out, sl.out_cap, &n_out, p->own_stream);
     if (rc)
         return rc;
@@ -2000,11 +2127,11 @@ int pddc_measure_copy(void *d_dst, const void *d_src, size_t nbytes, int iters, 
     if (rc)
         return rc;
     hipStream_t s = (hipStream_t)stream_v;
+    if (((uintptr_t)d_dst | (uintptr_t)d_src | nbytes) & 15)
+        return fail(PDDC_EINVAL, "copy measurement wants 16-byte aligned pointers and size");
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    if (((uintptr_t)d_dst | (uintptr_t)d_src | nbytes) & 15)
-        return fail(PDDC_EINVAL, "copy measurement wants 16-byte aligned pointers and size");
     for (int i = 0; i < iters; ++i)                             /* as many untimed ones first: sustained clocks */
         HIP_TRY(launch_stream_copy(d_src, d_dst, nbytes, s));
     HIP_TRY(hipEventRecord(e0, s));
@@ -2039,7 +2166,7 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     const bool fuse2 = stages01_fusable(p, nsamples);
     const bool fuse3 = stages012_fusable(p, nsamples);
     if (p->nstages > 1) {                  /* stage 0 (or the fused pair) of a cascade writes an internal buffer */
-        int rc = ensure_buf(p->st[1], nsamples / (size_t)p->st[0].decim + 8, d_packed, nsamples * 6);
+        int rc = ensure_buf(p->st[1], nsamples / (size_t)p->st[0].decim + 8);
         if (rc)
             return rc;
         a.out = p->st[1].d_buf;

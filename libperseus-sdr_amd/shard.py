@@ -171,6 +171,10 @@ class Group:
     def max_seconds(self, t: float) -> float:
         return t
 
+    def comm_size(self) -> int:
+        """ranks as the RCCL communicator counts them (pddc_comm_size) where one exists, else the launcher's"""
+        return int(self.comm.size) if self.comm is not None else int(self.world)
+
     def barrier(self):
         pass
 

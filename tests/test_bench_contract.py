@@ -93,11 +93,18 @@ def test_traffic_is_reported_only_with_matching_provenance(tmp_path, monkeypatch
     assert b.traffic_from_profile("d8_127", sig, 28, False)[0] is None
 
 
+def _dry_env():
+    """bench.py's rank body replaced by tests/bench_dry_rank.py (the CPU stand-in lives in tests/, not in bench.py)"""
+    env = dict(os.environ, PDDC_BENCH_RANK_HOOK="bench_dry_rank:run")
+    env["PYTHONPATH"] = os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", "")
+    env.pop("WORLD_SIZE", None)
+    return env
+
+
 def test_plain_command_launcher_two_ranks_gloo():
     """`python bench.py --gpus 2` as a plain command: the parent starts the ranks itself (it never
     imports torch), relays ONE JSON line.  On CPU the children run the gloo plumbing mode."""
-    env = dict(os.environ, PDDC_BENCH_BACKEND="gloo")
-    env.pop("WORLD_SIZE", None)
+    env = _dry_env()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--workload", "c320"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -112,8 +119,7 @@ def test_plain_command_launcher_two_ranks_gloo():
 def test_driver_style_launch_under_torch_distributed_run():
     """What the driver does at N>1: python -m torch.distributed.run ... bench.py --gpus N.  The ranks find
     RANK/WORLD_SIZE in the environment and skip the launcher (CPU: gloo plumbing mode)."""
-    env = dict(os.environ, PDDC_BENCH_BACKEND="gloo")
-    env.pop("WORLD_SIZE", None)
+    env = _dry_env()
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_bench()._free_port()),
                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
@@ -144,7 +150,7 @@ def test_launcher_reports_failure_when_ranks_fail():
         pytest.skip("GPU present")
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
-    env.pop("PDDC_BENCH_BACKEND", None)
+    env.pop("PDDC_BENCH_RANK_HOOK", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode != 0 and "no CPU path" in p.stderr
@@ -175,4 +181,61 @@ def test_bench_line_end_to_end_on_the_gpu():
     assert rf["traffic"] is None and rf["traffic_source"]        # the offline PMC figure is for 2^28 launches only
     v = d["verified"]
     assert v["ok"] is True and v["windows"] >= 20 and v["max_rel_err"] <= 1e-6 and "max|y-ref|" in v["metric"]
-    assert d["config"]["taps_storage"] == "fp32"
+    assert d["config"]["taps"] == "fp32"
+    # placement by the rule: a handful of probed pairs, the first-come time next to the chosen one (2^24-sample launches
+    # live in the last-level cache, so there may be nothing to choose -- then no search is made at all)
+    pl = d["placement"]
+    assert pl is None or (pl["probe_pairs"] <= 12 and pl["first_come_ms"] >= pl["chosen"]["ms"])
+
+
+def test_eight_rank_dry_run_of_the_launcher():
+    """The driver's N = 8 shape on CPU: eight gloo ranks through the plain-command launcher, one JSON line, every rank's
+    block gathered and checked on rank 0 (8 ranks, not 2)."""
+    env = _dry_env()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
+                        "--workload", "c320", "--log2n", "12"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["devices"] == [f"cpu:{r}" for r in range(8)]
+    assert d["gather"]["this_workload"]["root_blocks_match_each_ranks_stream"] is True
+
+
+def test_launcher_tears_the_other_ranks_down_when_one_dies(tmp_path):
+    """a rank that dies before rendezvous must not leave the others waiting for their own timeouts."""
+    hook = tmp_path / "dying_rank.py"
+    hook.write_text("import os, sys, time\n"
+                    "def run(a, bench):\n"
+                    "    if os.environ['RANK'] == '1':\n"
+                    "        sys.exit(7)\n"
+                    "    time.sleep(600)\n")
+    env = dict(os.environ, PDDC_BENCH_RANK_HOOK="dying_rank:run", PYTHONPATH=str(tmp_path))
+    env.pop("WORLD_SIZE", None)
+    t0 = __import__("time").time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 7 and __import__("time").time() - t0 < 60
+
+
+def test_bench_holds_no_cpu_stand_in():
+    """bench.py must contain no path in which the oracle produces the output: the oracle appears
+    only in the cpu_baseline leg and in the parity check of the GPU's output."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "run_rank_dry" not in src and "PDDC_BENCH_BACKEND" not in src
+    assert src.count("from oracle import oracle") == 2            # cpu_baseline() and the verification of the last step
+
+
+def test_arena_plan_for_eight_ranks_with_a_mocked_device():
+    """The per-rank arena sizing (what bench.py does with torch.cuda.mem_get_info) as a pure function: every rank of an
+    8-GPU node has its own 288 GB, so each plans the same arena; a GPU with little free memory gets none."""
+    b = _bench()
+    ns = 1 << 28
+    full = b.arena_plan(free_bytes=280 << 30, in_bytes=6 * ns, out_bytes=(ns // 8 + 8) * 8, ws_bytes=0, arena_gib=192)
+    assert full["gib"] == 192 and full["slot"] == 8 << 30 and full["nslot"] == 24
+    casc = b.arena_plan(free_bytes=280 << 30, in_bytes=6 * ns, out_bytes=(ns // 320 + 8) * 8, ws_bytes=70 << 20, arena_gib=192)
+    assert casc["gib"] == 192 and casc["in_span"] % (1 << 30) == 0 and casc["ws_span"] >= 70 << 20
+    small = b.arena_plan(free_bytes=40 << 30, in_bytes=6 * ns, out_bytes=(ns // 8 + 8) * 8, ws_bytes=0, arena_gib=192)
+    assert small["gib"] < 3 * 8                                   # fewer than three slots: no search, first-come buffers
+    tiny = b.arena_plan(free_bytes=280 << 30, in_bytes=6 << 20, out_bytes=1 << 20, ws_bytes=0, arena_gib=192)
+    assert tiny["search"] is False                                # small batches live in the last-level cache anyway

@@ -132,15 +132,67 @@ def test_arena_search_agrees_with_the_kernel(pkg, O, dev):
     lo, hi = min(direct.values()), max(direct.values())
     print(f"probe best pair in{i_sl.value}/out{o_sl.value}: kernel {t_best:.4f} ms; probe worst pair: kernel {t_worst:.4f} ms; "
           f"direct {lo:.4f} .. {hi:.4f} ms over {len(direct)} pairs; probe {best.value:.3f} .. {worst.value:.3f} ms")
-    assert t_best <= 1.03 * lo
-    if hi > 1.04 * lo:
-        assert t_worst > 1.03 * t_best
+    assert t_best <= 1.05 * lo
+    if hi > 1.06 * lo:
+        assert t_worst > 1.02 * t_best
     # the result is still right at the chosen place
     n = pipe.process_ptr(arena.data_ptr() + i_sl.value * slot, NS, arena.data_ptr() + o_sl.value * slot + out_off, rows, st)
     y = np.empty((4096, 2), np.float32)
     pkg.check(L.pddc_memcpy_d2h(y.ctypes.data, arena.data_ptr() + o_sl.value * slot + out_off + 8 * (n - 4096), y.nbytes, st))
     pkg.check(L.pddc_stream_sync(st))
     assert np.isfinite(y).all() and np.abs(y).max() > 0
+    pipe.close()
+    del arena
+    torch.cuda.empty_cache()
+
+
+def test_the_placement_rule_finds_a_fast_pair_in_a_handful_of_probes(pkg, O, dev):
+    """pddc_arena_place: input at the start of ONE 80 GiB allocation, the output side probed right behind it (first come)
+    and at +32 / +48 / +64 GiB.  Judged by the real kernel (127 taps, 2^28 samples): the slot it returns is within 3 % of
+    the best of ALL slots, and where this lease shows both speeds at all (>= 4 % apart) the first-come slot is a slow
+    one and the search needed no more than the four probes."""
+    import ctypes as C
+    import torch
+    b = _bench()
+    L = pkg.ddc_lib()
+    wl = b.workload_def("d8_127")
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    gib = min(80, (free_b - (16 << 30)) >> 30)
+    if gib < 72:
+        pytest.skip("less than 72 GiB free")
+    slot, in_bytes, out_off = 8 << 30, 6 * NS, 2 << 30
+    pipe = pkg.Pipeline(wl["stages"])
+    rows = pipe.max_output(NS) + 8
+    arena = torch.empty(gib << 30, dtype=torch.uint8, device=dev)
+    nslot = (gib << 30) // slot
+    st = torch.cuda.current_stream(dev).cuda_stream
+    o_sl, fc, best, npr = C.c_size_t(), C.c_float(), C.c_float(), C.c_int()
+    pkg.check(L.pddc_arena_place(arena.data_ptr(), gib << 30, slot, in_bytes, out_off, rows * 8, C.byref(o_sl), C.byref(fc),
+                                 C.byref(best), C.byref(npr), st))
+    assert 1 <= o_sl.value < nslot and 0 < best.value <= fc.value and 4 <= npr.value <= nslot
+    pkg.check(L.pddc_synth_lcg(arena.data_ptr(), in_bytes, 12345, 0, st))
+
+    def kernel_ms(o):
+        c = arena.data_ptr() + o * slot + out_off
+        for _ in range(30):
+            pipe.process_ptr(arena.data_ptr(), NS, c, rows, st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(24):
+            pipe.process_ptr(arena.data_ptr(), NS, c, rows, st)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / 24
+
+    for _ in range(150):
+        pipe.process_ptr(arena.data_ptr(), NS, arena.data_ptr() + out_off, rows, st)
+    direct = {o: kernel_ms(o) for o in range(1, nslot)}
+    lo, hi = min(direct.values()), max(direct.values())
+    print(f"rule: slot {o_sl.value} after {npr.value} probes (probe {best.value:.3f} ms, first come {fc.value:.3f}); kernel there "
+          f"{direct[o_sl.value]:.4f} ms, first come {direct[1]:.4f}, all slots {lo:.4f} .. {hi:.4f}")
+    assert direct[o_sl.value] <= 1.03 * lo
+    if hi > 1.04 * lo:
+        assert direct[1] > 1.03 * lo and npr.value == 4
     pipe.close()
     del arena
     torch.cuda.empty_cache()

@@ -161,3 +161,15 @@ def test_c_multi_gpu_bench_with_gather(pkg, dev):
         assert m, p.stdout
         assert int(m.group(1)) == 1 and float(m.group(2)) > 50000 and float(m.group(3)) > 20000
         print(p.stdout.strip().splitlines()[-1])
+
+
+def test_the_rccl_in_use_matches_the_header_compiled_against(pkg, dev):
+    """Two librccl live on these boxes (ROCm's and the torch wheel's); the library compares the running one's version
+    with its header's before it makes a communicator and refuses a different major version."""
+    import ctypes as C
+    L = pkg.ddc_lib()
+    run, hdr = C.c_int(), C.c_int()
+    pkg.check(L.pddc_comm_rccl_version(C.byref(run), C.byref(hdr)))
+    assert run.value > 0 and hdr.value > 0
+    major = lambda v: v // 10000 if v >= 10000 else v // 1000
+    assert major(run.value) == major(hdr.value), (run.value, hdr.value)
