@@ -657,13 +657,133 @@ static int ddc_deliver(perseus_descr *d, int budget)
     return did;
 }
 
+/* ---- submit helpers ---------------------------------------------------------------------------
+ * Pass 0 of the delivery thread hands every streaming receiver's next batch to its GPU: a dozen HIP calls per
+ * receiver (generator or H2D copy, kernels, D2H copy, events), ~65 us of host time each -- with eight receivers on
+ * one thread that serial half millisecond per round, not the GPUs, set the pace (eight receivers took 11x the time of
+ * one).  The calls of different receivers touch different pipelines and streams, so they are farmed out: the
+ * delivery thread posts the round's receivers as jobs, the helpers and the delivery thread itself take them one by
+ * one, and the round goes on when all are done.  Callbacks are NOT farmed out: passes 1 and 2 (collect, deliver)
+ * stay on the one library thread, serialized and in order, as in the reference (perseus-sdr.c:749-770).        */
+#define MAX_HELPERS (MAX_DESCR - 1)
+static pthread_t g_helper[MAX_HELPERS];
+static int g_nhelpers = 0;
+static pthread_mutex_t g_job_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_job_cv = PTHREAD_COND_INITIALIZER, g_done_cv = PTHREAD_COND_INITIALIZER;
+static int g_job_list[MAX_DESCR], g_job_n = 0, g_job_next = 0, g_job_done = 0, g_job_busy = 0, g_job_inflight = 0;
+static int g_helpers_stop = 0;
+
+static void submit_one(int i, int *busy, int *inflight)
+{
+    perseus_descr *d = &g_list[i];
+    pthread_mutex_lock(&d->pump_lock);
+    if (d->streaming && !d->cancelling && !d->source_done && d->cfg.mode != PERSEUS_AMD_MODE_WIRE) {
+        *busy |= ddc_submit(d);
+        *inflight += d->n_pend > 0;
+    }
+    pthread_mutex_unlock(&d->pump_lock);
+}
+
+/* take jobs of the posted round until none is left; returns with g_job_lock held */
+static void run_jobs_locked(void)
+{
+    while (g_job_next < g_job_n) {
+        const int i = g_job_list[g_job_next++];
+        pthread_mutex_unlock(&g_job_lock);
+        int busy = 0, inflight = 0;
+        submit_one(i, &busy, &inflight);
+        pthread_mutex_lock(&g_job_lock);
+        g_job_busy |= busy;
+        g_job_inflight += inflight;
+        if (++g_job_done == g_job_n)
+            pthread_cond_broadcast(&g_done_cv);
+    }
+}
+
+static void *helper_fn(void *arg)
+{
+    (void)arg;
+    pthread_mutex_lock(&g_job_lock);
+    while (!g_helpers_stop) {
+        if (g_job_next < g_job_n)
+            run_jobs_locked();
+        else
+            pthread_cond_wait(&g_job_cv, &g_job_lock);
+    }
+    pthread_mutex_unlock(&g_job_lock);
+    return NULL;
+}
+
+/* pass 0 for the receivers in list[0..n): in parallel when there are several and helpers exist */
+static void submit_round(const int *list, int n, int *busy, int *inflight)
+{
+    if (n <= 1 || g_nhelpers == 0) {
+        for (int k = 0; k < n; k++)
+            submit_one(list[k], busy, inflight);
+        return;
+    }
+    pthread_mutex_lock(&g_job_lock);
+    memcpy(g_job_list, list, sizeof(int) * (size_t)n);
+    g_job_n = n;
+    g_job_next = 0;
+    g_job_done = 0;
+    g_job_busy = 0;
+    g_job_inflight = 0;
+    pthread_cond_broadcast(&g_job_cv);
+    run_jobs_locked();                           /* the delivery thread takes its share */
+    while (g_job_done < g_job_n)
+        pthread_cond_wait(&g_done_cv, &g_job_lock);
+    *busy |= g_job_busy;
+    *inflight += g_job_inflight;
+    g_job_n = g_job_next = 0;
+    pthread_mutex_unlock(&g_job_lock);
+}
+
+static void helpers_start(int n)
+{
+    if (n > MAX_HELPERS)
+        n = MAX_HELPERS;
+    const char *e = getenv("PERSEUS_AMD_SUBMIT_THREADS");        /* 0: everything on the delivery thread */
+    if (e)
+        n = atoi(e) < n ? atoi(e) : n;
+    pthread_mutex_lock(&g_job_lock);
+    g_helpers_stop = 0;
+    g_job_n = g_job_next = g_job_done = 0;
+    pthread_mutex_unlock(&g_job_lock);
+    g_nhelpers = 0;
+    for (int k = 0; k < n; k++)
+        if (pthread_create(&g_helper[g_nhelpers], NULL, helper_fn, NULL) == 0)
+            g_nhelpers++;
+}
+
+static void helpers_stop(void)
+{
+    pthread_mutex_lock(&g_job_lock);
+    g_helpers_stop = 1;
+    pthread_cond_broadcast(&g_job_cv);
+    pthread_mutex_unlock(&g_job_lock);
+    for (int k = 0; k < g_nhelpers; k++)
+        pthread_join(g_helper[k], NULL);
+    g_nhelpers = 0;
+}
+
 static void *worker_fn(void *arg)
 {
     (void)arg;
     while (!g_thread_stop) {
         int busy = 0;
         int inflight = 0;
-        for (int pass = 0; pass < 3; pass++) {
+        {
+            /* pass 0: every streaming DDC receiver's next batch goes to its GPU -- all of them before any is waited for */
+            int list[MAX_DESCR], n = 0;
+            for (int i = 0; i < g_entries; i++) {
+                perseus_descr *d = &g_list[i];
+                if (d->streaming && !d->cancelling && !d->source_done && d->cfg.mode != PERSEUS_AMD_MODE_WIRE)
+                    list[n++] = i;
+            }
+            submit_round(list, n, &busy, &inflight);
+        }
+        for (int pass = 1; pass < 3; pass++) {
             /* after pass 0 every receiver's batch has been submitted and none has been waited for yet */
             if (pass == 1 && inflight > g_peak_inflight)
                 g_peak_inflight = inflight;
@@ -680,9 +800,6 @@ static void *worker_fn(void *arg)
                             d->source_done = 1;
                         else
                             busy |= pump_wire(d);
-                    } else if (pass == 0) {
-                        busy |= ddc_submit(d);
-                        inflight += d->n_pend > 0;
                     } else if (pass == 1) {
                         busy |= ddc_collect(d);
                     } else {
@@ -778,8 +895,11 @@ int perseus_init(void)
     g_peak_inflight = 0;
     if (g_entries > 0) {
         g_thread_stop = 0;
-        if (pthread_create(&g_thread, NULL, worker_fn, NULL) != 0)
+        helpers_start(g_entries - 1);              /* submit helpers: one per further receiver */
+        if (pthread_create(&g_thread, NULL, worker_fn, NULL) != 0) {
+            helpers_stop();
             return errorset(PERSEUS_CANTCREAT, "can't create the sample delivery thread");
+        }
         g_thread_on = 1;
     }
     return errornone(g_entries);
@@ -795,6 +915,7 @@ int perseus_exit(void)
         g_thread_stop = 1;
         pthread_join(g_thread, NULL);
         g_thread_on = 0;
+        helpers_stop();
     }
     for (int i = 0; i < g_entries; i++) {
         perseus_close(&g_list[i]);
