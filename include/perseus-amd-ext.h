@@ -90,6 +90,8 @@ typedef struct {
     int      peak_receivers_in_flight;   /* library-wide since perseus_init(): the most receivers that had
                                  a GPU batch in flight at the same moment (the delivery thread submits
                                  for all of them before it waits for any)           */
+    uint64_t ganged_batches;  /* batches of this receiver that shared their kernel launches with other
+                                 receivers on the same GPU (pddc_gang_push_async)   */
 } perseus_amd_stats;
 
 /* valid between perseus_open() and perseus_start_async_input() */

@@ -261,6 +261,39 @@ int pddc_pipeline_push_synth_async(pddc_pipeline *p, uint32_t seed, uint64_t byt
 int pddc_pipeline_ticket_done(pddc_pipeline *p, int ticket);
 int pddc_pipeline_wait_ticket(pddc_pipeline *p, int ticket);
 int pddc_pipeline_wait(pddc_pipeline *p);          /* everything pushed so far is complete */
+/* ---- gang: several pipelines of ONE GPU, one launch chain --------------------------------
+ * The reference serves up to eight receivers from one poll thread (perseus-sdr.c:43-47 the
+ * descriptor table, 736-774 the thread); here several of them may share a GPU.  A batch of
+ * 2^22 samples keeps the GPU busy for a few dozen microseconds -- about what ONE launch costs
+ * in front of it -- so a launch chain per receiver leaves the GPU waiting for the host.  A gang
+ * round pushes the next batch (the same nsamples) of up to PDDC_GANG_MAX pipelines through one
+ * stream with ONE launch per kernel: the generator (or one H2D copy each), the first-stage
+ * kernel with the receiver as the grid's second dimension -- every receiver its own tuning
+ * word, phase, histories and buffers --, the decimator behind it likewise, one D2H copy
+ * each and ONE event.  Results are bit-identical to pushing every pipeline by itself
+ * (pddc_pipeline_push_*_async): the kernels' code and every receiver's arguments are the same.
+ * Members whose plan is not "fused /8 first stage [+ /8 fused with it] [+ one plain
+ * decimator]" (resampling rates, a first stage that is not /8, packed output) still go out in
+ * the round, as launches of their own on the gang's stream; *n_ganged says how many shared.
+ * Tickets are the pipelines' own (pddc_pipeline_wait_ticket).  A pipeline may change between
+ * gang rounds and pushes of its own at any batch boundary (the change waits for what it still
+ * has in flight).  One thread at a time per gang.                                           */
+#define PDDC_GANG_MAX 8
+typedef struct pddc_gang pddc_gang;
+typedef struct {
+    pddc_pipeline *pipe;
+    const void    *h_packed;      /* host batch (6*nsamples bytes), or NULL: the on-device LCG source ... */
+    uint32_t       seed;          /* ... of this seed ...                                                 */
+    uint64_t       byte_offset;   /* ... from this byte of its stream                                     */
+    void          *h_out;         /* receives the outputs (float2, or packed with PDDC_F_OUT_PACKED24)     */
+    size_t         out_capacity;  /* in samples                                                            */
+    size_t         n_out;         /* out: outputs of this batch                                            */
+    int            ticket;        /* out                                                                   */
+} pddc_gang_item;
+int pddc_gang_create(pddc_gang **out, int device);
+int pddc_gang_destroy(pddc_gang *g);      /* after (or before) its pipelines: waits for what is in flight */
+int pddc_gang_push_async(pddc_gang *g, pddc_gang_item *items, int n, size_t nsamples, int *n_ganged);
+
 /* pinned host memory for the two calls above */
 int pddc_host_alloc(void **h_ptr, size_t nbytes);
 int pddc_host_free(void *h_ptr);

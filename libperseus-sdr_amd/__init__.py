@@ -33,6 +33,12 @@ PDDC_COMM_ID_BYTES = 128
 PDDC_F_MIX, PDDC_F_TAPS_FP16, PDDC_F_NO_FAST, PDDC_F_OUT_PACKED24 = 1, 2, 4, 8
 
 
+class GangItem(C.Structure):
+    """pddc_gang_item (include/perseus_ddc.h)"""
+    _fields_ = [("pipe", C.c_void_p), ("h_packed", C.c_void_p), ("seed", C.c_uint32), ("byte_offset", C.c_uint64),
+                ("h_out", C.c_void_p), ("out_capacity", C.c_size_t), ("n_out", C.c_size_t), ("ticket", C.c_int)]
+
+
 class PddcError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"pddc error {code}: {msg}")
@@ -139,6 +145,12 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_wait.argtypes = [vp]
     L.pddc_host_alloc.argtypes = [C.POINTER(vp), sz]
     L.pddc_host_free.argtypes = [vp]
+    L.pddc_gang_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.pddc_gang_create.restype = C.c_int
+    L.pddc_gang_destroy.argtypes = [vp]
+    L.pddc_gang_destroy.restype = C.c_int
+    L.pddc_gang_push_async.argtypes = [vp, C.POINTER(GangItem), C.c_int, sz, C.POINTER(C.c_int)]
+    L.pddc_gang_push_async.restype = C.c_int
     L.pddc_pipeline_time_stage0.argtypes = [vp, vp, sz, vp, C.c_int, vp, C.POINTER(C.c_float)]
     L.pddc_pipeline_time_stage0_inline.argtypes = [vp, C.c_int]
     L.pddc_pipeline_time_stage0_inline.restype = C.c_int
@@ -514,6 +526,38 @@ class Comm:
         check(ddc_lib().pddc_comm_gather_wait(self._h))
 
 
+class Gang:
+    """pddc_gang: the pipelines of one GPU that stream together share one launch chain (include/perseus_ddc.h;
+    the reference's eight descriptors behind one poll thread, perseus-sdr.c:43-47, 736-774)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        check(ddc_lib().pddc_gang_create(C.byref(h), device))
+        self._h = h
+
+    def push_async(self, items, nsamples: int):
+        """items: dicts with pipe (Pipeline), h_out (pinned pointer), out_cap and either h_packed (pinned pointer) or
+        seed + byte_offset (on-device source).  -> ([(n_out, ticket)], number of members that shared launches)."""
+        arr = (GangItem * len(items))()
+        for a, it in zip(arr, items):
+            a.pipe = it["pipe"]._h
+            a.h_packed = it.get("h_packed")
+            a.seed = it.get("seed", 0) & 0xFFFFFFFF
+            a.byte_offset = it.get("byte_offset", 0)
+            a.h_out = it["h_out"]
+            a.out_capacity = it["out_cap"]
+        ng = C.c_int()
+        check(ddc_lib().pddc_gang_push_async(self._h, arr, len(items), nsamples, C.byref(ng)))
+        return [(a.n_out, a.ticket) for a in arr], ng.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            ddc_lib().pddc_gang_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
 class PinnedBuffer:
     """nbytes of pinned host memory (pddc_host_alloc) viewed as a numpy uint8 array."""
 
@@ -600,7 +644,7 @@ class AmdStats(C.Structure):
     _fields_ = [("delivered", C.c_uint64), ("dropped", C.c_uint64), ("timeouts", C.c_uint64),
                 ("dead_transfers", C.c_uint64), ("transfers", C.c_uint64), ("bytes_received", C.c_uint64),
                 ("adc_samples", C.c_uint64), ("batches", C.c_uint64), ("gpu_device", C.c_int),
-                ("gpu_source", C.c_int), ("peak_receivers_in_flight", C.c_int)]
+                ("gpu_source", C.c_int), ("peak_receivers_in_flight", C.c_int), ("ganged_batches", C.c_uint64)]
 
 
 _sdr = None

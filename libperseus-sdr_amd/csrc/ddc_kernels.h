@@ -100,6 +100,33 @@ struct Fir8Args {
     float       lo_s_hist[8];
 };
 
+/* ---- several streams, one launch chain ("gang"): the drop-in API's virtual receivers that share a GPU --------------
+ * Up to kFir8ManyMax streams with the SAME plan and batch length go through one launch of each kernel: blockIdx.y is
+ * the stream, and every record below is that stream's own (buffers, histories, tuning word, phase, scheduler words).
+ * The records travel as kernel arguments (8 x sizeof(Fir8Args) stays under the 4 KiB a launch may carry).          */
+constexpr int kFir8ManyMax = 8;
+struct Fir8Many {
+    Fir8Args a[kFir8ManyMax];
+};
+static_assert(sizeof(Fir8Many) <= 4000, "Fir8Many must fit the kernel-argument segment");
+struct GenTailMany {
+    GenTail t[kFir8ManyMax];
+};
+struct SynthMany {
+    void              *dst[kFir8ManyMax];
+    unsigned long long byte_offset[kFir8ManyMax];
+    uint32_t           seed[kFir8ManyMax];
+};
+/* first stage of n streams: kind 2 = the fused pair (launch_fir8_fused2's kernel), kind 1 = the packed /8 stage alone
+ * (launch_fir8's, IN_PACKED24).  The (ntb, R) shapes the pipeline picks (fir8_many_supported), 256 threads; every
+ * a[i].n_in equal, a[i].tail empty, a[i].sched distinct. */
+bool fir8_many_supported(int kind, int ntb, int R);
+hipError_t launch_fir8_many(int kind, int ntb, int R, bool mix, const Fir8Many &m, int n, hipStream_t s);
+/* n tails (same D, ntaps and kind; n_out may differ by a block) */
+hipError_t launch_gen_tail_many(const GenTailMany &m, int n, hipStream_t s);
+/* n generator streams of nbytes each */
+hipError_t launch_synth_lcg_many(const SynthMany &m, int n, size_t nbytes, hipStream_t s);
+
 /* k_fir8 with packed input does not scale the unpacked integers (value * 256): the taps of
  * that stage must be uploaded multiplied by this, RN(1/8388607) / 256 -- the factor that
  * k_unpack24 applies per sample (bit-exact with the reference there; here the FIR tolerance

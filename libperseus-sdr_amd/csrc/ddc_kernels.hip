@@ -1101,899 +1101,20 @@ __device__ __forceinline__ void fir_window_tap_outer(const float *base, const fl
 template <int NTB, int R, int INFMT, bool MIX, int NTB2, int NT = 256, int SL3 = 0>
 __global__ __launch_bounds__(NT, 2) void k_fir8(Fir8Args p, int ntiles, int S, int K)
 {
-    constexpr bool FUSE3 = SL3 > 0;
-    constexpr int SLN = SL3 > 0 ? SL3 : 1;
-    /* CARRY (the fused pair): the grid's last p.tail.nblocks blocks are not part of the pair -- they run the generic
-     * decimator on the PREVIOUS batch's second-stage outputs (its tail, Fir8Args::tail).  They are dealt out behind the
-     * pair's persistent blocks and live on the waves those leave idle (the pair issues vector instructions 38 % of the
-     * time and holds two of a SIMD's three possible waves).                                                     */
-    constexpr bool CARRY = SL3 == 0 && NT == 256 && R == 4 && INFMT == IN_PACKED24;
-    if (CARRY && (int)blockIdx.x >= (int)gridDim.x - p.tail.nblocks) {
-        extern __shared__ __attribute__((aligned(16))) float2 sd_tail[];
-        run_tail_block(p.tail, (int)blockIdx.x - ((int)gridDim.x - p.tail.nblocks), sd_tail);
-        return;
-    }
-    static_assert(NT == 256 || (NT == 128 && R == 8 && NTB2 == 0), "128-thread blocks: R = 8, no fused second stage");
-    static_assert(!FUSE3 || (NTB2 > 0 && NT == 256), "the third stage sits behind the fused pair");
-#ifdef PDDC_CLOCK_PROBE
-    if (threadIdx.x == 0 && blockIdx.x < 4096) {
-        g_probe[blockIdx.x].c0 = clock64();
-        g_probe[blockIdx.x].w0 = wall_clock64();
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_probe[blockIdx.x].hw = hw;
-        g_probe[blockIdx.x].xcc = xcc;
-    }
-#endif
-    using G = Fir8Geom<NTB, R, NT>;
-    using G2 = Fir8Geom2<NTB2, R>;
-    constexpr bool FUSE2 = NTB2 > 0;     /* a second decimate-by-8 stage runs on the tile's outputs in LDS */
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sI = smem;
-    float *sQ = smem + G::PLANE;
-    float *ot = smem + 2 * G::PLANE;     /* stage-1 output staging (unfused) ...                            */
-    /* ... or (fused) the second stage's input planes -- set s: I at ot + 2s*PLANE2, Q behind it -- and its staging */
-    auto pl2_of = [&](int set, int q) { return ot + (2 * set + q) * G2::PLANE; };
-    float *ot2 = ot + 4 * G2::PLANE;
-    int cur2 = 0;                        /* the plane set of the tile in work (uniform)                      */
-    /* third stage (FUSE3), all in (I, Q) pairs: the four waves' partial sums, two ring sets -- [padf zeros | h3 history |
-     * g3 tiles of second-stage outputs] each, alternating group by group like the second stage's planes -- and the
-     * held-back outputs of the first groups of up to kPend3 chunks                                                */
-    const int RING = FUSE3 ? p.s3.padf + p.s3.h + p.s3.g * G2::TO2 : 0;
-    f32x2 *part3  = reinterpret_cast<f32x2 *>(ot2 + 4 * G2::TO2);      /* [4 waves][64]: partial sums of a group */
-    f32x2 *ring3  = part3 + 4 * 64;                   /* sets 0 and 1; set 2 is the scratch of the seam fix-ups */
-    f32x2 *pend3  = ring3 + 3 * RING;                 /* [kPend3][64] held-back outputs of chunks whose seam is open */
-    int   *pendh  = reinterpret_cast<int *>(pend3 + kPend3 * 64);   /* [kPend3][4] chunk id, samples, first output */
-    int   *poll3  = pendh + 4 * kPend3;               /* one word: thread 0's poll result for the block          */
-    /* plane offsets 0..6 (slots 0..6 of "group -1") never hold a sample: offset 0 of the
-     * I plane (smem[0], as raw bits) carries the next chunk index from thread 0 to the
-     * block.  Accessed as smem[0] so it stays an LDS access (a cast pointer becomes a
-     * flat load whose vmcnt(0) wait would also wait for the tile's stores).             */
+#include "fir8_block.inc"
+}
 
-    constexpr int NW = (INFMT == IN_PACKED24) ? 3 : 4;             /* 16-byte words per group */
-    constexpr int ES = (INFMT == IN_PACKED24) ? 6 : 8;             /* bytes per sample        */
-
-    const int tid = threadIdx.x;
-    /* group handled by this thread in the load/unpack phases: lane bits 2 and 3
-     * swapped, so that the 8-lane groups of ds_write_b128/_b96 hit 8 distinct
-     * 4-bank sets (32-byte group stride + the 16-byte pad every R groups)      */
-    const int gtid = (tid & ~12) | ((tid & 4) << 1) | ((tid & 8) >> 1);
-    const int nblk = (int)gridDim.x - (CARRY ? p.tail.nblocks : 0);      /* the persistent blocks */
-    const int dyn0 = nblk * S;                           /* first tile of the dynamic part */
-    const int ND   = (ntiles - dyn0 + K - 1) / K;        /* number of dynamic chunks       */
-
-    /* leaving: the last block out resets the schedule for the next launch (and, FUSE3, the chunks' flags: every
-     * other block has made its last poll by then) */
-    auto leave = [&]() {
-        bool last_out = false;
-        if (tid == 0 && atomicAdd(p.sched + 1, 1u) == (unsigned)(nblk - 1)) {
-            atomicExch(p.sched, 0u);
-            atomicExch(p.sched + 1, 0u);
-            last_out = true;
-        }
-        if (FUSE3) {
-            __syncthreads();                              /* nobody still reads smem[0] as a chunk index */
-            if (tid == 0)
-                smem[0] = last_out ? 1.0f : 0.0f;
-            __syncthreads();
-            if (smem[0] != 0.0f) {
-                const int nchunks = (S > 0 ? nblk : 0) + ND;
-                for (int i = tid; i < nchunks; i += NT)
-                    __hip_atomic_store(p.s3.flags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-#ifdef PDDC_CLOCK_PROBE
-        if (threadIdx.x == 0 && blockIdx.x < 4096) {
-            g_probe[blockIdx.x].c1 = clock64();
-            g_probe[blockIdx.x].w1 = wall_clock64();
-        }
-#endif
-    };
-
-    /* ---- first chunk: [c_lo, c_hi) are the tiles whose outputs the block writes ---- */
-    int c_lo, c_hi;
-    if (S > 0) {
-        c_lo = (int)blockIdx.x * S;
-        c_hi = c_lo + S;
-    } else {
-        if (tid == 0)
-            smem[0] = __int_as_float((int)atomicAdd(p.sched, 1u));
-        __syncthreads();
-        const int j = __builtin_amdgcn_readfirstlane(__float_as_int(smem[0]));
-        __syncthreads();
-        if (j >= ND) {
-            leave();
-            return;
-        }
-        c_lo = dyn0 + j * K;
-        c_hi = min(c_lo + K, ntiles);
-    }
-    /* fused second stage: its history is 8*NTB2 stage-1 outputs, i.e. the tile
-     * in front of a chunk is recomputed as a warm-up (no output) -- except for
-     * tile 0, whose stage-2 history comes from the previous call               */
-    if (FUSE2 && c_lo == 0 && tid < NTB2) {
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(static_cast<const float *>(p.hist2) + 16 * tid);
-        const u32x4 h2raw[4] = { src[0], src[1], src[2], src[3] };
-        float xi[8], xq[8];
-        group_to_float<IN_F32C, false, 4>(h2raw, xi, xq, 0ull, p);
-        if (MIX) {      /* stored values are final; inside tile 0 they must become final by * phi_0 */
-            float c0, s0;
-            nco_lo((uint32_t)p.n0 * p.freg + p.phase_off, c0, s0);
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                cmul(xi[e], xq[e], c0, -s0);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {            /* position p2 = 8*tid + e - 1, offset 8 + p2 */
-            pl2_of(cur2, 0)[7 + 8 * tid + e] = xi[e];
-            pl2_of(cur2, 1)[7 + 8 * tid + e] = xq[e];
-        }
-    }
-
-    /* one tile of prefetched input in registers: the next tile is requested while
-     * this one is filtered.  (A second tile in flight was measured no faster; it
-     * needs asm loads with hand-counted vmcnt because hipcc waits vmcnt(0) for
-     * loop-carried loads, and that form is fragile under register pressure --
-     * DESIGN.md 5.)  rawH: the NTB history groups of a chunk's first tile.       */
-    u32x4 rawA[G::GPT][NW];
-    u32x4 rawH[NW];
-    auto prefetch = [&](int tile, bool with_hist) {
-        const long long tin0 = (long long)tile * G::TI;
-        const u32x4 *src0 = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(p.in) +
-                                                            (tin0 + 8LL * gtid) * ES);
-        if (tin0 + G::TI <= p.n_in) {                         /* whole tile in range (wave-uniform) */
-#pragma unroll
-            for (int k = 0; k < G::GPT; ++k)
-#pragma unroll
-                for (int w = 0; w < NW; ++w)
-#ifdef PDDC_ABLATE_LOADS
-                    rawA[k][w] = u32x4{ (unsigned)tile * 2654435761u + tid, (unsigned)(k + w) << 20, (unsigned)tile << 9, 77u * tid };
-#else
-                    rawA[k][w] = src0[(NT * k * 8 * ES) / 16 + w];
-#endif
-        } else {                                        /* ragged last tile */
-#pragma unroll
-            for (int k = 0; k < G::GPT; ++k) {
-                const bool have = tin0 + 8LL * (gtid + NT * k) < p.n_in;
-#pragma unroll
-                for (int w = 0; w < NW; ++w)
-                    rawA[k][w] = have ? src0[(NT * k * 8 * ES) / 16 + w] : u32x4{ 0u, 0u, 0u, 0u };
-            }
-        }
-        if (with_hist && tid < NTB) {                   /* groups 0..NTB-1: the 8*NTB samples before the tile */
-            const long long s_abs = tin0 + 8LL * tid - 8 * NTB;
-            const uint8_t *src = (s_abs < 0) ? static_cast<const uint8_t *>(p.hist) + (s_abs + 8 * NTB) * ES
-                                             : static_cast<const uint8_t *>(p.in) + s_abs * ES;
-#pragma unroll
-            for (int k = 0; k < NW; ++k)
-                rawH[k] = (s_abs < p.n_in) ? reinterpret_cast<const u32x4 *>(src)[k] : u32x4{ 0u, 0u, 0u, 0u };
-        }
-    };
-
-    const int wave  = __builtin_amdgcn_readfirstlane(tid >> 6);   /* provably wave-uniform */
-    const int lane  = tid & 63;
-    const int plane = wave & 1;
-    /* segment (R outputs, 8R inputs) owned by this lane, 0..127 */
-    const int par   = (R == 4) ? (wave >> 1) : 0;                  /* R=4: even / odd half segments */
-    const int L     = (R == 4) ? (2 * lane + par) : ((wave >> 1) * 64 + lane);
-    const float *base = (plane ? sQ : sI) + 8 + 8 * R * L + 4 * ((R * L) >> 3);   /* goff(R*L) */
-    const float PDDC_CONSTANT *hb = (const float PDDC_CONSTANT *)p.taps_blk;
-    const long long n_out = p.n_in >> 3;
-
-    /* S (fused): the tile's TO2 second-stage outputs, 16 bytes per thread */
-    auto store_tile2 = [&](int tile, float pc, float ps) {
-        constexpr int NCH2 = G2::TO2 / 2;
-        if (tid < NCH2) {
-            const long long m = (long long)tile * G2::TO2 + 2LL * tid;     /* no ragged tiles when fused */
-            f32x4 v = *reinterpret_cast<const f32x4 *>(ot2 + 4 * tid);
-            v += *reinterpret_cast<const f32x4 *>(ot2 + 2 * G2::TO2 + 4 * tid);      /* the other half of the taps */
-            if (MIX)                        /* tile-relative NCO: the tile's phasor goes on at the very end */
-                v = cmul2(v, pc, ps);
-            float *dstp = p.out + 2 * m;
-            asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dstp), "v"(v) : "memory");
-        }
-    };
-    const float PDDC_CONSTANT *hb2 = (const float PDDC_CONSTANT *)p.taps2_blk;
-
-    /* ---- third stage (FUSE3) ------------------------------------------------------------------------------------
-     * APPEND: a tile's second-stage outputs are summed and leave the staging area after the next barrier A, where
-     * store_tile2 would have written them to HBM; they go into the ring set of the GROUP being filled (g tiles).
-     * JOB: when a group is complete its outputs are due -- lane j output j, wave w the taps [w*seglen, (w+1)*seglen),
-     * seglen = g*SL3.  Doing that on the spot stalls the whole block on a chain of latencies (LDS round trips, a
-     * barrier for the partial sums, parameters from the argument segment): measured 0.8 us per group, 26 groups per
-     * block, +27 us on a 0.29 ms launch, although the arithmetic is a tenth of the first stage's.  So the job is SLICED
-     * into the next g tiles: each F phase issues SL3 LDS reads before the first-stage FIR and takes SL3 taps -- two
-     * VGPRs hold the wave's taps, one per lane, read with v_readlane, so a tap has no memory latency -- into two packed
-     * accumulators after it; the last slice leaves the wave's partial sums in LDS and they are combined behind the
-     * tile's barrier B.  The group's ring set stays untouched meanwhile (the next group fills the other set).
-     * SEAMS: a chunk of tiles starts with an unknown history: the outputs of its first group are held back (pending
-     * list), its last h second-stage outputs are published for the chunk behind it (write-through stores, then a flag:
-     * MI355X_MICROARCH.md, inter-workgroup visibility), and at later chunk ends -- at the exit at the latest -- the
-     * block looks whether the chunk in front has published, and completes the held-back outputs (resolve3).     */
-    int rs3 = 0;                         /* ring set of the group being filled                                       */
-    int g_left = FUSE3 ? p.s3.g : 0;     /* tiles the group still takes                                              */
-    int npend = 0;                       /* chunks of this block whose seam with the chunk in front is still open    */
-    const Fir8Args PDDC_CONSTANT *kp = (const Fir8Args PDDC_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr();
-    auto ring_of = [&](int set) { return ring3 + set * RING; };
-    f32x2 *ap3 = FUSE3 ? ring_of(0) + p.s3.padf + p.s3.h + 2 * tid : nullptr;   /* where this thread's next pair goes */
-    /* chunk [lo, ..) in tile order: the static runs first, then the dynamic chunks */
-    auto chunk_id = [&](int lo) { return lo < dyn0 ? lo / S : (S > 0 ? nblk : 0) + (lo - dyn0) / K; };
-    float tapv0 = 0.0f, tapv1 = 0.0f;    /* the wave's taps: lane k holds taps k and 64 + k of its segment           */
-    if (FUSE3) {
-        const int seglen = p.s3.seglen;
-        const float *tp = p.s3.taps + wave * seglen;
-        if (lane < seglen)
-            tapv0 = tp[lane];
-        if (64 + lane < seglen)
-            tapv1 = tp[64 + lane];
-    }
-    /* the job in work */
-    const f32x2 *xr3 = ring3 + RING;     /* this lane's newest sample of the next slice (reads xr3[0 .. -(SL3-1)])   */
-    int sl_k = 0, sl_left = 0;           /* the next slice's first tap; slices to go (0: no job, the slices idle)    */
-    f32x2 acc3a = { 0.0f, 0.0f }, acc3b = { 0.0f, 0.0f };
-    bool sum_ready = false;              /* the waves' partial sums are in part3, to be combined behind a barrier    */
-    int job_nnew = 0, job_cid = -1;      /* the group's samples; >= 0: its outputs are held back for chunk job_cid   */
-    long long job_m0 = 0;                /* its first output                                                         */
-    /* SL3 plain ds_read_b64 (2 LDS cycles each; hipcc pairs neighbouring loads into ds_read2_b64, which runs at half
-     * that rate: MI355X_MICROARCH.md, LDS table), issued from inline asm: the compiler's own counted lgkmcnt waits stay
-     * correct because these reads are OLDER than anything it waits for (LDS returns in order); slice_taps waits.   */
-    auto slice_load = [&](f32x2 (&xs)[SLN], const f32x2 *xr) {
-        const unsigned lo = (unsigned)(size_t)(xr - (SLN - 1));       /* the LDS offset: low half of a flat LDS address */
-#pragma unroll
-        for (int u = 0; u < SLN; ++u)
-            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xs[u]) : "v"(lo), "n"(8 * (SLN - 1 - u)));
-    };
-    /* taps k0 .. k0+SL3-1 of the wave's segment (a slice never straddles lane 64: fir8_fused3_geometry) */
-    auto slice_taps = [&](f32x2 (&xs)[SLN], int k0, f32x2 &a, f32x2 &b) {
-        const int tv = __float_as_int(k0 < 64 ? tapv0 : tapv1);          /* uniform */
-        float hh[SLN];
-#pragma unroll
-        for (int u = 0; u < SLN; ++u)
-            hh[u] = __int_as_float(__builtin_amdgcn_readlane(tv, (k0 + u) & 63));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xs[0]) : : "memory");
-#pragma unroll
-        for (int u = 1; u < SLN; ++u)
-            asm volatile("" : "+v"(xs[u]));                              /* not before the wait */
-#pragma unroll
-        for (int u = 0; u < SLN; ++u) {
-            if (u & 1)
-                b = __builtin_elementwise_fma(f32x2{ hh[u], hh[u] }, xs[u], b);
-            else
-                a = __builtin_elementwise_fma(f32x2{ hh[u], hh[u] }, xs[u], a);
-        }
-    };
-    /* second half of a slice (the first is slice_load); with no job in work it accumulates nothing anybody reads */
-    auto slice_fma = [&](f32x2 (&xs)[SLN]) {
-        slice_taps(xs, sl_k, acc3a, acc3b);
-        if (sl_left > 0) {
-            xr3 -= SL3;
-            sl_k += SL3;
-            if (--sl_left == 0) {
-                part3[64 * wave + lane] = acc3a + acc3b;
-                sum_ready = true;
-            }
-        }
-    };
-    auto store_out3 = [&](float *out3, long long m, f32x2 v) {
-        float *dstp = out3 + 2 * m;
-        asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dstp), "v"(v) : "memory");   /* see store_tile */
-    };
-    /* all outputs of the group in ring set `rb` at once (the seam fix-ups; a handful per block and launch):
-     * returns output `tid` to the threads tid < 64, behind a barrier                                              */
-    auto visit3 = [&](const Fir8Stage3 PDDC_CONSTANT &q, const f32x2 *rb) {
-        const int seglen = q.seglen, ng = q.ng;
-        const int j = lane < ng ? lane : ng - 1;
-        const f32x2 *xr = rb + q.padf + q.h + q.off + j * q.d - wave * seglen;
-        f32x2 a = { 0.0f, 0.0f }, b = a;
-        for (int k0 = 0; k0 < seglen; k0 += SLN) {
-            f32x2 xs[SLN];
-            slice_load(xs, xr - k0);
-            slice_taps(xs, k0, a, b);
-        }
-        part3[64 * wave + lane] = a + b;
-        __syncthreads();
-        f32x2 sum = { 0.0f, 0.0f };
-        if (tid < 64)
-            sum = (part3[tid] + part3[64 + tid]) + (part3[128 + tid] + part3[192 + tid]);
-        return sum;
-    };
-    /* Settle open seams.  Entry i of the pending list is a chunk of this block whose first outputs wait for the last
-     * h second-stage outputs of the chunk in front of it (the previous call's for the batch's first chunk).  Thread 0
-     * looks at that chunk's flag -- once; or, `blocking`, until it is up (bounded) -- and when it is, the block loads
-     * the tail into the scratch ring set ([zeros | tail | zeros]), runs the third stage on it and adds the result to
-     * the held-back outputs.  Never waiting at a chunk's end matters: the two blocks of a CU run 15-25 % apart, a
-     * block that waited for its neighbour's static run would idle through exactly the time the dynamic tail is there
-     * to fill.  What is still open when the block runs out of work is waited for at the exit.                     */
-    auto resolve3 = [&](bool blocking) {
-        asm volatile("" : "+s"(kp));
-        const Fir8Stage3 PDDC_CONSTANT &q = kp->s3;
-        const int h3 = q.h, padf = q.padf;
-        f32x2 *fx = ring_of(2);
-        int keep = 0;
-        __syncthreads();                            /* the list as the last push left it */
-        for (int i = 0; i < npend; ++i) {
-            const int id = __builtin_amdgcn_readfirstlane(pendh[4 * i]);
-            if (tid == 0) {
-                int ok = 1;
-                if (id > 0) {
-                    unsigned spins = 0;
-                    while ((ok = __hip_atomic_load(q.flags + id - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) == 0 &&
-                           blocking) {
-                        __builtin_amdgcn_s_sleep(8);
-                        if (++spins > (1u << 20)) {                   /* ~0.3 s: something is badly wrong */
-                            atomicOr(p.sched + 2, 1u);
-                            ok = 1;
-                            break;
-                        }
-                    }
-                    if (ok)
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                }
-                *poll3 = ok;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const int ok = __builtin_amdgcn_readfirstlane(*poll3);
-            if (ok) {
-                if (tid < h3 / 2) {
-                    f32x4 v;
-                    if (id == 0) {
-                        v = *(reinterpret_cast<const f32x4 *>(q.hist) + tid);
-                    } else {
-                        const uint8_t *srcp = static_cast<const uint8_t *>(q.seam) + (size_t)(id - 1) * q.seam_stride + 16 * tid;
-                        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(srcp) : "memory");
-                    }
-                    *reinterpret_cast<f32x4 *>(fx + padf + 2 * tid) = v;
-                }
-                __syncthreads();
-                const f32x2 c = visit3(q, fx);
-                const int nnew = pendh[4 * i + 1];
-                const long long m0 = ((long long)pendh[4 * i + 3] << 32) | (unsigned)pendh[4 * i + 2];
-                if (tid < q.ng && q.off + tid * q.d < nnew && m0 + tid < q.n_out)
-                    store_out3(q.out, m0 + tid, pend3[64 * i + tid] + c);
-            } else {
-                if (keep != i) {                    /* stays open: move it down */
-                    if (tid < 64)
-                        pend3[64 * keep + tid] = pend3[64 * i + tid];
-                    if (tid < 4)
-                        pendh[4 * keep + tid] = pendh[4 * i + tid];
-                }
-                ++keep;
-            }
-            __syncthreads();                        /* poll3, the scratch ring set and the list are reused */
-        }
-        npend = keep;
-    };
-    /* the waves' partial sums of the finished job (in part3 since before the last barrier) -> its outputs: to HBM,
-     * or, for a chunk's first group, onto the pending list                                                         */
-    auto combine3 = [&]() {
-        asm volatile("" : "+s"(kp));
-        const Fir8Stage3 PDDC_CONSTANT &q = kp->s3;
-        f32x2 y = { 0.0f, 0.0f };
-        if (tid < 64)
-            y = (part3[tid] + part3[64 + tid]) + (part3[128 + tid] + part3[192 + tid]);
-        sum_ready = false;
-        if (job_cid >= 0) {
-            if (npend == kPend3)
-                resolve3(true);                     /* the list is full: wait for its oldest seams */
-            if (tid < 64)
-                pend3[64 * npend + tid] = y;
-            if (tid == 0) {
-                pendh[4 * npend] = job_cid;
-                pendh[4 * npend + 1] = job_nnew;
-                pendh[4 * npend + 2] = (int)(unsigned)(job_m0 & 0xffffffffLL);
-                pendh[4 * npend + 3] = (int)(job_m0 >> 32);
-            }
-            ++npend;
-        } else if (tid < q.ng && q.off + tid * q.d < job_nnew && job_m0 + tid < q.n_out) {
-            store_out3(q.out, job_m0 + tid, y);
-        }
-    };
-    /* finish the job in work on the spot (the block is about to leave, or groups follow each other faster than g tiles:
-     * a short last chunk) */
-    auto flush3 = [&]() {
-        while (sl_left > 0) {
-            f32x2 xs[SLN];
-            slice_load(xs, xr3);
-            slice_fma(xs);
-        }
-        if (sum_ready) {
-            __syncthreads();
-            combine3();
-        }
-    };
-    /* S (FUSE3): the tile's TO2 second-stage outputs go into the ring instead of HBM */
-    auto append3 = [&](float pc, float ps) {
-        if (tid < G2::TO2 / 2) {
-            f32x4 v = *reinterpret_cast<const f32x4 *>(ot2 + 4 * tid);
-            v += *reinterpret_cast<const f32x4 *>(ot2 + 2 * G2::TO2 + 4 * tid);
-            if (MIX)
-                v = cmul2(v, pc, ps);
-            *reinterpret_cast<f32x4 *>(ap3) = v;
-        }
-        ap3 += G2::TO2;
-        --g_left;
-    };
-    /* a group is complete (g tiles, or the chunk [a_lo, ..) ends with tile t_last): its job starts; unless the chunk
-     * ends, its last h samples become the history of the next group in the other ring set                         */
-    auto group_done3 = [&](int a_lo, int t_last, bool chunk_ends) {
-        flush3();                             /* normally long finished */
-        asm volatile("" : "+s"(kp));
-        const Fir8Stage3 PDDC_CONSTANT &q = kp->s3;
-        const int g_cnt = q.g - g_left;
-        const int g_t0 = t_last + 1 - g_cnt;
-        const int n_new = g_cnt * G2::TO2;
-        const int h3 = q.h, padf = q.padf;
-        acc3a = acc3b = f32x2{ 0.0f, 0.0f };
-        sl_k = 0;
-        sl_left = q.g;
-        xr3 = ring_of(rs3) + padf + h3 + q.off + (lane < q.ng ? lane : q.ng - 1) * q.d - wave * q.seglen;
-        job_nnew = n_new;
-        job_m0 = (long long)(g_t0 / q.g) * q.ng;
-        job_cid = g_t0 == a_lo ? chunk_id(a_lo) : -1;       /* a chunk's first group has no history yet: held back */
-        if (!chunk_ends) {
-            for (int i = tid; i < h3; i += NT)
-                ring_of(rs3 ^ 1)[padf + i] = ring_of(rs3)[padf + n_new + i];
-            rs3 ^= 1;
-            g_left = q.g;
-            ap3 = ring_of(rs3) + padf + h3 + 2 * tid;
-        }
-    };
-    /* the chunk [a_lo, a_hi) has ended (its last group's job has just started in ring set rs3): publish its last h
-     * second-stage outputs for the chunk behind it, settle whatever seams can be settled, and -- the batch's last chunk
-     * -- leave the next call's history.  The next chunk fills the other ring set, from a zero history.            */
-    auto chunk_end3 = [&](int a_lo, int a_hi, bool at_exit) {
-        asm volatile("" : "+s"(kp));
-        const Fir8Stage3 PDDC_CONSTANT &q = kp->s3;
-        const int h3 = q.h, padf = q.padf;
-        const int g_cnt = q.g - g_left;
-        const int n_new = g_cnt * G2::TO2;
-        const bool single = a_hi - g_cnt == a_lo;            /* the chunk's last group is also its first */
-        const int id = chunk_id(a_lo);
-        const bool batch_last = a_hi == ntiles;
-        if (!batch_last) {
-            if (tid < h3 / 2) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(ring_of(rs3) + padf + n_new + 2 * tid);
-                uint8_t *dstp = static_cast<uint8_t *>(q.seam) + (size_t)id * q.seam_stride + 16 * tid;
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dstp), "v"(v) : "memory");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          /* every storing wave drains ...          */
-            __syncthreads();                                          /* ... before ONE lane raises the flag    */
-            if (tid == 0)
-                __hip_atomic_store(q.flags + id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (at_exit)
-            flush3();                                /* nothing left to hide the last job behind */
-        resolve3(at_exit);
-        if (at_exit && batch_last && q.hist_out != nullptr) {
-            /* the stream's last h3 second-stage outputs: from the last group's ring set; where that group is the chunk's
-             * first and shorter than h3 (a tiny batch), from the tail of the chunk in front (settled just above)       */
-            const float2 *pred = id == 0 ? static_cast<const float2 *>(q.hist)
-                                         : reinterpret_cast<const float2 *>(static_cast<const uint8_t *>(q.seam) +
-                                                                            (size_t)(id - 1) * q.seam_stride);
-            for (int i = tid; i < h3; i += NT) {
-                const int rel = n_new - h3 + i;              /* relative to the first new sample of set rs3 */
-                float2 v;
-                if (rel >= 0 || !single) {
-                    const f32x2 r = ring_of(rs3)[padf + h3 + rel];
-                    v = make_float2(r.x, r.y);
-                } else {
-                    const float2 *srcp = pred + (h3 + rel);
-                    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(srcp) : "memory");
-                }
-                static_cast<float2 *>(q.hist_out)[i] = v;
-            }
-        }
-        rs3 ^= 1;                                            /* the job keeps reading the old set */
-        for (int i = tid; i < h3; i += NT)
-            ring_of(rs3)[padf + i] = f32x2{ 0.0f, 0.0f };
-        g_left = q.g;
-        ap3 = ring_of(rs3) + padf + h3 + 2 * tid;
-    };
-    if (FUSE3) {
-        for (int i = tid; i < 3 * RING; i += NT)
-            ring3[i] = f32x2{ 0.0f, 0.0f };
-    }
-
-    /* S: coalesced stores of one finished tile from the staging area */
-    auto store_tile = [&](int tile, float pc, float ps) {
-        const long long tile_o0 = (long long)tile * G::TO;
-        constexpr int NCH = G::TO / 2;                             /* 16-byte chunks */
-        if (tile_o0 + G::TO <= n_out) {                            /* whole tile in range (uniform) */
-#pragma unroll
-            for (int it = 0; it < NCH / NT; ++it) {
-                const int q = tid + NT * it;
-                const int qs = q ^ ((q >> 3) & 7);
-                /* streaming (nt) store: measured 0.349 vs 0.371 ms for this 6:1
-                 * read/write mix (tools/ubench/stream_mix.hip) */
-                f32x4 v = *reinterpret_cast<const f32x4 *>(ot + 4 * qs);
-                if (MIX)
-                    v = cmul2(v, pc, ps);
-                float *dstp = p.out + 2 * (tile_o0 + 2LL * q);
-                /* Issued from inline asm on purpose: hipcc then does not count the store
-                 * in its vmcnt bookkeeping, so the waits it places for the prefetched
-                 * loads stay COUNTED (vmcnt(N)) instead of collapsing to vmcnt(0) as they
-                 * do whenever loads and stores are both pending.  Memory operations
-                 * retire in issue order on gfx9, so a counted wait computed without
-                 * these stores is only ever stronger than needed, never weaker.  The
-                 * trailing s_nop 1 is the wait state a 128-bit store needs before the next
-                 * instruction may overwrite its data registers (hipcc pads nothing inside
-                 * or after an asm string).                                             */
-#ifdef PDDC_ABLATE_STORES
-                if (v.x == 1.2345e-30f)
-#endif
-                asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dstp), "v"(v) : "memory");
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < NCH / NT; ++it) {
-                const int q = tid + NT * it;
-                const int qs = q ^ ((q >> 3) & 7);
-                float4 v = *reinterpret_cast<const float4 *>(ot + 4 * qs);
-                if (MIX) {
-                    cmul(v.x, v.y, pc, ps);
-                    cmul(v.z, v.w, pc, ps);
-                }
-                const long long m = tile_o0 + 2LL * q;
-                if (m + 1 < n_out)
-                    *reinterpret_cast<float4 *>(p.out + 2 * m) = v;
-                else if (m < n_out)
-                    *reinterpret_cast<float2 *>(p.out + 2 * m) = make_float2(v.x, v.y);
-            }
-        }
-    };
-
-    /* NCO, tile-relative.  LO(n) of sample i of tile t factors as phi_t * w(i) with
-     * phi_t = LO(n0 + t*TI) and w(i) = exp(-j*2*pi*freg*i/2^32), i the index inside the tile
-     * (the phase is linear in the sample index).  U multiplies by w(i) only -- per-thread
-     * constants, no sin/cos and no rotation chain per group -- and everything downstream is
-     * linear, so phi_t is applied once per OUTPUT, at the stores.  A sample carried to the
-     * next tile as FIR history is rotated by conj(D), D = phi_(t+1)/phi_t = LO(TI).
-     * R=4: w for the thread's 8*GPT samples sits in registers; R=8 (no VGPRs to spare) keeps
-     * w of each group's first sample and steps through the group with the host's phasors.   */
-    constexpr bool WTAB = MIX && R == 4;
-    float w_c[WTAB ? G::GPT : 1][8], w_s[WTAB ? G::GPT : 1][8];
-    float wg_c[G::GPT], wg_s[G::GPT];
-    float d_c = 1.0f, d_s = 0.0f;
-#pragma unroll
-    for (int k = 0; k < G::GPT; ++k) {
-        wg_c[k] = 1.0f;
-        wg_s[k] = 0.0f;
-        if (MIX && !WTAB)
-            nco_lo((uint32_t)(8 * (gtid + NT * k)) * p.freg, wg_c[k], wg_s[k]);
-        if (WTAB) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                nco_lo((uint32_t)(8 * (gtid + NT * k) + e) * p.freg, w_c[k][e], w_s[k][e]);
-        }
-    }
-    if (MIX)
-        nco_lo((uint32_t)G::TI * p.freg, d_c, d_s);
-    /* The tile's phasor is the same for every lane: lane l computes the one of tile ph_base + l, once per 64
-     * consecutive tiles, and each tile fetches its own with v_readlane -- the sin/cos polynomial is ~25 VALU
-     * instructions, a tenth of what a wave of the fused pair issues per tile (same-box A/B -0.4 %).           */
-    /* (R = 4 only: the R = 8 mixing variants sit at 256 VGPRs and the two table registers would spill) */
-    constexpr bool PHTAB = MIX && R == 4;
-    float ph_c = 1.0f, ph_s = 0.0f;
-    int ph_base = -0x40000000;
-    auto tile_phasor = [&](int tile, float &c, float &sn) {
-        c = 1.0f;
-        sn = 0.0f;
-        if (MIX && !PHTAB)
-            nco_lo((uint32_t)(p.n0 + (unsigned long long)((long long)tile * G::TI)) * p.freg + p.phase_off, c, sn);
-        if (PHTAB) {
-            if (tile < ph_base || tile >= ph_base + 64) {            /* uniform */
-                ph_base = tile;
-                nco_lo(((uint32_t)p.n0 + (uint32_t)(tile + (tid & 63)) * (uint32_t)G::TI) * p.freg + p.phase_off, ph_c,
-                       ph_s);
-            }
-            c  = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ph_c), tile - ph_base));
-            sn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ph_s), tile - ph_base));
-        }
-    };
-
-    int  t = (FUSE2 && c_lo > 0) ? c_lo - 1 : c_lo;   /* tile in work (a fused chunk starts one tile early) */
-    bool first = true;                                /* t opens a chunk: history comes from rawH            */
-    int  tprev = -1;                                  /* tile whose outputs are staged, not yet stored        */
-    bool prev_out2 = false;                           /* ... and (fused) whether it produced stage-2 outputs  */
-    int  pv_lo = 0, pv_hi = 0;                        /* ... and (FUSE3) the chunk it belongs to              */
-    unsigned grabv = 0;                               /* thread 0: the chunk taken for after this one         */
-    float pp_c = 1.0f, pp_s = 0.0f;                   /* NCO phasor of tile tprev                             */
-    prefetch(t, true);
-    if (t + 1 == c_hi && tid == 0)
-        grabv = atomicAdd(p.sched, 1u);
-
-    for (;;) {
-        /* wave issue priority: the FIR phase runs at PDDC_PRIO_F (2), everything else at PDDC_PRIO_U (0).
-         * When the two waves of a SIMD both want to issue, the one inside its FMA run goes first and the
-         * other's loads / LDS traffic fill the gaps: 255 taps 0.481 -> 0.466 ms, 127 taps 0.3669 -> 0.3650,
-         * x320 cascade unchanged (same-box A/B, profiles/r02/ab_prio.txt); the reverse (loads first) gains nothing */
-        __builtin_amdgcn_s_setprio(PDDC_PRIO_U);
-        const bool last = (t + 1 == c_hi);            /* last tile of its chunk */
-        /* ---- U: registers -> LDS planes (groups NTB ..; a chunk's first tile also 0..NTB-1) ---- */
-        float pt_c, pt_s;                                /* this tile's phasor, used when its outputs leave */
-        tile_phasor(t, pt_c, pt_s);
-#pragma unroll
-        for (int k = 0; k < G::GPT; ++k) {
-            const int v = NTB + gtid + NT * k;
-            float xi[8], xq[8];
-            group_to_float<INFMT, false, NW>(rawA[k], xi, xq, 0ull, p);
-            if (WTAB) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    cmul(xi[e], xq[e], w_c[WTAB ? k : 0][e], w_s[WTAB ? k : 0][e]);
-            } else if (MIX) {
-                mix8_lo(xi, xq, wg_c[k], wg_s[k], p);
-            }
-            group_to_lds<R>(sI, sQ, v, xi, xq);
-        }
-        if (first && tid < NTB) {          /* after the tile's own groups: rawH was requested last */
-            float xi[8], xq[8];
-            group_to_float<INFMT, false, NW>(rawH, xi, xq, 0ull, p);
-            if (MIX) {
-                /* tile-relative index i = 8*tid - 8*NTB < 0 (the 32-bit phase wraps correctly).  The
-                 * samples in front of tile 0 belong to the previous batch: in the first batch after a
-                 * retune they were mixed with the OLD tuning word -- the switch is sample-accurate at
-                 * the batch boundary and phase-continuous there, like the FPGA's phase accumulator --
-                 * so relative to this tile's phasor they carry exp(-j*2*pi*i*freg_old/2^32).  The old
-                 * word and its step phasors come with the arguments (== the current ones otherwise). */
-                const bool old = (t == 0);                       /* uniform */
-                float cb, sb;
-                nco_lo((uint32_t)(8 * tid - 8 * NTB) * (old ? p.freg_hist : p.freg), cb, sb);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float sc = old ? p.lo_c_hist[e] : p.lo_c[e];
-                    const float ss = old ? p.lo_s_hist[e] : p.lo_s[e];
-                    cmul(xi[e], xq[e], cb * sc - sb * ss, cb * ss + sb * sc);
-                }
-            }
-            group_to_lds<R>(sI, sQ, tid, xi, xq);
-        }
-        /* ---- S (deferred): the PREVIOUS tile's stores go out here, behind this
-         * tile's load wait.  gfx9 has one vmcnt for loads and stores and hipcc
-         * waits vmcnt(0) whenever both kinds are pending, so stores issued just
-         * before the wait for prefetched loads would stall every tile on the
-         * write acknowledgements (measured: +0.12 ms per 2^28 samples).        */
-        /* publish the next chunk BEFORE the stores are issued: reading grabv waits
-         * for everything outstanding (vmcnt(0)), which here is nothing new -- after the
-         * stores it would wait for their acknowledgements                             */
-        if (last && tid == 0)
-            smem[0] = __int_as_float((int)grabv);
-        if (!FUSE2 && tprev >= 0)
-            store_tile(tprev, pp_c, pp_s);
-        __syncthreads();                                           /* A */
-        const bool appended = FUSE3 && prev_out2;
-        if (FUSE3) {
-            if (prev_out2)             /* into the third stage's ring */
-                append3(pp_c, pp_s);
-        } else if (FUSE2 && prev_out2) /* written by waves 0/1 after the previous barrier B */
-            store_tile2(tprev, pp_c, pp_s);
-
-        /* ---- P: next tile's loads (and, one tile before a chunk ends, the next chunk) ---- */
-        int tn = t + 1, n_lo = c_lo, n_hi = c_hi;
-        if (last) {
-            const int j = __builtin_amdgcn_readfirstlane(__float_as_int(smem[0]));
-            if (j < ND) {
-                n_lo = dyn0 + j * K;
-                n_hi = min(n_lo + K, ntiles);
-                tn = FUSE2 ? n_lo - 1 : n_lo;                        /* dynamic chunks never start at tile 0... */
-                if (FUSE2 && n_lo == 0)
-                    tn = 0;                                          /* ... unless S == 0                      */
-            } else {
-                tn = -1;
-            }
-        }
-        if (tn >= 0) {
-            prefetch(tn, last);
-            if (tn + 1 == n_hi && tid == 0)
-                grabv = atomicAdd(p.sched, 1u);
-        }
-
-        /* ---- F: FIR ------------------------------------------------------ */
-        /* Packed fp32: every VALU op costs ~4 cycles per wave64 on gfx950, and
-         * v_pk_fma_f32 does two FMAs in that slot (measured 68 vs 33 TFMA/s,
-         * tools/ubench/fma_issue.hip).  The dot product of one output is split
-         * into its even and odd terms: acc.x += h[k]*x[i], acc.y += h[k-1]*x[i+1]
-         * -- both operands are natural adjacent pairs (SGPR pair of taps, VGPR
-         * pair of samples from one ds_read_b128), no broadcast, no shuffles.   */
-        __builtin_amdgcn_s_setprio(PDDC_PRIO_F);
-        asm volatile("" : "+s"(hb));      /* keep the tap s_loads inside the tile loop (no SGPR spills) */
-        if (FUSE2)
-            asm volatile("" : "+s"(hb2));
-        f32x2 xs3[SLN];
-        if (FUSE3)                        /* third stage: this tile's slice of the job in work, loads first ... */
-            slice_load(xs3, xr3);
-        constexpr int NA = FirAcc<NTB>::N;
-        f32x2 accp[R][NA];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int a = 0; a < NA; ++a)
-                accp[r][a] = f32x2{ 0.0f, 0.0f };
-#ifdef PDDC_ABLATE_FIR
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            accp[r][0] = *reinterpret_cast<const f32x2 *>(base + 8 * r);
-#else
-        if (R == 4 && par)
-            fir_window<NTB, R, 1>(base, hb, accp);
-        else if (R == 8 && kTapOuterR8)
-            fir_window_tap_outer<NTB, R, 0>(base, hb, accp);
-        else
-            fir_window<NTB, R, 0>(base, hb, accp);
-#endif
-        f32x2 acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            acc[r] = NA == 2 ? accp[r][0] + accp[r][NA - 1] : accp[r][0];
-        if (FUSE3)                        /* ... taps behind the first-stage FIR, which hid the loads' latency */
-            slice_fma(xs3);
-        if (FUSE2) {
-            /* results -> the second stage's input plane, rotated like the first:
-             * position p2 = m + 8*NTB2 - 1 for tile-relative output m = R*L + r,
-             * float offset 8 + p2                                                  */
-            float *pl2 = pl2_of(cur2, plane);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                pl2[8 + (R * L + r + 8 * NTB2 - 1)] = acc[r].x + acc[r].y;
-            }
-        } else {
-            /* results -> staging (XOR-swizzled 16-byte chunks, interleaved I/Q) */
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int f  = 2 * (R * L + r) + plane;
-                const int q  = f >> 2;
-                const int qs = q ^ ((q >> 3) & 7);
-                ot[4 * qs + (f & 3)] = acc[r].x + acc[r].y;
-            }
-        }
-        __syncthreads();                                           /* B */
-
-        /* ---- C: tail groups -> history of the next tile of the chunk -------- */
-        if (!last && gtid >= NT - NTB) {
-            const int gd = gtid - (NT - NTB);                       /* 0..NTB-1 */
-            const int os = goff<R>(G::GT + gd), od = goff<R>(gd);
-            float4 i0 = *reinterpret_cast<const float4 *>(sI + os);
-            float4 i1 = *reinterpret_cast<const float4 *>(sI + os + 4);
-            float4 q0 = *reinterpret_cast<const float4 *>(sQ + os);
-            float4 q1 = *reinterpret_cast<const float4 *>(sQ + os + 4);
-            if (MIX) {          /* into the next tile's frame: * conj(D) */
-                cmul(i0.x, q0.x, d_c, -d_s);
-                cmul(i0.y, q0.y, d_c, -d_s);
-                cmul(i0.z, q0.z, d_c, -d_s);
-                cmul(i0.w, q0.w, d_c, -d_s);
-                cmul(i1.x, q1.x, d_c, -d_s);
-                cmul(i1.y, q1.y, d_c, -d_s);
-                cmul(i1.z, q1.z, d_c, -d_s);
-                cmul(i1.w, q1.w, d_c, -d_s);
-            }
-            *reinterpret_cast<float4 *>(sI + od) = i0;
-            *reinterpret_cast<float4 *>(sQ + od) = q0;
-            *reinterpret_cast<float2 *>(sI + od + 4) = make_float2(i1.x, i1.y);
-            *reinterpret_cast<float2 *>(sQ + od + 4) = make_float2(q1.x, q1.y);
-            sI[od + 6] = i1.z;
-            sQ[od + 6] = q1.z;
-            if (gd != NTB - 1) {          /* slot 7 of the last group belongs to the next tile's first sample */
-                sI[od + 7] = i1.w;
-                sQ[od + 7] = q1.w;
-            }
-        }
-        /* ---- F2 / C2 (fused): the second decimator on the TO stage-1 outputs now in LDS, all four waves: waves
-         * 0 / 1 take the OLDER half of the tap blocks of plane I / Q, waves 2 / 3 the newer half (the two partial
-         * sums meet in store_tile2) -- the 64 taps on two waves left SIMDs 0 and 1 with half as much FIR work again
-         * as SIMDs 2 and 3 (same-box A/B 0.2897 -> 0.2875 ms).  Then waves 0 / 1 carry the history INTO THE OTHER
-         * PLANE SET, which nobody reads before the next barrier B, so waves 2 / 3 may still be reading this one.
-         * Ordering needs no extra barrier: the inputs were written before B, the outputs (ot2) are read after the
-         * next A, and the next stage-1 results go into the other set after the next A as well.                  */
-        if (FUSE2) {
-            const float *pl2r = pl2_of(cur2, wave & 1);
-            const int newer = wave >> 1;
-            if (t >= c_lo) {
-                constexpr int R2 = G2::R2 > 0 ? G2::R2 : 1;
-                constexpr int HB = NTB2 > 1 ? NTB2 / 2 : 1;
-                static_assert(NTB2 == 0 || NTB2 % 2 == 0, "the split second stage needs an even number of tap blocks");
-                f32x2 acc2[R2][1];                 /* HB <= 4 tap blocks: one packed accumulator per output */
-#pragma unroll
-                for (int r = 0; r < R2; ++r)
-                    acc2[r][0] = f32x2{ 0.0f, 0.0f };
-                fir_window<HB, R2, 0, false>(pl2r + 8 + 8 * R2 * lane + (newer ? 8 * HB : 0), hb2 + (newer ? 0 : 8 * HB),
-                                             acc2);
-#pragma unroll
-                for (int r = 0; r < R2; ++r)
-                    ot2[newer * 2 * G2::TO2 + 2 * (R2 * lane + r) + (wave & 1)] = acc2[r][0].x + acc2[r][0].y;
-            }
-            if (wave < 2 && !last && lane < NTB2) {
-                float *nx2 = pl2_of(cur2 ^ 1, wave);                /* the next tile's plane of this wave */
-                const int os = 8 + 8 * (G2::GT2 + lane), od = 8 + 8 * lane;
-                float4 a0 = *reinterpret_cast<const float4 *>(pl2r + os);
-                float4 a1 = *reinterpret_cast<const float4 *>(pl2r + os + 4);
-                if (MIX) {
-                    /* * conj(D), like the first stage's history.  The rotation needs the other
-                     * plane's tail too: read-only here (written before B)                      */
-                    const float *ol2 = pl2_of(cur2, wave ^ 1);
-                    const float4 b0 = *reinterpret_cast<const float4 *>(ol2 + os);
-                    const float4 b1 = *reinterpret_cast<const float4 *>(ol2 + os + 4);
-                    /* wave 0: I' = I*dc + Q*ds ; wave 1: Q' = Q*dc - I*ds */
-                    const float sg = wave ? -d_s : d_s;
-                    a0.x = a0.x * d_c + b0.x * sg;
-                    a0.y = a0.y * d_c + b0.y * sg;
-                    a0.z = a0.z * d_c + b0.z * sg;
-                    a0.w = a0.w * d_c + b0.w * sg;
-                    a1.x = a1.x * d_c + b1.x * sg;
-                    a1.y = a1.y * d_c + b1.y * sg;
-                    a1.z = a1.z * d_c + b1.z * sg;
-                    a1.w = a1.w * d_c + b1.w * sg;
-                }
-                *reinterpret_cast<float4 *>(nx2 + od) = a0;
-                *reinterpret_cast<float2 *>(nx2 + od + 4) = make_float2(a1.x, a1.y);
-                nx2[od + 6] = a1.z;
-                if (lane != NTB2 - 1)
-                    nx2[od + 7] = a1.w;
-            }
-        }
-        /* ---- F3 (FUSE3): the ring holds tprev's outputs since before barrier B.  A full group, or the end of tprev's
-         * chunk: the third stage runs on it; a chunk's end also settles the seam with the chunk in front of it     */
-        if (FUSE3 && sum_ready)
-            combine3();
-        if (appended) {
-            const bool a_last = tprev + 1 == pv_hi;
-            if (g_left == 0 || a_last) {
-                group_done3(pv_lo, tprev, a_last);
-                if (a_last)
-                    chunk_end3(pv_lo, pv_hi, false);
-            }
-        }
-        tprev = t;
-        pp_c = pt_c;
-        pp_s = pt_s;
-        prev_out2 = FUSE2 && t >= c_lo;
-        pv_lo = c_lo;
-        pv_hi = c_hi;
-        if (tn < 0)
-            break;
-        if (FUSE2)
-            cur2 ^= 1;                    /* the next tile's stage-1 results and history live in the other set */
-        first = last;
-        t = tn;
-        c_lo = n_lo;
-        c_hi = n_hi;
-    }
-
-    if (FUSE2) {
-        __syncthreads();                 /* ot2 and the stage-2 planes of the last tile are complete */
-        if (FUSE3) {
-            if (prev_out2) {
-                append3(pp_c, pp_s);
-                __syncthreads();
-                group_done3(pv_lo, tprev, true);
-                chunk_end3(pv_lo, pv_hi, true);
-            }
-        } else if (prev_out2)
-            store_tile2(tprev, pp_c, pp_s);
-        /* the last 8*NTB2 stage-1 outputs are the second stage's next history */
-        if (p.hist2_out != nullptr && tprev == ntiles - 1 && tid < 8 * NTB2) {
-            const int o = 8 + (G::TO + tid - 1);       /* position of stage-1 output TO - 8*NTB2 + tid */
-            float hi = pl2_of(cur2, 0)[o], hq = pl2_of(cur2, 1)[o];
-            if (MIX)
-                cmul(hi, hq, pp_c, pp_s);              /* stored in final form */
-            static_cast<float2 *>(p.hist2_out)[tid] = make_float2(hi, hq);
-        }
-    } else {
-        store_tile(tprev, pp_c, pp_s);
-    }
-
-    /* the block that ran the last tile leaves the batch's last 8*NTB input
-     * samples as the next call's history (the host alternates two buffers, so
-     * tile 0 of THIS launch never sees them)                                  */
-    if (p.hist_out != nullptr && tprev == ntiles - 1 && p.n_in >= 8 * NTB) {
-        constexpr int HCH = 8 * NTB * ES / 16;                     /* 16-byte chunks */
-        const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(p.in) +
-                                                           (p.n_in - 8 * NTB) * ES);
-        for (int c = tid; c < HCH; c += NT)
-            static_cast<uint4 *>(p.hist_out)[c] = src[c];
-    }
-    leave();
+/* one batch of EACH of up to kFir8ManyMax streams that share a GPU (the drop-in API's virtual receivers): blockIdx.y is
+ * the stream, every stream has its own argument record (input, histories, tuning word and phase, output, scheduler words)
+ * and the same batch length, so ntiles / S / K are common.  One launch instead of one per stream: a 2^22-sample batch
+ * keeps a 512-block grid busy for a dozen microseconds, less than the launch gap in front of it.                   */
+template <int NTB, int R, int INFMT, bool MIX, int NTB2>
+__global__ __launch_bounds__(256, 2) void k_fir8_many(Fir8Many m, int ntiles, int S, int K)
+{
+    constexpr int NT = 256;
+    constexpr int SL3 = 0;
+    const Fir8Args &p = m.a[blockIdx.y];
+#include "fir8_block.inc"
 }
 
 bool fir8_supported(int ntb, int R)
@@ -2299,6 +1420,81 @@ hipError_t launch_fir8_fused2(int ntb, int R, bool mix, const Fir8Args &a, hipSt
     if (ntb == 4 && R == 8) return launch_fir8_fused2_t<4, 8>(mix, a, s);
     if (ntb == 8 && R == 8) return launch_fir8_fused2_t<8, 8>(mix, a, s);
     return hipErrorInvalidValue;
+}
+
+/* ---- several streams in one launch ------------------------------------------------------------------------------- */
+template <int NTB, int NTB2, int R>
+static hipError_t launch_fir8_many_t(bool mix, const Fir8Many &m, int n, hipStream_t s)
+{
+    using G = Fir8Geom<NTB, R>;
+    using G2 = Fir8Geom2<8, R>;
+    const size_t lds = NTB2 ? (size_t)(2 * G::PLANE + G2::LDS_FLT) * sizeof(float) : (size_t)G::LDS_FLT * sizeof(float);
+    const long long n_in = m.a[0].n_in;
+    if (n_in <= 0 || (NTB2 && n_in % G::TI))
+        return hipErrorInvalidValue;
+    for (int i = 0; i < n; ++i) {
+        if (m.a[i].n_in != n_in || m.a[i].sched == nullptr || m.a[i].tail.nblocks != 0)
+            return hipErrorInvalidValue;
+        for (int j = 0; j < i; ++j)
+            if (m.a[j].sched == m.a[i].sched)
+                return hipErrorInvalidValue;     /* every stream counts its own tiles */
+    }
+    const long long ntiles_ll = (n_in + G::TI - 1) / G::TI;
+    if (ntiles_ll > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+    const int ntiles = (int)ntiles_ll;
+    /* Every stream gets the grid and the tile schedule a launch of its own would have (not 1/n of it): with the NCO on,
+     * the first tile of a chunk mixes its history through another expression than a tile that inherits it in LDS, equal
+     * to the last bit or two -- so the same chunks mean the SAME BITS as the per-stream path.  The n grids simply queue
+     * behind each other on the chip; no block of this kernel ever waits for another one.                          */
+    const Fir8Sched sc = fir8_schedule(ntiles, R, NTB2 != 0);
+    const dim3 grid((unsigned)sc.nblocks, (unsigned)n), blk(256);
+#define PDDC_LAUNCHM(MIXV)                                                                        \
+    do {                                                                                          \
+        static unsigned long long attr_done = 0;                                                  \
+        int dev__ = 0;                                                                            \
+        (void)hipGetDevice(&dev__);                                                               \
+        if (!(attr_done >> (dev__ & 63) & 1ull)) {                                                \
+            hipError_t e = hipFuncSetAttribute(                                                   \
+                reinterpret_cast<const void *>(&k_fir8_many<NTB, R, IN_PACKED24, MIXV, NTB2>),    \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+            if (e != hipSuccess)                                                                  \
+                return e;                                                                         \
+            attr_done |= 1ull << (dev__ & 63);                                                    \
+        }                                                                                         \
+        hipLaunchKernelGGL((k_fir8_many<NTB, R, IN_PACKED24, MIXV, NTB2>), grid, blk, lds, s, m, ntiles, sc.S, sc.K); \
+    } while (0)
+    if (mix)
+        PDDC_LAUNCHM(true);
+    else
+        PDDC_LAUNCHM(false);
+#undef PDDC_LAUNCHM
+    return hipGetLastError();
+}
+
+bool fir8_many_supported(int kind, int ntb, int R)
+{
+    /* the shapes the pipeline itself picks: R = 4 for first stages of up to 64 taps (alone or as the fused pair),
+     * R = 8 for the long ones (128, 256 taps) */
+    if (kind == 2)
+        return R == 4 && (ntb == 4 || ntb == 8);
+    if (kind == 1)
+        return (R == 4 && (ntb == 4 || ntb == 8)) || (R == 8 && (ntb == 16 || ntb == 32));
+    return false;
+}
+
+hipError_t launch_fir8_many(int kind, int ntb, int R, bool mix, const Fir8Many &m, int n, hipStream_t s)
+{
+    if (n < 1 || n > kFir8ManyMax || !fir8_many_supported(kind, ntb, R))
+        return hipErrorInvalidValue;
+    if (kind == 2)
+        return ntb == 4 ? launch_fir8_many_t<4, 8, 4>(mix, m, n, s) : launch_fir8_many_t<8, 8, 4>(mix, m, n, s);
+    switch (ntb) {
+    case 4: return launch_fir8_many_t<4, 0, 4>(mix, m, n, s);
+    case 8: return launch_fir8_many_t<8, 0, 4>(mix, m, n, s);
+    case 16: return launch_fir8_many_t<16, 0, 8>(mix, m, n, s);
+    default: return launch_fir8_many_t<32, 0, 8>(mix, m, n, s);
+    }
 }
 
 void fir8_set_grid_blocks(int nblocks) { g_fir8_blocks = nblocks > 0 ? nblocks : 0; }
@@ -2721,6 +1917,44 @@ hipError_t launch_gen_tail(const GenTail &t, hipStream_t s)
     return hipGetLastError();
 }
 
+/* the tails of several streams in one launch: blockIdx.y is the stream */
+__global__ __launch_bounds__(256) void k_gen_tail_many(GenTailMany m)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 sd_tail_many[];
+    const GenTail &t = m.t[blockIdx.y];
+    if ((int)blockIdx.x >= t.nblocks)
+        return;
+    run_tail_block(t, (int)blockIdx.x, sd_tail_many);
+}
+
+hipError_t launch_gen_tail_many(const GenTailMany &m, int n, hipStream_t s)
+{
+    if (n < 1 || n > kFir8ManyMax)
+        return hipErrorInvalidValue;
+    int nb = 0;
+    unsigned lds = 0;
+    for (int i = 0; i < n; ++i) {
+        if (m.t[i].kind != m.t[0].kind || m.t[i].D != m.t[0].D || m.t[i].ntaps != m.t[0].ntaps)
+            return hipErrorInvalidValue;
+        nb = m.t[i].nblocks > nb ? m.t[i].nblocks : nb;
+        lds = m.t[i].lds > lds ? m.t[i].lds : lds;
+    }
+    if (nb <= 0)
+        return hipSuccess;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static bool attr_done[64] = { false };
+    if (!attr_done[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gen_tail_many),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess)
+            return e;
+        attr_done[dev & 63] = true;
+    }
+    hipLaunchKernelGGL(k_gen_tail_many, dim3((unsigned)nb, (unsigned)n), dim3(256), lds, s, m);
+    return hipGetLastError();
+}
+
 /* ======================================================================== */
 /* k_resample : rational L/M polyphase resampler on float2 (low rate)       */
 /* ======================================================================== */
@@ -3109,6 +2343,62 @@ hipError_t launch_synth_lcg(void *dst, size_t nbytes, uint32_t seed, uint64_t by
         blocks = 256 * 32;
     hipLaunchKernelGGL(k_synth_lcg, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint8_t *>(dst),
                        (unsigned long long)nbytes, seed, (unsigned long long)byte_offset);
+    return hipGetLastError();
+}
+
+/* The generator for several streams (blockIdx.y), 16 bytes per thread and iteration as above.  The jump to a thread's
+ * first chunk is split: the ladder to the BLOCK's first chunk is the same for all its threads (scalar unit), and the
+ * thread's own 16*tid steps behind it need 12 rounds, not 40.                                                     */
+__global__ __launch_bounds__(256) void k_synth_lcg_many(SynthMany m, unsigned long long nbytes)
+{
+    uint8_t *dst = static_cast<uint8_t *>(m.dst[blockIdx.y]);
+    const uint32_t seed = m.seed[blockIdx.y];
+    const unsigned long long nch = (nbytes + 15) >> 4;
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    const unsigned long long cb = (unsigned long long)blockIdx.x * 256;
+    unsigned long long c = cb + threadIdx.x;
+    if (c >= nch)
+        return;
+    uint32_t A, C, At, Ct, As, Cs;
+    lcg_jump(m.byte_offset[blockIdx.y] + (cb << 4), A, C);      /* uniform */
+    lcg_jump((unsigned long long)threadIdx.x << 4, At, Ct);
+    lcg_jump((stride - 1) << 4, As, Cs);                        /* uniform */
+    uint32_t st = At * (A * seed + C) + Ct;
+    for (; c < nch; c += stride) {
+        uint32_t w[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                st = st * 1664525u + 1013904223u;
+                v |= (st >> 24) << (8 * b);
+            }
+            w[d] = v;
+        }
+        const unsigned long long o = c << 4;
+        if (o + 16 <= nbytes) {
+            *reinterpret_cast<uint4 *>(dst + o) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (int b = 0; b < 16 && o + b < nbytes; ++b)
+                dst[o + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+        }
+        st = As * st + Cs;
+    }
+}
+
+hipError_t launch_synth_lcg_many(const SynthMany &m, int n, size_t nbytes, hipStream_t s)
+{
+    if (n < 1 || n > kFir8ManyMax)
+        return hipErrorInvalidValue;
+    if (nbytes == 0)
+        return hipSuccess;
+    const unsigned long long nch = ((unsigned long long)nbytes + 15) >> 4;
+    unsigned long long blocks = (nch + 255) / 256;
+    const unsigned long long cap = 256ull * 16 / (unsigned)n > 256 ? 256ull * 16 / (unsigned)n : 256;
+    if (blocks > cap)
+        blocks = cap;
+    hipLaunchKernelGGL(k_synth_lcg_many, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, s, m, (unsigned long long)nbytes);
     return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -134,6 +135,9 @@ struct pddc_pipeline {
         float *d_out = nullptr;
         size_t out_cap = 0;           /* samples */
         hipEvent_t ev_in = nullptr, ev_comp = nullptr, ev_out = nullptr;
+        hipEvent_t ev_wait = nullptr; /* what the slot's ticket waits for: ev_out, or the event of the gang round it went out with */
+        void *h_out_seen = nullptr;   /* gang rounds: the last host output buffer asked about, and its address as the   */
+        float *h_out_dev = nullptr;   /* device sees it (pinned memory, pddc_host_alloc) or NULL: copy out as usual     */
         bool used = false;
     } slot[2];
     int next_slot = 0;
@@ -155,11 +159,35 @@ struct pddc_pipeline {
     Fir8Stage3 s3;
     void *d_seam = nullptr;
     unsigned *d_flags = nullptr;
+    /* gang submission (pddc_gang_push_async): several pipelines of one GPU share one launch chain.  gang_rec != NULL
+     * turns pddc_pipeline_process into "record, do not launch": the first-stage launch and the tail behind it are
+     * written there, the gang launches them for all its members at once.                                          */
+    struct GangRec *gang_rec = nullptr;
+    struct pddc_gang *gang = nullptr;        /* the gang whose stream the last push used (NULL: the pipeline's own)   */
+};
+
+/* what one member's process() leaves for the gang: kind 0 = nothing recorded */
+struct GangRec {
+    int kind = 0;                 /* 1: the packed /8 first stage alone (launch_fir8), 2: the fused pair          */
+    int ntb = 0, R = 4;
+    bool mix = false;
+    Fir8Args a;
+    GenTail tail;                 /* nblocks == 0: the plan ends with the first-stage kernel                       */
+};
+
+struct pddc_gang {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    int next_ev = 0;
+    std::mutex lock;
+    std::vector<pddc_pipeline *> members;    /* pipelines whose last push went through this gang's stream            */
 };
 
 static bool stage0_fused(const pddc_pipeline *p);
 static bool stage0_packed_generic(const pddc_pipeline *p);
 static int setup_stage3(pddc_pipeline *p);
+static int leave_gang(pddc_pipeline *p);
 
 static float round_to_half(float v)
 {
@@ -828,6 +856,7 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
         return PDDC_OK;
     hipSetDevice(p->device);
     hipDeviceSynchronize();
+    (void)leave_gang(p);
     for (int i = 0; i < PDDC_MAX_STAGES; ++i) {
         if (p->st[i].d_taps_base)
             hipFree(p->st[i].d_taps_base);
@@ -1463,15 +1492,15 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
     /* Overlap mode: the plan's LAST stage `ti` (a plain decimator behind one first-stage kernel: the fused pair, or the
      * unfused fused-/8 stage 0) is held back and rides along with the next batch's first-stage launch.  Prepares its
      * record: shape, the half of the double-buffered input the first stage writes this time, history, output.   */
-    auto carry_setup = [&](int ti, float **dst_first, GenTail *mine) -> int {
+    auto carry_setup = [&](int ti, float **dst_first, GenTail *mine, bool use_alt, size_t lds_cap) -> int {
         Stage &sl = p->st[ti];
         mine->H = sl.hist;
         mine->D = sl.decim;
         mine->ntaps = sl.ntaps;
         mine->n_out = (long long)n_in[ti + 1];
-        if (!gen_tail_shape(mine, kCarryLdsCap, sl.d_taps_firp != nullptr))
+        if (!gen_tail_shape(mine, lds_cap, sl.d_taps_firp != nullptr))
             return 1;                                    /* does not fit: in line */
-        if (p->ov_parity == 1) {
+        if (use_alt) {
             if (sl.buf_in_ws) {
                 if (sl.d_buf_alt == nullptr || sl.buf_alt_cap < n_in[ti] + 8)
                     return fail(PDDC_ECAPACITY, "overlap mode: the workspace was set before pddc_pipeline_set_overlap, "
@@ -1529,6 +1558,23 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             compute_lo_steps(p);
         }
     }
+    /* Gang mode: this call only RECORDS the first-stage launch and the one plain decimator that may follow it; the gang
+     * launches them for all its members together.  Anything else (other plan shapes, the rare routes, an empty tail)
+     * answers 1 before anything has been touched, and the gang runs this member's batch as a chain of its own.   */
+    GangRec *const g = p->gang_rec;
+    if (g) {
+        g->kind = 0;
+        g->tail = GenTail{};
+        const int nfirst = stages01_fusable(p, nsamples) ? 2 : 1;
+        const int last = p->nstages - 1;
+        const bool tail_ok = p->nstages == nfirst ||
+                             (p->nstages == nfirst + 1 && p->st[last].interp == 1 && n_in[p->nstages] > 0);
+        if (mixed_hist || !stage0_fused(p) || p->NT != 256 || p->overlap || p->carry_pending ||
+            p->time_stage0 || p->fail_at_stage >= 0 || (p->flags & (PDDC_F_OUT_PACKED24 | PDDC_F_NO_FAST)) ||
+            stages012_fusable(p, nsamples) || !tail_ok || n_in[1] == 0 || nsamples < (size_t)p->st[0].hist ||
+            !fir8_many_supported(nfirst, p->st[0].ntb, p->R))
+            return 1;
+    }
     if (!mixed_hist && stages012_fusable(p, nsamples)) {
         /* stages 0, 1 and 2 in ONE kernel: neither intermediate touches HBM */
         Stage &s0 = p->st[0], &s1 = p->st[1];
@@ -1565,13 +1611,16 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             return rc;
         /* overlap mode: the one stage behind the pair is held back and rides along with the NEXT batch's pair */
         GenTail mine;
-        bool ov = carry_wanted(2);
+        bool ov = !g && carry_wanted(2);
         if (ov) {
-            rc = carry_setup(2, &dst, &mine);
+            rc = carry_setup(2, &dst, &mine, p->ov_parity == 1, kCarryLdsCap);
             if (rc < 0)
                 return rc;
             ov = rc == PDDC_OK;
         }
+        const bool gtail = g && p->nstages == 3;
+        if (gtail && (rc = carry_setup(2, &dst, &mine, false, 160u * 1024u)))
+            return rc;                                      /* (1: no shape for this tail -- nothing touched yet) */
         if (!ov && (rc = pddc_pipeline_fence(p, s)))        /* in line: what is held back goes first */
             return rc;
         Fir8Args a;
@@ -1589,13 +1638,25 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             a.tail = p->carry_tail;
         if ((rc = stage0_event(p, s, true)))
             return rc;
-        HIP_TRY(launch_fir8_fused2(s0.ntb, p->R, mix, a, s));
+        if (g) {
+            g->kind = 2;
+            g->ntb = s0.ntb;
+            g->R = p->R;
+            g->mix = mix;
+            g->a = a;
+            if (gtail) {
+                g->tail = mine;
+                flip[2] = true;
+            }
+        } else {
+            HIP_TRY(launch_fir8_fused2(s0.ntb, p->R, mix, a, s));
+        }
         if (ov)
             p->carry_pending = false;       /* (failure atomicity: only once the launch was accepted) */
         if ((rc = stage0_event(p, s, false)))
             return rc;
         flip[0] = flip[1] = true;
-        first = 2;
+        first = gtail ? 3 : 2;
         if (ov) {                           /* the previous tail went out with this launch; this batch's is held back */
             p->carry_tail = mine;
             p->carry_pending = true;
@@ -1650,13 +1711,16 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         } else if (i == 0 && stage0_fused(p)) {
             /* overlap mode, two-stage plan: stage 1 is held back and rides along with the next batch's stage 0 */
             GenTail mine;
-            bool ov = carry_wanted(1) && p->NT == 256;
+            bool ov = !g && carry_wanted(1) && p->NT == 256;
             if (ov) {
-                rc = carry_setup(1, &dst, &mine);
+                rc = carry_setup(1, &dst, &mine, p->ov_parity == 1, kCarryLdsCap);
                 if (rc < 0)
                     return rc;
                 ov = rc == PDDC_OK;
             }
+            const bool gtail = g && p->nstages == 2;
+            if (gtail && (rc = carry_setup(1, &dst, &mine, false, 160u * 1024u)))
+                return rc;
             if (!ov && (rc = pddc_pipeline_fence(p, s)))
                 return rc;
             Fir8Args a;
@@ -1671,7 +1735,20 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                 a.tail = p->carry_tail;
             if ((rc = stage0_event(p, s, true)))
                 return rc;
-            HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s, p->NT));
+            if (g) {
+                g->kind = 1;
+                g->ntb = st.ntb;
+                g->R = p->R;
+                g->mix = mix;
+                g->a = a;
+                if (gtail) {
+                    g->tail = mine;
+                    flip[1] = true;
+                    skip_from = 1;
+                }
+            } else {
+                HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s, p->NT));
+            }
             if ((rc = stage0_event(p, s, false)))
                 return rc;
             hist_done = a.hist_out != nullptr;
@@ -1787,6 +1864,52 @@ int pddc_host_free(void *h_ptr)
     return PDDC_OK;
 }
 
+/* a staging slot ready for a batch of nsamples: events, device buffers for the packed input and the final output */
+static int prep_slot(pddc_pipeline *p, pddc_pipeline::HostSlot &sl, size_t nsamples)
+{
+    if (!sl.ev_in) {
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_comp, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+    }
+    const size_t max_out = pddc_pipeline_max_output(p, nsamples) + 1;
+    if (sl.in_cap < nsamples || sl.out_cap < max_out) {
+        if (sl.used)                          /* growing a slot: its last batch must be out first */
+            HIP_TRY(hipEventSynchronize(sl.ev_wait ? sl.ev_wait : sl.ev_out));
+        if (sl.in_cap < nsamples) {
+            if (sl.d_in)
+                HIP_TRY(hipFree(sl.d_in));
+            sl.d_in = nullptr;
+            sl.in_cap = 0;
+            HIP_TRY(hipMalloc(&sl.d_in, nsamples * 6 + 64));
+            sl.in_cap = nsamples;
+        }
+        if (sl.out_cap < max_out) {
+            if (sl.d_out)
+                HIP_TRY(hipFree(sl.d_out));
+            sl.d_out = nullptr;
+            sl.out_cap = 0;
+            HIP_TRY(hipMalloc(&sl.d_out, max_out * 8 + 64));
+            sl.out_cap = max_out;
+        }
+    }
+    return PDDC_OK;
+}
+
+/* A pipeline's pushes are ordered by the stream they go through: its own, or a gang's.  Changing from one to the other
+ * (the number of receivers that stream together changed) waits for what is still in flight on the old one.        */
+static int leave_gang(pddc_pipeline *p)
+{
+    pddc_gang *g = p->gang;
+    if (!g)
+        return PDDC_OK;
+    std::lock_guard<std::mutex> lk(g->lock);
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->members.erase(std::remove(g->members.begin(), g->members.end(), p), g->members.end());
+    p->gang = nullptr;
+    return PDDC_OK;
+}
+
 /* one batch through a staging slot: input either copied from the host (h_packed) or generated
  * on the device (synthetic LCG source: no host -> device traffic at all), kernels, output D2H */
 static int push_async(pddc_pipeline *p, const void *h_packed, bool synth, uint32_t seed, uint64_t byte_offset,
@@ -1812,50 +1935,38 @@ static int push_async(pddc_pipeline *p, const void *h_packed, bool synth, uint32
             return fail(PDDC_ECAPACITY, "output capacity %zu < %zu", out_capacity, need);
     }
     HIP_TRY(hipSetDevice(p->device));
+    int rc0 = leave_gang(p);                  /* the batch before may have gone out with a gang, on the gang's stream */
+    if (rc0)
+        return rc0;
     if (!p->s_in) {
         HIP_TRY(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
     }
     const int si = p->next_slot;
     pddc_pipeline::HostSlot &sl = p->slot[si];
-    if (!sl.ev_in) {
-        HIP_TRY(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&sl.ev_comp, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
-    }
-    const size_t max_out = pddc_pipeline_max_output(p, nsamples) + 1;
-    if (sl.in_cap < nsamples || sl.out_cap < max_out) {
-        if (sl.used)                          /* growing a slot: its last batch must be out first */
-            HIP_TRY(hipEventSynchronize(sl.ev_out));
-        if (sl.in_cap < nsamples) {
-            if (sl.d_in)
-                HIP_TRY(hipFree(sl.d_in));
-            sl.d_in = nullptr;
-            sl.in_cap = 0;
-            HIP_TRY(hipMalloc(&sl.d_in, nsamples * 6 + 64));
-            sl.in_cap = nsamples;
-        }
-        if (sl.out_cap < max_out) {
-            if (sl.d_out)
-                HIP_TRY(hipFree(sl.d_out));
-            sl.d_out = nullptr;
-            sl.out_cap = 0;
-            HIP_TRY(hipMalloc(&sl.d_out, max_out * 8 + 64));
-            sl.out_cap = max_out;
-        }
-    }
+    if ((rc0 = prep_slot(p, sl, nsamples)))
+        return rc0;
+    /* The on-device source has no host-to-device copy to overlap, and its decimated output is small: generator, kernels
+     * and the copy out then all go on ONE stream.  The three-stream form below costs two cross-stream event hops per
+     * batch, ~18 us each on this runtime (profiles/r03/d_side_stream_overlap_delay.txt) -- more than the kernels of a
+     * 2^22-sample batch take.  Two slots still alternate, so the host fills / reads one while the GPU works on the other. */
+    const bool one_stream = synth && !getenv("PDDC_PUSH_THREE_STREAMS");
+    hipStream_t st_in = one_stream ? p->own_stream : p->s_in;
+    hipStream_t st_out = one_stream ? p->own_stream : p->s_out;
     /* H2D (or the generator): the slot's input buffer is free once the kernels of its previous batch are done */
-    if (sl.used)
-        HIP_TRY(hipStreamWaitEvent(p->s_in, sl.ev_comp, 0));
+    if (sl.used && !one_stream)
+        HIP_TRY(hipStreamWaitEvent(st_in, sl.ev_comp, 0));
     if (synth)
-        HIP_TRY(launch_synth_lcg(sl.d_in, nsamples * 6, seed, byte_offset, p->s_in));
+        HIP_TRY(launch_synth_lcg(sl.d_in, nsamples * 6, seed, byte_offset, st_in));
     else
-        HIP_TRY(hipMemcpyAsync(sl.d_in, h_packed, nsamples * 6, hipMemcpyHostToDevice, p->s_in));
-    HIP_TRY(hipEventRecord(sl.ev_in, p->s_in));
-    /* kernels: after this batch has arrived and the slot's previous output has left */
-    HIP_TRY(hipStreamWaitEvent(p->own_stream, sl.ev_in, 0));
-    if (sl.used)
-        HIP_TRY(hipStreamWaitEvent(p->own_stream, sl.ev_out, 0));
+        HIP_TRY(hipMemcpyAsync(sl.d_in, h_packed, nsamples * 6, hipMemcpyHostToDevice, st_in));
+    if (!one_stream) {
+        HIP_TRY(hipEventRecord(sl.ev_in, st_in));
+        /* kernels: after this batch has arrived and the slot's previous output has left */
+        HIP_TRY(hipStreamWaitEvent(p->own_stream, sl.ev_in, 0));
+        if (sl.used)
+            HIP_TRY(hipStreamWaitEvent(p->own_stream, sl.ev_out, 0));
+    }
     size_t n_out = 0;
     int rc = pddc_pipeline_process(p, sl.d_in, nsamples, sl.d_out, sl.out_cap, &n_out, p->own_stream);
     if (rc)
@@ -1865,11 +1976,13 @@ static int push_async(pddc_pipeline *p, const void *h_packed, bool synth, uint32
     HIP_TRY(hipEventRecord(sl.ev_comp, p->own_stream));
     sl.used = true;
     p->next_slot = si ^ 1;
-    HIP_TRY(hipStreamWaitEvent(p->s_out, sl.ev_comp, 0));
+    if (!one_stream)
+        HIP_TRY(hipStreamWaitEvent(st_out, sl.ev_comp, 0));
     if (n_out)
         HIP_TRY(hipMemcpyAsync(h_out, sl.d_out, n_out * ((p->flags & PDDC_F_OUT_PACKED24) ? 6 : 8),
-                               hipMemcpyDeviceToHost, p->s_out));
-    HIP_TRY(hipEventRecord(sl.ev_out, p->s_out));
+                               hipMemcpyDeviceToHost, st_out));
+    HIP_TRY(hipEventRecord(sl.ev_out, st_out));
+    sl.ev_wait = sl.ev_out;
     if (n_out_ret)
         *n_out_ret = n_out;
     if (ticket)
@@ -1896,7 +2009,7 @@ int pddc_pipeline_ticket_done(pddc_pipeline *p, int ticket)
     if (!p->slot[ticket].used)
         return fail(PDDC_ESTATE, "nothing was pushed on ticket %d", ticket);
     HIP_TRY(hipSetDevice(p->device));
-    hipError_t e = hipEventQuery(p->slot[ticket].ev_out);
+    hipError_t e = hipEventQuery(p->slot[ticket].ev_wait);
     if (e == hipSuccess)
         return 1;
     if (e == hipErrorNotReady)
@@ -1911,7 +2024,7 @@ int pddc_pipeline_wait_ticket(pddc_pipeline *p, int ticket)
     if (!p->slot[ticket].used)
         return fail(PDDC_ESTATE, "nothing was pushed on ticket %d", ticket);
     HIP_TRY(hipSetDevice(p->device));
-    HIP_TRY(hipEventSynchronize(p->slot[ticket].ev_out));
+    HIP_TRY(hipEventSynchronize(p->slot[ticket].ev_wait));
     return PDDC_OK;
 }
 
@@ -1925,6 +2038,214 @@ int pddc_pipeline_wait(pddc_pipeline *p)
     HIP_TRY(hipStreamSynchronize(p->own_stream));
     if (p->s_out)
         HIP_TRY(hipStreamSynchronize(p->s_out));
+    if (p->gang) {
+        std::lock_guard<std::mutex> lk(p->gang->lock);
+        HIP_TRY(hipStreamSynchronize(p->gang->stream));
+    }
+    return PDDC_OK;
+}
+
+/* The final stage of a gang round writes into the caller's output buffer ITSELF where that is pinned host memory (what
+ * pddc_host_alloc hands out; the device sees it through the bus): the few dozen kilobytes a receiver's batch decimates
+ * to need no copy engine, and the round has no eight copies -- 7 us of stream time and 6 us of host time each -- behind
+ * its kernels.  Pageable memory (or PDDC_GANG_COPY_OUT=1) keeps the staging buffer and the copy.                     */
+static float *direct_out(pddc_pipeline::HostSlot &sl, void *h_out)
+{
+    if (sl.h_out_seen != h_out) {
+        sl.h_out_seen = h_out;
+        sl.h_out_dev = nullptr;
+        hipPointerAttribute_t at;
+        if (!getenv("PDDC_GANG_COPY_OUT") && hipPointerGetAttributes(&at, h_out) == hipSuccess &&
+            at.type == hipMemoryTypeHost && at.devicePointer && ((uintptr_t)at.devicePointer & 15) == 0)
+            sl.h_out_dev = static_cast<float *>(at.devicePointer);
+        else
+            (void)hipGetLastError();
+    }
+    return sl.h_out_dev;
+}
+
+/* ---- gang: the pipelines of one GPU that stream together, one launch chain for all -------------------------------- */
+int pddc_gang_create(pddc_gang **out, int device)
+{
+    if (!out)
+        return fail(PDDC_EINVAL, "null argument");
+    *out = nullptr;
+    int rc = require_device();
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(device));
+    pddc_gang *g = new (std::nothrow) pddc_gang;
+    if (!g)
+        return fail(PDDC_ENOMEM, "out of memory");
+    g->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        e = hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        pddc_gang_destroy(g);
+        return fail(PDDC_EHIP, "gang stream/events: %s", hipGetErrorString(e));
+    }
+    *out = g;
+    return PDDC_OK;
+}
+
+int pddc_gang_destroy(pddc_gang *g)
+{
+    if (!g)
+        return PDDC_OK;
+    (void)hipSetDevice(g->device);
+    {
+        std::lock_guard<std::mutex> lk(g->lock);
+        if (g->stream)
+            (void)hipStreamSynchronize(g->stream);
+        for (pddc_pipeline *p : g->members)
+            p->gang = nullptr;                /* their next push goes through their own stream again */
+        g->members.clear();
+    }
+    for (int i = 0; i < 4; ++i)
+        if (g->ev[i])
+            (void)hipEventDestroy(g->ev[i]);
+    if (g->stream)
+        (void)hipStreamDestroy(g->stream);
+    delete g;
+    return PDDC_OK;
+}
+
+int pddc_gang_push_async(pddc_gang *g, pddc_gang_item *items, int n, size_t nsamples, int *n_ganged)
+{
+    if (n_ganged)
+        *n_ganged = 0;
+    if (!g || !items || n < 1 || n > PDDC_GANG_MAX)
+        return fail(PDDC_EINVAL, "gang push: 1..%d items", PDDC_GANG_MAX);
+    if (nsamples == 0 || nsamples % PDDC_INPUT_GRANULE)
+        return fail(PDDC_EINVAL, "nsamples (%zu) must be a positive multiple of %d", nsamples, PDDC_INPUT_GRANULE);
+    /* everything that can refuse the round is checked before anything is queued or any stream position moves */
+    bool all_synth = true;
+    for (int i = 0; i < n; ++i) {
+        pddc_gang_item &it = items[i];
+        it.n_out = 0;
+        it.ticket = -1;
+        if (!it.pipe || !it.h_out)
+            return fail(PDDC_EINVAL, "gang item %d: null pipeline or output buffer", i);
+        if (it.pipe->device != g->device)
+            return fail(PDDC_EINVAL, "gang item %d: pipeline on GPU %d, gang on GPU %d", i, it.pipe->device, g->device);
+        for (int j = 0; j < i; ++j)
+            if (items[j].pipe == it.pipe)
+                return fail(PDDC_EINVAL, "gang items %d and %d: the same pipeline", j, i);
+        if (it.pipe->carry_pending)
+            return fail(PDDC_ESTATE, "gang item %d: overlap mode holds a tail back (pddc_pipeline_fence first)", i);
+        const size_t need = predict_outputs(it.pipe, nsamples);
+        if (need > it.out_capacity)
+            return fail(PDDC_ECAPACITY, "gang item %d: output capacity %zu < %zu", i, it.out_capacity, need);
+        all_synth = all_synth && it.h_packed == nullptr;
+    }
+    HIP_TRY(hipSetDevice(g->device));
+    std::lock_guard<std::mutex> lk(g->lock);
+    hipStream_t s = g->stream;
+    int si[PDDC_GANG_MAX];
+    for (int i = 0; i < n; ++i) {
+        pddc_pipeline *p = items[i].pipe;
+        if (p->gang != g) {                    /* joining: what it queued on its own streams (or another gang's) first */
+            int rc = leave_gang(p);
+            if (!rc)
+                rc = pddc_pipeline_wait(p);
+            if (rc)
+                return rc;
+            p->gang = g;
+            g->members.push_back(p);
+        }
+        si[i] = p->next_slot;
+        int rc = prep_slot(p, p->slot[si[i]], nsamples);
+        if (rc)
+            return rc;
+    }
+    /* the inputs: one generator launch for the on-device sources, one copy each for the host-fed ones */
+    if (all_synth) {
+        SynthMany sm;
+        for (int i = 0; i < n; ++i) {
+            sm.dst[i] = items[i].pipe->slot[si[i]].d_in;
+            sm.byte_offset[i] = items[i].byte_offset;
+            sm.seed[i] = items[i].seed;
+        }
+        HIP_TRY(launch_synth_lcg_many(sm, n, nsamples * 6, s));
+    } else {
+        for (int i = 0; i < n; ++i) {
+            pddc_pipeline::HostSlot &sl = items[i].pipe->slot[si[i]];
+            if (items[i].h_packed)
+                HIP_TRY(hipMemcpyAsync(sl.d_in, items[i].h_packed, nsamples * 6, hipMemcpyHostToDevice, s));
+            else
+                HIP_TRY(launch_synth_lcg(sl.d_in, nsamples * 6, items[i].seed, items[i].byte_offset, s));
+        }
+    }
+    /* every member plans its batch: the ones whose plan is "first-stage kernel [+ one plain decimator]" leave a record,
+     * the others run their own launches on the gang's stream right here */
+    GangRec rec[PDDC_GANG_MAX];
+    bool open[PDDC_GANG_MAX];
+    float *direct[PDDC_GANG_MAX];
+    for (int i = 0; i < n; ++i) {
+        pddc_pipeline *p = items[i].pipe;
+        pddc_pipeline::HostSlot &sl = p->slot[si[i]];
+        direct[i] = (p->flags & PDDC_F_OUT_PACKED24) ? nullptr : direct_out(sl, items[i].h_out);
+        void *dst = direct[i] ? direct[i] : sl.d_out;
+        const size_t cap = direct[i] ? items[i].out_capacity : sl.out_cap;
+        p->gang_rec = n > 1 && !getenv("PDDC_GANG_SOLO") ? &rec[i] : nullptr;
+        int rc = p->gang_rec ? pddc_pipeline_process(p, sl.d_in, nsamples, dst, cap, &items[i].n_out, s) : 1;
+        p->gang_rec = nullptr;
+        open[i] = rc == PDDC_OK && rec[i].kind != 0;
+        if (rc == 1) {
+            rc = pddc_pipeline_process(p, sl.d_in, nsamples, dst, cap, &items[i].n_out, s);
+            if (rc == PDDC_OK)
+                rc = pddc_pipeline_fence(p, s);
+        }
+        if (rc)
+            return rc;                         /* (members before this one have moved on: the stream is broken) */
+    }
+    /* one launch per group of members with the same kernels */
+    for (int i = 0; i < n; ++i) {
+        if (!open[i])
+            continue;
+        Fir8Many fm;
+        GenTailMany tm;
+        int k = 0;
+        bool any_tail = false;
+        for (int j = i; j < n; ++j) {
+            if (!open[j] || rec[j].kind != rec[i].kind || rec[j].ntb != rec[i].ntb || rec[j].R != rec[i].R ||
+                rec[j].mix != rec[i].mix ||
+                rec[j].a.n_in != rec[i].a.n_in || (rec[j].tail.nblocks > 0) != (rec[i].tail.nblocks > 0) ||
+                rec[j].tail.kind != rec[i].tail.kind || rec[j].tail.D != rec[i].tail.D ||
+                rec[j].tail.ntaps != rec[i].tail.ntaps)
+                continue;
+            fm.a[k] = rec[j].a;
+            tm.t[k] = rec[j].tail;
+            any_tail = any_tail || rec[j].tail.nblocks > 0;
+            open[j] = false;
+            ++k;
+        }
+        HIP_TRY(launch_fir8_many(rec[i].kind, rec[i].ntb, rec[i].R, rec[i].mix, fm, k, s));
+        if (any_tail)
+            HIP_TRY(launch_gen_tail_many(tm, k, s));
+        if (n_ganged)
+            *n_ganged += k;
+    }
+    /* the outputs leave, one event for the round: every member's ticket waits for it */
+    hipEvent_t ev = g->ev[g->next_ev];
+    g->next_ev = (g->next_ev + 1) & 3;
+    for (int i = 0; i < n; ++i) {
+        pddc_pipeline *p = items[i].pipe;
+        pddc_pipeline::HostSlot &sl = p->slot[si[i]];
+        if (items[i].n_out && !direct[i])
+            HIP_TRY(hipMemcpyAsync(items[i].h_out, sl.d_out, items[i].n_out * ((p->flags & PDDC_F_OUT_PACKED24) ? 6 : 8),
+                                   hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipEventRecord(ev, s));
+    for (int i = 0; i < n; ++i) {
+        pddc_pipeline *p = items[i].pipe;
+        pddc_pipeline::HostSlot &sl = p->slot[si[i]];
+        sl.ev_wait = ev;
+        sl.used = true;
+        p->next_slot = si[i] ^ 1;
+        items[i].ticket = si[i];
+    }
     return PDDC_OK;
 }
 

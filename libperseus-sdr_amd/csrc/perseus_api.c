@@ -146,6 +146,7 @@ struct perseus_descr_ds {
     int n_pend;
     int input_done;             /* the source has nothing more to give           */
     int gpu_source;             /* the LCG stream is generated on the device     */
+    uint64_t ganged_batches;    /* batches that shared their launches with other receivers of the GPU */
     int gpu_dev;                /* HIP device of the current / last stream, -1: none */
     uint8_t *fifo;              /* ring of decimated bytes awaiting callbacks    */
     size_t fifo_rd, fifo_len, fifo_cap;
@@ -553,8 +554,9 @@ static size_t out_bytes_per_sample(const perseus_descr *d)
     return d->cfg.mode == PERSEUS_AMD_MODE_DDC_WIRE ? 6 : 8;
 }
 
-/* fill the next batch buffer from the source and hand it to the GPU; returns at once */
-static void submit_batch(perseus_descr *d)
+/* the receiver's own part of a submission: the next batch buffer filled from the source, the pace kept, the tuning
+ * word latched.  Returns the samples of the batch (0: nothing to submit) */
+static size_t batch_prepare(perseus_descr *d)
 {
     const int k = d->cur;
     size_t ns = d->cfg.batch_samples;
@@ -565,7 +567,7 @@ static void submit_batch(perseus_descr *d)
             d->input_done = 1;                   /* bounded source (file) ended */
         ns = got / 6;
         if (ns == 0)
-            return;
+            return 0;
     }
     pace_until(d, (double)(d->adc_samples + ns), d->adc_clk_freq);
     /* A retune takes effect at the batch boundary (reference clients retune while streaming,
@@ -582,6 +584,29 @@ static void submit_batch(perseus_descr *d)
         dbgprintf(3, "NCO word %u from ADC sample %llu", word, (unsigned long long)d->adc_samples);
     }
     pddc_pipeline_set_freg(d->pipe, word);
+    return ns;
+}
+
+static void batch_pushed(perseus_descr *d, int rc, size_t ns, size_t n_out, int ticket)
+{
+    if (rc != PDDC_OK) {
+        dbgprintf(0, "GPU pipeline failed (%d: %s); stream stopped", rc, pddc_last_error());
+        d->input_done = 1;
+        return;
+    }
+    d->adc_samples += ns;
+    d->batches++;
+    d->pend[d->n_pend++] = (pending_batch){ ticket, d->cur, n_out };
+    d->cur ^= 1;
+}
+
+/* fill the next batch buffer from the source and hand it to the GPU; returns at once */
+static void submit_batch(perseus_descr *d)
+{
+    const int k = d->cur;
+    const size_t ns = batch_prepare(d);
+    if (ns == 0)
+        return;
     size_t n_out = 0;
     int ticket = -1;
     int rc;
@@ -590,28 +615,23 @@ static void submit_batch(perseus_descr *d)
                                             d->out_cap, &n_out, &ticket);
     else
         rc = pddc_pipeline_push_host_async(d->pipe, d->batch_in[k], ns, d->batch_out[k], d->out_cap, &n_out, &ticket);
-    if (rc != PDDC_OK) {
-        dbgprintf(0, "GPU pipeline failed (%d: %s); stream stopped", rc, pddc_last_error());
-        d->input_done = 1;
-        return;
-    }
-    d->adc_samples += ns;
-    d->batches++;
-    d->pend[d->n_pend++] = (pending_batch){ ticket, k, n_out };
-    d->cur = k ^ 1;
+    batch_pushed(d, rc, ns, n_out, ticket);
 }
 
 /* pass 1: keep the GPU fed.  A free-running source has two batches in flight (source, PCIe and
  * kernels overlap); a paced, real-time one is not read ahead, that would only add latency.   */
+static int can_submit(const perseus_descr *d)
+{
+    const int depth = d->cfg.pace ? 1 : 2;
+    const size_t worst = d->out_cap * out_bytes_per_sample(d);
+    return d->n_pend < depth && !d->input_done && !d->source_done && fifo_room(d) >= worst * (size_t)(d->n_pend + 1) &&
+           !(d->cfg.max_buffers && d->seq >= d->cfg.max_buffers);
+}
+
 static int ddc_submit(perseus_descr *d)
 {
     int did = 0;
-    const int depth = d->cfg.pace ? 1 : 2;
-    const size_t worst = d->out_cap * out_bytes_per_sample(d);
-    while (d->n_pend < depth && !d->input_done && !d->source_done &&
-           fifo_room(d) >= worst * (size_t)(d->n_pend + 1)) {
-        if (d->cfg.max_buffers && d->seq >= d->cfg.max_buffers)
-            break;
+    while (can_submit(d)) {
         submit_batch(d);
         did = 1;
         if (d->n_pend == 0)
@@ -714,9 +734,117 @@ static void *helper_fn(void *arg)
     return NULL;
 }
 
-/* pass 0 for the receivers in list[0..n): in parallel when there are several and helpers exist */
-static void submit_round(const int *list, int n, int *busy, int *inflight)
+/* ---- gang submission ------------------------------------------------------------------------------
+ * Receivers that share a GPU and stream from the on-device source hand their batches to the GPU TOGETHER
+ * (pddc_gang_push_async): one generator launch, one first-stage launch, one decimator launch for all of them, the
+ * receiver being the grid's second dimension, and one event -- instead of a chain of launches per receiver, each
+ * shorter than the launch gap in front of it.  Outputs are bit-identical to the per-receiver path.  The reference's
+ * shape is the same: eight descriptors, one poll thread that serves them all (perseus-sdr.c:43-47, 736-774).
+ * PERSEUS_AMD_GANG=0 turns it off (every receiver a chain of its own, farmed out to the submit helpers).        */
+#define MAX_GANG_GPUS 16
+static pddc_gang *g_gang[MAX_GANG_GPUS];
+static int g_gang_off = 0;
+
+static int gang_candidate(const perseus_descr *d)
 {
+    return d->gpu_source && d->gpu_dev >= 0 && d->gpu_dev < MAX_GANG_GPUS && d->cfg.mode == PERSEUS_AMD_MODE_DDC;
+}
+
+/* the receivers sub[0..m) (ascending, all on GPU `dev`): up to `depth` rounds of one batch each */
+static void gang_submit(int dev, const int *sub, int m, int *busy, int *inflight)
+{
+    if (!g_gang[dev] && pddc_gang_create(&g_gang[dev], dev) != PDDC_OK) {
+        dbgprintf(0, "no gang on GPU %d (%s): receivers submit one by one", dev, pddc_last_error());
+        g_gang_off = 1;
+        return;
+    }
+    for (int k = 0; k < m; k++)
+        pthread_mutex_lock(&g_list[sub[k]].pump_lock);         /* ascending order everywhere: no deadlock */
+    for (int round = 0; round < 2; round++) {
+        perseus_descr *mem[MAX_DESCR];
+        int nm = 0;
+        size_t ns = 0;
+        for (int k = 0; k < m; k++) {
+            perseus_descr *d = &g_list[sub[k]];
+            if (!d->streaming || d->cancelling || d->source_done || !gang_candidate(d) || !can_submit(d))
+                continue;
+            if (nm == 0)
+                ns = d->cfg.batch_samples;
+            if (d->cfg.batch_samples != ns) {                  /* another batch length: a chain of its own */
+                submit_batch(d);
+                *busy = 1;
+                continue;
+            }
+            mem[nm++] = d;
+        }
+        if (nm == 0)
+            break;
+        *busy = 1;
+        /* (a round of one still goes through the gang's stream: changing between the gang's stream and the pipeline's
+         * own costs a wait for everything in flight, and the next round is likely to be a full one again) */
+        pddc_gang_item it[MAX_DESCR];
+        int ni = 0;
+        perseus_descr *in[MAX_DESCR];
+        for (int k = 0; k < nm; k++) {
+            perseus_descr *d = mem[k];
+            if (batch_prepare(d) != ns)
+                continue;
+            memset(&it[ni], 0, sizeof(it[ni]));
+            it[ni].pipe = d->pipe;
+            it[ni].seed = d->cfg.lcg_seed;
+            it[ni].byte_offset = d->adc_samples * 6;
+            it[ni].h_out = d->batch_out[d->cur];
+            it[ni].out_capacity = d->out_cap;
+            in[ni++] = d;
+        }
+        if (ni == 0)
+            continue;
+        int shared = 0;
+        const int rc = pddc_gang_push_async(g_gang[dev], it, ni, ns, &shared);
+        for (int k = 0; k < ni; k++) {
+            batch_pushed(in[k], rc, ns, it[k].n_out, it[k].ticket);
+            if (rc == PDDC_OK && shared > 1)
+                in[k]->ganged_batches++;
+        }
+    }
+    for (int k = m - 1; k >= 0; k--) {
+        *inflight += g_list[sub[k]].n_pend > 0;
+        pthread_mutex_unlock(&g_list[sub[k]].pump_lock);
+    }
+}
+
+/* pass 0 for the receivers in list[0..n): in parallel when there are several and helpers exist */
+static void submit_round(const int *list_in, int n_in, int *busy, int *inflight)
+{
+    int list[MAX_DESCR], n = 0;
+    if (!g_gang_off && n_in > 1) {
+        /* receivers that share a GPU go together; what is left goes one by one below */
+        char taken[MAX_DESCR] = { 0 };
+        for (int a = 0; a < n_in; a++) {
+            const perseus_descr *da = &g_list[list_in[a]];
+            if (taken[a] || !gang_candidate(da))
+                continue;
+            int sub[MAX_DESCR], m = 0;
+            for (int b = a; b < n_in; b++) {
+                const perseus_descr *db = &g_list[list_in[b]];
+                if (!taken[b] && gang_candidate(db) && db->gpu_dev == da->gpu_dev)
+                    sub[m++] = list_in[b];
+            }
+            if (m < 2)
+                continue;
+            for (int b = a; b < n_in; b++)
+                for (int k = 0; k < m; k++)
+                    if (list_in[b] == sub[k])
+                        taken[b] = 1;
+            gang_submit(da->gpu_dev, sub, m, busy, inflight);
+        }
+        for (int a = 0; a < n_in; a++)
+            if (!taken[a] || g_gang_off)
+                list[n++] = list_in[a];
+    } else {
+        memcpy(list, list_in, sizeof(int) * (size_t)n_in);
+        n = n_in;
+    }
     if (n <= 1 || g_nhelpers == 0) {
         for (int k = 0; k < n; k++)
             submit_one(list[k], busy, inflight);
@@ -893,6 +1021,10 @@ int perseus_init(void)
     }
     g_entries = n;
     g_peak_inflight = 0;
+    {
+        const char *e = getenv("PERSEUS_AMD_GANG");
+        g_gang_off = e && atoi(e) == 0;
+    }
     if (g_entries > 0) {
         g_thread_stop = 0;
         helpers_start(g_entries - 1);              /* submit helpers: one per further receiver */
@@ -920,6 +1052,10 @@ int perseus_exit(void)
     for (int i = 0; i < g_entries; i++) {
         perseus_close(&g_list[i]);
         plan_free(&g_list[i].plan);
+    }
+    for (int i = 0; i < MAX_GANG_GPUS; i++) {
+        pddc_gang_destroy(g_gang[i]);
+        g_gang[i] = NULL;
     }
     g_entries = 0;
     g_thread_stop = 0;
@@ -1291,6 +1427,7 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
     d->bytes_received = 0;
     d->adc_samples = 0;
     d->batches = 0;
+    d->ganged_batches = 0;
     d->n_retunes = 0;
     d->cur = 0;
     d->n_pend = 0;
@@ -1410,6 +1547,7 @@ int perseus_amd_get_stats(perseus_descr *d, perseus_amd_stats *st)
     st->batches = d->batches;
     st->gpu_device = d->gpu_dev;
     st->gpu_source = d->gpu_source;
+    st->ganged_batches = d->ganged_batches;
     st->peak_receivers_in_flight = g_peak_inflight;
     if (!on_worker)
         pthread_mutex_unlock(&d->pump_lock);

@@ -121,7 +121,7 @@ static void *fifo_thread(void *arg)
 
 int main(int argc, char **argv)
 {
-    int rate = 95000, nb = 6, bs = 1024, dbg = 3, seconds = 10, as_float = 0, test_fe = 1, nrx = 1;
+    int rate = 95000, nb = 6, bs = 1024, dbg = 3, seconds = 10, as_float = 0, test_fe = 1, nrx = 1, multi = 0;
     long max_buffers = 0;
     double freq = 7000000.0;
     const char *outname = "perseusdata";
@@ -139,7 +139,7 @@ int main(int argc, char **argv)
         case 'f': freq = atof(optarg); break;
         case 'm': max_buffers = atol(optarg); break;
         case 'F': fifo = optarg; break;
-        case 'N': nrx = atoi(optarg); break;
+        case 'N': nrx = atoi(optarg); multi = 1; break;   /* -N 1: the same loop with one receiver */
         case 'p': as_float = 1; break;
         case 'a': test_fe = 0; break;
         default:
@@ -171,7 +171,7 @@ int main(int argc, char **argv)
         perseus_exit();
         return 1;
     }
-    if (nrx > 1) {
+    if (multi) {
         /* several receivers at once: same call sequence per receiver, one callback sink each */
         if (ndev < nrx) {
             fprintf(stderr, "only %d receivers present, %d wanted\n", ndev, nrx);
@@ -228,7 +228,9 @@ int main(int argc, char **argv)
             perseus_stop_async_input(rx[i]);
             if (sk[i].out)
                 fclose(sk[i].out);
-            fprintf(stderr, "receiver %d (GPU %d): %llu buffers, %llu samples\n", i, st.gpu_device, sk[i].buffers, sk[i].samples);
+            fprintf(stderr, "receiver %d (GPU %d): %llu buffers, %llu samples, %llu GPU batches (%llu in shared launches)\n", i,
+                    st.gpu_device, sk[i].buffers, sk[i].samples, (unsigned long long)st.batches,
+                    (unsigned long long)st.ganged_batches);
             total += sk[i].samples;
         }
         const double el = (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);

@@ -86,18 +86,24 @@ def test_eight_receivers_share_one_gpu_and_overlap(L, pkg, O, monkeypatch):
     Every stream equals its single-stream run byte for byte and the oracle to 1e-6, and all eight
     have a batch on the GPU at the same moment (the delivery thread submits for every receiver
     before it waits for any: on eight GPUs that is eight GPUs working at once).  On ONE GPU the
-    eight streams share the device, so the wall time is only sanity-checked, not 8x better."""
+    eight receivers go through one launch chain (gang submission, pddc_gang_push_async: the
+    receiver is the grid's second dimension): eight streams take less than twice the time of one."""
     nbuf, batch, bufsize, rate, dtot = 600, 1 << 22, 12288, 125000, 640
     monkeypatch.setenv("PERSEUS_AMD_DEVICES", "8")
-    assert L.perseus_init() == 8
-    ds = [open_receiver(L, pkg, i, rate, 7.1e6, mode=1, batch_samples=batch, max_buffers=nbuf) for i in range(8)]
-    stages = plan_of(L, ds[0])
-    st = pkg.AmdStats()
-    outs8, wall8 = run_all(L, pkg, ds, bufsize=bufsize)
-    L.perseus_amd_get_stats(ds[3], C.byref(st))
-    assert st.gpu_source == 1 and st.delivered == nbuf and st.batches >= 1 and st.gpu_device == 0
-    assert st.peak_receivers_in_flight == 8
-    L.perseus_exit()
+    walls8 = []
+    for _ in range(2):                       # (timed twice, the better one counts: 4800 Python callbacks ride along)
+        assert L.perseus_init() == 8
+        ds = [open_receiver(L, pkg, i, rate, 7.1e6, mode=1, batch_samples=batch, max_buffers=nbuf) for i in range(8)]
+        stages = plan_of(L, ds[0])
+        st = pkg.AmdStats()
+        outs8, wall8 = run_all(L, pkg, ds, bufsize=bufsize)
+        walls8.append(wall8)
+        L.perseus_amd_get_stats(ds[3], C.byref(st))
+        assert st.gpu_source == 1 and st.delivered == nbuf and st.batches >= 1 and st.gpu_device == 0
+        assert st.peak_receivers_in_flight == 8
+        assert st.ganged_batches >= st.batches - 2          # its batches shared their launches with the others'
+        L.perseus_exit()
+    wall8 = min(walls8)
     # one stream alone, same settings, seeds 12345 + i
     singles, walls = [], []
     for i in (0, 5, 5):
@@ -115,10 +121,9 @@ def test_eight_receivers_share_one_gpu_and_overlap(L, pkg, O, monkeypatch):
         assert O.rel_err(y, ref[:y.size]) <= FIR_TOL
     print(f"8 receivers on one GPU: {wall8 * 1e3:.1f} ms first-to-last callback; one alone: "
           f"{min(walls) * 1e3:.1f} ms; ratio {wall8 / min(walls):.2f}")
-    # eight times the batches (eight small launch chains sharing one GPU) and eight times the serialized Python
-    # callbacks of one receiver: sanity only; the C client shows the library's own share
-    # (test_plumbing_client_eight_receivers_on_the_gpu_path, tools/api_receivers.sh)
-    assert wall8 < 25 * min(walls), (wall8, walls)
+    # eight times the samples and eight times the (serialized) Python callbacks of one receiver in less than twice its
+    # time; the C client shows the library's own share (tools/api_receivers.sh: 221 vs 40 GS/s of ADC-rate input)
+    assert wall8 < 2.0 * min(walls), (walls8, walls)
 
 
 # ------------------------------------------------------------------ N4: retune while streaming
