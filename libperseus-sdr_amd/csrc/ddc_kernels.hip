@@ -1443,10 +1443,11 @@ static hipError_t launch_fir8_many_t(bool mix, const Fir8Many &m, int n, hipStre
     if (ntiles_ll > 0x7fffffffLL)
         return hipErrorInvalidValue;
     const int ntiles = (int)ntiles_ll;
-    /* Every stream gets the grid and the tile schedule a launch of its own would have (not 1/n of it): with the NCO on,
-     * the first tile of a chunk mixes its history through another expression than a tile that inherits it in LDS, equal
-     * to the last bit or two -- so the same chunks mean the SAME BITS as the per-stream path.  The n grids simply queue
-     * behind each other on the chip; no block of this kernel ever waits for another one.                          */
+    /* Every stream gets the grid and the tile schedule a launch of its own would have: with the NCO on, the first tile of
+     * a chunk mixes its history through another expression than a tile that inherits it in LDS, equal to a bit or two --
+     * the same chunks mean the SAME BITS as the per-stream path.  The n grids queue behind each other on the chip; no
+     * block of this kernel waits for another one.  (Tried: 512/n blocks per stream drawing the same chunks through the
+     * chunk counter -- 8 streams 242-254 vs 246 GS/s through the API, no gain, not kept.)                          */
     const Fir8Sched sc = fir8_schedule(ntiles, R, NTB2 != 0);
     const dim3 grid((unsigned)sc.nblocks, (unsigned)n), blk(256);
 #define PDDC_LAUNCHM(MIXV)                                                                        \
@@ -2295,61 +2296,12 @@ __device__ __forceinline__ void lcg_jump(unsigned long long steps, uint32_t &A, 
     }
 }
 
-/* 16 bytes per thread and iteration.  The jump ladder (up to 64 rounds) runs twice per THREAD -- to the thread's first
- * chunk, and for the grid stride, which is the same map for every thread -- not once per chunk: a chunk then costs the
- * 16 steps of its bytes plus one multiply-add (2^28 samples: 0.84 -> the write stream's own time).              */
-__global__ __launch_bounds__(256) void k_synth_lcg(uint8_t *dst, unsigned long long nbytes, uint32_t seed,
-                                                    unsigned long long byte_offset)
-{
-    const unsigned long long nch = (nbytes + 15) >> 4;
-    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
-    unsigned long long c = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (c >= nch)
-        return;
-    uint32_t A, C, As, Cs;
-    lcg_jump(byte_offset + (c << 4), A, C);          /* state before byte (byte_offset + 16c) */
-    lcg_jump((stride - 1) << 4, As, Cs);             /* from the end of one chunk to the start of the thread's next */
-    uint32_t st = A * seed + C;
-    for (; c < nch; c += stride) {
-        uint32_t w[4];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            uint32_t v = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                st = st * 1664525u + 1013904223u;
-                v |= (st >> 24) << (8 * b);
-            }
-            w[d] = v;
-        }
-        const unsigned long long o = c << 4;
-        if (o + 16 <= nbytes) {
-            *reinterpret_cast<uint4 *>(dst + o) = make_uint4(w[0], w[1], w[2], w[3]);
-        } else {
-            for (int b = 0; b < 16 && o + b < nbytes; ++b)
-                dst[o + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
-        }
-        st = As * st + Cs;
-    }
-}
-
-hipError_t launch_synth_lcg(void *dst, size_t nbytes, uint32_t seed, uint64_t byte_offset, hipStream_t s)
-{
-    if (nbytes == 0)
-        return hipSuccess;
-    unsigned long long nch = ((unsigned long long)nbytes + 15) >> 4;
-    unsigned long long blocks = (nch + 255) / 256;
-    if (blocks > 256 * 32)
-        blocks = 256 * 32;
-    hipLaunchKernelGGL(k_synth_lcg, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint8_t *>(dst),
-                       (unsigned long long)nbytes, seed, (unsigned long long)byte_offset);
-    return hipGetLastError();
-}
-
-/* The generator for several streams (blockIdx.y), 16 bytes per thread and iteration as above.  The jump to a thread's
- * first chunk is split: the ladder to the BLOCK's first chunk is the same for all its threads (scalar unit), and the
- * thread's own 16*tid steps behind it need 12 rounds, not 40.                                                     */
-__global__ __launch_bounds__(256) void k_synth_lcg_many(SynthMany m, unsigned long long nbytes)
+/* The generator, for one stream or several (blockIdx.y): 16 bytes per thread and iteration.  The jump ladders run per
+ * THREAD, not per chunk: to the thread's first chunk -- split into the ladder to the BLOCK's first chunk, the same for
+ * all its threads (scalar unit, up to 64 rounds), and the thread's own 16*tid steps behind it (12 rounds) -- and for the
+ * grid stride, again the same map for every thread.  A chunk then costs the 16 steps of its bytes plus one multiply-add
+ * (2^22 samples: 31 -> 8 us with the split ladder; 2^28: the write stream's own time).                            */
+__global__ __launch_bounds__(256) void k_synth_lcg(SynthMany m, unsigned long long nbytes)
 {
     uint8_t *dst = static_cast<uint8_t *>(m.dst[blockIdx.y]);
     const uint32_t seed = m.seed[blockIdx.y];
@@ -2398,8 +2350,17 @@ hipError_t launch_synth_lcg_many(const SynthMany &m, int n, size_t nbytes, hipSt
     const unsigned long long cap = 256ull * 16 / (unsigned)n > 256 ? 256ull * 16 / (unsigned)n : 256;
     if (blocks > cap)
         blocks = cap;
-    hipLaunchKernelGGL(k_synth_lcg_many, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, s, m, (unsigned long long)nbytes);
+    hipLaunchKernelGGL(k_synth_lcg, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, s, m, (unsigned long long)nbytes);
     return hipGetLastError();
+}
+
+hipError_t launch_synth_lcg(void *dst, size_t nbytes, uint32_t seed, uint64_t byte_offset, hipStream_t s)
+{
+    SynthMany m = {};
+    m.dst[0] = dst;
+    m.byte_offset[0] = byte_offset;
+    m.seed[0] = seed;
+    return launch_synth_lcg_many(m, 1, nbytes, s);
 }
 
 } // namespace pddc

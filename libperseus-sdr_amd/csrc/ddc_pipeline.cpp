@@ -178,6 +178,8 @@ struct GangRec {
 struct pddc_gang {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t s_gen = nullptr;             /* the on-device source of the NEXT round runs beside this round's kernels */
+    hipEvent_t ev_gen[4] = { nullptr, nullptr, nullptr, nullptr };
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
     int next_ev = 0;
     std::mutex lock;
@@ -188,6 +190,7 @@ static bool stage0_fused(const pddc_pipeline *p);
 static bool stage0_packed_generic(const pddc_pipeline *p);
 static int setup_stage3(pddc_pipeline *p);
 static int leave_gang(pddc_pipeline *p);
+static float *direct_out(pddc_pipeline::HostSlot &sl, void *h_out);
 
 static float round_to_half(float v)
 {
@@ -1968,7 +1971,10 @@ static int push_async(pddc_pipeline *p, const void *h_packed, bool synth, uint32
             HIP_TRY(hipStreamWaitEvent(p->own_stream, sl.ev_out, 0));
     }
     size_t n_out = 0;
-    int rc = pddc_pipeline_process(p, sl.d_in, nsamples, sl.d_out, sl.out_cap, &n_out, p->own_stream);
+    /* (one stream: the last stage writes into the caller's buffer itself where that is pinned memory, see direct_out) */
+    float *direct = one_stream && !(p->flags & PDDC_F_OUT_PACKED24) ? direct_out(sl, h_out) : nullptr;
+    int rc = pddc_pipeline_process(p, sl.d_in, nsamples, direct ? (void *)direct : (void *)sl.d_out,
+                                   direct ? out_capacity : sl.out_cap, &n_out, p->own_stream);
     if (rc)
         return rc;
     if ((rc = pddc_pipeline_fence(p, p->own_stream)))     /* overlap mode: the D2H copy needs the tail's output */
@@ -1978,7 +1984,7 @@ static int push_async(pddc_pipeline *p, const void *h_packed, bool synth, uint32
     p->next_slot = si ^ 1;
     if (!one_stream)
         HIP_TRY(hipStreamWaitEvent(st_out, sl.ev_comp, 0));
-    if (n_out)
+    if (n_out && !direct)
         HIP_TRY(hipMemcpyAsync(h_out, sl.d_out, n_out * ((p->flags & PDDC_F_OUT_PACKED24) ? 6 : 8),
                                hipMemcpyDeviceToHost, st_out));
     HIP_TRY(hipEventRecord(sl.ev_out, st_out));
@@ -2045,10 +2051,11 @@ int pddc_pipeline_wait(pddc_pipeline *p)
     return PDDC_OK;
 }
 
-/* The final stage of a gang round writes into the caller's output buffer ITSELF where that is pinned host memory (what
- * pddc_host_alloc hands out; the device sees it through the bus): the few dozen kilobytes a receiver's batch decimates
- * to need no copy engine, and the round has no eight copies -- 7 us of stream time and 6 us of host time each -- behind
- * its kernels.  Pageable memory (or PDDC_GANG_COPY_OUT=1) keeps the staging buffer and the copy.                     */
+/* The final stage of a gang round (and of a push from the on-device source) writes into the caller's output buffer
+ * ITSELF where that is pinned host memory (what pddc_host_alloc hands out; the device sees it through the bus): the few
+ * dozen kilobytes a receiver's batch decimates to need no copy engine, and a round has no eight copies -- 7 us of stream
+ * time and 6 us of host time each -- behind its kernels (8 receivers: 145 -> 221 GS/s of ADC-rate input).  Pageable
+ * memory (or PDDC_GANG_COPY_OUT=1) keeps the staging buffer and the copy.                                          */
 static float *direct_out(pddc_pipeline::HostSlot &sl, void *h_out)
 {
     if (sl.h_out_seen != h_out) {
@@ -2079,8 +2086,13 @@ int pddc_gang_create(pddc_gang **out, int device)
         return fail(PDDC_ENOMEM, "out of memory");
     g->device = device;
     hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
-    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&g->s_gen, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&g->ev_gen[i], hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         pddc_gang_destroy(g);
         return fail(PDDC_EHIP, "gang stream/events: %s", hipGetErrorString(e));
@@ -2096,15 +2108,22 @@ int pddc_gang_destroy(pddc_gang *g)
     (void)hipSetDevice(g->device);
     {
         std::lock_guard<std::mutex> lk(g->lock);
+        if (g->s_gen)
+            (void)hipStreamSynchronize(g->s_gen);
         if (g->stream)
             (void)hipStreamSynchronize(g->stream);
         for (pddc_pipeline *p : g->members)
             p->gang = nullptr;                /* their next push goes through their own stream again */
         g->members.clear();
     }
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
         if (g->ev[i])
             (void)hipEventDestroy(g->ev[i]);
+        if (g->ev_gen[i])
+            (void)hipEventDestroy(g->ev_gen[i]);
+    }
+    if (g->s_gen)
+        (void)hipStreamDestroy(g->s_gen);
     if (g->stream)
         (void)hipStreamDestroy(g->stream);
     delete g;
@@ -2167,7 +2186,26 @@ int pddc_gang_push_async(pddc_gang *g, pddc_gang_item *items, int n, size_t nsam
             sm.byte_offset[i] = items[i].byte_offset;
             sm.seed[i] = items[i].seed;
         }
-        HIP_TRY(launch_synth_lcg_many(sm, n, nsamples * 6, s));
+        /* The generator depends on nothing but its buffers being free (the slot's previous batch, two rounds back): it
+         * goes to a stream of its own and runs BESIDE the kernels of the round before, which the main stream is still
+         * working on when this round is queued (a free-running source keeps two rounds in flight).  The main stream
+         * meets an event that is long complete.                                                                  */
+        if (n > 1 && !getenv("PDDC_GANG_GEN_INLINE")) {
+            hipEvent_t seen[PDDC_GANG_MAX];
+            int nseen = 0;
+            for (int i = 0; i < n; ++i) {
+                const pddc_pipeline::HostSlot &sl = items[i].pipe->slot[si[i]];
+                if (!sl.used || !sl.ev_wait || std::find(seen, seen + nseen, sl.ev_wait) != seen + nseen)
+                    continue;
+                seen[nseen++] = sl.ev_wait;
+                HIP_TRY(hipStreamWaitEvent(g->s_gen, sl.ev_wait, 0));
+            }
+            HIP_TRY(launch_synth_lcg_many(sm, n, nsamples * 6, g->s_gen));
+            HIP_TRY(hipEventRecord(g->ev_gen[g->next_ev], g->s_gen));
+            HIP_TRY(hipStreamWaitEvent(s, g->ev_gen[g->next_ev], 0));
+        } else {
+            HIP_TRY(launch_synth_lcg_many(sm, n, nsamples * 6, s));
+        }
     } else {
         for (int i = 0; i < n; ++i) {
             pddc_pipeline::HostSlot &sl = items[i].pipe->slot[si[i]];

@@ -895,6 +895,11 @@ static void helpers_stop(void)
     g_nhelpers = 0;
 }
 
+/* PERSEUS_AMD_TIMING=1: where the delivery thread's time goes (submit / wait+collect / callbacks), printed at perseus_exit */
+static int g_timing = 0;
+static double g_t_pass[3];
+static unsigned long long g_rounds;
+
 static void *worker_fn(void *arg)
 {
     (void)arg;
@@ -909,9 +914,15 @@ static void *worker_fn(void *arg)
                 if (d->streaming && !d->cancelling && !d->source_done && d->cfg.mode != PERSEUS_AMD_MODE_WIRE)
                     list[n++] = i;
             }
+            const double t0 = g_timing ? now_s() : 0.0;
             submit_round(list, n, &busy, &inflight);
+            if (g_timing && n > 0) {
+                g_t_pass[0] += now_s() - t0;
+                g_rounds++;
+            }
         }
         for (int pass = 1; pass < 3; pass++) {
+            const double t0 = g_timing ? now_s() : 0.0;
             /* after pass 0 every receiver's batch has been submitted and none has been waited for yet */
             if (pass == 1 && inflight > g_peak_inflight)
                 g_peak_inflight = inflight;
@@ -936,6 +947,8 @@ static void *worker_fn(void *arg)
                 }
                 pthread_mutex_unlock(&d->pump_lock);
             }
+            if (g_timing)
+                g_t_pass[pass] += now_s() - t0;
         }
         if (!busy)
             usleep(1000);
@@ -1024,6 +1037,10 @@ int perseus_init(void)
     {
         const char *e = getenv("PERSEUS_AMD_GANG");
         g_gang_off = e && atoi(e) == 0;
+        e = getenv("PERSEUS_AMD_TIMING");
+        g_timing = e && atoi(e) != 0;
+        g_t_pass[0] = g_t_pass[1] = g_t_pass[2] = 0.0;
+        g_rounds = 0;
     }
     if (g_entries > 0) {
         g_thread_stop = 0;
@@ -1053,6 +1070,9 @@ int perseus_exit(void)
         perseus_close(&g_list[i]);
         plan_free(&g_list[i].plan);
     }
+    if (g_timing && g_rounds)
+        fprintf(stderr, "perseus: delivery thread, %llu rounds: submit %.1f us, wait + collect %.1f us, deliver %.1f us per round\n",
+                g_rounds, 1e6 * g_t_pass[0] / g_rounds, 1e6 * g_t_pass[1] / g_rounds, 1e6 * g_t_pass[2] / g_rounds);
     for (int i = 0; i < MAX_GANG_GPUS; i++) {
         pddc_gang_destroy(g_gang[i]);
         g_gang[i] = NULL;
