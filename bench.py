@@ -407,11 +407,11 @@ def run_rank(a):
     # Where the buffers lie in HBM matters to this read/write stream.  HBM is laid out in a few classes of large
     # extents (tens of GiB each; three classes seen): with the input and the output in extents of the SAME class the
     # kernel takes 0.367 ms, in DIFFERENT classes 0.340 ms, on every box, for every pair tried (maps in
-    # profiles/r02/i_placement_map.txt, tools/placement_probe5.py / 6.py) -- streams that share a class get in each
+    # profiles/r02/i_placement_map.txt, tools/placement_probe.py --mode map) -- streams that share a class get in each
     # other's way (two write streams even more: tools/ubench/stream_classes.hip).  Buffers allocated one after the
     # other usually land in the same extent, and separate allocations 8 GiB apart do not reliably leave it (one
     # process saw a single class over 200 GiB of them).  Inside ONE large allocation the classes alternate every
-    # 32-64 GiB in every process tried (tools/placement_probe10.py), so: one arena (--arena-gib, default 192), cut
+    # 32-64 GiB in every process tried (tools/placement_probe.py --mode matrix), so: one arena (--arena-gib, default 192), cut
     # into 8 GiB slots; the input at three of them, the output at every one, 24 back-to-back steps per pair (about
     # 1.5 s in all), the fastest pair kept.  A receiver allocates once and runs for hours; 288 GB of HBM make this
     # affordable.

@@ -231,6 +231,29 @@ int main(int argc, char **argv)
                total / t_gather / 1e6, t_gather / steps * 1e3, ng > 1 ? (double)n_out * 8 * steps / t_gather / 1e9 : 0.0,
                (double)(ng - 1) * n_out * 8 * steps / t_gather / 1e9);
     printf("\n");
+    /* the same figures as ONE JSON line with bench.py's keys (its N > 1 line: value = the kernels' aggregate, the gather
+     * in its own object, never in `value`) so the two hosts can be compared by a script */
+    {
+        const char *label = cascade ? "80 MS/s synthetic 24-bit I/Q, NCO mix 7.1 MHz + cascade /320 (8*8*5)"
+                                    : "80 MS/s synthetic 24-bit I/Q, unpack + 127-tap polyphase decimate-by-8";
+        int rccl_run = 0, rccl_hdr = 0;                  /* version codes: the library in the process, the header built against */
+        (void)pddc_comm_rccl_version(&rccl_run, &rccl_hdr);
+        printf("{\"metric\": \"input MS/s through unpack+decimate, 1/2/4/8 GPU; %% HBM-roofline\", \"value\": %.1f, \"unit\": \"MS/s\", \"n_gpus\": %d, \"steps\": %d, "
+               "\"warmup\": %d, \"ms_per_step\": %.4f, \"higher_is_better\": true, \"scaling\": \"weak\", \"vs_baseline\": null, "
+               "\"dtype\": \"f32\", \"data\": \"synthetic\", \"host\": \"C (perseus_multi_bench, one process, pddc_comm_init_all)\", "
+               "\"config\": {\"workload\": \"%s\", \"samples_per_gpu_per_step\": %zu, \"input\": \"LCG bytes seed 12345+gpu, device "
+               "resident\", \"sharding\": \"independent stream per GPU, no data-path collective\"}, \"rccl\": {\"running\": %d, "
+               "\"header\": %d}",
+               total / t_kernel / 1e6, ng, steps, warm, t_kernel / steps * 1e3, label, ns, rccl_run, rccl_hdr);
+        if (gather)
+            printf(", \"gather\": {\"workload\": \"every GPU's output gathered on GPU 0 (pddc_comm_gather_async)\", \"value\": %.1f, "
+                   "\"unit\": \"MS/s\", \"ms_per_step\": %.4f, \"out_bytes_per_rank_per_step\": %zu, \"root_ingest_GBps\": %.2f, "
+                   "\"per_link_GBps\": %.2f}",
+                   total / t_gather / 1e6, t_gather / steps * 1e3, n_out * 8,
+                   (double)(ng - 1) * n_out * 8 * steps / t_gather / 1e9,
+                   ng > 1 ? (double)n_out * 8 * steps / t_gather / 1e9 : 0.0);
+        printf("}\n");
+    }
 
     for (int g = 0; g < ng; g++) {
         pddc_set_device(g);

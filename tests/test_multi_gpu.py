@@ -160,7 +160,15 @@ def test_c_multi_gpu_bench_with_gather(pkg, dev):
         m = re.search(r"(\d+) GPU\(s\).*: ([0-9.]+) MS/s aggregate.*with the gather to GPU 0: ([0-9.]+) MS/s", p.stdout)
         assert m, p.stdout
         assert int(m.group(1)) == 1 and float(m.group(2)) > 50000 and float(m.group(3)) > 20000
-        print(p.stdout.strip().splitlines()[-1])
+        # ... and the same figures as one JSON line with bench.py's keys
+        d = json.loads(p.stdout.strip().splitlines()[-1])
+        assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        assert d["n_gpus"] == 1 and d["steps"] == 20 and d["scaling"] == "weak" and d["unit"] == "MS/s"
+        assert abs(d["value"] - float(m.group(2))) <= 0.2 and abs(d["gather"]["value"] - float(m.group(3))) <= 0.2
+        assert d["config"]["samples_per_gpu_per_step"] == 1 << 24 and ("/320" in d["config"]["workload"]) == bool(extra)
+        assert d["gather"]["out_bytes_per_rank_per_step"] == (1 << 24) // (320 if extra else 8) * 8
+        assert d["rccl"]["running"] > 0
+        print(p.stdout.strip().splitlines()[-2])
 
 
 def test_the_rccl_in_use_matches_the_header_compiled_against(pkg, dev):

@@ -17,8 +17,8 @@ python tools/plan_rates.py > $OUT/plan_rates.txt 2>&1
 python tools/pcie_rate.py > $OUT/pcie_rate.txt 2>&1
 PDDC_BENCH_GATHER_C320=1 python bench.py --no-cpu --gather --steps 20 --warmup 5 > $OUT/bench_gather_1rank.json 2>/dev/null
 PERSEUS_AMD_PACE=0 PERSEUS_AMD_MODE=ddc libperseus-sdr_amd/perseus_plumbing -N 8 -s 250000 -o none -t 2 -d 0 > $OUT/plumbing_N8.txt 2>&1
-PDDC_PLACEMENT=0 python tools/placement_probe8.py c320 18 > $OUT/placement_input_c320.txt 2>&1
-for i in 1 2 3; do python tools/placement_probe10.py 192; done > $OUT/arena_map.txt 2>&1
+PDDC_PLACEMENT=0 python tools/placement_probe.py --mode input --workload c320 --arena-gib 144 > $OUT/placement_input_c320.txt 2>&1
+for i in 1 2 3; do python tools/placement_probe.py --mode matrix --arena-gib 192; done > $OUT/arena_map.txt 2>&1
 bash tools/bench_repeat.sh 5 > $OUT/bench_repeat_d8_127.txt 2>&1
 bash tools/bench_repeat.sh 3 --workload c320 > $OUT/bench_repeat_c320.txt 2>&1
 libperseus-sdr_amd/perseus_multi_bench -n 28 -s 200 > $OUT/multi_bench_c_host.txt 2>&1
