@@ -411,10 +411,12 @@ def run_rank(a):
     # other's way (two write streams even more: tools/ubench/stream_classes.hip).  Buffers allocated one after the
     # other usually land in the same extent, and separate allocations 8 GiB apart do not reliably leave it (one
     # process saw a single class over 200 GiB of them).  Inside ONE large allocation the classes alternate every
-    # 32-64 GiB in every process tried (tools/placement_probe.py --mode matrix), so: one arena (--arena-gib, default 192), cut
-    # into 8 GiB slots; the input at three of them, the output at every one, 24 back-to-back steps per pair (about
-    # 1.5 s in all), the fastest pair kept.  A receiver allocates once and runs for hours; 288 GB of HBM make this
-    # affordable.
+    # 32-64 GiB in every process tried (tools/placement_probe.py --mode matrix), so: one arena (--arena-gib, default 80), cut
+    # into 8 GiB slots, the input at its start.  The rule (profiles/r03/f_placement_rule.txt; the library's own form is
+    # pddc_arena_place): the slot right behind the input is always in the input's class ("first come"), one of the slots
+    # at +32 / +48 / +64 GiB always in another -- four probes of 24 back-to-back steps, the fastest kept, the first-come
+    # time reported next to it.  --placement full scans every slot for three input places (1.5 s; what round 2 did).
+    # A receiver allocates once and runs for hours; 288 GB of HBM make this affordable.
     placement = None
     arena = None
     in_bytes, out_bytes = 6 * ns, out_rows * 8
