@@ -78,6 +78,9 @@ def parse(argv=None):
     ap.add_argument("--arena-gib", type=int, default=80,
                     help="size of the allocation the placement cuts its 8 GiB slots from (less if less is free);\n"
                          "80 GiB hold the four offsets the rule probes")
+    ap.add_argument("--arena-grow-gib", type=int, default=192,
+                    help="rule placement: if every slot of the first arena runs at the first-come speed (one extent class\n"
+                         "over all of it), allocate this much instead (less if less is free) and look again; 0: never")
     ap.add_argument("--placement", default="rule", choices=["rule", "full"],
                     help="rule: input at the start of the arena, output probed at +8 (first come), +32, +48, +64 GiB;\n"
                          "full: three input slots x every output slot (the map; use --arena-gib 192)")
@@ -460,6 +463,7 @@ def run_rank(a):
         for _ in range(150):                                      # the first pair is not to be measured on cold clocks
             step()
         table, launches = {}, [150]
+        grown = None
 
         def probe(i, o):
             inbox[0], outbox[0] = in_view(i), out_view(o)
@@ -487,14 +491,39 @@ def run_rank(a):
             # right behind the input is always in it ("first come"), and +32, +48 or +64 GiB is always in another one.
             # So: four probes.  Only if none of them gains (a workload that does not care, or a layout not seen yet)
             # the other slots are looked at too.
-            first_come = probe(0, 1 if nslot > 1 else 0)
-            for o in (4, 6, 8):
-                if o < nslot:
-                    probe(0, o)
-            if min(table.values()) > 0.97 * first_come:
-                for o in range(2, nslot):
-                    if (0, o) not in table:
+            def rule_scan():
+                first = probe(0, 1 if nslot > 1 else 0)
+                for o in (4, 6, 8):
+                    if o < nslot:
                         probe(0, o)
+                if min(table.values()) > 0.97 * first:
+                    for o in range(2, nslot):
+                        if (0, o) not in table:
+                            probe(0, o)
+                return first
+
+            first_come = rule_scan()
+            # One class over the whole arena (about one process in five draws such a layout for 80 GiB): a LARGER
+            # allocation is laid out anew and has shown at least two classes every time (192-200 GiB arenas, round 2).
+            # The memory is there (288 GB); the receiver allocates once.
+            if min(table.values()) > 0.97 * first_come and a.arena_grow_gib > gib:
+                small = {"arena_GiB": gib, "step_ms": {str(o): round(v, 4) for (_, o), v in sorted(table.items())}}
+                inbox[0] = outbox[0] = None
+                arena = None
+                torch.cuda.empty_cache()
+                free_b, _ = torch.cuda.mem_get_info(dev)
+                big = min((free_b - (16 << 30)) >> 30, a.arena_grow_gib) // 8 * 8
+                want = big if big >= gib + 32 else gib
+                try:
+                    arena = torch.empty(want << 30, dtype=torch.uint8, device=dev)
+                except RuntimeError:
+                    want = gib
+                    arena = torch.empty(want << 30, dtype=torch.uint8, device=dev)
+                gib, nslot = want, (want << 30) // slot
+                pkg.check(pkg.ddc_lib().pddc_synth_lcg(in_view(0).data_ptr(), in_bytes, shard.stream_seed(rank), 0, stream))
+                table.clear()
+                first_come = rule_scan()
+                grown = small
         (bi, bo), best_ms = min(table.items(), key=lambda kv: kv[1])
         inbox[0], outbox[0] = in_view(bi), out_view(bo)
         placement = {"arena_GiB": gib, "slot_GiB": slot >> 30, "output_slots": nslot, "mode": a.placement,
@@ -504,6 +533,7 @@ def run_rank(a):
                      "first_come_ms": round(table.get((0, 1), table.get((0, 0))), 4),
                      "chosen": {"input_at_GiB": (bi * slot) >> 30, "output_slot": bo, "ms": round(best_ms, 4)},
                      "probe_pairs": len(table), "probe_launches": launches[0],
+                     "grown_after": grown,     # not None: the first, smaller arena showed ONE class only; its table
                      "note": "input and output (with a cascade's inter-stage workspace) cut from ONE allocation and placed in "
                              "different HBM extent classes: input at the start, the output probed right behind it (first "
                              "come: same class) and at +32 / +48 / +64 GiB (one of them is always another class); every "

@@ -185,7 +185,8 @@ def test_bench_line_end_to_end_on_the_gpu():
     # placement by the rule: a handful of probed pairs, the first-come time next to the chosen one (2^24-sample launches
     # live in the last-level cache, so there may be nothing to choose -- then no search is made at all)
     pl = d["placement"]
-    assert pl is None or (pl["probe_pairs"] <= 12 and pl["first_come_ms"] >= pl["chosen"]["ms"])
+    # (four probes when the rule holds; every slot of the arena -- and of a larger one, "grown_after" -- when it does not)
+    assert pl is None or ((pl["probe_pairs"] <= 12 or pl["grown_after"]) and pl["first_come_ms"] >= pl["chosen"]["ms"])
 
 
 def test_eight_rank_dry_run_of_the_launcher():

@@ -166,7 +166,7 @@ def test_c_multi_gpu_bench_with_gather(pkg, dev):
         assert d["n_gpus"] == 1 and d["steps"] == 20 and d["scaling"] == "weak" and d["unit"] == "MS/s"
         assert abs(d["value"] - float(m.group(2))) <= 0.2 and abs(d["gather"]["value"] - float(m.group(3))) <= 0.2
         assert d["config"]["samples_per_gpu_per_step"] == 1 << 24 and ("/320" in d["config"]["workload"]) == bool(extra)
-        assert d["gather"]["out_bytes_per_rank_per_step"] == (1 << 24) // (320 if extra else 8) * 8
+        assert 0 <= d["gather"]["out_bytes_per_rank_per_step"] - (1 << 24) // (320 if extra else 8) * 8 <= 16
         assert d["rccl"]["running"] > 0
         print(p.stdout.strip().splitlines()[-2])
 
