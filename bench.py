@@ -342,7 +342,7 @@ def traffic_from_profile(workload, kernel_sig, log2n, taps_fp16):
 def kernel_source_sig():
     import hashlib
     h = hashlib.sha256()
-    for f in ("ddc_kernels.hip", "ddc_kernels.h"):
+    for f in ("ddc_kernels.hip", "ddc_kernels.h", "fir8_block.inc"):
         h.update(open(os.path.join(ROOT, "libperseus-sdr_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -30,7 +30,7 @@ for w, k in kern.items():
         print(f"{w:8s} {k:12s} corrected HBM bytes per launch {res[w]:.4e}   algorithmic {alg[w] * 2**28:.4e}")
 import hashlib, subprocess
 h = hashlib.sha256()
-for f in ("ddc_kernels.hip", "ddc_kernels.h"):
+for f in ("ddc_kernels.hip", "ddc_kernels.h", "fir8_block.inc"):
     h.update(open("libperseus-sdr_amd/csrc/" + f, "rb").read())
 try:
     commit = subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
