@@ -683,6 +683,7 @@ def run_rank(a):
                          "frac_of_copy_ceiling": round(achieved / copy_gbps, 4) if copy_gbps else None,
                          "kernel": ("k_fir8 (fused cascade: all stages in one launch)" if cascade else
                                     "k_fir8 (fused pair + the previous batch's tail as extra blocks of the launch)" if overlap
+                                    else "k_fir_i8 (int8 matrix cores on the wire bytes)" if pipe.on_i8(ns)
                                     else "k_fir8") if fused else "pipeline",
                          "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_sample": bps,

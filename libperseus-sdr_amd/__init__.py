@@ -118,6 +118,8 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_uses_fused_pair.restype = C.c_int
     L.pddc_pipeline_uses_fused_cascade.argtypes = [vp, sz]
     L.pddc_pipeline_uses_fused_cascade.restype = C.c_int
+    L.pddc_pipeline_stage0_on_i8.argtypes = [vp, sz]
+    L.pddc_pipeline_stage0_on_i8.restype = C.c_int
     L.pddc_pipeline_check.argtypes = [vp, vp]
     L.pddc_pipeline_check.restype = C.c_int
     L.pddc_arena_place.argtypes = [vp, sz, sz, sz, sz, sz, C.POINTER(sz), C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -294,6 +296,10 @@ class Pipeline:
     def fused_cascade(self, nsamples: int) -> bool:
         """stages 0, 1 and 2 as one kernel for a batch of this size"""
         return bool(ddc_lib().pddc_pipeline_uses_fused_cascade(self._h, nsamples))
+
+    def on_i8(self, nsamples: int) -> bool:
+        """stage 0 of a batch of nsamples runs on the int8 matrix cores (k_fir_i8: 129..256 taps, /8, no NCO)"""
+        return bool(ddc_lib().pddc_pipeline_stage0_on_i8(self._h, nsamples))
 
     def check(self, stream: int = 0):
         """wait for `stream`; raises if a kernel of this pipeline flagged a failure"""

@@ -48,6 +48,7 @@
  */
 #include "ddc_kernels.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1953,6 +1954,270 @@ hipError_t launch_gen_tail_many(const GenTailMany &m, int n, hipStream_t s)
         attr_done[dev & 63] = true;
     }
     hipLaunchKernelGGL(k_gen_tail_many, dim3((unsigned)nb, (unsigned)n), dim3(256), lds, s, m);
+    return hipGetLastError();
+}
+
+/* ======================================================================== */
+/* k_fir_i8 : 129..256 taps, decimate by 8, packed input, no NCO -- int8 MFMA */
+/* ======================================================================== */
+/* The 255-tap first stage is the one configuration that is bound by vector issue, not by HBM: 17 G
+ * multiply-adds per 2^28 samples on a power-capped clock.  fp32 MFMA has the vector unit's own peak; int8 MFMA has
+ * thirty times that, and this data fits it exactly: a 24-bit sample is three bytes, a tap quantised to 2^-E (E = 30 -
+ * ceil(log2 max|h|), i.e. 31 significant bits on the largest tap) is four balanced base-256 digits, every digit x
+ * byte-plane product sum over 256 taps stays below 2^24, so int32 accumulation is EXACT; products of equal weight
+ * 256^(i+j) share an accumulator, the three lightest (i + j < 2: below 1.2e-7 of full scale even if every term had the
+ * same sign, 2e-9 typical) are dropped, and the four sums are recombined in fp32 once per output.  The unpack is gone:
+ * the loader only de-interleaves bytes (v_perm) into six planes (planes 0 and 1 xor 0x80: unsigned -> signed, the
+ * offset comes back as one constant per filter).
+ *   out[32 n + r] = sum_c T[r][c] X[c][n],  T[r][c] = h[256 - (c - 8 r)] (banded Toeplitz, 32 x 512),
+ *   X[c][n] = xp[8192 tile + 256 n + c],    xp = the 256 history samples followed by the batch.
+ * A tile = 32 x 32 outputs = 8192 inputs (+256).  Persistent block of 8 waves per CU: waves 4..7 load -- two tiles
+ * ahead, two register sets used alternately so that no register copy waits for a load -- and write the planes of the
+ * next tile; waves 0..3 (component x half of the 16 k-steps, their 32 tap fragments resident in registers) run 72
+ * MFMAs per tile and leave partial sums in LDS; ONE barrier per tile; then the MFMA waves add the halves, scale and
+ * store float2.  Planes and sums exist twice.  LDS rows are padded (lane stride 272 B / 33 floats): conflict-free.
+ * Measured as a stand-alone prototype first (tools/ubench/fir_i8_planes.hip).                                      */
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+namespace i8 {
+constexpr int TILE = 8192, SPAN = TILE + 256, PLANE = SPAN + 16 * (SPAN / 256), NG = SPAN / 8, KSTEPS = 16;
+constexpr int OS = 33 * 32, NQ = (NG + 255) / 256;
+constexpr size_t LDS_BYTES = 12 * (size_t)PLANE + 8 * (size_t)OS * sizeof(float);
+
+__device__ __forceinline__ int swz(int p) { return p + 16 * (p >> 8); }
+
+/* the 8 bytes at offsets 6 s + O (s = 0..7) of the 48 bytes w[0..11] */
+template <int O>
+__device__ __forceinline__ void plane_bytes(const uint32_t (&w)[12], uint32_t &lo, uint32_t &hi)
+{
+    uint32_t out[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint32_t pair[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int b0 = 6 * (4 * half + 2 * q) + O, b1 = b0 + 6;
+            const uint32_t sel = (uint32_t)(b0 & 3) | ((uint32_t)(4 + (b1 & 3)) << 8) | 0x0c0c0000u;
+            pair[q] = __builtin_amdgcn_perm(w[b1 >> 2], w[b0 >> 2], sel);
+        }
+        out[half] = __builtin_amdgcn_perm(pair[1], pair[0], 0x05040100u);
+    }
+    lo = out[0];
+    hi = out[1];
+}
+
+/* the loads of one tile: group g of tile t is xp[8192 t + 8 g ..+8) -- history, batch, or (behind the batch) zeros */
+__device__ __forceinline__ void issue_tile(const FirI8Args &a, long long t, uint4 (&raw)[NQ][3], int lt)
+{
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int g = lt + 256 * q;
+        if (g < NG) {
+            const long long b = t * TILE + 8LL * g - 256;          /* first sample of the group, relative to the batch */
+            const uint4 *p = b < 0 ? reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.hist) + (b + 256) * 6)
+                                   : reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + b * 6);
+            if (b + 8 <= a.n_in) {
+                raw[q][0] = p[0];
+                raw[q][1] = p[1];
+                raw[q][2] = p[2];
+            } else {
+                raw[q][0] = raw[q][1] = raw[q][2] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void planes_from(const uint4 (&raw)[NQ][3], uint8_t *plane, int lt)
+{
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int g = lt + 256 * q;
+        if (g < NG) {
+            const uint32_t w[12] = { raw[q][0].x, raw[q][0].y, raw[q][0].z, raw[q][0].w, raw[q][1].x, raw[q][1].y,
+                                     raw[q][1].z, raw[q][1].w, raw[q][2].x, raw[q][2].y, raw[q][2].z, raw[q][2].w };
+            const int at = swz(8 * g);
+            uint32_t lo, hi;
+#define PDDC_PL(C, I, O, X)                                                                       \
+            plane_bytes<O>(w, lo, hi);                                                            \
+            *reinterpret_cast<uint2 *>(plane + (3 * C + I) * PLANE + at) = make_uint2(lo ^ X, hi ^ X);
+            PDDC_PL(0, 0, 0, 0x80808080u)
+            PDDC_PL(0, 1, 1, 0x80808080u)
+            PDDC_PL(0, 2, 2, 0u)
+            PDDC_PL(1, 0, 3, 0x80808080u)
+            PDDC_PL(1, 1, 4, 0x80808080u)
+            PDDC_PL(1, 2, 5, 0u)
+#undef PDDC_PL
+        }
+    }
+}
+} // namespace i8
+
+__global__ __launch_bounds__(512, 1) void k_fir_i8(FirI8Args a, long long ntiles)
+{
+    using namespace i8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_i8[];
+    /* [2 buffers][2 components][3 planes][PLANE], then [2 buffers][2 components][2 k halves][OS] partial sums */
+    float *osum_base = reinterpret_cast<float *>(lds_i8 + 12 * PLANE);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long G = gridDim.x;
+    long long t = blockIdx.x;
+    if (wave >= 4) {
+        /* ---- loaders */
+        const int lt = tid - 256;
+        if (blockIdx.x == 0 && a.hist_out) {             /* the next call's history: the batch's last 256 samples */
+            const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + (a.n_in - 256) * 6);
+            if (lt < 96)
+                static_cast<uint4 *>(a.hist_out)[lt] = src[lt];
+        }
+        uint4 ra[NQ][3], rb[NQ][3];
+        issue_tile(a, t, ra, lt);
+        planes_from(ra, lds_i8, lt);
+        if (t + G < ntiles)
+            issue_tile(a, t + G, ra, lt);
+        __syncthreads();
+        for (;;) {
+            /* tile t is computed from buffer 0; t + G (in ra) goes to buffer 1, t + 2 G starts towards rb */
+            if (t + G < ntiles) {
+                if (t + 2 * G < ntiles)
+                    issue_tile(a, t + 2 * G, rb, lt);
+                planes_from(ra, lds_i8 + 6 * PLANE, lt);
+            }
+            __syncthreads();
+            t += G;
+            if (t >= ntiles)
+                break;
+            if (t + G < ntiles) {
+                if (t + 2 * G < ntiles)
+                    issue_tile(a, t + 2 * G, ra, lt);
+                planes_from(rb, lds_i8, lt);
+            }
+            __syncthreads();
+            t += G;
+            if (t >= ntiles)
+                break;
+        }
+        return;
+    }
+    /* ---- MFMA waves: component, half of the k-steps; their share of the tap operand stays in registers */
+    const int comp = wave >> 1, kh = wave & 1;
+    const int n = lane & 31, h = lane >> 5;
+    const v4i_t *atab = static_cast<const v4i_t *>(a.atab);
+    v4i_t A[KSTEPS / 2][4];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS / 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            A[kk][j] = atab[(j * KSTEPS + kh * (KSTEPS / 2) + kk) * 64 + lane];
+    const long long n_out = a.n_in >> 3;
+    __syncthreads();
+    int buf = 0;
+    for (; t < ntiles; t += G, buf ^= 1) {
+        const uint8_t *pb = lds_i8 + buf * 6 * PLANE + 3 * comp * PLANE;
+        float *osum = osum_base + buf * 4 * OS;
+        v16i_t acc[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                acc[s][v] = 0;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS / 2; ++kk) {
+            const int ks = kh * (KSTEPS / 2) + kk;
+            const int at = swz(256 * n + 32 * ks + 16 * h);
+            v4i_t B[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                B[i] = *reinterpret_cast<const v4i_t *>(pb + i * PLANE + at);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i + j >= 2)
+                        acc[i + j - 2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[kk][j], B[i], acc[i + j - 2], 0, 0, 0);
+        }
+        /* y = sum_s acc[s] 256^(s+2), as floats (every acc[s] is below 2^24: the conversions are exact) */
+        float y[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            y[v] = ((float)acc[0][v] * 65536.0f + (float)acc[1][v] * 16777216.0f) +
+                   ((float)acc[2][v] * 4294967296.0f + (float)acc[3][v] * 1099511627776.0f);
+        /* this lane: column n, rows (v & 3) + 8 (v >> 2) + 4 h -> output 32 n + row of the tile */
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            osum[(2 * comp + kh) * OS + 33 * n + (v & 3) + 8 * (v >> 2) + 4 * h] = y[v];
+        __syncthreads();                 /* the next tile's planes are written, this tile's sums are in LDS */
+        float2 *dst = reinterpret_cast<float2 *>(a.out) + t * 1024;
+        const long long left = n_out - t * 1024;
+        for (int o = tid; o < 1024; o += 256) {
+            const int q = 33 * (o >> 5) + (o & 31);
+            if (o < left)
+                dst[o] = make_float2((osum[q] + osum[OS + q]) * a.scale + a.cterm,
+                                     (osum[2 * OS + q] + osum[3 * OS + q]) * a.scale + a.cterm);
+        }
+    }
+}
+
+bool fir_i8_build_table(const float *taps, int ntaps, int8_t *table, float *scale, float *cterm)
+{
+    if (!taps || ntaps < 1 || ntaps > 256 || !table)
+        return false;
+    double hmax = 0.0;
+    for (int k = 0; k < ntaps; ++k)
+        hmax = std::fmax(hmax, std::fabs((double)taps[k]));
+    if (!(hmax > 0.0) || !std::isfinite(hmax))
+        return false;
+    const int E = 30 - (int)std::ceil(std::log2(hmax));            /* |H| <= 2^30: the top digit stays within +-64 */
+    int8_t dig[4][256];
+    long long hsum = 0;
+    for (int k = 0; k < 256; ++k) {
+        long long r = k < ntaps ? std::llround(std::ldexp((double)taps[k], E)) : 0;
+        hsum += r;
+        for (int j = 0; j < 4; ++j) {
+            const long long d = j == 3 ? r : ((r + 128) & 255) - 128;
+            if (d < -128 || d > 127)
+                return false;
+            dig[j][k] = (int8_t)d;
+            r = (r - d) / 256;
+        }
+    }
+    /* lane l of k-step ks holds A[row l & 31][k = 16 (l >> 5) + jj]: T[r][c] = h[256 - (c - 8 r)] */
+    for (int j = 0; j < 4; ++j)
+        for (int ks = 0; ks < i8::KSTEPS; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int r = l & 31, c = 32 * ks + 16 * (l >> 5) + jj, tt = c - 8 * r;
+                    table[(((size_t)j * i8::KSTEPS + ks) * 64 + l) * 16 + jj] = (tt >= 1 && tt <= 256) ? dig[j][256 - tt] : 0;
+                }
+    /* sample = (v24 << 8) / (INT_MAX - 256): the reference's float (perseustest.c:466-502) */
+    const double unit = std::ldexp(1.0, -E) * 256.0 / 2147483391.0;
+    *scale = (float)unit;
+    *cterm = (float)((double)hsum * 32896.0 * unit);               /* planes 0 and 1 are stored minus 128: 128 + 128*256 */
+    return true;
+}
+
+hipError_t launch_fir_i8(const FirI8Args &a, hipStream_t s)
+{
+    if (a.n_in <= 0)
+        return hipSuccess;
+    if ((a.n_in & 7) || !a.in || !a.hist || !a.out || !a.atab || (a.hist_out && a.n_in < 256))
+        return hipErrorInvalidValue;
+    const long long ntiles = (a.n_in + i8::TILE - 1) / i8::TILE;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static int cus[64] = { 0 };
+    if (cus[dev & 63] == 0) {
+        int v = 0;
+        hipError_t e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess)
+            return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_i8), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)i8::LDS_BYTES);
+        if (e != hipSuccess)
+            return e;
+        cus[dev & 63] = v > 0 ? v : 256;
+    }
+    const long long grid = ntiles < cus[dev & 63] ? ntiles : cus[dev & 63];
+    hipLaunchKernelGGL(k_fir_i8, dim3((unsigned)grid), dim3(512), i8::LDS_BYTES, s, a, ntiles);
     return hipGetLastError();
 }
 

@@ -71,6 +71,8 @@ struct Stage {
     float *d_taps_poly = nullptr; /* rational stage: [L][Kp] polyphase rows g[ph][j] = h[j*L + ph] */
     float *d_taps_seg = nullptr;  /* stage 2 as the fused cascade's third stage: h[k] zero padded to spl*seglen */
     float *d_taps_firp = nullptr; /* k_firp (plain decimators by 4, 5, 10): (h[k], h[k]) zero padded to firp_taps_len */
+    void *d_taps_i8 = nullptr;    /* k_fir_i8 (stage 0, 129..256 taps, /8): the int8 tap operand table, with ...       */
+    float i8_scale = 0.0f, i8_cterm = 0.0f;      /* ... the integer -> float scale and the planes' offset constant     */
     int poly_k = 0, poly_kp = 0;
     int ntb = 0;                  /* tap blocks if fused-capable, else 0        */
     int hist = 0;                 /* history length in samples (mult. of 8)     */
@@ -188,6 +190,7 @@ struct pddc_gang {
 
 static bool stage0_fused(const pddc_pipeline *p);
 static bool stage0_packed_generic(const pddc_pipeline *p);
+static bool stage0_on_i8(const pddc_pipeline *p, size_t nsamples);
 static int setup_stage3(pddc_pipeline *p);
 static int leave_gang(pddc_pipeline *p);
 static float *direct_out(pddc_pipeline::HostSlot &sl, void *h_out);
@@ -270,6 +273,18 @@ static int upload_taps(pddc_pipeline *p, int si)
     if (s.d_taps_firp) {
         hipFree(s.d_taps_firp);
         s.d_taps_firp = nullptr;
+    }
+    if (s.d_taps_i8) {
+        hipFree(s.d_taps_i8);
+        s.d_taps_i8 = nullptr;
+    }
+    if (si == 0 && s.decim == 8 && s.interp == 1 && s.ntaps > 128 && s.ntaps <= 256 && !(p->flags & PDDC_F_NO_FAST)) {
+        /* the long first stage on the int8 matrix cores (k_fir_i8): taps as four planes of balanced base-256 digits */
+        std::vector<int8_t> tab(kFirI8TableBytes);
+        if (fir_i8_build_table(s.taps.data(), s.ntaps, tab.data(), &s.i8_scale, &s.i8_cterm)) {
+            HIP_TRY(hipMalloc(&s.d_taps_i8, tab.size()));
+            HIP_TRY(hipMemcpy(s.d_taps_i8, tab.data(), tab.size(), hipMemcpyHostToDevice));
+        }
     }
     if (s.interp == 1 && !(p->flags & PDDC_F_NO_FAST) && firp_supported(s.decim, s.ntaps)) {
         /* stage 0 runs k_firp on the packed samples, which leaves the unpack scale to the taps (like k_fir8) */
@@ -873,6 +888,8 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
             hipFree(p->st[i].d_taps_seg);
         if (p->st[i].d_taps_firp)
             hipFree(p->st[i].d_taps_firp);
+        if (p->st[i].d_taps_i8)
+            hipFree(p->st[i].d_taps_i8);
         if (p->st[i].d_buf && !p->st[i].buf_in_ws)
             hipFree(p->st[i].d_buf);
         if (p->st[i].d_buf_alt && !p->st[i].buf_in_ws)
@@ -1119,6 +1136,15 @@ static bool stage0_fused(const pddc_pipeline *p)
 }
 
 int pddc_pipeline_uses_fused(const pddc_pipeline *p) { return p && stage0_fused(p) ? 1 : 0; }
+
+/* the long first stage (129..256 taps, /8, no NCO) runs on the int8 matrix cores: k_fir_i8 (PDDC_NO_I8: k_fir8 always) */
+static bool stage0_on_i8(const pddc_pipeline *p, size_t nsamples)
+{
+    return stage0_fused(p) && p->st[0].d_taps_i8 != nullptr && p->st[0].hist == 256 && !(p->flags & PDDC_F_MIX) &&
+           nsamples >= 256 && !getenv("PDDC_NO_I8");
+}
+
+int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples) { return p && stage0_on_i8(p, nsamples) ? 1 : 0; }
 
 /* a first stage that is a plain decimator but not the fused decimate-by-8 (e.g. the /10 of the
  * 1.6 MS/s plan): the generic kernel reads the packed samples itself (unpack and mix while it
@@ -1749,6 +1775,18 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                     flip[1] = true;
                     skip_from = 1;
                 }
+            } else if (stage0_on_i8(p, nsamples) && !ov) {
+                /* 129..256 taps, no NCO: the int8 matrix cores (same history, same outputs to 1e-7 of full scale) */
+                FirI8Args q;
+                q.in = d_packed;
+                q.hist = h_in;
+                q.hist_out = a.hist_out;
+                q.out = dst;
+                q.atab = st.d_taps_i8;
+                q.n_in = (long long)nsamples;
+                q.scale = st.i8_scale;
+                q.cterm = st.i8_cterm;
+                HIP_TRY(launch_fir_i8(q, s));
             } else {
                 HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s, p->NT));
             }
