@@ -1,0 +1,133 @@
+"""GPU tests (-m gpu) of k_fir_i8: the long first stage (129..256 taps, decimate by 8, no NCO) on the int8 matrix cores
+(DESIGN.md 4).  The wire bytes are the operand -- three int8 planes per component --, the taps are four planes of
+balanced base-256 digits, int32 accumulation is exact; what is left is the tap quantisation (2^-31 of the largest tap)
+and three dropped low-order plane products.  Same bar as every FIR path here: max|y - ref| / max|ref| <= 1e-6 against
+the CPU oracle, on the same stream state as k_fir8 (history, hist_out), so the two kernels can alternate
+batch by batch."""
+import numpy as np
+import pytest
+
+from conftest import load_taps
+
+pytestmark = pytest.mark.gpu
+FIR_TOL = 1e-6
+
+
+def to_dev(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def lowpass(ntaps, cutoff):
+    k = np.arange(ntaps) - (ntaps - 1) / 2.0
+    h = np.sinc(2 * cutoff * k) * np.hamming(ntaps)
+    return (h / h.sum()).astype(np.float32)
+
+
+def run(pkg, dev, stages, packed, cuts, monkeypatch=None, no_i8_at=()):
+    pipe = pkg.Pipeline(stages)
+    parts, on = [], []
+    for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if monkeypatch is not None:
+            if k in no_i8_at:
+                monkeypatch.setenv("PDDC_NO_I8", "1")
+            else:
+                monkeypatch.delenv("PDDC_NO_I8", raising=False)
+        on.append(pipe.on_i8(b - a))
+        parts.append(pipe.process(to_dev(packed[6 * a:6 * b], dev)).cpu().numpy().reshape(-1))
+    pipe.close()
+    return np.concatenate(parts), on
+
+
+@pytest.mark.parametrize("ntaps", [129, 160, 200, 255, 256])
+def test_i8_first_stage_vs_oracle_ragged_batches(pkg, dev, O, ntaps):
+    """Tap counts over the kernel's whole range; batches of whole tiles (8192), ragged ones, one of a single group of 8
+    behind the history length, and tiny ones (< 256 samples: k_fir8's generic history path on the same state)."""
+    h = load_taps("d8_255") if ntaps == 255 else lowpass(ntaps, 0.05)
+    sizes = [8192 * 3, 8192 + 8, 264, 8, 128, 256, 8192 * 40 + 4096 + 16, 1 << 20, 8192 * 2 - 8]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    packed = O.lcg_bytes(6 * int(cuts[-1]), 2026)
+    ref = O.ddc_chain(packed, [(8, h)])
+    y, on = run(pkg, dev, [(8, h)], packed, cuts)
+    assert on == [s >= 256 for s in sizes]
+    assert y.size == ref.size
+    assert O.rel_err(y, ref) <= FIR_TOL, (ntaps, O.rel_err(y, ref))
+
+
+def test_i8_and_fp32_kernels_alternate_on_one_stream(pkg, dev, O, monkeypatch):
+    """k_fir_i8 and k_fir8 keep the same stream state (256 packed history samples): switching between them batch by
+    batch -- PDDC_NO_I8 read per call -- still gives the oracle's stream, and the two agree with each other to 1e-6."""
+    h = load_taps("d8_255")
+    sizes = [1 << 16, 8192 * 5 + 24, 1 << 15, 1 << 17, 8192, 1 << 16]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    packed = O.lcg_bytes(6 * int(cuts[-1]), 77)
+    ref = O.ddc_chain(packed, [(8, h)])
+    y_mixed, on = run(pkg, dev, [(8, h)], packed, cuts, monkeypatch, no_i8_at=(1, 3, 4))
+    assert on == [True, False, True, False, False, True]
+    y_i8, _ = run(pkg, dev, [(8, h)], packed, cuts, monkeypatch)
+    y_f32, on = run(pkg, dev, [(8, h)], packed, cuts, monkeypatch, no_i8_at=range(len(sizes)))
+    assert not any(on)
+    for y in (y_mixed, y_i8, y_f32):
+        assert O.rel_err(y, ref) <= FIR_TOL
+    assert O.rel_err(y_i8, y_f32) <= FIR_TOL
+
+
+def test_i8_extreme_samples_and_one_signed_taps(pkg, dev, O):
+    """The accumulators' bound and the dropped plane products at their worst: every sample at +-full scale (bytes 0xff /
+    0x00 in every plane: the planes' digits at -128 / +127), taps all of one sign and nearly equal -- every term of every
+    plane product has the same sign."""
+    h = (np.ones(256, np.float32) / 256 * (1 + 1e-3 * np.arange(256))).astype(np.float32)
+    rng = np.random.default_rng(5)
+    ns = 8192 * 6 + 40
+    v = np.where(rng.random((ns, 2)) < 0.5, -(1 << 23), (1 << 23) - 1).astype(np.int64)
+    v[: ns // 3] = (1 << 23) - 1                                 # a long run of the positive extreme ...
+    v[ns // 3: 2 * ns // 3] = -(1 << 23)                         # ... and of the negative one
+    b = np.zeros((ns, 2, 3), np.uint8)
+    for i in range(3):
+        b[:, :, i] = (v >> (8 * i)) & 0xFF
+    packed = b.reshape(-1)
+    ref = O.ddc_chain(packed, [(8, h)])
+    y, on = run(pkg, dev, [(8, h)], packed, [0, 8192 * 2, ns])
+    assert all(on)
+    assert O.rel_err(y, ref) <= FIR_TOL, O.rel_err(y, ref)
+
+
+def test_i8_binary16_taps_set_taps_and_checkpoint(pkg, dev, O):
+    """The kernel's tap table follows the pipeline's taps: binary16-rounded values (config 5's fp16 leg), new taps from
+    pddc_pipeline_set_taps, and a checkpoint taken in one pipeline and restored into another continue the stream."""
+    import ctypes as C
+    h = load_taps("d8_255")
+    h16 = h.astype(np.float16).astype(np.float32)
+    ns = 8192 * 9
+    packed = O.lcg_bytes(6 * ns, 31)
+    pipe = pkg.Pipeline([(8, h)], taps_fp16=True)
+    assert pipe.on_i8(ns)
+    y = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+    assert O.rel_err(y, O.ddc_chain(packed, [(8, h16)])) <= FIR_TOL
+    pipe.close()
+    g = lowpass(233, 0.03)
+    pipe = pkg.Pipeline([(8, h)])
+    pkg.check(pkg.ddc_lib().pddc_pipeline_set_taps(pipe._h, 0, g.ctypes.data_as(C.POINTER(C.c_float)), g.size))
+    pipe.reset()
+    half = 8192 * 4 + 808
+    y1 = pipe.process(to_dev(packed[:6 * half], dev)).cpu().numpy().reshape(-1)
+    blob = pipe.save_state()
+    other = pkg.Pipeline([(8, g)])
+    other.restore_state(blob)
+    y2 = other.process(to_dev(packed[6 * half:], dev)).cpu().numpy().reshape(-1)
+    assert O.rel_err(np.concatenate([y1, y2]), O.ddc_chain(packed, [(8, g)])) <= FIR_TOL
+    pipe.close()
+    other.close()
+
+
+def test_nco_and_short_filters_keep_the_vector_kernel(pkg, dev):
+    h = load_taps("d8_255")
+    p = pkg.Pipeline([(8, h)], mix=True)
+    assert not p.on_i8(1 << 20)                                  # the mix happens before the filter, in floats
+    p.close()
+    p = pkg.Pipeline([(8, load_taps("d8_127"))])
+    assert not p.on_i8(1 << 20)                                  # 127 taps are HBM-bound on the vector kernel already
+    p.close()
+    p = pkg.Pipeline([(8, h)], no_fast=True)
+    assert not p.on_i8(1 << 20)
+    p.close()
