@@ -142,7 +142,7 @@ struct FirI8Args {
     float       scale;       /* integer result -> float                                         */
     float       cterm;       /* the planes' unsigned -> signed offset, times the taps' sum      */
 };
-constexpr size_t kFirI8TableBytes = 4 * 16 * 64 * 16;
+constexpr size_t kFirI8TableBytes = 4 * 6 * 64 * 16;
 /* host: the operand table for `ntaps` <= 256 taps; false if the taps are all zero */
 bool fir_i8_build_table(const float *taps, int ntaps, int8_t *table, float *scale, float *cterm);
 hipError_t launch_fir_i8(const FirI8Args &a, hipStream_t s);

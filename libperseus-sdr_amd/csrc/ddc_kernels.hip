@@ -1969,22 +1969,24 @@ hipError_t launch_gen_tail_many(const GenTailMany &m, int n, hipStream_t s)
  * same sign, 2e-9 typical) are dropped, and the four sums are recombined in fp32 once per output.  The unpack is gone:
  * the loader only de-interleaves bytes (v_perm) into six planes (planes 0 and 1 xor 0x80: unsigned -> signed, the
  * offset comes back as one constant per filter).
- *   out[32 n + r] = sum_c T[r][c] X[c][n],  T[r][c] = h[256 - (c - 8 r)] (banded Toeplitz, 32 x 512),
- *   X[c][n] = xp[8192 tile + 256 n + c],    xp = the 256 history samples followed by the batch.
- * A tile = 32 x 32 outputs = 8192 inputs (+256).  Persistent block of 8 waves per CU: waves 4..7 load -- two tiles
- * ahead, two register sets used alternately so that no register copy waits for a load -- and write the planes of the
- * next tile; waves 0..3 (component x half of the 16 k-steps, their 32 tap fragments resident in registers) run 72
- * MFMAs per tile and leave partial sums in LDS; ONE barrier per tile; then the MFMA waves add the halves, scale and
- * store float2.  Planes and sums exist twice.  LDS rows are padded (lane stride 272 B / 33 floats): conflict-free.
- * Measured as a stand-alone prototype first (tools/ubench/fir_i8_planes.hip).                                      */
+ *   out[16 n + r] = sum_c T[r][c] X[c][n],  T[r][c] = h[256 - (c - 8 r)] (banded Toeplitz, 16 x 384: two thirds full),
+ *   X[c][n] = xp[8192 tile + 128 n + c],    xp = the 256 history samples followed by the batch.
+ * v_mfma_i32_16x16x64_i8: 16 output rows, 16 columns, 6 k-steps of 64; 9 plane products per step.  (The first version
+ * used 32x32x32: a 32 x 512 band that is half zeros, the k range split over two waves and their partial sums added
+ * through LDS: 0.409 ms; this one 0.37.)  A tile = 64 columns x 16 outputs = 8192 inputs (+256).  Persistent block of 12
+ * waves per CU: waves 8..11 load -- two tiles ahead, two register sets used alternately so that no register copy waits
+ * for a load -- and write the planes of the next tile; waves 0..7 (component x block of 16 columns; ALL 24 tap
+ * fragments, 96 VGPRs, resident in registers) run 54 MFMAs per tile, recombine, scale and leave their outputs in LDS;
+ * ONE barrier per tile; then they store float2.  Planes and outputs exist twice.  LDS rows are padded (lane stride
+ * 144 B / 20 floats): conflict-free.  Measured as stand-alone prototypes first (tools/ubench/fir_i8_planes*.hip).     */
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 namespace i8 {
-constexpr int TILE = 8192, SPAN = TILE + 256, PLANE = SPAN + 16 * (SPAN / 256), NG = SPAN / 8, KSTEPS = 16;
-constexpr int OS = 33 * 32, NQ = (NG + 255) / 256;
-constexpr size_t LDS_BYTES = 12 * (size_t)PLANE + 8 * (size_t)OS * sizeof(float);
+constexpr int TILE = 8192, SPAN = TILE + 256, PLANE = SPAN + 16 * (SPAN / 128), NG = SPAN / 8, KSTEPS = 6;
+constexpr int OS = 20 * 64, NQ = (NG + 255) / 256, NMW = 8;
+constexpr size_t LDS_BYTES = 12 * (size_t)PLANE + 4 * (size_t)OS * sizeof(float);
 
-__device__ __forceinline__ int swz(int p) { return p + 16 * (p >> 8); }
+__device__ __forceinline__ int swz(int p) { return p + 16 * (p >> 7); }
 
 /* the 8 bytes at offsets 6 s + O (s = 0..7) of the 48 bytes w[0..11] */
 template <int O>
@@ -2052,18 +2054,18 @@ __device__ __forceinline__ void planes_from(const uint4 (&raw)[NQ][3], uint8_t *
 }
 } // namespace i8
 
-__global__ __launch_bounds__(512, 1) void k_fir_i8(FirI8Args a, long long ntiles)
+__global__ __launch_bounds__(768, 1) void k_fir_i8(FirI8Args a, long long ntiles)
 {
     using namespace i8;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_i8[];
-    /* [2 buffers][2 components][3 planes][PLANE], then [2 buffers][2 components][2 k halves][OS] partial sums */
+    /* [2 buffers][2 components][3 planes][PLANE], then [2 buffers][2 components][OS] outputs */
     float *osum_base = reinterpret_cast<float *>(lds_i8 + 12 * PLANE);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long G = gridDim.x;
     long long t = blockIdx.x;
-    if (wave >= 4) {
-        /* ---- loaders */
-        const int lt = tid - 256;
+    if (wave >= NMW) {
+        /* ---- loaders (waves 8..11) */
+        const int lt = tid - 64 * NMW;
         if (blockIdx.x == 0 && a.hist_out) {             /* the next call's history: the batch's last 256 samples */
             const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + (a.n_in - 256) * 6);
             if (lt < 96)
@@ -2098,32 +2100,30 @@ __global__ __launch_bounds__(512, 1) void k_fir_i8(FirI8Args a, long long ntiles
         }
         return;
     }
-    /* ---- MFMA waves: component, half of the k-steps; their share of the tap operand stays in registers */
-    const int comp = wave >> 1, kh = wave & 1;
-    const int n = lane & 31, h = lane >> 5;
+    /* ---- MFMA waves (0..7): component x block of 16 columns; the whole tap operand stays in registers */
+    const int comp = wave & 1, nb = wave >> 1;
+    const int n = lane & 15, kq = lane >> 4;
+    const int col = 16 * nb + n;
     const v4i_t *atab = static_cast<const v4i_t *>(a.atab);
-    v4i_t A[KSTEPS / 2][4];
+    v4i_t A[KSTEPS][4];
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS / 2; ++kk)
+    for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            A[kk][j] = atab[(j * KSTEPS + kh * (KSTEPS / 2) + kk) * 64 + lane];
+            A[ks][j] = atab[(j * KSTEPS + ks) * 64 + lane];
     const long long n_out = a.n_in >> 3;
     __syncthreads();
     int buf = 0;
     for (; t < ntiles; t += G, buf ^= 1) {
         const uint8_t *pb = lds_i8 + buf * 6 * PLANE + 3 * comp * PLANE;
-        float *osum = osum_base + buf * 4 * OS;
-        v16i_t acc[4];
+        float *osum = osum_base + buf * 2 * OS;
+        v4i_t acc[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
+            acc[s] = v4i_t{ 0, 0, 0, 0 };
 #pragma unroll
-            for (int v = 0; v < 16; ++v)
-                acc[s][v] = 0;
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS / 2; ++kk) {
-            const int ks = kh * (KSTEPS / 2) + kk;
-            const int at = swz(256 * n + 32 * ks + 16 * h);
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int at = swz(128 * col + 64 * ks + 16 * kq);
             v4i_t B[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -2133,26 +2133,24 @@ __global__ __launch_bounds__(512, 1) void k_fir_i8(FirI8Args a, long long ntiles
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (i + j >= 2)
-                        acc[i + j - 2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[kk][j], B[i], acc[i + j - 2], 0, 0, 0);
+                        acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks][j], B[i], acc[i + j - 2], 0, 0, 0);
         }
-        /* y = sum_s acc[s] 256^(s+2), as floats (every acc[s] is below 2^24: the conversions are exact) */
-        float y[16];
+        /* y = sum_s acc[s] 256^(s+2), as floats (every acc[s] is below 2^24: the conversions are exact).  This lane:
+         * column `col`, rows 4 kq + v -> outputs 16 col + 4 kq + v of the tile, four consecutive ones */
+        float4 y;
+        float *yp = &y.x;
 #pragma unroll
-        for (int v = 0; v < 16; ++v)
-            y[v] = ((float)acc[0][v] * 65536.0f + (float)acc[1][v] * 16777216.0f) +
-                   ((float)acc[2][v] * 4294967296.0f + (float)acc[3][v] * 1099511627776.0f);
-        /* this lane: column n, rows (v & 3) + 8 (v >> 2) + 4 h -> output 32 n + row of the tile */
-#pragma unroll
-        for (int v = 0; v < 16; ++v)
-            osum[(2 * comp + kh) * OS + 33 * n + (v & 3) + 8 * (v >> 2) + 4 * h] = y[v];
-        __syncthreads();                 /* the next tile's planes are written, this tile's sums are in LDS */
+        for (int v = 0; v < 4; ++v)
+            yp[v] = (((float)acc[0][v] * 65536.0f + (float)acc[1][v] * 16777216.0f) +
+                     ((float)acc[2][v] * 4294967296.0f + (float)acc[3][v] * 1099511627776.0f)) * a.scale + a.cterm;
+        *reinterpret_cast<float4 *>(osum + comp * OS + 20 * col + 4 * kq) = y;
+        __syncthreads();                 /* ONE barrier per tile: the next tile's planes are written, this tile's outputs are in LDS */
         float2 *dst = reinterpret_cast<float2 *>(a.out) + t * 1024;
         const long long left = n_out - t * 1024;
-        for (int o = tid; o < 1024; o += 256) {
-            const int q = 33 * (o >> 5) + (o & 31);
+        for (int o = tid; o < 1024; o += 64 * NMW) {
+            const int q = 20 * (o >> 4) + (o & 15);
             if (o < left)
-                dst[o] = make_float2((osum[q] + osum[OS + q]) * a.scale + a.cterm,
-                                     (osum[2 * OS + q] + osum[3 * OS + q]) * a.scale + a.cterm);
+                dst[o] = make_float2(osum[q], osum[OS + q]);
         }
     }
 }
@@ -2180,12 +2178,12 @@ bool fir_i8_build_table(const float *taps, int ntaps, int8_t *table, float *scal
             r = (r - d) / 256;
         }
     }
-    /* lane l of k-step ks holds A[row l & 31][k = 16 (l >> 5) + jj]: T[r][c] = h[256 - (c - 8 r)] */
+    /* lane l of k-step ks holds A[row l & 15][k = 16 (l >> 4) + jj]: T[r][c] = h[256 - (c - 8 r)] */
     for (int j = 0; j < 4; ++j)
         for (int ks = 0; ks < i8::KSTEPS; ++ks)
             for (int l = 0; l < 64; ++l)
                 for (int jj = 0; jj < 16; ++jj) {
-                    const int r = l & 31, c = 32 * ks + 16 * (l >> 5) + jj, tt = c - 8 * r;
+                    const int r = l & 15, c = 64 * ks + 16 * (l >> 4) + jj, tt = c - 8 * r;
                     table[(((size_t)j * i8::KSTEPS + ks) * 64 + l) * 16 + jj] = (tt >= 1 && tt <= 256) ? dig[j][256 - tt] : 0;
                 }
     /* sample = (v24 << 8) / (INT_MAX - 256): the reference's float (perseustest.c:466-502) */
@@ -2217,7 +2215,7 @@ hipError_t launch_fir_i8(const FirI8Args &a, hipStream_t s)
         cus[dev & 63] = v > 0 ? v : 256;
     }
     const long long grid = ntiles < cus[dev & 63] ? ntiles : cus[dev & 63];
-    hipLaunchKernelGGL(k_fir_i8, dim3((unsigned)grid), dim3(512), i8::LDS_BYTES, s, a, ntiles);
+    hipLaunchKernelGGL(k_fir_i8, dim3((unsigned)grid), dim3(768), i8::LDS_BYTES, s, a, ntiles);
     return hipGetLastError();
 }
 
