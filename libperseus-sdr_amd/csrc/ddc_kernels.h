@@ -127,25 +127,25 @@ hipError_t launch_gen_tail_many(const GenTailMany &m, int n, hipStream_t s);
 /* n generator streams of nbytes each */
 hipError_t launch_synth_lcg_many(const SynthMany &m, int n, size_t nbytes, hipStream_t s);
 
-/* ---- k_fir_i8: the long packed first stage (129..256 taps, decimate by 8, no NCO) on the INT8 matrix cores ----------
+/* ---- k_fir_i8: the long packed first stage (65..256 taps, decimate by 8, no NCO) on the INT8 matrix cores -----------
  * A 24-bit sample is three int8 planes -- the wire bytes -- and taps quantised to 32-bit integers are four balanced
  * base-256 digits: v_mfma_i32_32x32x32_i8 forms the byte-plane products exactly, the planes are recombined once per
  * output (DESIGN.md 4 "k_fir_i8").  History and results as k_fir8's: 256 packed samples in front, out[m] =
  * sum_k h[k] x[8m - k].                                                                                        */
 struct FirI8Args {
     const void *in;          /* packed batch, 16-byte aligned                                  */
-    const void *hist;        /* the 256 packed samples in front of it                          */
-    void       *hist_out;    /* receives the batch's last 256 samples (or NULL; needs n_in >= 256) */
+    const void *hist;        /* the `hist` (128 or 256) packed samples in front of it          */
+    void       *hist_out;    /* receives the batch's last `hist` samples (or NULL; needs n_in >= hist) */
     float      *out;         /* float2 outputs, n_in / 8                                        */
     const void *atab;        /* the tap operand table (fir_i8_build_table), kFirI8TableBytes    */
     long long   n_in;        /* samples, multiple of 8                                          */
     float       scale;       /* integer result -> float                                         */
     float       cterm;       /* the planes' unsigned -> signed offset, times the taps' sum      */
 };
-constexpr size_t kFirI8TableBytes = 4 * 6 * 64 * 16;
-/* host: the operand table for `ntaps` <= 256 taps; false if the taps are all zero */
-bool fir_i8_build_table(const float *taps, int ntaps, int8_t *table, float *scale, float *cterm);
-hipError_t launch_fir_i8(const FirI8Args &a, hipStream_t s);
+constexpr size_t kFirI8TableBytes = 4 * 6 * 64 * 16;       /* (hist 256; 4 k-steps instead of 6 for hist 128) */
+/* host: the operand table for `ntaps` <= hist taps (hist = 128 or 256); false if the taps are all zero */
+bool fir_i8_build_table(const float *taps, int ntaps, int hist, int8_t *table, float *scale, float *cterm);
+hipError_t launch_fir_i8(const FirI8Args &a, int hist, hipStream_t s);
 
 /* k_fir8 with packed input does not scale the unpacked integers (value * 256): the taps of
  * that stage must be uploaded multiplied by this, RN(1/8388607) / 256 -- the factor that

@@ -1982,9 +1982,15 @@ hipError_t launch_gen_tail_many(const GenTailMany &m, int n, hipStream_t s)
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 namespace i8 {
-constexpr int TILE = 8192, SPAN = TILE + 256, PLANE = SPAN + 16 * (SPAN / 128), NG = SPAN / 8, KSTEPS = 6;
-constexpr int OS = 20 * 64, NQ = (NG + 255) / 256, NMW = 8;
-constexpr size_t LDS_BYTES = 12 * (size_t)PLANE + 4 * (size_t)OS * sizeof(float);
+/* HIST = 256 (129..256 taps) or 128 (65..128 taps): history samples in front of the batch = the filter's reach */
+template <int HIST>
+struct Geo {
+    static constexpr int TILE = 8192, SPAN = TILE + HIST, PLANE = SPAN + 16 * ((SPAN + 127) / 128), NG = SPAN / 8;
+    static constexpr int KSTEPS = (120 + HIST + 63) / 64;          /* the band is 16 x (8 * 15 + HIST) wide */
+    static constexpr int NQ = (NG + 255) / 256;
+    static constexpr size_t LDS_BYTES = 12 * (size_t)PLANE + 4 * (size_t)(20 * 64) * sizeof(float);
+};
+constexpr int OS = 20 * 64, NMW = 8, TILE = 8192;
 
 __device__ __forceinline__ int swz(int p) { return p + 16 * (p >> 7); }
 
@@ -2009,14 +2015,16 @@ __device__ __forceinline__ void plane_bytes(const uint32_t (&w)[12], uint32_t &l
 }
 
 /* the loads of one tile: group g of tile t is xp[8192 t + 8 g ..+8) -- history, batch, or (behind the batch) zeros */
-__device__ __forceinline__ void issue_tile(const FirI8Args &a, long long t, uint4 (&raw)[NQ][3], int lt)
+template <int HIST>
+__device__ __forceinline__ void issue_tile(const FirI8Args &a, long long t, uint4 (&raw)[Geo<HIST>::NQ][3], int lt)
 {
+    constexpr int NQ = Geo<HIST>::NQ, NG = Geo<HIST>::NG;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int g = lt + 256 * q;
         if (g < NG) {
-            const long long b = t * TILE + 8LL * g - 256;          /* first sample of the group, relative to the batch */
-            const uint4 *p = b < 0 ? reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.hist) + (b + 256) * 6)
+            const long long b = t * TILE + 8LL * g - HIST;         /* first sample of the group, relative to the batch */
+            const uint4 *p = b < 0 ? reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.hist) + (b + HIST) * 6)
                                    : reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + b * 6);
             if (b + 8 <= a.n_in) {
                 raw[q][0] = p[0];
@@ -2029,8 +2037,10 @@ __device__ __forceinline__ void issue_tile(const FirI8Args &a, long long t, uint
     }
 }
 
-__device__ __forceinline__ void planes_from(const uint4 (&raw)[NQ][3], uint8_t *plane, int lt)
+template <int HIST>
+__device__ __forceinline__ void planes_from(const uint4 (&raw)[Geo<HIST>::NQ][3], uint8_t *plane, int lt)
 {
+    constexpr int NQ = Geo<HIST>::NQ, NG = Geo<HIST>::NG, PLANE = Geo<HIST>::PLANE;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int g = lt + 256 * q;
@@ -2054,9 +2064,11 @@ __device__ __forceinline__ void planes_from(const uint4 (&raw)[NQ][3], uint8_t *
 }
 } // namespace i8
 
+template <int HIST>
 __global__ __launch_bounds__(768, 1) void k_fir_i8(FirI8Args a, long long ntiles)
 {
     using namespace i8;
+    constexpr int PLANE = Geo<HIST>::PLANE, KSTEPS = Geo<HIST>::KSTEPS, NQ = Geo<HIST>::NQ;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_i8[];
     /* [2 buffers][2 components][3 planes][PLANE], then [2 buffers][2 components][OS] outputs */
     float *osum_base = reinterpret_cast<float *>(lds_i8 + 12 * PLANE);
@@ -2067,22 +2079,22 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8(FirI8Args a, long long ntiles
         /* ---- loaders (waves 8..11) */
         const int lt = tid - 64 * NMW;
         if (blockIdx.x == 0 && a.hist_out) {             /* the next call's history: the batch's last 256 samples */
-            const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + (a.n_in - 256) * 6);
-            if (lt < 96)
+            const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + (a.n_in - HIST) * 6);
+            if (lt < HIST * 6 / 16)
                 static_cast<uint4 *>(a.hist_out)[lt] = src[lt];
         }
         uint4 ra[NQ][3], rb[NQ][3];
-        issue_tile(a, t, ra, lt);
-        planes_from(ra, lds_i8, lt);
+        issue_tile<HIST>(a, t, ra, lt);
+        planes_from<HIST>(ra, lds_i8, lt);
         if (t + G < ntiles)
-            issue_tile(a, t + G, ra, lt);
+            issue_tile<HIST>(a, t + G, ra, lt);
         __syncthreads();
         for (;;) {
             /* tile t is computed from buffer 0; t + G (in ra) goes to buffer 1, t + 2 G starts towards rb */
             if (t + G < ntiles) {
                 if (t + 2 * G < ntiles)
-                    issue_tile(a, t + 2 * G, rb, lt);
-                planes_from(ra, lds_i8 + 6 * PLANE, lt);
+                    issue_tile<HIST>(a, t + 2 * G, rb, lt);
+                planes_from<HIST>(ra, lds_i8 + 6 * PLANE, lt);
             }
             __syncthreads();
             t += G;
@@ -2090,8 +2102,8 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8(FirI8Args a, long long ntiles
                 break;
             if (t + G < ntiles) {
                 if (t + 2 * G < ntiles)
-                    issue_tile(a, t + 2 * G, ra, lt);
-                planes_from(rb, lds_i8, lt);
+                    issue_tile<HIST>(a, t + 2 * G, ra, lt);
+                planes_from<HIST>(rb, lds_i8, lt);
             }
             __syncthreads();
             t += G;
@@ -2155,9 +2167,9 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8(FirI8Args a, long long ntiles
     }
 }
 
-bool fir_i8_build_table(const float *taps, int ntaps, int8_t *table, float *scale, float *cterm)
+bool fir_i8_build_table(const float *taps, int ntaps, int hist, int8_t *table, float *scale, float *cterm)
 {
-    if (!taps || ntaps < 1 || ntaps > 256 || !table)
+    if (!taps || ntaps < 1 || (hist != 128 && hist != 256) || ntaps > hist || !table)
         return false;
     double hmax = 0.0;
     for (int k = 0; k < ntaps; ++k)
@@ -2167,7 +2179,7 @@ bool fir_i8_build_table(const float *taps, int ntaps, int8_t *table, float *scal
     const int E = 30 - (int)std::ceil(std::log2(hmax));            /* |H| <= 2^30: the top digit stays within +-64 */
     int8_t dig[4][256];
     long long hsum = 0;
-    for (int k = 0; k < 256; ++k) {
+    for (int k = 0; k < hist; ++k) {
         long long r = k < ntaps ? std::llround(std::ldexp((double)taps[k], E)) : 0;
         hsum += r;
         for (int j = 0; j < 4; ++j) {
@@ -2178,13 +2190,14 @@ bool fir_i8_build_table(const float *taps, int ntaps, int8_t *table, float *scal
             r = (r - d) / 256;
         }
     }
-    /* lane l of k-step ks holds A[row l & 15][k = 16 (l >> 4) + jj]: T[r][c] = h[256 - (c - 8 r)] */
+    /* lane l of k-step ks holds A[row l & 15][k = 16 (l >> 4) + jj]: T[r][c] = h[hist - (c - 8 r)] */
+    const int ksteps = (120 + hist + 63) / 64;
     for (int j = 0; j < 4; ++j)
-        for (int ks = 0; ks < i8::KSTEPS; ++ks)
+        for (int ks = 0; ks < ksteps; ++ks)
             for (int l = 0; l < 64; ++l)
                 for (int jj = 0; jj < 16; ++jj) {
                     const int r = l & 15, c = 64 * ks + 16 * (l >> 4) + jj, tt = c - 8 * r;
-                    table[(((size_t)j * i8::KSTEPS + ks) * 64 + l) * 16 + jj] = (tt >= 1 && tt <= 256) ? dig[j][256 - tt] : 0;
+                    table[(((size_t)j * ksteps + ks) * 64 + l) * 16 + jj] = (tt >= 1 && tt <= hist) ? dig[j][hist - tt] : 0;
                 }
     /* sample = (v24 << 8) / (INT_MAX - 256): the reference's float (perseustest.c:466-502) */
     const double unit = std::ldexp(1.0, -E) * 256.0 / 2147483391.0;
@@ -2193,12 +2206,9 @@ bool fir_i8_build_table(const float *taps, int ntaps, int8_t *table, float *scal
     return true;
 }
 
-hipError_t launch_fir_i8(const FirI8Args &a, hipStream_t s)
+template <int HIST>
+static hipError_t launch_fir_i8_t(const FirI8Args &a, hipStream_t s)
 {
-    if (a.n_in <= 0)
-        return hipSuccess;
-    if ((a.n_in & 7) || !a.in || !a.hist || !a.out || !a.atab || (a.hist_out && a.n_in < 256))
-        return hipErrorInvalidValue;
     const long long ntiles = (a.n_in + i8::TILE - 1) / i8::TILE;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -2208,15 +2218,28 @@ hipError_t launch_fir_i8(const FirI8Args &a, hipStream_t s)
         hipError_t e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess)
             return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_i8), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)i8::LDS_BYTES);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_i8<HIST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)i8::Geo<HIST>::LDS_BYTES);
         if (e != hipSuccess)
             return e;
         cus[dev & 63] = v > 0 ? v : 256;
     }
     const long long grid = ntiles < cus[dev & 63] ? ntiles : cus[dev & 63];
-    hipLaunchKernelGGL(k_fir_i8, dim3((unsigned)grid), dim3(768), i8::LDS_BYTES, s, a, ntiles);
+    hipLaunchKernelGGL(k_fir_i8<HIST>, dim3((unsigned)grid), dim3(768), i8::Geo<HIST>::LDS_BYTES, s, a, ntiles);
     return hipGetLastError();
+}
+
+hipError_t launch_fir_i8(const FirI8Args &a, int hist, hipStream_t s)
+{
+    if (a.n_in <= 0)
+        return hipSuccess;
+    if ((a.n_in & 7) || !a.in || !a.hist || !a.out || !a.atab || (a.hist_out && a.n_in < hist))
+        return hipErrorInvalidValue;
+    if (hist == 256)
+        return launch_fir_i8_t<256>(a, s);
+    if (hist == 128)
+        return launch_fir_i8_t<128>(a, s);
+    return hipErrorInvalidValue;
 }
 
 /* ======================================================================== */

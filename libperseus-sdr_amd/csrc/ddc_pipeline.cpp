@@ -278,10 +278,13 @@ static int upload_taps(pddc_pipeline *p, int si)
         hipFree(s.d_taps_i8);
         s.d_taps_i8 = nullptr;
     }
-    if (si == 0 && s.decim == 8 && s.interp == 1 && s.ntaps > 128 && s.ntaps <= 256 && !(p->flags & PDDC_F_NO_FAST)) {
+    /* (the history length is fixed at create time -- 8 * tap blocks -- and not known yet when this runs for the first time) */
+    const int i8_hist = s.hist ? s.hist : 8 * pick_ntb(s.ntaps);
+    if (si == 0 && stage_fused_capable(s) && s.ntaps <= i8_hist && (i8_hist == 128 || i8_hist == 256) &&
+        !(p->flags & PDDC_F_NO_FAST)) {
         /* the long first stage on the int8 matrix cores (k_fir_i8): taps as four planes of balanced base-256 digits */
         std::vector<int8_t> tab(kFirI8TableBytes);
-        if (fir_i8_build_table(s.taps.data(), s.ntaps, tab.data(), &s.i8_scale, &s.i8_cterm)) {
+        if (fir_i8_build_table(s.taps.data(), s.ntaps, i8_hist, tab.data(), &s.i8_scale, &s.i8_cterm)) {
             HIP_TRY(hipMalloc(&s.d_taps_i8, tab.size()));
             HIP_TRY(hipMemcpy(s.d_taps_i8, tab.data(), tab.size(), hipMemcpyHostToDevice));
         }
@@ -800,8 +803,10 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
     if (const char *e = getenv("PDDC_FIR8_R"))
         if (atoi(e) == 4 || atoi(e) == 8)
             p->R = atoi(e);
-    if (const char *e = getenv("PDDC_FIR8_BLOCKS"))
-        fir8_set_grid_blocks(atoi(e));
+    {
+        const char *e = getenv("PDDC_FIR8_BLOCKS");      /* (process-wide; back to the default when the variable is gone) */
+        fir8_set_grid_blocks(e ? atoi(e) : 0);
+    }
     for (int i = 0; i < nstages; ++i) {
         Stage &s = p->st[i];
         s.decim = stages[i].decim;
@@ -1140,8 +1145,16 @@ int pddc_pipeline_uses_fused(const pddc_pipeline *p) { return p && stage0_fused(
 /* the long first stage (129..256 taps, /8, no NCO) runs on the int8 matrix cores: k_fir_i8 (PDDC_NO_I8: k_fir8 always) */
 static bool stage0_on_i8(const pddc_pipeline *p, size_t nsamples)
 {
-    return stage0_fused(p) && p->st[0].d_taps_i8 != nullptr && p->st[0].hist == 256 && !(p->flags & PDDC_F_MIX) &&
-           nsamples >= 256 && !getenv("PDDC_NO_I8");
+    if (!stage0_fused(p) || p->st[0].d_taps_i8 == nullptr || (p->flags & PDDC_F_MIX) || nsamples < (size_t)p->st[0].hist ||
+        getenv("PDDC_NO_I8"))
+        return false;
+    if (p->st[0].hist == 256)
+        return true;
+    /* 65..128 taps: up to 2^25 samples a batch lives (partly) in the last-level cache and the matrix cores win by up to 2x
+     * (2^22: 287 -> 562 GS/s, 2^24: 555 -> 706); beyond that both kernels stream from HBM and the vector kernel's load path
+     * is the better one (2^26: 711 vs 696, 2^28: 0.340 vs 0.366 ms).  PDDC_I8_128 = 0 / 1 forces the choice (development). */
+    const char *e = getenv("PDDC_I8_128");
+    return e ? atoi(e) != 0 : nsamples <= ((size_t)1 << 25);
 }
 
 int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples) { return p && stage0_on_i8(p, nsamples) ? 1 : 0; }
@@ -1786,7 +1799,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                 q.n_in = (long long)nsamples;
                 q.scale = st.i8_scale;
                 q.cterm = st.i8_cterm;
-                HIP_TRY(launch_fir_i8(q, s));
+                HIP_TRY(launch_fir_i8(q, st.hist, s));
             } else {
                 HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s, p->NT));
             }

@@ -171,7 +171,8 @@ def test_bench_line_end_to_end_on_the_gpu():
     assert abs(d["value"] - (1 << 24) * 8 / (d["ms_per_step"] * 8 * 1e-3) / 1e6) / d["value"] < 0.01
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["kernel"] == "k_fir8"
+    # (2^24-sample launches of the 127-tap stage run on the int8 matrix cores; from 2^26 on the vector kernel k_fir8)
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["kernel"].startswith("k_fir_i8")
     assert abs(rf["achieved"] - 7.0 * (1 << 24) / (rf["kernel_ms"] * 1e-3) / 1e9) / rf["achieved"] < 0.01
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "MS/s"
