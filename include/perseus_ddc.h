@@ -198,8 +198,9 @@ size_t pddc_pipeline_next_output(const pddc_pipeline *p, size_t nsamples_in);
 /* 1 if stage 0 runs the fused unpack+mix+polyphase kernel for this geometry   */
 int pddc_pipeline_uses_fused(const pddc_pipeline *p);
 /* 1 if a batch of nsamples_in would run stage 0 on the int8 matrix cores (k_fir_i8: a /8 first stage
- * of 129..256 taps without the NCO; the wire bytes are the operand, the taps are quantised to
- * 2^-31 of the largest one; same history, same outputs to 1e-7 of full scale)              */
+ * without the NCO of 129..256 taps, or of 65..128 taps for batches up to 2^25 samples; the wire bytes
+ * are the operand, the taps are quantised to 2^-31 of the largest one; same history, same outputs to
+ * 1e-7 of full scale)                                                                       */
 int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples_in);
 /* 1 if stage 0 reads the packed samples itself (the fused decimate-by-8, or the generic decimator
  * with its unpack-while-staging load phase for any other first decimation): no float32

@@ -1,4 +1,4 @@
-"""GPU tests (-m gpu) of k_fir_i8: the long first stage (129..256 taps, decimate by 8, no NCO) on the int8 matrix cores
+"""GPU tests (-m gpu) of k_fir_i8: the long first stage (65..256 taps, decimate by 8, no NCO) on the int8 matrix cores
 (DESIGN.md 4).  The wire bytes are the operand -- three int8 planes per component --, the taps are four planes of
 balanced base-256 digits, int32 accumulation is exact; what is left is the tap quantisation (2^-31 of the largest tap)
 and three dropped low-order plane products.  Same bar as every FIR path here: max|y - ref| / max|ref| <= 1e-6 against
