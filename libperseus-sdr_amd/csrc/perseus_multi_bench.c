@@ -139,6 +139,10 @@ int main(int argc, char **argv)
     for (int g = 0; g < ng; g++) {
         CHECK(pddc_set_device(g));
         CHECK(pddc_pipeline_create(&pipe[g], g, st, nst, flags));   /* same host memory: nothing to broadcast */
+        /* the cascade's last stage rides along with the next batch's first-stage launch (one launch per step); with the
+         * gather each batch's output has to be complete when its transfer is queued, so that leg keeps the in-line chain */
+        if (cascade && !gather)
+            CHECK(pddc_pipeline_set_overlap(pipe[g], 1));
         CHECK(pddc_pipeline_set_freg(pipe[g], freg));
         cap = pddc_pipeline_max_output(pipe[g], ns) + 8;
         /* Input, inter-stage workspace and the two output buffers of a GPU are cut from ONE arena, at the pair of
@@ -215,6 +219,7 @@ int main(int argc, char **argv)
             CHECK(pddc_set_device(g));
             if (leg == 1)
                 CHECK(pddc_comm_gather_wait(comm[g]));
+            CHECK(pddc_pipeline_fence(pipe[g], NULL));          /* overlap mode: the last batch's held-back stage */
             CHECK(pddc_stream_sync(NULL));
         }
         if (leg == 0)

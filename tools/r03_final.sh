@@ -17,6 +17,7 @@ bash tools/api_receivers.sh > $OUT/api_receivers.txt 2>&1
 bash tools/bench_repeat.sh 4 > $OUT/bench_repeat_d8_127.txt 2>&1
 bash tools/bench_repeat.sh 3 --workload c320 > $OUT/bench_repeat_c320.txt 2>&1
 libperseus-sdr_amd/perseus_multi_bench -n 28 -s 200 > $OUT/multi_bench_c_host.txt 2>&1
+libperseus-sdr_amd/perseus_multi_bench -n 28 -s 200 -c >> $OUT/multi_bench_c_host.txt 2>&1
 libperseus-sdr_amd/perseus_multi_bench -n 28 -s 100 -c -G >> $OUT/multi_bench_c_host.txt 2>&1
 bash tools/small_batch_default.sh > $OUT/small_batches.txt 2>&1
 bash tools/trace_gaps.sh d8_127 $OUT/trace_d8_127 --steps 200 --warmup 5 > $OUT/trace_d8_127.txt 2>&1
