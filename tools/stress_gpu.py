@@ -1,6 +1,7 @@
 # randomized stress of the stream state machine against the oracle: random plans, cuts, NCO words retuned
 # between batches (phase-continuous), scheduler settings (PDDC_FIR8_BLOCKS / DYN_PCT / CHUNK / R), caller-provided
-# workspaces and checkpoint/restore hops to a fresh pipeline in mid-stream.
+# workspaces, checkpoint/restore hops to a fresh pipeline in mid-stream, overlap mode (the last stage carried by the next
+# launch), and the int8 matrix-core first stage switched on and off between batches (PDDC_NO_I8 / PDDC_I8_128).
 # Usage: python tools/stress_gpu.py [n]
 import sys, os, importlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -43,6 +44,9 @@ for it in range(n_iter):
     segs = [(a, w) for k, (a, w) in enumerate(zip(cuts[:-1], words)) if k == 0 or w != words[k - 1]]
     ref = O.ddc_chain_retuned(packed, stages, segs) if mix else O.ddc_chain(packed, stages)
     pipe = pkg.Pipeline(stages, mix=mix)
+    ov = len(stages) > 1 and bool(rng.integers(0, 2))
+    if ov:
+        pipe.set_overlap(True)
     # caller-provided workspace for the inter-stage buffers (sometimes dropped again in mid-stream), and sometimes a
     # hop to a fresh pipeline through save_state / restore_state between two batches
     use_ws = len(stages) > 1 and bool(rng.integers(0, 2))
@@ -55,6 +59,13 @@ for it in range(n_iter):
     parts = []
     for k, ((a, b), w) in enumerate(zip(zip(cuts[:-1], cuts[1:]), words)):
         pipe.set_freg(w)
+        i8 = int(rng.integers(0, 3))                       # the int8 first stage: library's choice / off / forced on (<= 128 taps)
+        os.environ.pop("PDDC_NO_I8", None)
+        os.environ.pop("PDDC_I8_128", None)
+        if i8 == 1:
+            os.environ["PDDC_NO_I8"] = "1"
+        elif i8 == 2:
+            os.environ["PDDC_I8_128"] = "1"
         parts.append(pipe.process(torch.from_numpy(packed[6 * a:6 * b].copy()).to(dev)).cpu().numpy().reshape(-1))
         act = int(rng.integers(0, 6))
         if act == 0 and use_ws:
@@ -63,6 +74,8 @@ for it in range(n_iter):
         elif act == 1:
             blob = pipe.save_state()
             q = pkg.Pipeline(stages, mix=mix)
+            if ov:
+                q.set_overlap(True)
             q.restore_state(blob)
             pipe.close()
             pipe = q
@@ -76,7 +89,7 @@ for it in range(n_iter):
     tag = "ok " if ok and err <= 1e-6 else "BAD"
     print(f"{tag} it {it} stages {[(s[0], len(s[1])) for s in stages]} mix {mix} ns {ns} cuts {len(cuts)-1} "
           f"blocks {os.environ['PDDC_FIR8_BLOCKS']} dyn {os.environ.get('PDDC_FIR8_DYN_PCT', 'default')} K {os.environ.get('PDDC_FIR8_CHUNK', 'default')} "
-          f"R {os.environ['PDDC_FIR8_R']} retunes {len(segs) - 1} ws {ws is not None} hops {hops} err {err:.2e}", flush=True)
+          f"R {os.environ['PDDC_FIR8_R']} retunes {len(segs) - 1} ws {ws is not None} hops {hops} overlap {ov} err {err:.2e}", flush=True)
     if tag == "BAD":
         sys.exit(1)
 print("worst", worst)
