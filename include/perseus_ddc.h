@@ -202,6 +202,13 @@ int pddc_pipeline_uses_fused(const pddc_pipeline *p);
  * are the operand, the taps are quantised to 2^-31 of the largest one; same history, same outputs to
  * 1e-7 of full scale)                                                                       */
 int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples_in);
+/* The tap operand that kernel reads, as the library builds it (host arithmetic, no device needed; for tests and for
+ * hosts that want to look at the quantisation): taps -> H[k] = round(h[k] * 2^E), E = 30 - ceil(log2 max|h|), as four
+ * balanced base-256 digits d_j[k] in [-128, 127]; table[j][ks][lane][jj] = d_j[hist - (c - 8 r)] for r = lane & 15,
+ * c = 64 ks + 16 (lane >> 4) + jj and 1 <= c - 8 r <= hist, else 0 (the banded Toeplitz matrix in the lane order of
+ * v_mfma_i32_16x16x64_i8); 4 * ksteps * 1024 bytes with ksteps = 6 (hist 256) or 4 (hist 128).  *scale turns the
+ * integer result into the reference's float, *cterm is the constant that undoes the byte planes' -128 offset.       */
+int pddc_fir_i8_table(const float *taps, int ntaps, int hist, int8_t *table, size_t table_bytes, float *scale, float *cterm);
 /* 1 if stage 0 reads the packed samples itself (the fused decimate-by-8, or the generic decimator
  * with its unpack-while-staging load phase for any other first decimation): no float32
  * intermediate of the input is ever written; 6 + 8/D bytes per input sample                  */

@@ -2018,12 +2018,25 @@ __device__ __forceinline__ void plane_bytes(const uint32_t (&w)[12], uint32_t &l
 template <int HIST>
 __device__ __forceinline__ void issue_tile(const FirI8Args &a, long long t, uint4 (&raw)[Geo<HIST>::NQ][3], int lt)
 {
-    constexpr int NQ = Geo<HIST>::NQ, NG = Geo<HIST>::NG;
+    constexpr int NQ = Geo<HIST>::NQ, NG = Geo<HIST>::NG, SPAN = Geo<HIST>::SPAN;
+    const long long b0 = t * TILE - HIST;                          /* first sample of the tile's span, relative to the batch */
+    if (b0 >= 0 && b0 + SPAN <= a.n_in) {
+        /* an interior tile (all but the first and the last one or two): one base pointer, constant strides */
+        const uint4 *p = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + b0 * 6) + 3 * lt;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (lt + 256 * q < NG) {
+                raw[q][0] = p[768 * q];
+                raw[q][1] = p[768 * q + 1];
+                raw[q][2] = p[768 * q + 2];
+            }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int g = lt + 256 * q;
         if (g < NG) {
-            const long long b = t * TILE + 8LL * g - HIST;         /* first sample of the group, relative to the batch */
+            const long long b = b0 + 8LL * g;                      /* first sample of the group: history, batch, or behind it */
             const uint4 *p = b < 0 ? reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.hist) + (b + HIST) * 6)
                                    : reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + b * 6);
             if (b + 8 <= a.n_in) {
@@ -2159,10 +2172,17 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8(FirI8Args a, long long ntiles
         __syncthreads();                 /* ONE barrier per tile: the next tile's planes are written, this tile's outputs are in LDS */
         float2 *dst = reinterpret_cast<float2 *>(a.out) + t * 1024;
         const long long left = n_out - t * 1024;
-        for (int o = tid; o < 1024; o += 64 * NMW) {
-            const int q = 20 * (o >> 4) + (o & 15);
-            if (o < left)
+        if (left >= 1024) {
+#pragma unroll
+            for (int o = tid; o < 1024; o += 64 * NMW) {
+                const int q = 20 * (o >> 4) + (o & 15);
                 dst[o] = make_float2(osum[q], osum[OS + q]);
+            }
+        } else {
+            for (int o = tid; o < left; o += 64 * NMW) {
+                const int q = 20 * (o >> 4) + (o & 15);
+                dst[o] = make_float2(osum[q], osum[OS + q]);
+            }
         }
     }
 }

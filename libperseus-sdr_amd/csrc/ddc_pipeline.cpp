@@ -356,6 +356,21 @@ uint32_t pddc_nco_freg(double center_freq_hz, double adc_clk_hz)
     return (uint32_t)(center_freq_hz / adc_clk_hz * 4.294967296E9);
 }
 
+/* host arithmetic only (no device needed): the tap operand of k_fir_i8, so that its digits can be checked on any machine */
+int pddc_fir_i8_table(const float *taps, int ntaps, int hist, int8_t *table, size_t table_bytes, float *scale, float *cterm)
+{
+    if (!taps || !table || !scale || !cterm)
+        return fail(PDDC_EINVAL, "null argument");
+    if (hist != 128 && hist != 256)
+        return fail(PDDC_EINVAL, "history %d: 128 or 256", hist);
+    const size_t need = (size_t)4 * (size_t)((120 + hist + 63) / 64) * 64 * 16;
+    if (table_bytes < need)
+        return fail(PDDC_ECAPACITY, "table needs %zu bytes, buffer has %zu", need, table_bytes);
+    if (!fir_i8_build_table(taps, ntaps, hist, table, scale, cterm))
+        return fail(PDDC_EINVAL, "no int8 form for these taps (1..%d taps, not all zero, finite)", hist);
+    return PDDC_OK;
+}
+
 static int require_device(void)
 {
     int n = pddc_device_count();
