@@ -289,7 +289,12 @@ int pddc_pipeline_wait(pddc_pipeline *p);          /* everything pushed so far i
  * the round, as launches of their own on the gang's stream; *n_ganged says how many shared.
  * Tickets are the pipelines' own (pddc_pipeline_wait_ticket).  A pipeline may change between
  * gang rounds and pushes of its own at any batch boundary (the change waits for what it still
- * has in flight).  One thread at a time per gang.                                           */
+ * has in flight).  One thread at a time per gang.  Everything that can refuse a round (null
+ * pointers, capacities, a pipeline twice, a held-back overlap tail) is checked before anything is
+ * queued: such a call leaves every stream where it was.  A failure AFTER that (a HIP error while
+ * queueing) leaves the round's members in an undefined position: reset or destroy them.  A
+ * member's h_out must stay the kind of memory it was when first seen (pinned or pageable): the
+ * answer is remembered per staging slot.                                                     */
 #define PDDC_GANG_MAX 8
 typedef struct pddc_gang pddc_gang;
 typedef struct {

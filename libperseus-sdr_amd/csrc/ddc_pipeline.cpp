@@ -2196,6 +2196,8 @@ int pddc_gang_destroy(pddc_gang *g)
     return PDDC_OK;
 }
 
+static_assert(PDDC_GANG_MAX <= kFir8ManyMax, "a gang round must fit one k_fir8_many launch");
+
 int pddc_gang_push_async(pddc_gang *g, pddc_gang_item *items, int n, size_t nsamples, int *n_ganged)
 {
     if (n_ganged)
