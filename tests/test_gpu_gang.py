@@ -203,3 +203,26 @@ def test_gang_refuses_bad_rounds_without_moving_any_stream(pkg, O, dev):
     a.close()
     b.close()
     gang.close()
+
+
+def test_gang_members_in_overlap_mode_run_chains_of_their_own(pkg, O, dev):
+    """A pipeline in overlap mode holds its last stage back for its own next launch: such a member does not share the
+    round's kernels (its batch runs on the gang's stream as a chain of its own, fenced), and its stream is the same."""
+    stages = plans()["8*8*5"]
+    gang = pkg.Gang(0)
+    rx = [Rx(pkg, stages, 11 + i, max(SIZES)) for i in range(3)]
+    rx[1].pipe.set_overlap(True)
+    shared = []
+    for k, ns in enumerate(SIZES):
+        res, ng = gang.push_async([r.item(k & 1) for r in rx], ns)
+        shared.append(ng)
+        for r, (n_out, t) in zip(rx, res):
+            r.pipe.wait_ticket(t)
+            r.take(k & 1, n_out)
+            r.pos += ns
+    assert shared == [2] * len(SIZES)
+    for i, r in enumerate(rx):
+        solo = run_solo(pkg, stages, 11 + i, SIZES, max(SIZES))
+        assert np.array_equal(np.concatenate(r.out).view(np.uint32), solo.view(np.uint32)), i
+        r.close()
+    gang.close()
