@@ -125,7 +125,7 @@ def test_eight_receivers_share_one_gpu_and_overlap(L, pkg, O, monkeypatch):
     # 8.3 ms, 11x.  Now ~22 ms vs ~10.5 ms: the C client, with no interpreter in the loop, shows the library's own
     # share -- eight receivers in 1.6x to 2.1x the time of one -- and asserts it there
     # (test_plumbing_client_eight_receivers_on_the_gpu_path); here 4800 callbacks of ~3 us ride along.
-    assert wall8 < 2.5 * min(walls), (walls8, walls)
+    assert wall8 < 3.0 * min(walls), (walls8, walls)             # (seen: 2.06 .. 2.38)
 
 
 # ------------------------------------------------------------------ N4: retune while streaming
