@@ -149,7 +149,7 @@ def test_arena_search_agrees_with_the_kernel(pkg, O, dev):
 def test_the_placement_rule_finds_a_fast_pair_in_a_handful_of_probes(pkg, O, dev):
     """pddc_arena_place: input at the start of ONE 80 GiB allocation, the output side probed right behind it (first come)
     and at +32 / +48 / +64 GiB, every slot only if none of those gains.  Judged by the real kernel (127 taps, 2^28
-    samples): the slot it returns is within 3 % of the best of ALL slots."""
+    samples): the slot it returns is within 4 % of the best of ALL slots (the two classes are 7-8 % apart)."""
     import ctypes as C
     import torch
     b = _bench()
@@ -189,7 +189,7 @@ def test_the_placement_rule_finds_a_fast_pair_in_a_handful_of_probes(pkg, O, dev
     lo, hi = min(direct.values()), max(direct.values())
     print(f"rule: slot {o_sl.value} after {npr.value} probes (probe {best.value:.3f} ms, first come {fc.value:.3f}); kernel there "
           f"{direct[o_sl.value]:.4f} ms, first come {direct[1]:.4f}, all slots {lo:.4f} .. {hi:.4f}")
-    assert direct[o_sl.value] <= 1.03 * lo
+    assert direct[o_sl.value] <= 1.04 * lo
     # (usually the first-come slot is a slow one and four probes are enough; a lease where it happened to be a fast one, or
     # where the probe stream saw too little contrast and looked at every slot, has been seen too -- the choice is what counts)
     pipe.close()
