@@ -12,8 +12,9 @@ runs = []
 for wl, extra in (("d8_127", []), ("d8_127", ["--taps-fp16"]), ("d8_255", []), ("d8_255", ["--taps-fp16"]),
                   ("unpack", []), ("c320", [])):
     for log2n in (22, 24, 26, 28, 30):
+        steps = max(30, 1 << max(0, 33 - log2n))      # a timed region of at least ~2^33 samples: 2048 steps at 2^22
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--workload", wl, "--log2n", str(log2n),
-               "--steps", "30", "--warmup", "5", "--settle-ms", "30"] + extra
+               "--steps", str(steps), "--warmup", "5", "--settle-ms", "30"] + extra
         p = subprocess.run(cmd, capture_output=True, text=True)
         try:
             d = json.loads(p.stdout.strip().splitlines()[-1])
