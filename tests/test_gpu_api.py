@@ -385,3 +385,71 @@ def test_retunes_between_batches_shorter_than_the_history(pkg, dev, O):
         assert y.size == ref.size
         assert O.rel_err(y, ref) <= FIR_TOL, [(s[0], len(s[1])) for s in stages]
         pipe.close()
+
+
+def test_gang_membership_churn_leaves_the_other_receivers_streams_intact(L, pkg, O, monkeypatch):
+    """Eight receivers on one GPU go out as a gang; while receivers 0 and 1 stream a fixed number of buffers, another
+    thread keeps stopping and restarting receivers 2..7 (each restart is a new pipeline that joins the gang, each stop
+    destroys one that leaves it) and retunes them.  Nothing may hang or crash, and the two undisturbed streams must equal
+    their single-receiver runs byte for byte."""
+    import threading
+    import hashlib
+    nbuf, batch, bufsize, rate = 20000, 1 << 20, 12288, 250000
+    monkeypatch.setenv("PERSEUS_AMD_DEVICES", "8")
+    assert L.perseus_init() == 8
+    ds = [open_receiver(L, pkg, i, rate, 7.1e6, mode=1, batch_samples=batch, max_buffers=nbuf if i < 2 else 0)
+          for i in range(8)]
+    sums = [hashlib.sha256(), hashlib.sha256()]
+    counts = [0, 0]
+    lock = threading.Lock()
+
+    def make_cb(i):
+        def cb(b, n, x):
+            if i < 2:
+                sums[i].update(C.string_at(b, n))
+                counts[i] += 1
+            return 0
+        return pkg.PERSEUS_CALLBACK(cb)
+
+    cbs = [make_cb(i) for i in range(8)]
+    for i, d in enumerate(ds):
+        assert L.perseus_start_async_input(d, bufsize, cbs[i], None) == 0, L.perseus_errorstr()
+    stop = threading.Event()
+    churns = [0]
+
+    def churn():
+        rng = np.random.default_rng(3)
+        while not stop.is_set():
+            i = int(rng.integers(2, 8))
+            with lock:
+                if L.perseus_stop_async_input(ds[i]) == 0:
+                    L.perseus_set_ddc_center_freq(ds[i], C.c_double(float(rng.uniform(1e6, 30e6))), 1)
+                    assert L.perseus_start_async_input(ds[i], bufsize, cbs[i], None) == 0, L.perseus_errorstr()
+                    churns[0] += 1
+            time.sleep(0.003)
+
+    th = threading.Thread(target=churn)
+    th.start()
+    t0 = time.time()
+    while (L.perseus_amd_source_running(ds[0]) or L.perseus_amd_source_running(ds[1])) and time.time() - t0 < 90:
+        time.sleep(0.005)
+    stop.set()
+    th.join(timeout=30)
+    assert not th.is_alive()
+    st = pkg.AmdStats()
+    L.perseus_amd_get_stats(ds[0], C.byref(st))
+    ganged = st.ganged_batches
+    for d in ds:
+        L.perseus_stop_async_input(d)
+    L.perseus_exit()
+    assert time.time() - t0 < 90 and churns[0] >= 20, churns
+    assert counts == [nbuf, nbuf], counts
+    for i in (0, 1):
+        assert L.perseus_init() == 8
+        d = open_receiver(L, pkg, i, rate, 7.1e6, mode=1, batch_samples=batch, max_buffers=nbuf)
+        o, _ = run_all(L, pkg, [d], bufsize=bufsize)
+        L.perseus_exit()
+        assert hashlib.sha256(o[0]).hexdigest() == sums[i].hexdigest(), i
+    print(f"{churns[0]} stop/start cycles of receivers 2..7 beside two streams of {nbuf} buffers; receiver 0 shared "
+          f"{ganged} batches")
+    assert ganged > 0
