@@ -643,15 +643,21 @@ int pddc_arena_place(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_
     std::vector<float> ms(nslot, -1.0f);
     hipError_t e = hipSuccess;
     int n = 0;
+    /* The probes compare times a few per cent apart, so they must all see the same clocks: after idle the chip boosts
+     * for a few launches and then undershoots for some tens of milliseconds (DVFS) -- a first-come slot
+     * timed during the boost and the others after it once ranked a slow slot first.  So: ~40 ms of untimed launches
+     * up front, and every probe queued back to back with no host wait inside (6 untimed, 12 timed).          */
+    for (int r = 0; r < 100 && e == hipSuccess; ++r)
+        e = launch_stream_probe(base, in_bytes & ~(size_t)15, base + slot_bytes + out_offset, dst_bytes, total, st);
     auto probe = [&](size_t o) {
         if (o >= nslot || ms[o] >= 0.0f || e != hipSuccess)
             return;
         void *dst = base + o * slot_bytes + out_offset;
-        for (int r = 0; r < 2 && e == hipSuccess; ++r)
+        for (int r = 0; r < 6 && e == hipSuccess; ++r)
             e = launch_stream_probe(base, in_bytes & ~(size_t)15, dst, dst_bytes, total, st);
         if (e == hipSuccess)
             e = hipEventRecord(e0, st);
-        for (int r = 0; r < 4 && e == hipSuccess; ++r)
+        for (int r = 0; r < 12 && e == hipSuccess; ++r)
             e = launch_stream_probe(base, in_bytes & ~(size_t)15, dst, dst_bytes, total, st);
         if (e == hipSuccess)
             e = hipEventRecord(e1, st);
@@ -660,7 +666,7 @@ int pddc_arena_place(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_
         float t = 0.0f;
         if (e == hipSuccess)
             e = hipEventElapsedTime(&t, e0, e1);
-        ms[o] = t / 4.0f;
+        ms[o] = t / 12.0f;
         ++n;
     };
     const size_t gib8 = ((size_t)8 << 30) / slot_bytes ? ((size_t)8 << 30) / slot_bytes : 1;      /* slots per 8 GiB */
