@@ -417,7 +417,7 @@ def run_rank(a):
     # 32-64 GiB in every process tried (tools/placement_probe.py --mode matrix), so: one arena (--arena-gib, default 80), cut
     # into 8 GiB slots, the input at its start.  The rule (profiles/r03/f_placement_rule.txt; the library's own form is
     # pddc_arena_place): the slot right behind the input is always in the input's class ("first come"), one of the slots
-    # at +32 / +48 / +64 GiB always in another -- four probes of 24 back-to-back steps, the fastest kept, the first-come
+    # at +32 / +48 / +64 GiB nearly always in another (every slot is looked at when none of them gains 3 %) -- four probes of 24 back-to-back steps, the fastest kept, the first-come
     # time reported next to it.  --placement full scans every slot for three input places (1.5 s; what round 2 did).
     # A receiver allocates once and runs for hours; 288 GB of HBM make this affordable.
     placement = None
@@ -488,7 +488,7 @@ def run_rank(a):
         else:
             # The rule read off those maps (some twenty leases, profiles/r0[23]/*placement*): with the
             # input at the START of one allocation, the extent class it lies in reaches 32, 48 or 64 GiB up; the slot
-            # right behind the input is always in it ("first come"), and +32, +48 or +64 GiB is always in another one.
+            # right behind the input is nearly always in it ("first come"), and +32, +48 or +64 GiB nearly always in another one.
             # So: four probes.  Only if none of them gains (a workload that does not care, or a layout not seen yet)
             # the other slots are looked at too.
             def rule_scan():
@@ -536,7 +536,7 @@ def run_rank(a):
                      "grown_after": grown,     # not None: the first, smaller arena showed ONE class only; its table
                      "note": "input and output (with a cascade's inter-stage workspace) cut from ONE allocation and placed in "
                              "different HBM extent classes: input at the start, the output probed right behind it (first "
-                             "come: same class) and at +32 / +48 / +64 GiB (one of them is always another class); every "
+                             "come: same class) and at +32 / +48 / +64 GiB (one of them is nearly always another class; if none gains 3 % every slot is probed); every "
                              "probed pair's step time is listed (key = output slot)"}
     out = outbox[0]
     d_in = inbox[0]

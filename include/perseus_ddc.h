@@ -138,8 +138,8 @@ int pddc_arena_search(void *d_arena, size_t arena_bytes, size_t slot_bytes, size
                       size_t out_bytes, int n_in_slots, size_t *in_slot, size_t *out_slot, float *ms_table,
                       float *ms_best, float *ms_worst);
 /* The cheap form, from what those searches showed on some twenty leases: with the input at the START of one allocation
- * (slot 0), its extent class reaches 32, 48 or 64 GiB up -- the slot right behind it is always in it (the "first come"
- * case) and +32, +48 or +64 GiB is always in another one.  Probes the output side at those four places on `stream`
+ * (slot 0), its extent class reaches 32, 48 or 64 GiB up -- the slot right behind it is nearly always in it (the "first come"
+ * case) and +32, +48 or +64 GiB nearly always in another one (leases with the other classes at +24 / +40 / +72 GiB exist).  Probes the output side at those four places on `stream`
  * (0.1 s), looks at the remaining slots only if none gains 3 %, returns the fastest in *out_slot with the first-come
  * and the chosen probe times and the number of probes made.  An arena of 80 GiB (ten 8-GiB slots) is enough.      */
 int pddc_arena_place(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t in_bytes, size_t out_offset,

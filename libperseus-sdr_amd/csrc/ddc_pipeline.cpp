@@ -615,7 +615,7 @@ int pddc_arena_search(void *d_arena, size_t arena_bytes, size_t slot_bytes, size
 
 /* The rule those maps gave (some twenty leases, profiles/r02/k_arena_map.txt, profiles/r03/f_placement_rule.txt): with the
  * input at the START of one allocation, the extent class it lies in reaches 32, 48 or 64 GiB up -- the slot right behind
- * the input is always in it (what "first come" buffers get) and +32, +48 or +64 GiB is always in another one.  So the
+ * the input is nearly always in it (what "first come" buffers get) and +32, +48 or +64 GiB nearly always in another one.  So the
  * input goes to slot 0 and the output side is probed at four places; only if none of them gains 3 % over the first-come
  * slot are the remaining slots looked at.  At most nslot probes, normally four (0.1 s).                          */
 int pddc_arena_place(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t in_bytes, size_t out_offset,
