@@ -570,12 +570,16 @@ int pddc_arena_search(void *d_arena, size_t arena_bytes, size_t slot_bytes, size
     float best = 0.0f, worst = 0.0f;
     size_t bi = 0, bo = 0;
     hipError_t e = hipSuccess;
+    /* settled clocks before anything is compared (see pddc_arena_place): ~40 ms of untimed launches; the pairs then
+     * follow each other with one short host wait each */
+    for (int r = 0; r < 100 && e == hipSuccess; ++r)
+        e = launch_stream_probe(base, in_bytes & ~(size_t)15, base + out_offset, dst_bytes, total, nullptr);
     for (int k = 0; k < n_in_slots && e == hipSuccess; ++k) {
         const size_t i = (size_t)k * nslot / (size_t)n_in_slots;
         for (size_t o = 0; o < nslot && e == hipSuccess; ++o) {
             const void *src = base + i * slot_bytes;
             void *dst = base + o * slot_bytes + out_offset;
-            for (int r = 0; r < 2 && e == hipSuccess; ++r)
+            for (int r = 0; r < 3 && e == hipSuccess; ++r)
                 e = launch_stream_probe(src, in_bytes & ~(size_t)15, dst, dst_bytes, total, nullptr);
             if (e == hipSuccess)
                 e = hipEventRecord(e0, nullptr);
