@@ -97,6 +97,25 @@ __device__ __forceinline__ void planes_from(const uint4 (&raw)[NQ][3], uint8_t *
             const uint32_t w[12] = { raw[q][0].x, raw[q][0].y, raw[q][0].z, raw[q][0].w, raw[q][1].x, raw[q][1].y,
                                      raw[q][1].z, raw[q][1].w, raw[q][2].x, raw[q][2].y, raw[q][2].z, raw[q][2].w };
             const int at = swz(8 * g);
+#ifndef PERM36
+            // 24 v_perm_b32 per 8 samples: three per PAIR of samples put two bytes of two planes into one dword each --
+            // (I0,I1), (I2,Q0), (Q1,Q2) --, two per plane gather four samples' bytes from two of those
+            uint32_t a[4], b[4], c[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = __builtin_amdgcn_perm(w[3 * t + 1], w[3 * t], 0x07010600u);
+                b[t] = __builtin_amdgcn_perm(w[3 * t + 2], w[3 * t], 0x05030402u);
+                c[t] = __builtin_amdgcn_perm(w[3 * t + 2], w[3 * t + 1], 0x07010600u);
+            }
+#pragma unroll
+            for (int q6 = 0; q6 < 6; ++q6) {
+                const uint32_t *src = q6 < 2 ? a : q6 < 4 ? b : c;
+                const uint32_t sel = (q6 & 1) ? 0x07060302u : 0x05040100u, x = (q6 % 3) == 2 ? 0u : 0x80808080u;
+                *reinterpret_cast<uint2 *>(plane + q6 * PLANE + at) =
+                    make_uint2(__builtin_amdgcn_perm(src[1], src[0], sel) ^ x, __builtin_amdgcn_perm(src[3], src[2], sel) ^ x);
+            }
+            continue;
+#endif
             uint32_t lo, hi;
 #define PL(C, I, O, X)                                                                            \
             plane_bytes<O>(w, lo, hi);                                                            \
