@@ -1994,53 +1994,40 @@ constexpr int OS = 20 * 64, NMW = 8, TILE = 8192;
 
 __device__ __forceinline__ int swz(int p) { return p + 16 * (p >> 7); }
 
-/* 48 wire bytes (8 samples: I0 I1 I2 Q0 Q1 Q2 each) -> the 8 bytes of each of the six planes, in 24 v_perm_b32: three per
- * pair of samples (12 bytes = 3 dwords) put two bytes of TWO planes into one dword each -- (I0,I1), (I2,Q0), (Q1,Q2) --,
- * and two per plane gather four samples' bytes from two of those.  (One plane at a time costs 36.) */
-__device__ __forceinline__ void planes8(const uint32_t (&w)[12], uint32_t (&pl)[6][2])
+/* the 8 bytes at offsets 6 s + O (s = 0..7) of the 48 bytes w[0..11] */
+template <int O>
+__device__ __forceinline__ void plane_bytes(const uint32_t (&w)[12], uint32_t &lo, uint32_t &hi)
 {
-    uint32_t a[4], b[4], c[4];
+    uint32_t out[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const uint32_t d0 = w[3 * t], d1 = w[3 * t + 1], d2 = w[3 * t + 2];
-        a[t] = __builtin_amdgcn_perm(d1, d0, 0x07010600u);      /* I0 s, I0 s+1, I1 s, I1 s+1 */
-        b[t] = __builtin_amdgcn_perm(d2, d0, 0x05030402u);      /* I2 s, I2 s+1, Q0 s, Q0 s+1 */
-        c[t] = __builtin_amdgcn_perm(d2, d1, 0x07010600u);      /* Q1 s, Q1 s+1, Q2 s, Q2 s+1 */
-    }
+    for (int half = 0; half < 2; ++half) {
+        uint32_t pair[2];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        pl[0][hh] = __builtin_amdgcn_perm(a[2 * hh + 1], a[2 * hh], 0x05040100u);
-        pl[1][hh] = __builtin_amdgcn_perm(a[2 * hh + 1], a[2 * hh], 0x07060302u);
-        pl[2][hh] = __builtin_amdgcn_perm(b[2 * hh + 1], b[2 * hh], 0x05040100u);
-        pl[3][hh] = __builtin_amdgcn_perm(b[2 * hh + 1], b[2 * hh], 0x07060302u);
-        pl[4][hh] = __builtin_amdgcn_perm(c[2 * hh + 1], c[2 * hh], 0x05040100u);
-        pl[5][hh] = __builtin_amdgcn_perm(c[2 * hh + 1], c[2 * hh], 0x07060302u);
+        for (int q = 0; q < 2; ++q) {
+            const int b0 = 6 * (4 * half + 2 * q) + O, b1 = b0 + 6;
+            const uint32_t sel = (uint32_t)(b0 & 3) | ((uint32_t)(4 + (b1 & 3)) << 8) | 0x0c0c0000u;
+            pair[q] = __builtin_amdgcn_perm(w[b1 >> 2], w[b0 >> 2], sel);
+        }
+        out[half] = __builtin_amdgcn_perm(pair[1], pair[0], 0x05040100u);
     }
+    lo = out[0];
+    hi = out[1];
 }
 
-/* the loads of one tile: group g of tile t is xp[8192 t + 8 g ..+8) -- history, batch, or (behind the batch) zeros */
+/* the loads of one tile: group g of tile t is xp[8192 t + 8 g ..+8) -- history, batch, or (behind the batch) zeros.
+ * (Measured and NOT kept, same-box A/B of whole library builds, tools/ab_i8.sh, profiles/r03/i_fir_i8_prototype.txt: a
+ * branch-free path for interior tiles -- one base pointer, constant strides -- 0.378 -> 0.399 ms; on top of it the byte
+ * de-interleave in 24 instead of 36 v_perm -- 0.409 ms, although the stand-alone prototype gains 2.7 % from it.  With the
+ * address arithmetic between them the loads leave spread out; as one burst they are slower.)                      */
 template <int HIST>
 __device__ __forceinline__ void issue_tile(const FirI8Args &a, long long t, uint4 (&raw)[Geo<HIST>::NQ][3], int lt)
 {
-    constexpr int NQ = Geo<HIST>::NQ, NG = Geo<HIST>::NG, SPAN = Geo<HIST>::SPAN;
-    const long long b0 = t * TILE - HIST;                          /* first sample of the tile's span, relative to the batch */
-    if (b0 >= 0 && b0 + SPAN <= a.n_in) {
-        /* an interior tile (all but the first and the last one or two): one base pointer, constant strides */
-        const uint4 *p = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + b0 * 6) + 3 * lt;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            if (lt + 256 * q < NG) {
-                raw[q][0] = p[768 * q];
-                raw[q][1] = p[768 * q + 1];
-                raw[q][2] = p[768 * q + 2];
-            }
-        return;
-    }
+    constexpr int NQ = Geo<HIST>::NQ, NG = Geo<HIST>::NG;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int g = lt + 256 * q;
         if (g < NG) {
-            const long long b = b0 + 8LL * g;                      /* first sample of the group: history, batch, or behind it */
+            const long long b = t * TILE + 8LL * g - HIST;         /* first sample of the group, relative to the batch */
             const uint4 *p = b < 0 ? reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.hist) + (b + HIST) * 6)
                                    : reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + b * 6);
             if (b + 8 <= a.n_in) {
@@ -2065,15 +2052,17 @@ __device__ __forceinline__ void planes_from(const uint4 (&raw)[Geo<HIST>::NQ][3]
             const uint32_t w[12] = { raw[q][0].x, raw[q][0].y, raw[q][0].z, raw[q][0].w, raw[q][1].x, raw[q][1].y,
                                      raw[q][1].z, raw[q][1].w, raw[q][2].x, raw[q][2].y, raw[q][2].z, raw[q][2].w };
             const int at = swz(8 * g);
-            uint32_t pl[6][2];
-            planes8(w, pl);
-            /* planes in wire order: I0 I1 I2 Q0 Q1 Q2 = (component 0: 0 1 2) (component 1: 0 1 2); bytes 0 and 1 of a
-             * sample are unsigned on the wire: xor 0x80 makes them the signed digits the matrix instruction takes */
-#pragma unroll
-            for (int q6 = 0; q6 < 6; ++q6) {
-                const uint32_t x = (q6 % 3) == 2 ? 0u : 0x80808080u;
-                *reinterpret_cast<uint2 *>(plane + q6 * PLANE + at) = make_uint2(pl[q6][0] ^ x, pl[q6][1] ^ x);
-            }
+            uint32_t lo, hi;
+#define PDDC_PL(C, I, O, X)                                                                       \
+            plane_bytes<O>(w, lo, hi);                                                            \
+            *reinterpret_cast<uint2 *>(plane + (3 * C + I) * PLANE + at) = make_uint2(lo ^ X, hi ^ X);
+            PDDC_PL(0, 0, 0, 0x80808080u)
+            PDDC_PL(0, 1, 1, 0x80808080u)
+            PDDC_PL(0, 2, 2, 0u)
+            PDDC_PL(1, 0, 3, 0x80808080u)
+            PDDC_PL(1, 1, 4, 0x80808080u)
+            PDDC_PL(1, 2, 5, 0u)
+#undef PDDC_PL
         }
     }
 }
@@ -2174,17 +2163,10 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8(FirI8Args a, long long ntiles
         __syncthreads();                 /* ONE barrier per tile: the next tile's planes are written, this tile's outputs are in LDS */
         float2 *dst = reinterpret_cast<float2 *>(a.out) + t * 1024;
         const long long left = n_out - t * 1024;
-        if (left >= 1024) {
-#pragma unroll
-            for (int o = tid; o < 1024; o += 64 * NMW) {
-                const int q = 20 * (o >> 4) + (o & 15);
+        for (int o = tid; o < 1024; o += 64 * NMW) {
+            const int q = 20 * (o >> 4) + (o & 15);
+            if (o < left)
                 dst[o] = make_float2(osum[q], osum[OS + q]);
-            }
-        } else {
-            for (int o = tid; o < left; o += 64 * NMW) {
-                const int q = 20 * (o >> 4) + (o & 15);
-                dst[o] = make_float2(osum[q], osum[OS + q]);
-            }
         }
     }
 }
