@@ -2066,6 +2066,49 @@ __device__ __forceinline__ void planes_from(const uint4 (&raw)[Geo<HIST>::NQ][3]
         }
     }
 }
+/* one loader step: the loads of tile `tn` (if any) go out group by group BETWEEN the conversions of the tile that has
+ * arrived -- spread over the whole step instead of one burst */
+template <int HIST>
+__device__ __forceinline__ void load_and_convert(const FirI8Args &a, long long tn, bool have_next,
+                                                 uint4 (&nxt)[Geo<HIST>::NQ][3], const uint4 (&cur)[Geo<HIST>::NQ][3],
+                                                 uint8_t *plane, int lt)
+{
+    constexpr int NQ = Geo<HIST>::NQ, NG = Geo<HIST>::NG, PLANE = Geo<HIST>::PLANE;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int g = lt + 256 * q;
+        if (g < NG) {
+            if (have_next) {
+                const long long b = tn * TILE + 8LL * g - HIST;
+                const uint4 *p = b < 0 ? reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.hist) + (b + HIST) * 6)
+                                       : reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + b * 6);
+                if (b + 8 <= a.n_in) {
+                    nxt[q][0] = p[0];
+                    nxt[q][1] = p[1];
+                    nxt[q][2] = p[2];
+                } else {
+                    nxt[q][0] = nxt[q][1] = nxt[q][2] = make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t w[12] = { cur[q][0].x, cur[q][0].y, cur[q][0].z, cur[q][0].w, cur[q][1].x, cur[q][1].y,
+                                     cur[q][1].z, cur[q][1].w, cur[q][2].x, cur[q][2].y, cur[q][2].z, cur[q][2].w };
+            const int at = swz(8 * g);
+            uint32_t lo, hi;
+#define PDDC_PL(C, I, O, X)                                                                       \
+            plane_bytes<O>(w, lo, hi);                                                            \
+            *reinterpret_cast<uint2 *>(plane + (3 * C + I) * PLANE + at) = make_uint2(lo ^ X, hi ^ X);
+            PDDC_PL(0, 0, 0, 0x80808080u)
+            PDDC_PL(0, 1, 1, 0x80808080u)
+            PDDC_PL(0, 2, 2, 0u)
+            PDDC_PL(1, 0, 3, 0x80808080u)
+            PDDC_PL(1, 1, 4, 0x80808080u)
+            PDDC_PL(1, 2, 5, 0u)
+#undef PDDC_PL
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
 } // namespace i8
 
 template <int HIST>
@@ -2095,20 +2138,14 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8(FirI8Args a, long long ntiles
         __syncthreads();
         for (;;) {
             /* tile t is computed from buffer 0; t + G (in ra) goes to buffer 1, t + 2 G starts towards rb */
-            if (t + G < ntiles) {
-                if (t + 2 * G < ntiles)
-                    issue_tile<HIST>(a, t + 2 * G, rb, lt);
-                planes_from<HIST>(ra, lds_i8 + 6 * PLANE, lt);
-            }
+            if (t + G < ntiles)
+                load_and_convert<HIST>(a, t + 2 * G, t + 2 * G < ntiles, rb, ra, lds_i8 + 6 * PLANE, lt);
             __syncthreads();
             t += G;
             if (t >= ntiles)
                 break;
-            if (t + G < ntiles) {
-                if (t + 2 * G < ntiles)
-                    issue_tile<HIST>(a, t + 2 * G, ra, lt);
-                planes_from<HIST>(rb, lds_i8, lt);
-            }
+            if (t + G < ntiles)
+                load_and_convert<HIST>(a, t + 2 * G, t + 2 * G < ntiles, ra, rb, lds_i8, lt);
             __syncthreads();
             t += G;
             if (t >= ntiles)
