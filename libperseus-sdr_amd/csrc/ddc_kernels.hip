@@ -2015,7 +2015,7 @@ __device__ __forceinline__ void plane_bytes(const uint32_t (&w)[12], uint32_t &l
 }
 
 /* the loads of one tile: group g of tile t is xp[8192 t + 8 g ..+8) -- history, batch, or (behind the batch) zeros.
- * (Measured and NOT kept, same-box A/B of whole library builds, tools/ab_i8.sh, profiles/r03/i_fir_i8_prototype.txt: a
+ * (Measured and NOT kept, same-box A/B of whole library builds, tools/ab_libs.sh, profiles/r03/i_fir_i8_prototype.txt: a
  * branch-free path for interior tiles -- one base pointer, constant strides -- 0.378 -> 0.399 ms; on top of it the byte
  * de-interleave in 24 instead of 36 v_perm -- 0.409 ms, although the stand-alone prototype gains 2.7 % from it.  With the
  * address arithmetic between them the loads leave spread out; as one burst they are slower.)                      */
