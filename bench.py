@@ -316,7 +316,7 @@ def verify_last_output(O, shard, fetch_bytes, out_np_fn, ns, wl, n0_last, sched,
             "of": "last timed step's output, windows on the tile scheduler's seams + %d random" % k_random}
 
 
-def traffic_from_profile(workload, kernel_sig, log2n, taps_fp16):
+def traffic_from_profile(workload, kernel_sig, log2n, taps_fp16, kernel_in_use=None):
     """HBM bytes per launch from the committed offline PMC passes -- reported only when the
     file says it was measured for THIS kernel source and launch shape; otherwise null."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -335,6 +335,9 @@ def traffic_from_profile(workload, kernel_sig, log2n, taps_fp16):
     if prov.get("kernel_source_sha16") != kernel_sig:
         return None, ("stale: offline PMC was taken for kernel source %s, this build is %s"
                       % (prov.get("kernel_source_sha16"), kernel_sig))
+    measured = (prov.get("kernels") or {}).get(workload)
+    if kernel_in_use is not None and measured is not None and not kernel_in_use.startswith(measured):
+        return None, "stale: offline PMC was taken on kernel %s, this run used %s" % (measured, kernel_in_use.split(" ")[0])
     return float(ent), ("offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh), commit %s, "
                         "kernel source %s" % (prov.get("commit", "?"), kernel_sig))
 
@@ -660,7 +663,11 @@ def run_rank(a):
                                                                    else wl["bytes_per_sample"])
         achieved = bps * ns / (kern_ms * 1e-3) / 1e9
         step_achieved = wl["bytes_per_sample"] * ns / (dt_max / a.steps) / 1e9      # the whole step, gaps and tails included
-        traffic, traffic_src = traffic_from_profile(a.workload, kernel_source_sig(), a.log2n, a.taps_fp16)
+        klabel = (("k_fir8 (fused cascade: all stages in one launch)" if cascade else
+                   "k_fir8 (fused pair + the previous batch's tail as extra blocks of the launch)" if overlap
+                   else "k_fir_i8 (int8 matrix cores on the wire bytes)" if pipe.on_i8(ns)
+                   else "k_fir8") if fused else "k_unpack24" if stages is None else "pipeline")
+        traffic, traffic_src = traffic_from_profile(a.workload, kernel_source_sig(), a.log2n, a.taps_fp16, klabel)
         if verified is not None:
             verified["all_ranks_ok"] = bool(all(o for o in oks))
         res = {
@@ -681,10 +688,7 @@ def run_rank(a):
                          "traffic": traffic, "traffic_source": traffic_src,
                          "copy_ceiling_GBps": round(copy_gbps, 1) if copy_gbps else None,
                          "frac_of_copy_ceiling": round(achieved / copy_gbps, 4) if copy_gbps else None,
-                         "kernel": ("k_fir8 (fused cascade: all stages in one launch)" if cascade else
-                                    "k_fir8 (fused pair + the previous batch's tail as extra blocks of the launch)" if overlap
-                                    else "k_fir_i8 (int8 matrix cores on the wire bytes)" if pipe.on_i8(ns)
-                                    else "k_fir8") if fused else "pipeline",
+                         "kernel": klabel,
                          "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_sample": bps,
                          "step_achieved": round(step_achieved, 1), "step_frac": round(step_achieved / HBM_PEAK_GBS, 4),

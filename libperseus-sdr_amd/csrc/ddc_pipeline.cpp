@@ -1175,11 +1175,12 @@ static bool stage0_on_i8(const pddc_pipeline *p, size_t nsamples)
         return false;
     if (p->st[0].hist == 256)
         return true;
-    /* 65..128 taps: up to 2^25 samples a batch lives (partly) in the last-level cache and the matrix cores win by up to 2x
-     * (2^22: 287 -> 562 GS/s, 2^24: 555 -> 706); beyond that both kernels stream from HBM and the vector kernel's load path
-     * is the better one (2^26: 711 vs 696, 2^28: 0.340 vs 0.366 ms).  PDDC_I8_128 = 0 / 1 forces the choice (development). */
+    /* 65..128 taps: the vector kernel is HBM-bound there too, but since k_fir_i8's loader spreads its loads over the tile
+     * step it streams at least as well -- 2^25: 757 -> 899 GS/s, 2^26: 725 -> 787, 2^27: 761 -> 809, 2^28: 0.3588-0.3616 ->
+     * 0.3464-0.3483 ms (three alternating rounds on one box), 2^30 equal -- and it is the more accurate of the two
+     * (8e-8 against 2.9e-7).  PDDC_I8_128 = 0 forces the vector kernel (development). */
     const char *e = getenv("PDDC_I8_128");
-    return e ? atoi(e) != 0 : nsamples <= ((size_t)1 << 25);
+    return e ? atoi(e) != 0 : true;
 }
 
 int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples) { return p && stage0_on_i8(p, nsamples) ? 1 : 0; }

@@ -20,7 +20,7 @@ grep -v amdgpu.ids $F/plan_rates.txt > $P/m_rate_plans.txt
 (echo "rocprofv3 --kernel-trace of: python3 bench.py --workload c320 --no-cpu --steps 200 --warmup 5 (tools/trace_gaps.sh)"; grep -E "timed region|then gap|last 200" $F/trace_c320.txt) > $P/k_trace_c320.txt
 (echo "# bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu, five processes on one box: value MS/s, ms/step, kernel ms, frac of 8 TB/s, frac of copy ceiling, chosen slots, (fastest pair, slowest pair, pairs within 3 % of the fastest, pairs tried), verified"; cat $F/bench_repeat_d8_127.txt; echo "# --workload c320, three processes"; cat $F/bench_repeat_c320.txt) > $P/m_bench_repeat.txt
 [ -f $F/small_batches.txt ] && (echo "# bench.py --workload W --log2n n --steps 2000: value MS/s, ms/step, kernel ms, verified (tools/small_batch_default.sh)"; cat $F/small_batches.txt) > $P/m_small_batches.txt
-[ -f $F/trace_d8_127.txt ] && (echo "rocprofv3 --kernel-trace --stats of: python3 bench.py --workload d8_127 --no-cpu --steps 200 --warmup 5 (tools/trace_gaps.sh); bench line of the same process:"; python3 -c "import json; d=json.load(open('$F/trace_d8_127/bench.json')); print('value', d['value'], 'MS/s, roofline.kernel_ms', d['roofline']['kernel_ms'], '(HIP events over the timed region)')"; echo "whole process (placement probes into slow pairs, settle phase and warm-up included):"; grep "k_fir8" $F/trace_d8_127.txt | head -1 | cut -c1-160; grep -E "timed region|then gap|last 200" $F/trace_d8_127.txt) > $P/m_trace_d8_127.txt
+[ -f $F/trace_d8_127.txt ] && (echo "rocprofv3 --kernel-trace --stats of: python3 bench.py --workload d8_127 --no-cpu --steps 200 --warmup 5 (tools/trace_gaps.sh); bench line of the same process:"; python3 -c "import json; d=json.load(open('$F/trace_d8_127/bench.json')); print('value', d['value'], 'MS/s, roofline.kernel_ms', d['roofline']['kernel_ms'], '(HIP events over the timed region)')"; echo "whole process (placement probes into slow pairs, settle phase and warm-up included):"; grep -E "k_fir8|k_fir_i8" $F/trace_d8_127.txt | head -1 | cut -c1-160; grep -E "timed region|then gap|last 200" $F/trace_d8_127.txt) > $P/m_trace_d8_127.txt
 grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Lib" $F/multi_bench_c_host.txt > $P/m_multi_bench_c_host.txt
 R=$R python3 - <<'PY'
 import json

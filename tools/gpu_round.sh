@@ -24,10 +24,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = []
     for f in glob.glob(f"{out}/pmc_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_fir8" in r["Kernel_Name"] and r["Counter_Name"] == c:
+            if ("k_fir8" in r["Kernel_Name"] or "k_fir_i8" in r["Kernel_Name"]) and r["Counter_Name"] == c:
                 vals.append(float(r["Counter_Value"]))
     res[c] = sum(vals) / len(vals) if vals else None
-print("PMC per k_fir8 launch (KiB units as reported):", res)
+print("PMC per first-stage kernel launch (k_fir8 or k_fir_i8; KiB units as reported):", res)
 if res["FETCH_SIZE"] and res["WRITE_SIZE"]:
     # rocprofv3 reports KiB; FETCH_SIZE x2 correction for wide coalesced reads on gfx950
     traffic = (2 * res["FETCH_SIZE"] + res["WRITE_SIZE"]) * 1024

@@ -13,7 +13,7 @@ done
 python3 - $OUT <<'PY'
 import csv, glob, json, sys
 out = sys.argv[1]
-kern = {"d8_127": "k_fir8", "d8_255": "k_fir_i8", "c320": "k_fir8", "unpack": "k_unpack24"}
+kern = {"d8_127": "k_fir_i8", "d8_255": "k_fir_i8", "c320": "k_fir8", "unpack": "k_unpack24"}
 alg = {"d8_127": 7.0, "d8_255": 7.0, "c320": 6.125, "unpack": 14.0}      # bytes per input sample of that kernel
 res = {}
 for w, k in kern.items():

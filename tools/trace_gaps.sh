@@ -10,7 +10,7 @@ python3 - $OUT <<'PY'
 import csv, glob, statistics, sys
 f = glob.glob(sys.argv[1] + "/prof/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_fir8" in r["Kernel_Name"] or "k_unpack24" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "k_fir8" in r["Kernel_Name"] or "k_fir_i8" in r["Kernel_Name"] or "k_unpack24" in r["Kernel_Name"]]
 seg = rows[idx[-40]:idx[-30] + 1] if len(idx) >= 40 else rows[-24:]           # inside the timed region
 print("consecutive kernels inside the timed region (duration, then the gap to the next launch):")
 for a, b in zip(seg, seg[1:]):
