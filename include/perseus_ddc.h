@@ -144,6 +144,13 @@ int pddc_arena_search(void *d_arena, size_t arena_bytes, size_t slot_bytes, size
  * and the chosen probe times and the number of probes made.  An arena of 80 GiB (ten 8-GiB slots) is enough.      */
 int pddc_arena_place(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t in_bytes, size_t out_offset,
                      size_t out_bytes, size_t *out_slot, float *ms_first_come, float *ms_best, int *nprobes, void *stream);
+/* The same with the pipeline's OWN first-stage kernel as the probe (one fused stage: the kernel reads the batch at the
+ * arena's start and writes its nsamples / 8 outputs at out_offset of the candidate slot; stream state is not advanced).
+ * Which slots are fast depends on the kernel's access pattern: the probe stream of pddc_arena_place models the vector
+ * kernels, the matrix-core kernel (k_fir_i8) ranks the slots differently.  Fill the input BEFORE the call.            */
+int pddc_pipeline_arena_place(pddc_pipeline *p, void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t nsamples,
+                              size_t out_offset, size_t *out_slot, float *ms_first_come, float *ms_best, int *nprobes,
+                              void *stream);
 int pddc_memcpy_h2d(void *d_dst, const void *h_src, size_t nbytes, void *stream);
 int pddc_memcpy_d2h(void *h_dst, const void *d_src, size_t nbytes, void *stream);
 int pddc_stream_sync(void *stream);

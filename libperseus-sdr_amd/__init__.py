@@ -120,6 +120,9 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_uses_fused_cascade.restype = C.c_int
     L.pddc_pipeline_stage0_on_i8.argtypes = [vp, sz]
     L.pddc_pipeline_stage0_on_i8.restype = C.c_int
+    L.pddc_pipeline_arena_place.argtypes = [vp, vp, sz, sz, sz, sz, C.POINTER(sz), C.POINTER(C.c_float),
+                                            C.POINTER(C.c_float), C.POINTER(C.c_int), vp]
+    L.pddc_pipeline_arena_place.restype = C.c_int
     L.pddc_fir_i8_table.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, vp, sz, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.pddc_fir_i8_table.restype = C.c_int
     L.pddc_pipeline_check.argtypes = [vp, vp]

@@ -2624,6 +2624,16 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     a.n_in = (long long)nsamples;
     fill_fir8_args(p, a);
     const bool mix = (p->flags & PDDC_F_MIX) != 0;
+    const bool i8 = !fuse2 && !fuse3 && stage0_on_i8(p, nsamples);     /* what process() would launch for this batch */
+    FirI8Args q;
+    q.in = d_packed;
+    q.hist = a.hist;
+    q.hist_out = nullptr;
+    q.out = a.out;
+    q.atab = p->st[0].d_taps_i8;
+    q.n_in = (long long)nsamples;
+    q.scale = p->st[0].i8_scale;
+    q.cterm = p->st[0].i8_cterm;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -2633,6 +2643,8 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
             HIP_TRY(launch_fir8_fused3(p->st[0].ntb, p->R, mix, a, s));
         else if (fuse2)
             HIP_TRY(launch_fir8_fused2(p->st[0].ntb, p->R, mix, a, s));
+        else if (i8)
+            HIP_TRY(launch_fir_i8(q, p->st[0].hist, s));
         else
             HIP_TRY(launch_fir8(p->st[0].ntb, p->R, IN_PACKED24, mix, a, s, p->NT));
     }
@@ -2646,6 +2658,72 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
 #ifdef PDDC_CLOCK_PROBE
     fir8_probe_dump();
 #endif
+    return PDDC_OK;
+}
+
+/* pddc_arena_place with the pipeline's OWN first-stage kernel as the probe (a one-stage pipeline: the kernel reads the
+ * batch at the arena's start and writes its output into the candidate slot).  Which slots are fast depends on the
+ * kernel's access pattern: the read+write probe stream of pddc_arena_place models the vector kernels; k_fir_i8 walks the
+ * batch tile-interleaved across the CUs and ranks the slots differently (seen: the stream probe's best slot the slowest
+ * of ten for it).  bench.py has always probed with the real kernel.                                             */
+int pddc_pipeline_arena_place(pddc_pipeline *p, void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t nsamples,
+                              size_t out_offset, size_t *out_slot, float *ms_first_come, float *ms_best, int *nprobes,
+                              void *stream_v)
+{
+    if (!p || !d_arena || !out_slot || slot_bytes == 0 || ((uintptr_t)d_arena & 15) || (slot_bytes & 15) || (out_offset & 15))
+        return fail(PDDC_EINVAL, "bad argument");
+    if (p->nstages != 1 || !stage0_fused(p))
+        return fail(PDDC_ESTATE, "one fused stage only: a cascade's first kernel writes the pipeline's workspace "
+                                 "(pddc_arena_place + pddc_pipeline_set_workspace)");
+    const size_t n_out = pddc_pipeline_max_output(p, nsamples) + 8;
+    if (nsamples * 6 > out_offset || out_offset + n_out * 8 > slot_bytes)
+        return fail(PDDC_EINVAL, "the slot does not hold the batch and its output at this offset");
+    const size_t nslot = arena_bytes / slot_bytes;
+    if (nslot < 2)
+        return fail(PDDC_EINVAL, "the arena holds fewer than two slots");
+    uint8_t *base = static_cast<uint8_t *>(d_arena);
+    std::vector<float> ms(nslot, -1.0f);
+    int n = 0, rc = PDDC_OK;
+    float t = 0.0f;
+    /* settled clocks first (see pddc_arena_place), then 6 untimed + 12 timed launches per slot */
+    if ((rc = pddc_pipeline_time_stage0(p, base, nsamples, base + slot_bytes + out_offset, 100, stream_v, &t)))
+        return rc;
+    auto probe = [&](size_t o) {
+        if (o >= nslot || ms[o] >= 0.0f || rc)
+            return;
+        void *dst = base + o * slot_bytes + out_offset;
+        if ((rc = pddc_pipeline_time_stage0(p, base, nsamples, dst, 6, stream_v, &t)))
+            return;
+        if ((rc = pddc_pipeline_time_stage0(p, base, nsamples, dst, 12, stream_v, &t)))
+            return;
+        ms[o] = t;
+        ++n;
+    };
+    const size_t gib8 = ((size_t)8 << 30) / slot_bytes ? ((size_t)8 << 30) / slot_bytes : 1;
+    probe(1);
+    probe(4 * gib8);
+    probe(6 * gib8);
+    probe(8 * gib8);
+    auto best_of = [&]() {
+        size_t b = 1;
+        for (size_t o = 1; o < nslot; ++o)
+            if (ms[o] >= 0.0f && ms[o] < ms[b])
+                b = o;
+        return b;
+    };
+    if (!rc && ms[best_of()] > 0.97f * ms[1])
+        for (size_t o = 2; o < nslot; ++o)
+            probe(o);
+    if (rc)
+        return rc;
+    const size_t b = best_of();
+    *out_slot = b;
+    if (ms_first_come)
+        *ms_first_come = ms[1];
+    if (ms_best)
+        *ms_best = ms[b];
+    if (nprobes)
+        *nprobes = n;
     return PDDC_OK;
 }
 

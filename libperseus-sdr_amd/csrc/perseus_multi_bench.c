@@ -163,9 +163,18 @@ int main(int argc, char **argv)
         if (arena[g]) {
             size_t si = 0, so = 0;
             float fast = 0, slow = 0;
-            CHECK(pddc_arena_search(arena[g], got, slot, ns * 6, in_span, ws + 2 * ob, 3, &si, &so, NULL, &fast, &slow));
-            fprintf(stderr, "GPU %d: %zu GiB arena, input in slot %zu, outputs in slot %zu: probe %.3f ms (slowest pair %.3f ms)\n",
-                    g, got / GiB, si, so, fast, slow);
+            if (!cascade) {
+                /* one stage: the pipeline's own kernel is the probe (input at the arena's start, filled first) */
+                int np = 0;
+                CHECK(pddc_synth_lcg(arena[g], ns * 6, 12345u + (uint32_t)g, 0, NULL));
+                CHECK(pddc_pipeline_arena_place(pipe[g], arena[g], got, slot, ns, in_span, &so, &slow, &fast, &np, NULL));
+                fprintf(stderr, "GPU %d: %zu GiB arena, input at its start, outputs in slot %zu after %d probes with the kernel "
+                                "itself: %.4f ms (first come %.4f ms)\n", g, got / GiB, so, np, fast, slow);
+            } else {
+                CHECK(pddc_arena_search(arena[g], got, slot, ns * 6, in_span, ws + 2 * ob, 3, &si, &so, NULL, &fast, &slow));
+                fprintf(stderr, "GPU %d: %zu GiB arena, input in slot %zu, outputs in slot %zu: probe %.3f ms (slowest pair %.3f ms)\n",
+                        g, got / GiB, si, so, fast, slow);
+            }
             d_in[g] = (char *)arena[g] + si * slot;
             char *o = (char *)arena[g] + so * slot + in_span;
             if (ws)

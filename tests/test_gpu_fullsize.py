@@ -147,9 +147,11 @@ def test_arena_search_agrees_with_the_kernel(pkg, O, dev):
 
 
 def test_the_placement_rule_finds_a_fast_pair_in_a_handful_of_probes(pkg, O, dev):
-    """pddc_arena_place: input at the start of ONE 80 GiB allocation, the output side probed right behind it (first come)
-    and at +32 / +48 / +64 GiB, every slot only if none of those gains.  Judged by the real kernel (127 taps, 2^28
-    samples): the slot it returns is within 4 % of the best of ALL slots (the two classes are 7-8 % apart)."""
+    """Input at the start of ONE 80 GiB allocation, the output side probed right behind it (first come) and at +32 / +48 /
+    +64 GiB, every slot only if none of those gains.  Two forms: pddc_pipeline_arena_place probes with the pipeline's own
+    kernel, pddc_arena_place with a read+write stream that models the vector kernels.  Each is judged by the real kernel
+    it is meant for (127 taps, 2^28 samples: the matrix-core kernel by default, the vector kernel under PDDC_NO_I8): the
+    slot it returns is within 4 % of the best of ALL slots."""
     import ctypes as C
     import torch
     b = _bench()
@@ -160,38 +162,48 @@ def test_the_placement_rule_finds_a_fast_pair_in_a_handful_of_probes(pkg, O, dev
     if gib < 72:
         pytest.skip("less than 72 GiB free")
     slot, in_bytes, out_off = 8 << 30, 6 * NS, 2 << 30
-    pipe = pkg.Pipeline(wl["stages"])
-    rows = pipe.max_output(NS) + 8
     arena = torch.empty(gib << 30, dtype=torch.uint8, device=dev)
     nslot = (gib << 30) // slot
     st = torch.cuda.current_stream(dev).cuda_stream
-    o_sl, fc, best, npr = C.c_size_t(), C.c_float(), C.c_float(), C.c_int()
-    pkg.check(L.pddc_arena_place(arena.data_ptr(), gib << 30, slot, in_bytes, out_off, rows * 8, C.byref(o_sl), C.byref(fc),
-                                 C.byref(best), C.byref(npr), st))
-    assert 1 <= o_sl.value < nslot and 0 < best.value <= fc.value and 4 <= npr.value <= nslot
     pkg.check(L.pddc_synth_lcg(arena.data_ptr(), in_bytes, 12345, 0, st))
+    for vector in (False, True):
+        if vector:
+            os.environ["PDDC_NO_I8"] = "1"
+        try:
+            pipe = pkg.Pipeline(wl["stages"])
+            assert pipe.on_i8(NS) == (not vector)
+            rows = pipe.max_output(NS) + 8
+            o_sl, fc, best, npr = C.c_size_t(), C.c_float(), C.c_float(), C.c_int()
+            if vector:
+                pkg.check(L.pddc_arena_place(arena.data_ptr(), gib << 30, slot, in_bytes, out_off, rows * 8, C.byref(o_sl),
+                                             C.byref(fc), C.byref(best), C.byref(npr), st))
+            else:
+                pkg.check(L.pddc_pipeline_arena_place(pipe._h, arena.data_ptr(), gib << 30, slot, NS, out_off, C.byref(o_sl),
+                                                      C.byref(fc), C.byref(best), C.byref(npr), st))
+            assert 1 <= o_sl.value < nslot and 0 < best.value <= fc.value and 4 <= npr.value <= nslot
 
-    def kernel_ms(o):
-        c = arena.data_ptr() + o * slot + out_off
-        for _ in range(30):
-            pipe.process_ptr(arena.data_ptr(), NS, c, rows, st)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(24):
-            pipe.process_ptr(arena.data_ptr(), NS, c, rows, st)
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / 24
+            def kernel_ms(o):
+                c = arena.data_ptr() + o * slot + out_off
+                for _ in range(30):
+                    pipe.process_ptr(arena.data_ptr(), NS, c, rows, st)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(24):
+                    pipe.process_ptr(arena.data_ptr(), NS, c, rows, st)
+                e1.record()
+                e1.synchronize()
+                return e0.elapsed_time(e1) / 24
 
-    for _ in range(150):
-        pipe.process_ptr(arena.data_ptr(), NS, arena.data_ptr() + out_off, rows, st)
-    direct = {o: kernel_ms(o) for o in range(1, nslot)}
-    lo, hi = min(direct.values()), max(direct.values())
-    print(f"rule: slot {o_sl.value} after {npr.value} probes (probe {best.value:.3f} ms, first come {fc.value:.3f}); kernel there "
-          f"{direct[o_sl.value]:.4f} ms, first come {direct[1]:.4f}, all slots {lo:.4f} .. {hi:.4f}")
-    assert direct[o_sl.value] <= 1.04 * lo
-    # (usually the first-come slot is a slow one and four probes are enough; a lease where it happened to be a fast one, or
-    # where the probe stream saw too little contrast and looked at every slot, has been seen too -- the choice is what counts)
-    pipe.close()
+            for _ in range(150):
+                pipe.process_ptr(arena.data_ptr(), NS, arena.data_ptr() + out_off, rows, st)
+            direct = {o: kernel_ms(o) for o in range(1, nslot)}
+            lo, hi = min(direct.values()), max(direct.values())
+            print(f"{'stream probe, vector kernel' if vector else 'kernel probe, matrix-core kernel'}: slot {o_sl.value} after "
+                  f"{npr.value} probes (probe {best.value:.4f} ms, first come {fc.value:.4f}); kernel there "
+                  f"{direct[o_sl.value]:.4f} ms, first come {direct[1]:.4f}, all slots {lo:.4f} .. {hi:.4f}")
+            assert direct[o_sl.value] <= 1.04 * lo
+            pipe.close()
+        finally:
+            os.environ.pop("PDDC_NO_I8", None)
     del arena
     torch.cuda.empty_cache()
