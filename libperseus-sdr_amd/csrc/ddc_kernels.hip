@@ -1982,15 +1982,23 @@ hipError_t launch_gen_tail_many(const GenTailMany &m, int n, hipStream_t s)
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 namespace i8 {
+#ifndef PDDC_I8_WIDE
+#define PDDC_I8_WIDE 1
+#endif
+/* MFMA waves + loader threads per block.  The loaders (global loads, byte de-interleave, plane writes) are the half the
+ * kernel sits on, the matrix work has room: 8 + 256 (4 loader waves) 0.3608 ms, 4 + 512 0.3454 ms for 255 taps,
+ * 0.3378 -> 0.3250 ms for 127 (same-box A/B, tools/ab_libs.sh). */
+constexpr int NMW = PDDC_I8_WIDE == 2 ? 2 : PDDC_I8_WIDE == 1 ? 4 : 8, NLT = PDDC_I8_WIDE == 2 ? 640 : PDDC_I8_WIDE == 1 ? 512 : 256,
+              NB = 8 / NMW;
 /* HIST = 256 (129..256 taps) or 128 (65..128 taps): history samples in front of the batch = the filter's reach */
 template <int HIST>
 struct Geo {
     static constexpr int TILE = 8192, SPAN = TILE + HIST, PLANE = SPAN + 16 * ((SPAN + 127) / 128), NG = SPAN / 8;
     static constexpr int KSTEPS = (120 + HIST + 63) / 64;          /* the band is 16 x (8 * 15 + HIST) wide */
-    static constexpr int NQ = (NG + 255) / 256;
+    static constexpr int NQ = (NG + NLT - 1) / NLT;
     static constexpr size_t LDS_BYTES = 12 * (size_t)PLANE + 4 * (size_t)(20 * 64) * sizeof(float);
 };
-constexpr int OS = 20 * 64, NMW = 8, TILE = 8192;
+constexpr int OS = 20 * 64, TILE = 8192;
 
 __device__ __forceinline__ int swz(int p) { return p + 16 * (p >> 7); }
 
@@ -2025,7 +2033,7 @@ __device__ __forceinline__ void issue_tile(const FirI8Args &a, long long t, uint
     constexpr int NQ = Geo<HIST>::NQ, NG = Geo<HIST>::NG;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int g = lt + 256 * q;
+        const int g = lt + NLT * q;
         if (g < NG) {
             const long long b = t * TILE + 8LL * g - HIST;         /* first sample of the group, relative to the batch */
             const uint4 *p = b < 0 ? reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.hist) + (b + HIST) * 6)
@@ -2047,7 +2055,7 @@ __device__ __forceinline__ void planes_from(const uint4 (&raw)[Geo<HIST>::NQ][3]
     constexpr int NQ = Geo<HIST>::NQ, NG = Geo<HIST>::NG, PLANE = Geo<HIST>::PLANE;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int g = lt + 256 * q;
+        const int g = lt + NLT * q;
         if (g < NG) {
             const uint32_t w[12] = { raw[q][0].x, raw[q][0].y, raw[q][0].z, raw[q][0].w, raw[q][1].x, raw[q][1].y,
                                      raw[q][1].z, raw[q][1].w, raw[q][2].x, raw[q][2].y, raw[q][2].z, raw[q][2].w };
@@ -2076,7 +2084,7 @@ __device__ __forceinline__ void load_and_convert(const FirI8Args &a, long long t
     constexpr int NQ = Geo<HIST>::NQ, NG = Geo<HIST>::NG, PLANE = Geo<HIST>::PLANE;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int g = lt + 256 * q;
+        const int g = lt + NLT * q;
         if (g < NG) {
             if (have_next) {
                 const long long b = tn * TILE + 8LL * g - HIST;
@@ -2112,7 +2120,7 @@ __device__ __forceinline__ void load_and_convert(const FirI8Args &a, long long t
 } // namespace i8
 
 template <int HIST>
-__global__ __launch_bounds__(768, 1) void k_fir_i8(FirI8Args a, long long ntiles)
+__global__ __launch_bounds__(64 * i8::NMW + i8::NLT, 1) void k_fir_i8(FirI8Args a, long long ntiles)
 {
     using namespace i8;
     constexpr int PLANE = Geo<HIST>::PLANE, KSTEPS = Geo<HIST>::KSTEPS, NQ = Geo<HIST>::NQ;
@@ -2154,9 +2162,8 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8(FirI8Args a, long long ntiles
         return;
     }
     /* ---- MFMA waves (0..7): component x block of 16 columns; the whole tap operand stays in registers */
-    const int comp = wave & 1, nb = wave >> 1;
+    const int comp = wave & 1, nb0 = (wave >> 1) * NB;
     const int n = lane & 15, kq = lane >> 4;
-    const int col = 16 * nb + n;
     const v4i_t *atab = static_cast<const v4i_t *>(a.atab);
     v4i_t A[KSTEPS][4];
 #pragma unroll
@@ -2170,33 +2177,37 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8(FirI8Args a, long long ntiles
     for (; t < ntiles; t += G, buf ^= 1) {
         const uint8_t *pb = lds_i8 + buf * 6 * PLANE + 3 * comp * PLANE;
         float *osum = osum_base + buf * 2 * OS;
-        v4i_t acc[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            acc[s] = v4i_t{ 0, 0, 0, 0 };
+        for (int b = 0; b < NB; ++b) {
+            const int col = 16 * (nb0 + b) + n;
+            v4i_t acc[4];
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const int at = swz(128 * col + 64 * ks + 16 * kq);
-            v4i_t B[3];
+            for (int s = 0; s < 4; ++s)
+                acc[s] = v4i_t{ 0, 0, 0, 0 };
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                B[i] = *reinterpret_cast<const v4i_t *>(pb + i * PLANE + at);
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const int at = swz(128 * col + 64 * ks + 16 * kq);
+                v4i_t B[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < 3; ++i)
+                    B[i] = *reinterpret_cast<const v4i_t *>(pb + i * PLANE + at);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (i + j >= 2)
-                        acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks][j], B[i], acc[i + j - 2], 0, 0, 0);
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (i + j >= 2)
+                            acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks][j], B[i], acc[i + j - 2], 0, 0, 0);
+            }
+            /* y = sum_s acc[s] 256^(s+2), as floats (every acc[s] is below 2^24: the conversions are exact).  This lane:
+             * column `col`, rows 4 kq + v -> outputs 16 col + 4 kq + v of the tile, four consecutive ones */
+            float4 y;
+            float *yp = &y.x;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                yp[v] = (((float)acc[0][v] * 65536.0f + (float)acc[1][v] * 16777216.0f) +
+                         ((float)acc[2][v] * 4294967296.0f + (float)acc[3][v] * 1099511627776.0f)) * a.scale + a.cterm;
+            *reinterpret_cast<float4 *>(osum + comp * OS + 20 * col + 4 * kq) = y;
         }
-        /* y = sum_s acc[s] 256^(s+2), as floats (every acc[s] is below 2^24: the conversions are exact).  This lane:
-         * column `col`, rows 4 kq + v -> outputs 16 col + 4 kq + v of the tile, four consecutive ones */
-        float4 y;
-        float *yp = &y.x;
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-            yp[v] = (((float)acc[0][v] * 65536.0f + (float)acc[1][v] * 16777216.0f) +
-                     ((float)acc[2][v] * 4294967296.0f + (float)acc[3][v] * 1099511627776.0f)) * a.scale + a.cterm;
-        *reinterpret_cast<float4 *>(osum + comp * OS + 20 * col + 4 * kq) = y;
         __syncthreads();                 /* ONE barrier per tile: the next tile's planes are written, this tile's outputs are in LDS */
         float2 *dst = reinterpret_cast<float2 *>(a.out) + t * 1024;
         const long long left = n_out - t * 1024;
@@ -2266,7 +2277,7 @@ static hipError_t launch_fir_i8_t(const FirI8Args &a, hipStream_t s)
         cus[dev & 63] = v > 0 ? v : 256;
     }
     const long long grid = ntiles < cus[dev & 63] ? ntiles : cus[dev & 63];
-    hipLaunchKernelGGL(k_fir_i8<HIST>, dim3((unsigned)grid), dim3(768), i8::Geo<HIST>::LDS_BYTES, s, a, ntiles);
+    hipLaunchKernelGGL(k_fir_i8<HIST>, dim3((unsigned)grid), dim3(64 * i8::NMW + i8::NLT), i8::Geo<HIST>::LDS_BYTES, s, a, ntiles);
     return hipGetLastError();
 }
 
