@@ -495,11 +495,14 @@ def run_rank(a):
             # So: four probes.  Only if none of them gains (a workload that does not care, or a layout not seen yet)
             # the other slots are looked at too.
             def rule_scan():
+                # four probes settle it when one of them is clearly in another class (the vector kernels lose 8-12 % in
+                # the input's class); a smaller gain may be a THIRD class or the matrix-core kernel, whose classes are
+                # only 3 % apart: then every slot is looked at (nine probes, 0.15 s)
                 first = probe(0, 1 if nslot > 1 else 0)
                 for o in (4, 6, 8):
                     if o < nslot:
                         probe(0, o)
-                if min(table.values()) > 0.97 * first:
+                if min(table.values()) > 0.93 * first:
                     for o in range(2, nslot):
                         if (0, o) not in table:
                             probe(0, o)
@@ -509,7 +512,7 @@ def run_rank(a):
             # One class over the whole arena (about one process in five draws such a layout for 80 GiB): a LARGER
             # allocation is laid out anew and has shown at least two classes every time (192-200 GiB arenas, round 2).
             # The memory is there (288 GB); the receiver allocates once.
-            if min(table.values()) > 0.97 * first_come and a.arena_grow_gib > gib:
+            if min(table.values()) > 0.985 * first_come and a.arena_grow_gib > gib:
                 small = {"arena_GiB": gib, "step_ms": {str(o): round(v, 4) for (_, o), v in sorted(table.items())}}
                 inbox[0] = outbox[0] = None
                 arena = None
