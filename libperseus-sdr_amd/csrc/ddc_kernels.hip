@@ -11,6 +11,13 @@
  *   k_fir8       fused  unpack -> [NCO mix] -> polyphase decimate-by-8 FIR.
  *                The 8 B/sample float intermediate never touches HBM:
  *                algorithmic traffic 6 B in + 1 B out per input sample.
+ *                (+ a fused second /8 stage, + the previous batch's last stage as extra
+ *                blocks of the launch; k_fir8_many: up to eight streams, one launch;
+ *                body in fir8_block.inc)
+ *   k_fir_i8     the same filter for 65..256 taps without the NCO on the INT8 matrix
+ *                cores: the wire bytes are the operand planes, the taps four planes of
+ *                balanced base-256 digits, int32 accumulation is exact.
+ *   k_firp       register-blocked decimators by 4, 5, 10 (packed first stages, float2 tails).
  *   k_fir_generic  any-D decimating FIR on float2 (later cascade stages).
  *   k_resample     rational L/M polyphase resampler (non-integer rates).
  *   k_pack24       float32 -> 24-bit packed (inverse of the unpack).
@@ -43,8 +50,9 @@
  *     chunks) into interleaved float2 and leave as coalesced nontemporal
  *     dwordx4 stores, one tile late so they sit behind the next load wait
  *   - optional fused second decimate-by-8 stage on the tile's outputs (NTB2)
- *   No MFMA: 9 flop/B, a banded single-filter FIR would waste 2/3 of a matrix
- *   op, and the stream is memory- and power-bound.
+ *   No fp32 MFMA here: 9 flop/B, a banded single-filter FIR wastes a third to a half of a
+ *   matrix op and fp32 MFMA has the vector unit's own peak.  The INT8 matrix cores are another
+ *   matter for this data: k_fir_i8 below.
  */
 #include "ddc_kernels.h"
 
