@@ -637,7 +637,12 @@ def run_rank(a):
         if stages is not None:
             n0_last = (calls[0] - 1) * ns
             sched = pipe.schedule(ns) if pipe.fused else None
-            verified = verify_last_output(O, shard, fetch, lambda j0, j1: out[j0:j1].cpu().numpy(), ns, wl, n0_last,
+            wl_v = wl
+            if a.taps_fp16:                             # the oracle gets the taps the pipeline really uses: binary16 values
+                wl_v = dict(wl)
+                wl_v["stages"] = [(st[0], np.asarray(st[1], np.float32).astype(np.float16).astype(np.float32)) + tuple(st[2:])
+                                  for st in wl["stages"]]
+            verified = verify_last_output(O, shard, fetch, lambda j0, j1: out[j0:j1].cpu().numpy(), ns, wl_v, n0_last,
                                           sched)
             verified["n_outputs_ok"] = bool(n_last == verified["n_outputs"])
             verified["ok"] = bool(verified["ok"] and verified["n_outputs_ok"])
@@ -683,7 +688,10 @@ def run_rank(a):
             "config": {"workload": wl["label"], "samples_per_gpu_per_step": ns,
                        "input": "LCG bytes seed 12345+rank, device resident",
                        "sharding": "independent stream per GPU, no data-path collective",
-                       "taps": "binary16 VALUES held in fp32 registers (PDDC_F_TAPS_FP16)" if a.taps_fp16 else "fp32",
+                       "taps": (("binary16 VALUES as int8 digit planes (k_fir_i8; PDDC_F_TAPS_FP16)" if pipe is not None and pipe.on_i8(ns)
+                                 else "binary16 VALUES held in fp32 registers (PDDC_F_TAPS_FP16)") if a.taps_fp16 else
+                                ("fp32 values as four int8 digit planes, 2^-31 of the largest tap (k_fir_i8)"
+                                 if pipe is not None and pipe.on_i8(ns) else "fp32")),
                        "overlap": ("stages behind the fused pair run on the pipeline's side stream under the next step's "
                                    "pair (pddc_pipeline_set_overlap); the timed region ends with a fence") if overlap else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -23,9 +23,11 @@ for wl, extra in (("d8_127", []), ("d8_127", ["--taps-fp16"]), ("d8_255", []), (
             continue
         r = {"workload": wl, "taps": "fp16" if extra else "fp32", "log2n": log2n, "MS_per_s": d["value"],
              "ms_per_step": d["ms_per_step"], "kernel_ms": d["roofline"]["kernel_ms"],
-             "GBps": d["roofline"]["achieved"], "frac_of_8TBps": d["roofline"]["frac"]}
+             "GBps": d["roofline"]["achieved"], "frac_of_8TBps": d["roofline"]["frac"],
+             "kernel": d["roofline"]["kernel"].split(" ")[0], "verified_ok": bool(d["verified"]["ok"]) if d.get("verified") else None}
         runs.append(r)
-        print("%-7s %-4s 2^%-2d  %10.1f MS/s  %8.4f ms  %7.1f GB/s  %.3f" %
-              (wl, r["taps"], log2n, r["MS_per_s"], r["ms_per_step"], r["GBps"], r["frac_of_8TBps"]), flush=True)
+        print("%-7s %-4s 2^%-2d  %10.1f MS/s  %8.4f ms  %7.1f GB/s  %.3f  %s %s" %
+              (wl, r["taps"], log2n, r["MS_per_s"], r["ms_per_step"], r["GBps"], r["frac_of_8TBps"], r["kernel"],
+               "ok" if r["verified_ok"] else "NOT VERIFIED"), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(runs, open(os.path.join(ROOT, "gpurun_out", "sweep.json"), "w"), indent=1)
