@@ -317,6 +317,11 @@ struct GenMixArgs {
     uint32_t freg_hist;         /* word the history samples were mixed with (first batch after a retune) */
     float lo_c[8], lo_s[8];     /* step phasors of freg                                        */
     float lo_c_hist[8], lo_s_hist[8];
+    /* k_firp's packed staging: a thread's pairs of samples lie 512 apart; LO(512 u freg), u = 0..15, from the host in
+     * double.  (A recurrence phasor *= LO(512) carried the rounding of that ONE step phasor u times: 7.8e-7 of full
+     * scale in the worst of 1200 random cases, against the 1e-6 bar; from this table it is one product from an exact
+     * phase whatever u is.) */
+    float lo512_c[16], lo512_s[16];
 };
 
 /* the body of one block: `bid` its index, `sd` its LDS, NT its threads -- also run by the extra blocks k_fir8 carries
@@ -618,12 +623,11 @@ __device__ __forceinline__ void firp_block(const FirpArgs &a, const int bid, flo
 #pragma unroll
             for (int u = 0; u < NPF; ++u)
                 rw[u] = *reinterpret_cast<const W3 *>(src0 + 12 * 256 * u);
-            float gc = 1.0f, gs = 0.0f, kc = 1.0f, ks = 0.0f;
-            if (MIX) {
-                nco_lo((uint32_t)(mx.n0 + (unsigned long long)(xa + 2LL * tid)) * mx.freg + mx.phase_off, gc, gs);
-                nco_lo(512u * mx.freg, kc, ks);
-            }
+            float g0c = 1.0f, g0s = 0.0f;
+            if (MIX)
+                nco_lo((uint32_t)(mx.n0 + (unsigned long long)(xa + 2LL * tid)) * mx.freg + mx.phase_off, g0c, g0s);
             const float stc = mx.lo_c[1], sts = mx.lo_s[1];
+            static_assert(NPF <= 16, "GenMixArgs::lo512 holds 16 steps");
 #pragma unroll
             for (int u = 0; u < NPF; ++u) {
                 float x0i = (float)(int32_t)__builtin_amdgcn_perm(rw[u].a, rw[u].a, 0x0201000cu);
@@ -631,8 +635,9 @@ __device__ __forceinline__ void firp_block(const FirpArgs &a, const int bid, flo
                 float x1i = (float)(int32_t)__builtin_amdgcn_perm(rw[u].c, rw[u].b, 0x0403020cu);
                 float x1q = (float)(int32_t)(rw[u].c & 0xffffff00u);
                 if (MIX) {
+                    float gc = g0c, gs = g0s;
                     if (u > 0)
-                        cmul(gc, gs, kc, ks);
+                        cmul(gc, gs, mx.lo512_c[u], mx.lo512_s[u]);
                     const float c1 = gc * stc - gs * sts, s1 = gc * sts + gs * stc;
                     cmul(x0i, x0q, gc, gs);
                     cmul(x1i, x1q, c1, s1);
@@ -662,18 +667,17 @@ __device__ __forceinline__ void firp_block(const FirpArgs &a, const int bid, flo
             }
             raw[u] = src ? *reinterpret_cast<const W3 *>(src) : W3{ 0u, 0u, 0u };
         }
-        float gc = 1.0f, gs = 0.0f, kc = 1.0f, ks = 0.0f;
+        float g0c = 1.0f, g0s = 0.0f;
         const bool has_old = MIX && xa < 0;                    /* uniform: the batch's first block only */
         const uint32_t off_old = mx.phase_off + (uint32_t)mx.n0 * (mx.freg - mx.freg_hist);
-        if (MIX) {
-            nco_lo((uint32_t)(mx.n0 + (unsigned long long)(xa + 2LL * tid)) * mx.freg + mx.phase_off, gc, gs);
-            nco_lo(512u * mx.freg, kc, ks);
-        }
+        if (MIX)
+            nco_lo((uint32_t)(mx.n0 + (unsigned long long)(xa + 2LL * tid)) * mx.freg + mx.phase_off, g0c, g0s);
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
             const int j = tid + 256 * u;
+            float gc = g0c, gs = g0s;
             if (u > 0 && MIX)
-                cmul(gc, gs, kc, ks);
+                cmul(gc, gs, mx.lo512_c[u], mx.lo512_s[u]);
             if (j >= npairs)
                 continue;
             /* 3 dwords = 2 samples -> MSB-aligned integers (the iq_sample placement, cf. unpack8_msb) */
@@ -1872,6 +1876,12 @@ hipError_t launch_firp_packed(const void *in_packed, const void *hist_packed, in
         mx.lo_s[e] = lo_s ? lo_s[e] : 0.0f;
         mx.lo_c_hist[e] = lo_c_hist ? lo_c_hist[e] : 1.0f;
         mx.lo_s_hist[e] = lo_s_hist ? lo_s_hist[e] : 0.0f;
+    }
+    for (int u = 0; u < 16; ++u) {                      /* exp(-j 2 pi (512 u freg mod 2^32) / 2^32), in double */
+        const uint32_t ph = (uint32_t)(512ull * (unsigned long long)u * freg);
+        const double th = 6.283185307179586476925 * (double)ph / 4294967296.0;
+        mx.lo512_c[u] = (float)std::cos(th);
+        mx.lo512_s[u] = (float)(-std::sin(th));
     }
     return launch_firp(IN_PACKED24, mix, in_packed, hist_packed, H, first, n_out, D, taps2, ntaps, out, hist_out_packed,
                        n_batch, &mx, s);
