@@ -147,6 +147,26 @@ __device__ __forceinline__ void cmul(float &a, float &b, float c, float s)
     b = i;
 }
 
+/* (x.x + j x.y) * (p.x + j p.y) in TWO packed instructions: (xi c, xi s), then (xq, xq) * (-s, c) on top -- the
+ * half selects and the sign ride in the instruction's op_sel / neg_lo fields.  Written as scalar code the compiler
+ * vectorises four of these per pair of samples into 14 packed operations and 7 moves (k_firp<10,2,packed,MIX>, 21 of a
+ * pair's 41 vector instructions); from vector code it folds the broadcasts but builds (-s, c) with an xor and a move. */
+__device__ __forceinline__ f32x2 cmul_pk(f32x2 x, f32x2 p)
+{
+    f32x2 t, y;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(x), "v"(p));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(y) : "v"(x), "v"(p), "v"(t));
+    return y;
+}
+/* the same for a wave-uniform second factor (kernel arguments): from vector code the compiler folds the broadcasts into
+ * op_sel itself and builds (-s, c) on the scalar unit.  (An "s" constraint on a pair assembled from two kernarg floats
+ * sent the whole table through scratch memory.) */
+__device__ __forceinline__ f32x2 cmul_pk_s(f32x2 x, float c, float s)
+{
+    const f32x2 t = __builtin_shufflevector(x, x, 0, 0) * f32x2{ c, s };
+    return __builtin_elementwise_fma(__builtin_shufflevector(x, x, 1, 1), f32x2{ -s, c }, t);
+}
+
 /* both complex values of an interleaved (I0,Q0,I1,Q1) vector times (c + j s) */
 __device__ __forceinline__ f32x4 cmul2(f32x4 v, float c, float s)
 {
@@ -604,9 +624,10 @@ __device__ __forceinline__ void firp_block(const FirpArgs &a, const int bid, flo
          * per lane, as k_fir_generic stages them, the lanes of a write are 64 bytes apart: an 8-way bank conflict on every
          * one, 0.3 ms of LDS-array time per 2^28 samples -- what held this kernel (and holds that one) at 3.3 TB/s.
          * The samples stay the integers the unpack yields (the host folds RN(1/8388607)/256 into this stage's taps, like
-         * k_fir8); the NCO takes ONE sin/cos per thread -- a thread's pairs lie 512 samples apart, the next one's phasor
-         * is the last one's times LO(512); only the batch's first block can meet samples of the previous batch, mixed
-         * with the previous tuning word (exact phase per pair there).                                             */
+         * k_fir8); the NCO takes ONE sin/cos per thread -- a thread's pairs lie 512 samples apart, pair u's phasor is the
+         * thread's times LO(512 u) from the host's table, and every rotation is two packed instructions (cmul_pk); only
+         * a batch's two edge blocks leave this path (the first can meet samples of the previous batch, mixed with the
+         * previous tuning word): there every pair takes its own sin/cos.                                           */
         const uint8_t *inb = static_cast<const uint8_t *>(a.in);
         const uint8_t *hb8 = static_cast<const uint8_t *>(a.hist);
         const GenMixArgs &mx = a.mx;
@@ -616,32 +637,35 @@ __device__ __forceinline__ void firp_block(const FirpArgs &a, const int bid, flo
         constexpr int NPF = (G::PD * (256 + 16) / 2 + 1 + 255) / 256;       /* pairs per thread */
         struct W3 { uint32_t a, b, c; };
         if (xa >= 0 && xa + 2LL * 256 * NPF <= a.n_batch) {
-            /* interior block (uniform): no history, nothing beyond the batch, and every staged index a pair can
-             * touch (-1 .. span) has a slot thanks to the spare segments: straight-line code                  */
+            /* interior block (uniform): no history, nothing beyond the batch, and every staged index one of the
+             * span's pairs can touch (-1 .. span) has a slot thanks to the spare segments: straight-line code but for
+             * the span's last pairs (rounds of 256 pairs wholly behind the span are skipped, uniformly)          */
             const uint8_t *src0 = inb + xa * 6 + 12 * tid;
             W3 rw[NPF];
 #pragma unroll
             for (int u = 0; u < NPF; ++u)
-                rw[u] = *reinterpret_cast<const W3 *>(src0 + 12 * 256 * u);
+                if (256 * u < npairs)
+                    rw[u] = *reinterpret_cast<const W3 *>(src0 + 12 * 256 * u);
             float g0c = 1.0f, g0s = 0.0f;
             if (MIX)
                 nco_lo((uint32_t)(mx.n0 + (unsigned long long)(xa + 2LL * tid)) * mx.freg + mx.phase_off, g0c, g0s);
             const float stc = mx.lo_c[1], sts = mx.lo_s[1];
+            const f32x2 g0 = { g0c, g0s };
             static_assert(NPF <= 16, "GenMixArgs::lo512 holds 16 steps");
 #pragma unroll
             for (int u = 0; u < NPF; ++u) {
-                float x0i = (float)(int32_t)__builtin_amdgcn_perm(rw[u].a, rw[u].a, 0x0201000cu);
-                float x0q = (float)(int32_t)__builtin_amdgcn_perm(rw[u].b, rw[u].a, 0x0504030cu);
-                float x1i = (float)(int32_t)__builtin_amdgcn_perm(rw[u].c, rw[u].b, 0x0403020cu);
-                float x1q = (float)(int32_t)(rw[u].c & 0xffffff00u);
+                if (tid + 256 * u >= npairs)
+                    continue;
+                f32x2 x0 = { (float)(int32_t)__builtin_amdgcn_perm(rw[u].a, rw[u].a, 0x0201000cu),
+                             (float)(int32_t)__builtin_amdgcn_perm(rw[u].b, rw[u].a, 0x0504030cu) };
+                f32x2 x1 = { (float)(int32_t)__builtin_amdgcn_perm(rw[u].c, rw[u].b, 0x0403020cu),
+                             (float)(int32_t)(rw[u].c & 0xffffff00u) };
                 if (MIX) {
-                    float gc = g0c, gs = g0s;
-                    if (u > 0)
-                        cmul(gc, gs, mx.lo512_c[u], mx.lo512_s[u]);
-                    const float c1 = gc * stc - gs * sts, s1 = gc * sts + gs * stc;
-                    cmul(x0i, x0q, gc, gs);
-                    cmul(x1i, x1q, c1, s1);
+                    const f32x2 g = u > 0 ? cmul_pk_s(g0, mx.lo512_c[u], mx.lo512_s[u]) : g0;
+                    x1 = cmul_pk(x1, cmul_pk_s(g, stc, sts));
+                    x0 = cmul_pk(x0, g);
                 }
+                const float x0i = x0.x, x0q = x0.y, x1i = x1.x, x1q = x1.y;
                 /* staged index of the pair's first sample, plus one segment: -1 .. span+ lands in the spare segments */
                 const unsigned i0 = (unsigned)(2 * (tid + 256 * u) - shift + G::PD);
                 const unsigned seg = i0 / G::PD;
@@ -667,19 +691,16 @@ __device__ __forceinline__ void firp_block(const FirpArgs &a, const int bid, flo
             }
             raw[u] = src ? *reinterpret_cast<const W3 *>(src) : W3{ 0u, 0u, 0u };
         }
-        float g0c = 1.0f, g0s = 0.0f;
         const bool has_old = MIX && xa < 0;                    /* uniform: the batch's first block only */
         const uint32_t off_old = mx.phase_off + (uint32_t)mx.n0 * (mx.freg - mx.freg_hist);
-        if (MIX)
-            nco_lo((uint32_t)(mx.n0 + (unsigned long long)(xa + 2LL * tid)) * mx.freg + mx.phase_off, g0c, g0s);
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
             const int j = tid + 256 * u;
-            float gc = g0c, gs = g0s;
-            if (u > 0 && MIX)
-                cmul(gc, gs, mx.lo512_c[u], mx.lo512_s[u]);
             if (j >= npairs)
                 continue;
+            float gc = 1.0f, gs = 0.0f;                        /* a batch's two edge blocks: every pair from its own phase */
+            if (MIX)
+                nco_lo((uint32_t)(mx.n0 + (unsigned long long)(xa + 2LL * j)) * mx.freg + mx.phase_off, gc, gs);
             /* 3 dwords = 2 samples -> MSB-aligned integers (the iq_sample placement, cf. unpack8_msb) */
             float x0i = (float)(int32_t)__builtin_amdgcn_perm(raw[u].a, raw[u].a, 0x0201000cu);
             float x0q = (float)(int32_t)__builtin_amdgcn_perm(raw[u].b, raw[u].a, 0x0504030cu);
