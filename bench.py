@@ -69,6 +69,9 @@ def parse(argv=None):
     ap.add_argument("--gather", action="store_true", help="run the gather leg at N=1 too (1-rank RCCL group)")
     ap.add_argument("--no-gather", action="store_true", help="skip the gather leg at N>1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--per-step-events", action="store_true",
+                    help="diagnostics: a HIP event after every timed step; the line gains `per_step_ms` (the extra\n"
+                         "records cost about a microsecond per step, so this is not the default)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle window check of the last output")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--out-candidates", type=int, default=24,
@@ -561,6 +564,7 @@ def run_rank(a):
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize(dev)
+    t_idle0 = time.perf_counter()                       # the GPU is idle from here to the first timed launch
     grp.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
@@ -571,11 +575,15 @@ def run_rank(a):
     multi_kernel = stages is not None and pipe.fused and len(stages) > 1 and not cascade and not overlap
     if multi_kernel:
         pipe.time_stage0_inline(True)
+    step_evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)] if a.per_step_events else None
     t0 = time.perf_counter()
+    idle_ms = (t0 - t_idle0) * 1e3
     ev0.record()
     n_last = 0
-    for _ in range(a.steps):
+    for k in range(a.steps):
         n_last = step()
+        if step_evs:
+            step_evs[k].record()
     if overlap:
         pipe.fence(stream)                              # the last steps' tails belong to the timed region
     ev1.record()
@@ -705,6 +713,10 @@ def run_rank(a):
                          "step_achieved": round(step_achieved, 1), "step_frac": round(step_achieved / HBM_PEAK_GBS, 4),
                          "step_algorithmic_bytes_per_sample": wl["bytes_per_sample"]},
             "events_ms_per_step": round(ev_ms / a.steps, 4),
+            "idle_before_timed_ms": round(idle_ms, 3),      # barrier + synchronize, as the contract asks: the clocks
+                                                            # the first timed steps see depend on how long this was
+            "per_step_ms": ([round(x.elapsed_time(y), 4) for x, y in zip([ev0] + step_evs[:-1], step_evs)]
+                            if step_evs else None),
             "placement": placement,
             "verified": verified,
             "ranks_seen": grp.comm_size(), "devices": names,
