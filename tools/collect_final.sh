@@ -6,7 +6,18 @@ F=gpurun_out/${R}_final; P=profiles/$R
 cp $F/bench_driver_args.json $P/m_final_bench.json; cp $F/bench.json $P/m_bench_default_args.json
 for w in d8_255 c320 unpack; do cp $F/bench_$w.json $P/m_bench_$w.json; done
 cp $F/bench_gather_1rank.json $P/m_bench_gather_1rank.json; cp $F/kernel_stats.csv $P/m_final_kernel_stats.csv
-cp $F/pmc_traffic/pmc_traffic.json profiles/pmc_traffic.json; cp $F/pmc_traffic/pmc_traffic.json $P/m_pmc_traffic_all_workloads.json
+cp $F/pmc_traffic/pmc_traffic.json profiles/pmc_traffic.json
+# the GPU box has no .git: the commit recorded is the HEAD this pass is collected on top of (the kernel source hash in
+# the same record is what bench.py checks, and what ties the numbers to a source)
+python3 - <<PY
+import json, subprocess
+d = json.load(open("profiles/pmc_traffic.json"))
+head = subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD"], text=True).strip()
+dirty = bool(subprocess.check_output(["git", "status", "--porcelain", "--", "libperseus-sdr_amd/csrc"], text=True).strip())
+d["provenance"]["commit"] = head + (" + uncommitted changes under csrc/ (committed next)" if dirty else "")
+json.dump(d, open("profiles/pmc_traffic.json", "w"), indent=1)
+PY
+cp profiles/pmc_traffic.json $P/m_pmc_traffic_all_workloads.json
 [ -f $F/pmc_127/pmc_summary.txt ] && cp $F/pmc_127/pmc_summary.txt $P/m_pmc_summary_d8_127.txt
 [ -f $F/pmc_255/pmc_summary.txt ] && cp $F/pmc_255/pmc_summary.txt $P/m_pmc_summary_d8_255.txt
 [ -f $F/sweep.json ] && cp $F/sweep.json $P/m_sweep_config5.json
