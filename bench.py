@@ -64,8 +64,10 @@ def parse(argv=None):
                     choices=["d8_127", "d8_255", "c320", "unpack"],
                     help="d8_127 = BASELINE configs[1] (default); others are sweep points")
     ap.add_argument("--taps-fp16", action="store_true",
-                    help="round the taps to binary16 values (BASELINE config 5's fp16 leg: its numerics; taps never touch\n"
-                         "HBM in the hot loop -- they sit in SGPRs -- so there is no storage to halve)")
+                    help="binary16 taps (BASELINE config 5's fp16 leg).  The 127-/255-tap workloads run on k_fir_i8, which\n"
+                         "then holds the taps on the device as binary16 (2 bytes a tap) and quantises them into its\n"
+                         "matrix operand itself; the vector kernels keep the binary16 VALUES in fp32 registers (their\n"
+                         "taps sit in SGPRs in the hot loop: no storage to halve)")
     ap.add_argument("--gather", action="store_true", help="run the gather leg at N=1 too (1-rank RCCL group)")
     ap.add_argument("--no-gather", action="store_true", help="skip the gather leg at N>1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -696,7 +698,7 @@ def run_rank(a):
             "config": {"workload": wl["label"], "samples_per_gpu_per_step": ns,
                        "input": "LCG bytes seed 12345+rank, device resident",
                        "sharding": "independent stream per GPU, no data-path collective",
-                       "taps": (("binary16 VALUES as int8 digit planes (k_fir_i8; PDDC_F_TAPS_FP16)" if pipe is not None and pipe.on_i8(ns)
+                       "taps": (("binary16 STORAGE: 2 bytes a tap on the device, quantised into int8 digit planes by k_fir_i8's blocks themselves (PDDC_F_TAPS_FP16)" if pipe is not None and pipe.on_i8(ns)
                                  else "binary16 VALUES held in fp32 registers (PDDC_F_TAPS_FP16)") if a.taps_fp16 else
                                 ("fp32 values as four int8 digit planes, 2^-31 of the largest tap (k_fir_i8)"
                                  if pipe is not None and pipe.on_i8(ns) else "fp32")),

@@ -70,7 +70,9 @@ extern "C" {
 
 /* pipeline flags */
 #define PDDC_F_MIX         0x1u   /* NCO complex mix before stage 0            */
-#define PDDC_F_TAPS_FP16   0x2u   /* round taps to fp16 storage (config 5)     */
+#define PDDC_F_TAPS_FP16   0x2u   /* binary16 taps (config 5): rounded to binary16; a /8 first stage of 65..256 taps
+                                     without NCO (k_fir_i8) then holds them on the device AS binary16, 2 bytes a tap,
+                                     and quantises them itself; the other kernels keep the rounded values in fp32 */
 #define PDDC_F_NO_FAST     0x4u   /* force the generic kernels (testing)       */
 #define PDDC_F_OUT_PACKED24 0x8u  /* process()/push_host() emit 24-bit packed (6 B/sample)
                                      instead of float32: "FPGA emulation"      */

@@ -141,10 +141,20 @@ struct FirI8Args {
     long long   n_in;        /* samples, multiple of 8                                          */
     float       scale;       /* integer result -> float                                         */
     float       cterm;       /* the planes' unsigned -> signed offset, times the taps' sum      */
+    /* binary16 tap STORAGE (PDDC_F_TAPS_FP16; BASELINE config 5): instead of the operand table the device holds the
+     * taps as IEEE binary16 values -- kFirI8Taps16Len of them, G[128 + tt] = h[hist - tt] for tt = 1 .. hist, zeros
+     * elsewhere (fir_i8_taps16) -- and every block's matrix waves quantise them into their operand registers
+     * themselves: the same integers the host would have put in the table.  atab is NULL then. */
+    const void *taps16;
+    double      two_e;       /* 2^E of fir_i8_build_table                                       */
 };
 constexpr size_t kFirI8TableBytes = 4 * 6 * 64 * 16;       /* (hist 256; 4 k-steps instead of 6 for hist 128) */
 /* host: the operand table for `ntaps` <= hist taps (hist = 128 or 256); false if the taps are all zero */
-bool fir_i8_build_table(const float *taps, int ntaps, int hist, int8_t *table, float *scale, float *cterm);
+bool fir_i8_build_table(const float *taps, int ntaps, int hist, int8_t *table, float *scale, float *cterm,
+                        int *exp2 = nullptr);
+constexpr int kFirI8Taps16Len = 128 + 6 * 64;               /* 1 KB */
+/* host: the binary16 array k_fir_i8 reads with FirI8Args::taps16 (values must be binary16-representable) */
+void fir_i8_taps16(const float *taps, int ntaps, int hist, uint16_t *out /* kFirI8Taps16Len */);
 hipError_t launch_fir_i8(const FirI8Args &a, int hist, hipStream_t s);
 
 /* k_fir8 with packed input does not scale the unpacked integers (value * 256): the taps of

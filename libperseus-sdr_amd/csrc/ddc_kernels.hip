@@ -2205,11 +2205,52 @@ __global__ __launch_bounds__(64 * i8::NMW + i8::NLT, 1) void k_fir_i8(FirI8Args 
     const int n = lane & 15, kq = lane >> 4;
     const v4i_t *atab = static_cast<const v4i_t *>(a.atab);
     v4i_t A[KSTEPS][4];
+    if (a.taps16 == nullptr) {                             /* uniform */
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
+        for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            A[ks][j] = atab[(j * KSTEPS + ks) * 64 + lane];
+            for (int j = 0; j < 4; ++j)
+                A[ks][j] = atab[(j * KSTEPS + ks) * 64 + lane];
+    } else {
+        /* binary16 tap storage: this lane's 16 columns of every k-step, quantised here exactly as fir_i8_build_table
+         * does on the host (H = llround(h 2^E), four balanced base-256 digits).  The device array is laid out for this
+         * read: G[128 + tt] = h[HIST - tt] for tt = 1 .. HIST, zeros around it (kFirI8Taps16Len entries), so that the
+         * 16 values of a k-step -- T[r][c] = G[128 + c - 8 r] -- are two aligned 16-byte loads */
+        const uint4 *g16 = static_cast<const uint4 *>(a.taps16);
+        const float two_e = (float)a.two_e;                 /* a power of two: h 2^E is exact in binary32 */
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int i0 = (128 + 64 * ks + 16 * kq - 8 * n) >> 3;      /* in units of 8 values */
+            const uint4 lo = g16[i0], hi = g16[i0 + 1];
+            const uint32_t hw[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+            int w[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                w[0][q] = w[1][q] = w[2][q] = w[3][q] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int jj = 4 * q + b;
+                    const uint32_t bits = (jj & 1) ? hw[jj >> 1] >> 16 : hw[jj >> 1] & 0xffffu;
+                    _Float16 hv;
+                    const uint16_t b16 = (uint16_t)bits;
+                    __builtin_memcpy(&hv, &b16, 2);
+                    const float x = (float)hv * two_e;
+                    int r = (int)(x + __builtin_copysignf(0.5f, x));   /* llround: exact, |x| <= 2^30 and 11 bits wide */
+                    /* balanced digits: d = the low byte, signed; what is left is (r - d) / 256 = (r + 128) >> 8.  Byte b of
+                     * plane j's word takes the low byte as it is (one v_perm_b32) */
+                    const uint32_t sel = 0x03020100u ^ ((0x04u ^ (uint32_t)b) << (8 * b));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        w[j][q] = (int)__builtin_amdgcn_perm((uint32_t)r, (uint32_t)w[j][q], sel);
+                        r = (r + 128) >> 8;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                A[ks][j] = v4i_t{ w[j][0], w[j][1], w[j][2], w[j][3] };
+        }
+    }
     const long long n_out = a.n_in >> 3;
     __syncthreads();
     int buf = 0;
@@ -2258,7 +2299,7 @@ __global__ __launch_bounds__(64 * i8::NMW + i8::NLT, 1) void k_fir_i8(FirI8Args 
     }
 }
 
-bool fir_i8_build_table(const float *taps, int ntaps, int hist, int8_t *table, float *scale, float *cterm)
+bool fir_i8_build_table(const float *taps, int ntaps, int hist, int8_t *table, float *scale, float *cterm, int *exp2)
 {
     if (!taps || ntaps < 1 || (hist != 128 && hist != 256) || ntaps > hist || !table)
         return false;
@@ -2268,6 +2309,8 @@ bool fir_i8_build_table(const float *taps, int ntaps, int hist, int8_t *table, f
     if (!(hmax > 0.0) || !std::isfinite(hmax))
         return false;
     const int E = 30 - (int)std::ceil(std::log2(hmax));            /* |H| <= 2^30: the top digit stays within +-64 */
+    if (exp2)
+        *exp2 = E;
     int8_t dig[4][256];
     long long hsum = 0;
     for (int k = 0; k < hist; ++k) {
@@ -2297,6 +2340,19 @@ bool fir_i8_build_table(const float *taps, int ntaps, int hist, int8_t *table, f
     return true;
 }
 
+void fir_i8_taps16(const float *taps, int ntaps, int hist, uint16_t *out)
+{
+    for (int i = 0; i < kFirI8Taps16Len; ++i)
+        out[i] = 0;
+    for (int tt = 1; tt <= hist; ++tt) {
+        const int k = hist - tt;
+        if (k < ntaps) {
+            const _Float16 hv = (_Float16)taps[k];
+            __builtin_memcpy(&out[128 + tt], &hv, 2);
+        }
+    }
+}
+
 template <int HIST>
 static hipError_t launch_fir_i8_t(const FirI8Args &a, hipStream_t s)
 {
@@ -2324,7 +2380,7 @@ hipError_t launch_fir_i8(const FirI8Args &a, int hist, hipStream_t s)
 {
     if (a.n_in <= 0)
         return hipSuccess;
-    if ((a.n_in & 7) || !a.in || !a.hist || !a.out || !a.atab || (a.hist_out && a.n_in < hist))
+    if ((a.n_in & 7) || !a.in || !a.hist || !a.out || (!a.atab && !a.taps16) || (a.hist_out && a.n_in < hist))
         return hipErrorInvalidValue;
     if (hist == 256)
         return launch_fir_i8_t<256>(a, s);

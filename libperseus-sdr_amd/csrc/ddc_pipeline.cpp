@@ -73,6 +73,9 @@ struct Stage {
     float *d_taps_firp = nullptr; /* k_firp (plain decimators by 4, 5, 10): (h[k], h[k]) zero padded to firp_taps_len */
     void *d_taps_i8 = nullptr;    /* k_fir_i8 (stage 0, 129..256 taps, /8): the int8 tap operand table, with ...       */
     float i8_scale = 0.0f, i8_cterm = 0.0f;      /* ... the integer -> float scale and the planes' offset constant     */
+    void *d_taps_f16 = nullptr;   /* PDDC_F_TAPS_FP16: instead of that table the taps as binary16 values (1 KB with padding) -- the only
+                                   * form of them k_fir_i8 reads; its blocks quantise them into their operand registers */
+    double i8_two_e = 0.0;
     int poly_k = 0, poly_kp = 0;
     int ntb = 0;                  /* tap blocks if fused-capable, else 0        */
     int hist = 0;                 /* history length in samples (mult. of 8)     */
@@ -278,15 +281,30 @@ static int upload_taps(pddc_pipeline *p, int si)
         hipFree(s.d_taps_i8);
         s.d_taps_i8 = nullptr;
     }
+    if (s.d_taps_f16) {
+        hipFree(s.d_taps_f16);
+        s.d_taps_f16 = nullptr;
+    }
     /* (the history length is fixed at create time -- 8 * tap blocks -- and not known yet when this runs for the first time) */
     const int i8_hist = s.hist ? s.hist : 8 * pick_ntb(s.ntaps);
     if (si == 0 && stage_fused_capable(s) && s.ntaps <= i8_hist && (i8_hist == 128 || i8_hist == 256) &&
         !(p->flags & PDDC_F_NO_FAST)) {
         /* the long first stage on the int8 matrix cores (k_fir_i8): taps as four planes of balanced base-256 digits */
         std::vector<int8_t> tab(kFirI8TableBytes);
-        if (fir_i8_build_table(s.taps.data(), s.ntaps, i8_hist, tab.data(), &s.i8_scale, &s.i8_cterm)) {
-            HIP_TRY(hipMalloc(&s.d_taps_i8, tab.size()));
-            HIP_TRY(hipMemcpy(s.d_taps_i8, tab.data(), tab.size(), hipMemcpyHostToDevice));
+        int e2 = 0;
+        if (fir_i8_build_table(s.taps.data(), s.ntaps, i8_hist, tab.data(), &s.i8_scale, &s.i8_cterm, &e2)) {
+            if (p->flags & PDDC_F_TAPS_FP16) {
+                /* binary16 tap storage (BASELINE config 5): s.taps hold binary16 values already; the device gets them
+                 * as such, 2 bytes a tap, and no table (the host's serves for scale and offset constant only) */
+                std::vector<uint16_t> h16((size_t)kFirI8Taps16Len);
+                fir_i8_taps16(s.taps.data(), s.ntaps, i8_hist, h16.data());
+                HIP_TRY(hipMalloc(&s.d_taps_f16, h16.size() * sizeof(uint16_t)));
+                HIP_TRY(hipMemcpy(s.d_taps_f16, h16.data(), h16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+                s.i8_two_e = std::ldexp(1.0, e2);
+            } else {
+                HIP_TRY(hipMalloc(&s.d_taps_i8, tab.size()));
+                HIP_TRY(hipMemcpy(s.d_taps_i8, tab.data(), tab.size(), hipMemcpyHostToDevice));
+            }
         }
     }
     if (s.interp == 1 && !(p->flags & PDDC_F_NO_FAST) && firp_supported(s.decim, s.ntaps)) {
@@ -920,6 +938,8 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
             hipFree(p->st[i].d_taps_firp);
         if (p->st[i].d_taps_i8)
             hipFree(p->st[i].d_taps_i8);
+        if (p->st[i].d_taps_f16)
+            hipFree(p->st[i].d_taps_f16);
         if (p->st[i].d_buf && !p->st[i].buf_in_ws)
             hipFree(p->st[i].d_buf);
         if (p->st[i].d_buf_alt && !p->st[i].buf_in_ws)
@@ -1170,7 +1190,7 @@ int pddc_pipeline_uses_fused(const pddc_pipeline *p) { return p && stage0_fused(
 /* the long first stage (129..256 taps, /8, no NCO) runs on the int8 matrix cores: k_fir_i8 (PDDC_NO_I8: k_fir8 always) */
 static bool stage0_on_i8(const pddc_pipeline *p, size_t nsamples)
 {
-    if (!stage0_fused(p) || p->st[0].d_taps_i8 == nullptr || (p->flags & PDDC_F_MIX) || nsamples < (size_t)p->st[0].hist ||
+    if (!stage0_fused(p) || (p->st[0].d_taps_i8 == nullptr && p->st[0].d_taps_f16 == nullptr) || (p->flags & PDDC_F_MIX) || nsamples < (size_t)p->st[0].hist ||
         getenv("PDDC_NO_I8"))
         return false;
     if (p->st[0].hist == 256)
@@ -1822,6 +1842,8 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                 q.hist_out = a.hist_out;
                 q.out = dst;
                 q.atab = st.d_taps_i8;
+                q.taps16 = st.d_taps_f16;
+                q.two_e = st.i8_two_e;
                 q.n_in = (long long)nsamples;
                 q.scale = st.i8_scale;
                 q.cterm = st.i8_cterm;
@@ -2631,6 +2653,8 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     q.hist_out = nullptr;
     q.out = a.out;
     q.atab = p->st[0].d_taps_i8;
+    q.taps16 = p->st[0].d_taps_f16;
+    q.two_e = p->st[0].i8_two_e;
     q.n_in = (long long)nsamples;
     q.scale = p->st[0].i8_scale;
     q.cterm = p->st[0].i8_cterm;

@@ -106,6 +106,19 @@ def test_i8_binary16_taps_set_taps_and_checkpoint(pkg, dev, O):
     y = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
     assert O.rel_err(y, O.ddc_chain(packed, [(8, h16)])) <= FIR_TOL
     pipe.close()
+    # binary16 STORAGE: with the flag the device holds 2 bytes a tap and the kernel's blocks quantise them into their
+    # operand registers; without it the host builds the int8 operand table from the same values -- the same integers,
+    # so the same bits, for both history lengths (65..128 and 129..256 taps) and for taps that need the rounding
+    # (subnormal binary16 values far below the largest tap)
+    for g in (h16, lowpass(100, 0.05).astype(np.float16).astype(np.float32),
+              (h16 * (1.0 + 0.0 * h16) * np.where(np.arange(h16.size) % 7 == 0, 2.0 ** -14, 1.0)).astype(np.float16).astype(np.float32)):
+        outs = []
+        for flag in (False, True):
+            pipe = pkg.Pipeline([(8, g)], taps_fp16=flag)
+            assert pipe.on_i8(ns)
+            outs.append(pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1))
+            pipe.close()
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
     g = lowpass(233, 0.03)
     pipe = pkg.Pipeline([(8, h)])
     pkg.check(pkg.ddc_lib().pddc_pipeline_set_taps(pipe._h, 0, g.ctypes.data_as(C.POINTER(C.c_float)), g.size))
