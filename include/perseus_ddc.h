@@ -218,6 +218,12 @@ int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples_in);
  * v_mfma_i32_16x16x64_i8); 4 * ksteps * 1024 bytes with ksteps = 6 (hist 256) or 4 (hist 128).  *scale turns the
  * integer result into the reference's float, *cterm is the constant that undoes the byte planes' -128 offset.       */
 int pddc_fir_i8_table(const float *taps, int ntaps, int hist, int8_t *table, size_t table_bytes, float *scale, float *cterm);
+/* With PDDC_F_TAPS_FP16 the device holds no such table but the taps as IEEE binary16, and the kernel's blocks quantise
+ * them into their operand registers: out[128 + tt] = binary16(h[hist - tt]) for tt = 1 .. hist, zeros elsewhere,
+ * PDDC_FIR_I8_TAPS16_LEN entries (lane (r, kq) reads the 16 values 128 + 64 ks + 16 kq - 8 r + jj of k-step ks as two
+ * aligned 16-byte loads); H = llround(value * *two_e), digits as above.  Host arithmetic, no device needed. */
+#define PDDC_FIR_I8_TAPS16_LEN 512
+int pddc_fir_i8_taps16(const float *taps, int ntaps, int hist, uint16_t *out, size_t out_len, double *two_e);
 /* 1 if stage 0 reads the packed samples itself (the fused decimate-by-8, or the generic decimator
  * with its unpack-while-staging load phase for any other first decimation): no float32
  * intermediate of the input is ever written; 6 + 8/D bytes per input sample                  */

@@ -125,6 +125,8 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_arena_place.restype = C.c_int
     L.pddc_fir_i8_table.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, vp, sz, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.pddc_fir_i8_table.restype = C.c_int
+    L.pddc_fir_i8_taps16.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, vp, sz, C.POINTER(C.c_double)]
+    L.pddc_fir_i8_taps16.restype = C.c_int
     L.pddc_pipeline_check.argtypes = [vp, vp]
     L.pddc_pipeline_check.restype = C.c_int
     L.pddc_arena_place.argtypes = [vp, sz, sz, sz, sz, sz, C.POINTER(sz), C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -389,6 +389,28 @@ int pddc_fir_i8_table(const float *taps, int ntaps, int hist, int8_t *table, siz
     return PDDC_OK;
 }
 
+/* host arithmetic only: the binary16 tap array k_fir_i8 reads under PDDC_F_TAPS_FP16, and the 2^E it scales them with */
+int pddc_fir_i8_taps16(const float *taps, int ntaps, int hist, uint16_t *out, size_t out_len, double *two_e)
+{
+    if (!taps || !out || !two_e)
+        return fail(PDDC_EINVAL, "null argument");
+    if (hist != 128 && hist != 256)
+        return fail(PDDC_EINVAL, "history %d: 128 or 256", hist);
+    if (out_len < (size_t)kFirI8Taps16Len)
+        return fail(PDDC_ECAPACITY, "the array has %d entries, buffer has %zu", kFirI8Taps16Len, out_len);
+    std::vector<int8_t> tab(kFirI8TableBytes);
+    std::vector<float> h16(taps, taps + (ntaps > 0 ? ntaps : 0));
+    for (float &v : h16)
+        v = round_to_half(v);
+    float sc = 0.0f, ct = 0.0f;
+    int e2 = 0;
+    if (ntaps < 1 || !fir_i8_build_table(h16.data(), ntaps, hist, tab.data(), &sc, &ct, &e2))
+        return fail(PDDC_EINVAL, "no int8 form for these taps (1..%d taps, not all zero, finite)", hist);
+    fir_i8_taps16(h16.data(), ntaps, hist, out);
+    *two_e = std::ldexp(1.0, e2);
+    return PDDC_OK;
+}
+
 static int require_device(void)
 {
     int n = pddc_device_count();

@@ -123,3 +123,41 @@ def test_table_refuses_what_it_cannot_hold(pkg):
     assert call(h, 200, 128, buf.nbytes) != 0                      # more taps than the history reaches
     assert call(h, 200, 200, buf.nbytes) != 0                      # a history the kernel has no form for
     assert call(h, 200, 256, 1000) != 0                            # buffer too small
+
+
+@pytest.mark.parametrize("name,hist", [("d8_255", 256), ("d8_127", 128)])
+def test_binary16_stored_taps_quantise_to_the_host_table(pkg, name, hist):
+    """PDDC_F_TAPS_FP16 on k_fir_i8: the device holds the taps as binary16 (pddc_fir_i8_taps16) and the kernel's matrix
+    waves build their operand from them.  Restated here lane by lane as the kernel does it -- two 16-byte loads of eight
+    values per k-step at 128 + 64 ks + 16 kq - 8 r, float32 product with 2^E, halves away from zero, low byte of r, then
+    (r + 128) >> 8 -- the result must be the table the host builds from the same binary16 values, byte for byte; also
+    with taps far below the largest one (subnormal binary16 values, halves that need the rounding)."""
+    L = pkg.ddc_lib()
+    h = load_taps(name).astype(np.float64)
+    h[::7] *= 2.0 ** -13                                           # some taps thirteen octaves down: binary16 subnormals
+    h[3::11] = np.ldexp(np.round(np.ldexp(h[3::11], 20)) + 0.5, -20)   # ... and some that end in a half after scaling
+    h = h.astype(np.float32)
+    h16 = h.astype(np.float16).astype(np.float32)
+    tab, _, _ = table(pkg, h16, hist)
+    G = np.zeros(512, np.uint16)
+    two_e = C.c_double()
+    pkg.check(L.pddc_fir_i8_taps16(h.ctypes.data_as(C.POINTER(C.c_float)), h.size, hist, G.ctypes.data, G.size, C.byref(two_e)))
+    E = 30 - int(np.ceil(np.log2(np.abs(h16).max())))
+    assert two_e.value == 2.0 ** E
+    assert not G[:129].any() and not G[129 + hist:].any()
+    assert np.array_equal(G[129:129 + hist].view(np.float16).astype(np.float32)[::-1][:h.size], h16)
+    vals = G.view(np.float16).astype(np.float32)
+    ks = tab.shape[1]
+    got = np.zeros_like(tab)
+    for k in range(ks):
+        for lane in range(64):
+            r0, kq = lane & 15, lane >> 4
+            i0 = 128 + 64 * k + 16 * kq - 8 * r0
+            assert i0 % 8 == 0 and 0 <= i0 and i0 + 16 <= G.size
+            x = vals[i0:i0 + 16] * np.float32(two_e.value)              # exact in binary32
+            r = (x + np.copysign(np.float32(0.5), x)).astype(np.int32)  # conversion truncates: halves away from zero
+            for j in range(4):
+                got[j, k, lane, :] = (r & 255).astype(np.uint8).view(np.int8)
+                r = (r + 128) >> 8
+            assert not r.any()
+    assert np.array_equal(got, tab)
