@@ -119,7 +119,19 @@ def test_i8_binary16_taps_set_taps_and_checkpoint(pkg, dev, O):
             outs.append(pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1))
             pipe.close()
         assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    # new taps under the flag: the binary16 array on the device is replaced, not a stale table read
     g = lowpass(233, 0.03)
+    g16 = g.astype(np.float16).astype(np.float32)
+    pipe = pkg.Pipeline([(8, h)], taps_fp16=True)
+    pkg.check(pkg.ddc_lib().pddc_pipeline_set_taps(pipe._h, 0, g.ctypes.data_as(C.POINTER(C.c_float)), g.size))
+    pipe.reset()
+    assert pipe.on_i8(ns)
+    y_new = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+    pipe.close()
+    pipe = pkg.Pipeline([(8, g16)])
+    y_ref = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+    pipe.close()
+    assert np.array_equal(y_new.view(np.uint32), y_ref.view(np.uint32))
     pipe = pkg.Pipeline([(8, h)])
     pkg.check(pkg.ddc_lib().pddc_pipeline_set_taps(pipe._h, 0, g.ctypes.data_as(C.POINTER(C.c_float)), g.size))
     pipe.reset()
