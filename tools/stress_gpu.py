@@ -1,7 +1,8 @@
 # randomized stress of the stream state machine against the oracle: random plans, cuts, NCO words retuned
 # between batches (phase-continuous), scheduler settings (PDDC_FIR8_BLOCKS / DYN_PCT / CHUNK / R), caller-provided
 # workspaces, checkpoint/restore hops to a fresh pipeline in mid-stream, overlap mode (the last stage carried by the next
-# launch), and the int8 matrix-core first stage switched on and off between batches (PDDC_NO_I8 / PDDC_I8_128).
+# launch), the int8 matrix-core first stage switched on and off between batches (PDDC_NO_I8 / PDDC_I8_128), and binary16
+# tap storage (one case in four).
 # Usage: python tools/stress_gpu.py [n]
 import sys, os, importlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,8 +43,13 @@ for it in range(n_iter):
     for _ in cuts[1:-1]:
         words.append(int(rng.integers(0, 2**32)) if (mix and rng.integers(0, 3) == 0) else words[-1])
     segs = [(a, w) for k, (a, w) in enumerate(zip(cuts[:-1], words)) if k == 0 or w != words[k - 1]]
+    # one case in four with binary16 taps (PDDC_F_TAPS_FP16: k_fir_i8 then reads them as binary16 and quantises them itself);
+    # drawn from a generator of its own so that the other cases stay the ones of the earlier runs
+    f16 = bool(np.random.default_rng(7000 + it).integers(0, 4) == 0)
+    if f16:
+        stages = [(s[0], np.asarray(s[1], np.float32).astype(np.float16).astype(np.float32)) + tuple(s[2:]) for s in stages]
     ref = O.ddc_chain_retuned(packed, stages, segs) if mix else O.ddc_chain(packed, stages)
-    pipe = pkg.Pipeline(stages, mix=mix)
+    pipe = pkg.Pipeline(stages, mix=mix, taps_fp16=f16)
     ov = len(stages) > 1 and bool(rng.integers(0, 2))
     if ov:
         pipe.set_overlap(True)
@@ -73,7 +79,7 @@ for it in range(n_iter):
             use_ws = False
         elif act == 1:
             blob = pipe.save_state()
-            q = pkg.Pipeline(stages, mix=mix)
+            q = pkg.Pipeline(stages, mix=mix, taps_fp16=f16)
             if ov:
                 q.set_overlap(True)
             q.restore_state(blob)
@@ -89,7 +95,7 @@ for it in range(n_iter):
     tag = "ok " if ok and err <= 1e-6 else "BAD"
     print(f"{tag} it {it} stages {[(s[0], len(s[1])) for s in stages]} mix {mix} ns {ns} cuts {len(cuts)-1} "
           f"blocks {os.environ['PDDC_FIR8_BLOCKS']} dyn {os.environ.get('PDDC_FIR8_DYN_PCT', 'default')} K {os.environ.get('PDDC_FIR8_CHUNK', 'default')} "
-          f"R {os.environ['PDDC_FIR8_R']} retunes {len(segs) - 1} ws {ws is not None} hops {hops} overlap {ov} err {err:.2e}", flush=True)
+          f"R {os.environ['PDDC_FIR8_R']} f16 {f16} retunes {len(segs) - 1} ws {ws is not None} hops {hops} overlap {ov} err {err:.2e}", flush=True)
     if tag == "BAD":
         sys.exit(1)
 print("worst", worst)
