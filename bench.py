@@ -71,6 +71,9 @@ def parse(argv=None):
     ap.add_argument("--gather", action="store_true", help="run the gather leg at N=1 too (1-rank RCCL group)")
     ap.add_argument("--no-gather", action="store_true", help="skip the gather leg at N>1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--recheck-placement", action="store_true",
+                    help="diagnostics: right after the timed region, time every probed output slot again (24 launches\n"
+                         "each, the chosen one first and last): the line gains `placement_recheck_ms`")
     ap.add_argument("--per-step-events", action="store_true",
                     help="diagnostics: a HIP event after every timed step; the line gains `per_step_ms` (the extra\n"
                          "records cost about a microsecond per step, so this is not the default)")
@@ -603,6 +606,22 @@ def run_rank(a):
         assert n_k == min(a.steps, 8192), (n_k, a.steps)
     else:
         kern_ms = ev_ms / a.steps
+    recheck = None
+    if a.recheck_placement and placement is not None and not overlap:
+        def again(o):
+            outbox[0] = out_view(o)
+            for _ in range(10):
+                step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(24):
+                step()
+            e1.record()
+            e1.synchronize()
+            return round(e0.elapsed_time(e1) / 24, 4)
+        order = [bo] + [o for (i, o) in sorted(table) if i == bi and o != bo] + [bo]
+        recheck = [(o, again(o)) for o in order]
+        outbox[0] = out_view(bo)
     # measured copy ceiling: a device-to-device copy that moves as many bytes through HBM as
     # one launch of the dominant kernel does (nbytes read + nbytes written)
     copy_gbps = None
@@ -718,6 +737,7 @@ def run_rank(a):
             "events_ms_per_step": round(ev_ms / a.steps, 4),
             "idle_before_timed_ms": round(idle_ms, 3),      # barrier + synchronize, as the contract asks: the clocks
                                                             # the first timed steps see depend on how long this was
+            "placement_recheck_ms": recheck,
             "per_step_ms": ([round(x.elapsed_time(y), 4) for x, y in zip([ev0] + step_evs[:-1], step_evs)]
                             if step_evs else None),
             "placement": placement,
