@@ -27,10 +27,14 @@ def ms(o, n=24):
     e1.record()
     e1.synchronize()
     return e0.elapsed_time(e1) / n
+if os.environ.get("SLOT_WALK_SLEEP"):             # let whatever the driver does behind a fresh 80 GiB allocation finish first
+    import time
+    torch.cuda.synchronize()
+    time.sleep(float(os.environ["SLOT_WALK_SLEEP"]))
 for _ in range(150):
     ms(1, 1)
 mode = sys.argv[1] if len(sys.argv) > 1 else "walk"
-for r in range(30):
+for r in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     if mode == "walk":
         row = [ms(o) for o in range(1, 10)]
     else:                                      # stay: the same number of launches on two slots only
