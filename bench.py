@@ -86,6 +86,13 @@ def parse(argv=None):
     ap.add_argument("--arena-gib", type=int, default=80,
                     help="size of the allocation the placement cuts its 8 GiB slots from (less if less is free);\n"
                          "80 GiB hold the four offsets the rule probes")
+    ap.add_argument("--arena-rest-s", type=float, default=3.0,
+                    help="pause after the arena has been allocated, before the first launch into it.  During the first\n"
+                         "second or so behind an 80 GiB allocation the chip sometimes (one process in five) runs every\n"
+                         "stream 4-5 %% slower for some tenths of a second, whatever its placement -- what the driver\n"
+                         "does to freshly handed-out memory, most likely -- and a 20-step timed region can fall into\n"
+                         "that; with the pause none of thirty processes did (profiles/r03/n_slow_state_investigation.txt).\n"
+                         "A receiver allocates once and streams for hours; 0 switches the pause off")
     ap.add_argument("--arena-grow-gib", type=int, default=192,
                     help="rule placement: if every slot of the first arena runs at the first-come speed (one extent class\n"
                          "over all of it), allocate this much instead (less if less is free) and look again; 0: never")
@@ -451,6 +458,9 @@ def run_rank(a):
                 break
             except RuntimeError:
                 gib = gib * 3 // 4
+        if arena is not None and a.arena_rest_s > 0:
+            torch.cuda.synchronize(dev)
+            time.sleep(a.arena_rest_s)
         if arena is None:                                         # no room: first come, first served
             inbox[0] = pkg.synth_lcg(in_bytes, shard.stream_seed(rank), 0, dev)
             outbox[0] = torch.empty((out_rows, 2), dtype=torch.float32, device=dev)
@@ -533,6 +543,9 @@ def run_rank(a):
                 except RuntimeError:
                     want = gib
                     arena = torch.empty(want << 30, dtype=torch.uint8, device=dev)
+                if a.arena_rest_s > 0:
+                    torch.cuda.synchronize(dev)
+                    time.sleep(a.arena_rest_s)
                 gib, nslot = want, (want << 30) // slot
                 pkg.check(pkg.ddc_lib().pddc_synth_lcg(in_view(0).data_ptr(), in_bytes, shard.stream_seed(rank), 0, stream))
                 table.clear()
@@ -546,7 +559,7 @@ def run_rank(a):
                                                for i in in_slots},
                      "first_come_ms": round(table.get((0, 1), table.get((0, 0))), 4),
                      "chosen": {"input_at_GiB": (bi * slot) >> 30, "output_slot": bo, "ms": round(best_ms, 4)},
-                     "probe_pairs": len(table), "probe_launches": launches[0],
+                     "probe_pairs": len(table), "probe_launches": launches[0], "arena_rest_s": a.arena_rest_s,
                      "grown_after": grown,     # not None: the first, smaller arena showed ONE class only; its table
                      "note": "input and output (with a cascade's inter-stage workspace) cut from ONE allocation and placed in "
                              "different HBM extent classes: input at the start, the output probed right behind it (first "
