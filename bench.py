@@ -606,6 +606,8 @@ def run_rank(a):
     if overlap:
         pipe.fence(stream)                              # the last steps' tails belong to the timed region
     ev1.record()
+    while not ev1.query():                              # the host waits by polling: a blocking synchronize adds its wake-up
+        pass                                            # latency (30-200 us on these hosts) to a 6.5 ms region
     torch.cuda.synchronize(dev)
     grp.barrier()
     dt = time.perf_counter() - t0
