@@ -16,6 +16,15 @@ pytestmark = pytest.mark.gpu
 NS = 1 << 28
 
 
+def _rest_behind_a_large_allocation(dev):
+    """During the first second or so behind an allocation of tens of GiB the chip sometimes runs every stream 4-5 % slower
+    for some tenths of a second (profiles/r03/n_slow_state_investigation.txt); timing comparisons wait it out, as bench.py does"""
+    import time
+    import torch
+    torch.cuda.synchronize(dev)
+    time.sleep(3.0)
+
+
 def _bench():
     sys.path.insert(0, ROOT)
     return importlib.import_module("bench")
@@ -98,6 +107,7 @@ def test_arena_search_agrees_with_the_kernel(pkg, O, dev):
     pipe = pkg.Pipeline(wl["stages"])
     rows = pipe.max_output(NS) + 8
     arena = torch.empty(gib << 30, dtype=torch.uint8, device=dev)
+    _rest_behind_a_large_allocation(dev)
     nslot = (gib << 30) // slot
     i_sl, o_sl, best, worst = C.c_size_t(), C.c_size_t(), C.c_float(), C.c_float()
     table = (C.c_float * (2 * nslot))()
@@ -167,6 +177,7 @@ def test_the_placement_rule_finds_a_fast_pair_in_a_handful_of_probes(pkg, O, dev
         pytest.skip("less than 72 GiB free")
     slot, in_bytes, out_off = 8 << 30, 6 * NS, 2 << 30
     arena = torch.empty(gib << 30, dtype=torch.uint8, device=dev)
+    _rest_behind_a_large_allocation(dev)
     nslot = (gib << 30) // slot
     st = torch.cuda.current_stream(dev).cuda_stream
     pkg.check(L.pddc_synth_lcg(arena.data_ptr(), in_bytes, 12345, 0, st))
