@@ -143,7 +143,10 @@ int pddc_arena_search(void *d_arena, size_t arena_bytes, size_t slot_bytes, size
  * (slot 0), its extent class reaches 32, 48 or 64 GiB up -- the slot right behind it is nearly always in it (the "first come"
  * case) and +32, +48 or +64 GiB nearly always in another one (leases with the other classes at +24 / +40 / +72 GiB exist).  Probes the output side at those four places on `stream`
  * (0.1 s), looks at the remaining slots only if none gains 3 %, returns the fastest in *out_slot with the first-come
- * and the chosen probe times and the number of probes made.  An arena of 80 GiB (ten 8-GiB slots) is enough.      */
+ * and the chosen probe times and the number of probes made.  An arena of 80 GiB (ten 8-GiB slots) is enough.
+ * Let a freshly allocated arena rest for a second or two before probing it: during the first second behind an
+ * allocation of that size the chip sometimes runs EVERY pair 4-5 % slower for some tenths of a second (bench.py waits
+ * 3 s; profiles/r03/n_slow_state_investigation.txt).                                                              */
 int pddc_arena_place(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t in_bytes, size_t out_offset,
                      size_t out_bytes, size_t *out_slot, float *ms_first_come, float *ms_best, int *nprobes, void *stream);
 /* The same with the pipeline's OWN first-stage kernel as the probe (one fused stage: the kernel reads the batch at the
