@@ -590,6 +590,12 @@ def run_rank(a):
     cascade = stages is not None and len(stages) > 2 and pipe.fused_cascade(ns)     # the whole cascade is ONE kernel
     # (overlap mode: the step is ONE launch -- the pair with the previous step's tail as extra blocks -- so ev0/ev1 do)
     multi_kernel = stages is not None and pipe.fused and len(stages) > 1 and not cascade and not overlap
+    for e in [ev0, ev1] + (step_evs or []):             # torch makes the HIP event at the first record(): 10-100 us that would
+        e.record()                                      # otherwise fall between t0 and the first timed launch
+    ev_w = torch.cuda.Event()
+    ev_w.record()
+    while not ev_w.query():                             # polled, so that the host is back within microseconds of the last
+        pass                                            # warm-up step's end (a blocking wait adds its wake-up latency to the idle gap)
     torch.cuda.synchronize(dev)
     t_idle0 = time.perf_counter()                       # the GPU is idle from here to the first timed launch
     grp.barrier()
@@ -598,19 +604,25 @@ def run_rank(a):
     t0 = time.perf_counter()
     idle_ms = (t0 - t_idle0) * 1e3
     ev0.record()
+    marks = [time.perf_counter()]                       # host clock: after the first event, ...
     n_last = 0
     for k in range(a.steps):
         n_last = step()
         if step_evs:
             step_evs[k].record()
+        if k == 0:
+            marks.append(time.perf_counter())           # ... after the first launch call, ...
     if overlap:
         pipe.fence(stream)                              # the last steps' tails belong to the timed region
     ev1.record()
+    marks.append(time.perf_counter())                   # ... after the last one, ...
     while not ev1.query():                              # the host waits by polling: a blocking synchronize adds its wake-up
         pass                                            # latency (30-200 us on these hosts) to a 6.5 ms region
+    marks.append(time.perf_counter())                   # ... when the poll sees the end, ...
     torch.cuda.synchronize(dev)
     grp.barrier()
     dt = time.perf_counter() - t0
+    marks.append(t0 + dt)                               # ... and behind synchronize + barrier
     ev_ms = ev0.elapsed_time(ev1)                       # HIP events on the launch stream
     # dominant-kernel duration, HIP events on the launch stream over the timed region itself (a separate
     # region after a host synchronisation would see other clocks: a pause of a few hundred microseconds buys
@@ -752,6 +764,8 @@ def run_rank(a):
             "events_ms_per_step": round(ev_ms / a.steps, 4),
             "idle_before_timed_ms": round(idle_ms, 3),      # barrier + synchronize, as the contract asks: the clocks
                                                             # the first timed steps see depend on how long this was
+            "host_marks_ms": [round((m - t0) * 1e3, 3) for m in marks],   # first event / first launch / last launch /
+                                                                         # end seen by the poll / behind synchronize + barrier
             "placement_recheck_ms": recheck,
             "per_step_ms": ([round(x.elapsed_time(y), 4) for x, y in zip([ev0] + step_evs[:-1], step_evs)]
                             if step_evs else None),
