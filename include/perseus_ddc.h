@@ -214,6 +214,28 @@ int pddc_pipeline_uses_fused(const pddc_pipeline *p);
  * are the operand, the taps are quantised to 2^-31 of the largest one; same history, same outputs to
  * 1e-7 of full scale)                                                                       */
 int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples_in);
+/* Round 4: the return value says WHICH matrix-core kernel: 0 none (k_fir8), 1 k_fir_i8 (65..256 taps, no NCO), 2 k_fir_i8x
+ * -- the NCO folded into the taps, y[m] = LO(n0 + 8m) sum_k (h[k] e^{+j theta k}) x_raw[8m - k]: complex taps on the raw
+ * integer planes, one float rotation per output -- which every tuned (PDDC_F_MIX) decimate-by-8 first stage of 1..256
+ * taps runs on, i.e. every pipeline the drop-in API builds behind perseus_set_ddc_center_freq (perseus-sdr.c:556-619);
+ * with a decimate-by-8 second stage of <= 64 taps behind it and whole 8192-sample tiles, both stages are one kernel
+ * (pddc_pipeline_uses_fused_pair answers 2).  The one batch whose history window straddles a retune takes k_fir8.   */
+/* The operands k_fir_i8x reads, as the library builds them (host arithmetic, no device needed): `mix` = 0 one table of
+ * H[k] = round(h[k] 2^E) as pddc_fir_i8_table's; `mix` = 1 the tables of Hc[k] = round(h[k] cos(theta k) 2^E) and
+ * Hs[k] = round(h[k] sin(theta k) 2^E), theta k = 2 pi ((k freg) mod 2^32) / 2^32, and for hist <= 64 a third one of -Hs
+ * (there a wave adds both of its band products into one set of int32 accumulators).  hist = 32, 64, 128 or 256;
+ * 4 * ksteps * 1024 bytes per table, ksteps = (120 + hist + 63) / 64.  ct[0], ct[1]: the byte planes' offset constants of
+ * uI = gc * xI - gs * xQ and uQ = gs * xI + gc * xQ.  Returns the number of tables written.                        */
+int pddc_fir_i8x_tables(const float *taps, int ntaps, int hist, int mix, uint32_t freg, int8_t *tables, size_t tables_bytes,
+                        float *scale, float *ct /* [2] */);
+/* ... and the fused second stage's taps: out[i] = Re g2[64 - i], out[68 + i] = Im g2[64 - i], i = 0 .. 64,
+ * g2[k] = h2[k] e^{+j 8 theta k} (a first-stage output is 8 input samples); 136 floats */
+int pddc_fir_i8x_taps2(const float *taps2, int ntaps2, int mix, uint32_t freg, float *out, size_t out_len);
+/* Kernel selection is API state, not environment: name = "no_i8", "i8_128", "i8x", "i8x_pair", "i8x_plain", "i8x_blocks",
+ * "no_fuse2", "fuse3" (the PDDC_* environment variables of the same names are read once, when the pipeline is created).
+ * PDDC_ESTATE while overlap mode holds a tail back (fence first), PDDC_EINVAL for an unknown name.                  */
+int pddc_pipeline_set_option(pddc_pipeline *p, const char *name, int value);
+int pddc_pipeline_get_option(const pddc_pipeline *p, const char *name, int *value);
 /* The tap operand that kernel reads, as the library builds it (host arithmetic, no device needed; for tests and for
  * hosts that want to look at the quantisation): taps -> H[k] = round(h[k] * 2^E), E = 30 - ceil(log2 max|h|), as four
  * balanced base-256 digits d_j[k] in [-128, 127]; table[j][ks][lane][jj] = d_j[hist - (c - 8 r)] for r = lane & 15,

@@ -127,6 +127,15 @@ def ddc_lib() -> C.CDLL:
     L.pddc_fir_i8_table.restype = C.c_int
     L.pddc_fir_i8_taps16.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, vp, sz, C.POINTER(C.c_double)]
     L.pddc_fir_i8_taps16.restype = C.c_int
+    L.pddc_fir_i8x_tables.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_uint32, vp, sz,
+                                      C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.pddc_fir_i8x_tables.restype = C.c_int
+    L.pddc_fir_i8x_taps2.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_float), sz]
+    L.pddc_fir_i8x_taps2.restype = C.c_int
+    L.pddc_pipeline_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.pddc_pipeline_set_option.restype = C.c_int
+    L.pddc_pipeline_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
+    L.pddc_pipeline_get_option.restype = C.c_int
     L.pddc_pipeline_check.argtypes = [vp, vp]
     L.pddc_pipeline_check.restype = C.c_int
     L.pddc_arena_place.argtypes = [vp, sz, sz, sz, sz, sz, C.POINTER(sz), C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -297,16 +306,27 @@ class Pipeline:
     def stage0_reads_packed(self) -> bool:
         return bool(ddc_lib().pddc_pipeline_stage0_reads_packed(self._h))
 
-    def fused_pair(self, nsamples: int) -> bool:
-        return bool(ddc_lib().pddc_pipeline_uses_fused_pair(self._h, nsamples))
+    def fused_pair(self, nsamples: int) -> int:
+        """0: stages 0 and 1 are separate kernels; 1: k_fir8's fused pair; 2: k_fir_i8x's (matrix cores, NCO in the taps)"""
+        return int(ddc_lib().pddc_pipeline_uses_fused_pair(self._h, nsamples))
+
+    def set_option(self, name: str, value: int):
+        """kernel selection as API state: no_i8, i8_128, i8x, i8x_pair, i8x_plain, i8x_blocks, no_fuse2, fuse3"""
+        check(ddc_lib().pddc_pipeline_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        check(ddc_lib().pddc_pipeline_get_option(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def fused_cascade(self, nsamples: int) -> bool:
         """stages 0, 1 and 2 as one kernel for a batch of this size"""
         return bool(ddc_lib().pddc_pipeline_uses_fused_cascade(self._h, nsamples))
 
-    def on_i8(self, nsamples: int) -> bool:
-        """stage 0 of a batch of nsamples runs on the int8 matrix cores (k_fir_i8: 129..256 taps, /8, no NCO)"""
-        return bool(ddc_lib().pddc_pipeline_stage0_on_i8(self._h, nsamples))
+    def on_i8(self, nsamples: int) -> int:
+        """stage 0 of a batch of nsamples runs on the int8 matrix cores: 0 no (k_fir8), 1 k_fir_i8 (65..256 taps, no NCO),
+        2 k_fir_i8x (NCO folded into the taps)"""
+        return int(ddc_lib().pddc_pipeline_stage0_on_i8(self._h, nsamples))
 
     def check(self, stream: int = 0):
         """wait for `stream`; raises if a kernel of this pipeline flagged a failure"""

@@ -157,6 +157,37 @@ constexpr int kFirI8Taps16Len = 128 + 6 * 64;               /* 1 KB */
 void fir_i8_taps16(const float *taps, int ntaps, int hist, uint16_t *out /* kFirI8Taps16Len */);
 hipError_t launch_fir_i8(const FirI8Args &a, int hist, hipStream_t s);
 
+/* ---- k_fir_i8x: the same product with the NCO folded into the taps, and optionally the second decimate-by-8 stage of a
+ * cascade fused behind it (ddc_fir_i8.hip).  hist = 32, 64, 128 or 256 packed samples of history (the stage's 8 * ntb);
+ * stream state as k_fir8's / k_fir_i8's: packed history, and for the fused pair the 64 first-stage outputs (float2, mixed)
+ * in front of the batch.  phase(n) = n * freg + phase_off for EVERY sample the batch's outputs touch, i.e. the history
+ * window must have been mixed with the same word (the pipeline routes the one batch behind a retune through k_fir8). */
+struct FirI8xArgs {
+    const void *in;          /* packed batch, 16-byte aligned                                   */
+    const void *hist;        /* the `hist` packed samples in front of it                        */
+    void       *hist_out;    /* receives the batch's last `hist` samples (or NULL; needs n_in >= hist) */
+    float      *out;         /* float2 outputs: n_in / 8, or n_in / 64 with the fused second stage */
+    const void *atab;        /* fir_i8x_build_tables: 1 (no NCO), 2 (NCO, hist > 64: c, s) or 3 (NCO, hist <= 64: c, s, -s) tables */
+    long long   n_in;        /* samples, multiple of 8 (of 8192 with the fused second stage)     */
+    float       scale;       /* integer result -> float                                         */
+    float       ct[2];       /* the planes' unsigned -> signed offset times the tap sums, per component of u */
+    unsigned long long n0;   /* absolute index of batch sample 0                                */
+    uint32_t    freg, phase_off;
+    const float *taps2 = nullptr;   /* fused second stage: fir_i8x_taps2 (kFirI8xTaps2Len floats, device)  */
+    const void  *hist2 = nullptr;   /* the 64 first-stage outputs (float2) in front of the batch           */
+    void        *hist2_out = nullptr;
+};
+constexpr int kFirI8xTaps2Len = 2 * 68;
+int    fir_i8x_mode(int hist, bool mix);                 /* 0: no NCO, 1: NCO split over waves, 2: NCO, both tap sets per wave */
+size_t fir_i8x_table_bytes(int hist, bool mix);
+/* host: the tap operand(s) for `ntaps` <= hist taps, NCO word freg when mix; false if the taps are all zero */
+bool fir_i8x_build_tables(const float *taps, int ntaps, int hist, bool mix, uint32_t freg, int8_t *tables, float *scale,
+                          float ct[2], int *exp2 = nullptr);
+/* host: the second stage's taps (<= 64) as the kernel reads them: complex g2[k] = h2[k] e^{+j 8 theta k}, descending */
+void fir_i8x_taps2(const float *taps2, int ntaps2, bool mix, uint32_t freg, float *out /* kFirI8xTaps2Len */);
+bool fir_i8x_supported(int hist, bool mix, bool fuse2);
+hipError_t launch_fir_i8x(const FirI8xArgs &a, int hist, bool mix, bool fuse2, hipStream_t s, int max_blocks = 0);
+
 /* k_fir8 with packed input does not scale the unpacked integers (value * 256): the taps of
  * that stage must be uploaded multiplied by this, RN(1/8388607) / 256 -- the factor that
  * k_unpack24 applies per sample (bit-exact with the reference there; here the FIR tolerance

@@ -76,6 +76,7 @@ struct Stage {
     void *d_taps_f16 = nullptr;   /* PDDC_F_TAPS_FP16: instead of that table the taps as binary16 values (1 KB with padding) -- the only
                                    * form of them k_fir_i8 reads; its blocks quantise them into their operand registers */
     double i8_two_e = 0.0;
+    bool i8x_ok = false;          /* stage 0: k_fir_i8x can hold these taps (not all zero, finite) */
     int poly_k = 0, poly_kp = 0;
     int ntb = 0;                  /* tap blocks if fused-capable, else 0        */
     int hist = 0;                 /* history length in samples (mult. of 8)     */
@@ -169,7 +170,39 @@ struct pddc_pipeline {
      * written there, the gang launches them for all its members at once.                                          */
     struct GangRec *gang_rec = nullptr;
     struct pddc_gang *gang = nullptr;        /* the gang whose stream the last push used (NULL: the pipeline's own)   */
+    /* kernel selection (pddc_pipeline_set_option; defaults = what the measurements chose; the environment is looked at
+     * once, when the pipeline is created, never on the data path) */
+    struct Opts {
+        int no_i8 = 0;            /* 1: the vector kernels only (k_fir8)                                              */
+        int i8_128 = 1;           /* 65..128 taps without NCO on k_fir_i8 (0: k_fir8)                                 */
+        int i8x = 1;              /* tuned first stages (PDDC_F_MIX) on k_fir_i8x (0: k_fir8)                         */
+        int i8x_pair = 1;         /* ... and the cascade's first two stages as its fused pair (0: unfused, or k_fir8)  */
+        int i8x_plain = 0;        /* untuned first stages on k_fir_i8x too (LDS-carried history; 0: k_fir_i8 / k_fir8) */
+        int i8x_blocks = 0;       /* persistent grid override of k_fir_i8x (0: one block per CU)                       */
+        int no_fuse2 = 0, fuse3 = 0;
+    } opt;
+    /* k_fir_i8x's operands follow the tuning word: they are rebuilt on the host when the word, the taps or the form
+     * (mix / fused pair) change and travel to the device in stream order -- a retune is one 37..50 KB asynchronous copy.
+     * Four slots (pinned host staging + device copy) so that a launch queued earlier keeps reading its own table; a slot is
+     * reused only after everything that was queued when it was left has finished (its event).                         */
+    struct I8xSlot {
+        void *d = nullptr, *h = nullptr;
+        hipEvent_t left = nullptr;
+        bool left_valid = false;
+    };
+    struct I8x {
+        I8xSlot slot[4];
+        int cur = -1;
+        uint32_t freg = 0;
+        bool mix = false, fuse2 = false;
+        unsigned taps_ver = 0;
+        hipStream_t stream = nullptr;
+        float scale = 0.0f, ct[2] = { 0.0f, 0.0f };
+    } i8x;
+    unsigned taps_ver = 1;        /* bumped whenever a stage's taps change */
 };
+static constexpr size_t kI8xSlotBytes = 64 * 1024;     /* tables (<= 48 KB) + the second stage's taps at kI8xTaps2Off */
+static constexpr size_t kI8xTaps2Off = 60 * 1024;
 
 /* what one member's process() leaves for the gang: kind 0 = nothing recorded */
 struct GangRec {
@@ -193,8 +226,9 @@ struct pddc_gang {
 
 static bool stage0_fused(const pddc_pipeline *p);
 static bool stage0_packed_generic(const pddc_pipeline *p);
-static bool stage0_on_i8(const pddc_pipeline *p, size_t nsamples);
+static int stage0_i8_kind(const pddc_pipeline *p, size_t nsamples);
 static int setup_stage3(pddc_pipeline *p);
+static bool stages01_i8x(const pddc_pipeline *p, size_t nsamples);
 static int leave_gang(pddc_pipeline *p);
 static float *direct_out(pddc_pipeline::HostSlot &sl, void *h_out);
 
@@ -241,6 +275,7 @@ static int pick_ntb(int ntaps)
 static int upload_taps(pddc_pipeline *p, int si)
 {
     Stage &s = p->st[si];
+    p->taps_ver++;
     if (s.d_taps_base) {
         hipFree(s.d_taps_base);
         s.d_taps_base = nullptr;
@@ -287,6 +322,12 @@ static int upload_taps(pddc_pipeline *p, int si)
     }
     /* (the history length is fixed at create time -- 8 * tap blocks -- and not known yet when this runs for the first time) */
     const int i8_hist = s.hist ? s.hist : 8 * pick_ntb(s.ntaps);
+    {
+        double hmax = 0.0;
+        for (int k = 0; k < s.ntaps; ++k)
+            hmax = std::fmax(hmax, std::fabs((double)s.taps[k]));
+        s.i8x_ok = si == 0 && hmax > 0.0 && std::isfinite(hmax);
+    }
     if (si == 0 && stage_fused_capable(s) && s.ntaps <= i8_hist && (i8_hist == 128 || i8_hist == 256) &&
         !(p->flags & PDDC_F_NO_FAST)) {
         /* the long first stage on the int8 matrix cores (k_fir_i8): taps as four planes of balanced base-256 digits */
@@ -390,6 +431,29 @@ int pddc_fir_i8_table(const float *taps, int ntaps, int hist, int8_t *table, siz
 }
 
 /* host arithmetic only: the binary16 tap array k_fir_i8 reads under PDDC_F_TAPS_FP16, and the 2^E it scales them with */
+int pddc_fir_i8x_tables(const float *taps, int ntaps, int hist, int mix, uint32_t freg, int8_t *tables, size_t tables_bytes,
+                        float *scale, float *ct)
+{
+    if (!taps || !tables || !scale || !ct)
+        return fail(PDDC_EINVAL, "null argument");
+    if (!fir_i8x_supported(hist, mix != 0, false))
+        return fail(PDDC_EINVAL, "hist must be 32, 64, 128 or 256");
+    if (tables_bytes < fir_i8x_table_bytes(hist, mix != 0))
+        return fail(PDDC_EINVAL, "tables need %zu bytes", fir_i8x_table_bytes(hist, mix != 0));
+    if (!fir_i8x_build_tables(taps, ntaps, hist, mix != 0, freg, tables, scale, ct))
+        return fail(PDDC_EINVAL, "taps cannot be quantised (all zero, not finite, or more than hist)");
+    const int mode = fir_i8x_mode(hist, mix != 0);
+    return mode == 0 ? 1 : mode == 1 ? 2 : 3;
+}
+
+int pddc_fir_i8x_taps2(const float *taps2, int ntaps2, int mix, uint32_t freg, float *out, size_t out_len)
+{
+    if (!taps2 || !out || ntaps2 < 1 || ntaps2 > 64 || out_len < (size_t)kFirI8xTaps2Len)
+        return fail(PDDC_EINVAL, "bad argument (1..64 taps, %d floats out)", kFirI8xTaps2Len);
+    fir_i8x_taps2(taps2, ntaps2, mix != 0, freg, out);
+    return PDDC_OK;
+}
+
 int pddc_fir_i8_taps16(const float *taps, int ntaps, int hist, uint16_t *out, size_t out_len, double *two_e)
 {
     if (!taps || !out || !two_e)
@@ -864,6 +928,22 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
     p->device = device;
     p->flags = flags;
     p->nstages = nstages;
+    /* kernel selection: the environment is read HERE, once per pipeline, and never on the data path
+     * (pddc_pipeline_set_option changes it afterwards) */
+    {
+        auto env_int = [](const char *name, int dflt) {
+            const char *e = getenv(name);
+            return e ? atoi(e) : dflt;
+        };
+        p->opt.no_i8 = getenv("PDDC_NO_I8") ? 1 : 0;
+        p->opt.i8_128 = env_int("PDDC_I8_128", 1);
+        p->opt.i8x = env_int("PDDC_I8X", 1);
+        p->opt.i8x_pair = env_int("PDDC_I8X_PAIR", 1);
+        p->opt.i8x_plain = env_int("PDDC_I8X_PLAIN", 0);
+        p->opt.i8x_blocks = env_int("PDDC_I8X_BLOCKS", 0);
+        p->opt.no_fuse2 = getenv("PDDC_NO_FUSE2") ? 1 : 0;
+        p->opt.fuse3 = env_int("PDDC_FUSE3", 0);
+    }
     /* tuning knobs (development): outputs per lane and persistent grid size */
     if (const char *e = getenv("PDDC_FIR8_R"))
         if (atoi(e) == 4 || atoi(e) == 8)
@@ -994,6 +1074,14 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
         hipEventDestroy(e.first);
         hipEventDestroy(e.second);
     }
+    for (auto &sl : p->i8x.slot) {
+        if (sl.d)
+            hipFree(sl.d);
+        if (sl.h)
+            hipHostFree(sl.h);
+        if (sl.left)
+            hipEventDestroy(sl.left);
+    }
     if (p->d_sched)
         hipFree(p->d_sched);
     if (p->d_seam)
@@ -1057,6 +1145,47 @@ int pddc_pipeline_set_freg(pddc_pipeline *p, uint32_t freg)
 }
 
 uint32_t pddc_pipeline_get_phase_offset(const pddc_pipeline *p) { return p ? p->phase_off : 0; }
+
+/* kernel selection by API state (not by environment): name -> field */
+static int *option_field(pddc_pipeline *p, const char *name)
+{
+    if (!name)
+        return nullptr;
+    const struct {
+        const char *n;
+        int *f;
+    } tab[] = { { "no_i8", &p->opt.no_i8 },       { "i8_128", &p->opt.i8_128 },         { "i8x", &p->opt.i8x },
+                { "i8x_pair", &p->opt.i8x_pair }, { "i8x_plain", &p->opt.i8x_plain },   { "i8x_blocks", &p->opt.i8x_blocks },
+                { "no_fuse2", &p->opt.no_fuse2 }, { "fuse3", &p->opt.fuse3 } };
+    for (const auto &t : tab)
+        if (!strcmp(t.n, name))
+            return t.f;
+    return nullptr;
+}
+
+int pddc_pipeline_set_option(pddc_pipeline *p, const char *name, int value)
+{
+    if (!p)
+        return fail(PDDC_EINVAL, "null pipeline");
+    if (p->carry_pending)
+        return fail(PDDC_ESTATE, "overlap mode holds a tail back: pddc_pipeline_fence(p, stream) first");
+    int *f = option_field(p, name);
+    if (!f)
+        return fail(PDDC_EINVAL, "unknown option '%s'", name ? name : "(null)");
+    *f = value;
+    return PDDC_OK;
+}
+
+int pddc_pipeline_get_option(const pddc_pipeline *p, const char *name, int *value)
+{
+    if (!p || !value)
+        return fail(PDDC_EINVAL, "null argument");
+    int *f = option_field(const_cast<pddc_pipeline *>(p), name);
+    if (!f)
+        return fail(PDDC_EINVAL, "unknown option '%s'", name ? name : "(null)");
+    *value = *f;
+    return PDDC_OK;
+}
 
 int pddc_pipeline_set_center_freq(pddc_pipeline *p, double hz)
 {
@@ -1209,23 +1338,39 @@ static bool stage0_fused(const pddc_pipeline *p)
 
 int pddc_pipeline_uses_fused(const pddc_pipeline *p) { return p && stage0_fused(p) ? 1 : 0; }
 
-/* the long first stage (129..256 taps, /8, no NCO) runs on the int8 matrix cores: k_fir_i8 (PDDC_NO_I8: k_fir8 always) */
-static bool stage0_on_i8(const pddc_pipeline *p, size_t nsamples)
+/* how many tuning words do stage 0's history window [n0 - H, n0) and the batch behind it see?  1: one word, one offset */
+static size_t words_in_window(const pddc_pipeline *p)
 {
-    if (!stage0_fused(p) || (p->st[0].d_taps_i8 == nullptr && p->st[0].d_taps_f16 == nullptr) || (p->flags & PDDC_F_MIX) || nsamples < (size_t)p->st[0].hist ||
-        getenv("PDDC_NO_I8"))
-        return false;
-    if (p->st[0].hist == 256)
-        return true;
+    const long long w0 = (long long)p->n0 - (long long)p->st[0].hist;
+    size_t first = 0;
+    while (first + 1 < p->segs.size() && p->segs[first + 1].n_begin <= w0)
+        ++first;
+    return p->segs.size() - first;
+}
+
+/* Which kernel runs the decimate-by-8 first stage of this batch: 0 the vector kernel (k_fir8), 1 k_fir_i8 (65..256 taps,
+ * no NCO: the wire bytes on the int8 matrix cores), 2 k_fir_i8x (the same with the NCO folded into the taps -- every tuned
+ * first stage of 1..256 taps whose history window was mixed with the word in force: the one batch behind a retune goes
+ * through k_fir8, which re-mixes its packed history with the old word; the two share the stream state).          */
+static int stage0_i8_kind(const pddc_pipeline *p, size_t nsamples)
+{
+    const Stage &s0 = p->st[0];
+    if (!stage0_fused(p) || p->opt.no_i8 || nsamples < (size_t)s0.hist || s0.ntaps > s0.hist)
+        return 0;
+    if (p->flags & PDDC_F_MIX)
+        return p->opt.i8x && s0.i8x_ok && fir_i8x_supported(s0.hist, true, false) && words_in_window(p) == 1 ? 2 : 0;
+    if (p->opt.i8x_plain && s0.i8x_ok && !(p->flags & PDDC_F_TAPS_FP16) && fir_i8x_supported(s0.hist, false, false))
+        return 2;
+    if (s0.d_taps_i8 == nullptr && s0.d_taps_f16 == nullptr)
+        return 0;
     /* 65..128 taps: the vector kernel is HBM-bound there too, but since k_fir_i8's loader spreads its loads over the tile
      * step it streams at least as well -- 2^25: 757 -> 899 GS/s, 2^26: 725 -> 787, 2^27: 761 -> 809, 2^28: 0.3588-0.3616 ->
      * 0.3464-0.3483 ms (three alternating rounds on one box), 2^30 equal -- and it is the more accurate of the two
-     * (8e-8 against 2.9e-7).  PDDC_I8_128 = 0 forces the vector kernel (development). */
-    const char *e = getenv("PDDC_I8_128");
-    return e ? atoi(e) != 0 : true;
+     * (8e-8 against 2.9e-7).  Option i8_128 = 0 forces the vector kernel (development). */
+    return s0.hist == 256 || p->opt.i8_128 ? 1 : 0;
 }
 
-int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples) { return p && stage0_on_i8(p, nsamples) ? 1 : 0; }
+int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples) { return p ? stage0_i8_kind(p, nsamples) : 0; }
 
 /* a first stage that is a plain decimator but not the fused decimate-by-8 (e.g. the /10 of the
  * 1.6 MS/s plan): the generic kernel reads the packed samples itself (unpack and mix while it
@@ -1245,7 +1390,7 @@ int pddc_pipeline_stage0_reads_packed(const pddc_pipeline *p)
  * stages sit on an 8-sample phase boundary */
 static bool stages01_fusable(const pddc_pipeline *p, size_t nsamples)
 {
-    if (p->nstages < 2 || !stage0_fused(p) || getenv("PDDC_NO_FUSE2"))
+    if (p->nstages < 2 || !stage0_fused(p) || p->opt.no_fuse2)
         return false;
     const Stage &s0 = p->st[0], &s1 = p->st[1];
     if (s1.decim != 8 || s1.interp != 1 || s1.ntb != 8 || s1.hist != 64)
@@ -1256,9 +1401,83 @@ static bool stages01_fusable(const pddc_pipeline *p, size_t nsamples)
            s1.consumed % 8 == 0;
 }
 
+/* the cascade's first two stages as k_fir_i8x's fused pair: stage 0 on the matrix cores, stage 1 -- a plain decimate-by-8
+ * of <= 64 taps -- on its values while they are still in LDS; whole tiles of 8192 samples */
+static bool stages01_i8x(const pddc_pipeline *p, size_t nsamples)
+{
+    if (p->nstages < 2 || !p->opt.i8x_pair || p->opt.no_fuse2 || stage0_i8_kind(p, nsamples) != 2)
+        return false;
+    const Stage &s0 = p->st[0], &s1 = p->st[1];
+    if (s1.decim != 8 || s1.interp != 1 || s1.ntb != 8 || s1.hist != 64 || s1.ntaps > 64)
+        return false;
+    if (!fir_i8x_supported(s0.hist, (p->flags & PDDC_F_MIX) != 0, true))
+        return false;
+    return nsamples > 0 && nsamples % 8192 == 0 && s0.consumed % 8 == 0 && s1.consumed % 8 == 0;
+}
+
+/* k_fir_i8x's operands for the word in force (rebuilt and uploaded in stream order when word, taps, form or stream changed)
+ * and the constant part of its argument record */
+static int i8x_prepare(pddc_pipeline *p, bool mix, bool fuse2, hipStream_t s, FirI8xArgs &q)
+{
+    pddc_pipeline::I8x &x = p->i8x;
+    const Stage &s0 = p->st[0];
+    const uint32_t word = mix ? p->freg : 0u;
+    if (!(x.cur >= 0 && x.freg == word && x.mix == mix && x.fuse2 == fuse2 && x.taps_ver == p->taps_ver && x.stream == s)) {
+        if (x.cur >= 0) {
+            if (x.stream == s) {
+                HIP_TRY(hipEventRecord(x.slot[x.cur].left, s));
+                x.slot[x.cur].left_valid = true;
+            } else {
+                /* another stream (joining or leaving a gang): whatever reads the old tables there has to be through */
+                HIP_TRY(hipDeviceSynchronize());
+                for (auto &sl : x.slot)
+                    sl.left_valid = false;
+            }
+        }
+        const int nx = (x.cur + 1) & 3;
+        pddc_pipeline::I8xSlot &sl = x.slot[nx];
+        if (!sl.d) {
+            HIP_TRY(hipMalloc(&sl.d, kI8xSlotBytes));
+            HIP_TRY(hipHostMalloc(&sl.h, kI8xSlotBytes, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&sl.left, hipEventDisableTiming));
+        }
+        if (sl.left_valid) {
+            HIP_TRY(hipEventSynchronize(sl.left));
+            sl.left_valid = false;
+        }
+        if (fir_i8x_table_bytes(s0.hist, mix) > kI8xTaps2Off)
+            return fail(PDDC_EINVAL, "k_fir_i8x: tap tables do not fit their slot");
+        float sc = 0.0f, ct[2] = { 0.0f, 0.0f };
+        if (!fir_i8x_build_tables(s0.taps.data(), s0.ntaps, s0.hist, mix, word, static_cast<int8_t *>(sl.h), &sc, ct))
+            return fail(PDDC_EINVAL, "k_fir_i8x: the taps cannot be quantised (all zero, or not finite)");
+        float *t2 = reinterpret_cast<float *>(static_cast<uint8_t *>(sl.h) + kI8xTaps2Off);
+        if (fuse2)
+            fir_i8x_taps2(p->st[1].taps.data(), p->st[1].ntaps, mix, word, t2);
+        HIP_TRY(hipMemcpyAsync(sl.d, sl.h, kI8xSlotBytes, hipMemcpyHostToDevice, s));
+        x.cur = nx;
+        x.freg = word;
+        x.mix = mix;
+        x.fuse2 = fuse2;
+        x.taps_ver = p->taps_ver;
+        x.stream = s;
+        x.scale = sc;
+        x.ct[0] = ct[0];
+        x.ct[1] = ct[1];
+    }
+    q.atab = x.slot[x.cur].d;
+    q.taps2 = fuse2 ? reinterpret_cast<const float *>(static_cast<const uint8_t *>(x.slot[x.cur].d) + kI8xTaps2Off) : nullptr;
+    q.scale = x.scale;
+    q.ct[0] = x.ct[0];
+    q.ct[1] = x.ct[1];
+    q.n0 = p->n0;
+    q.freg = word;
+    q.phase_off = mix ? p->phase_off : 0u;
+    return PDDC_OK;
+}
+
 extern "C" int pddc_pipeline_uses_fused_pair(const pddc_pipeline *p, size_t nsamples)
 {
-    return p && stages01_fusable(p, nsamples) ? 1 : 0;
+    return p && (stages01_i8x(p, nsamples) ? 2 : stages01_fusable(p, nsamples) ? 1 : 0);
 }
 
 /* The whole cascade in one kernel: behind the fused pair, stage 2 -- a plain decimator at 1/64 of the input rate --
@@ -1307,8 +1526,7 @@ static int setup_stage3(pddc_pipeline *p)
  * waves lengthens it one for one; the tail costs less on OTHER waves (pddc_pipeline_set_overlap).                  */
 static bool stages012_fusable(const pddc_pipeline *p, size_t nsamples)
 {
-    const char *e = getenv("PDDC_FUSE3");
-    return p->s3_ok && p->nstages >= 3 && e && atoi(e) == 1 && stages01_fusable(p, nsamples);
+    return p->s3_ok && p->nstages >= 3 && p->opt.fuse3 == 1 && stages01_fusable(p, nsamples);
 }
 
 extern "C" int pddc_pipeline_uses_fused_cascade(const pddc_pipeline *p, size_t nsamples)
@@ -1682,10 +1900,39 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         if (mixed_hist || !stage0_fused(p) || p->NT != 256 || p->overlap || p->carry_pending ||
             p->time_stage0 || p->fail_at_stage >= 0 || (p->flags & (PDDC_F_OUT_PACKED24 | PDDC_F_NO_FAST)) ||
             stages012_fusable(p, nsamples) || !tail_ok || n_in[1] == 0 || nsamples < (size_t)p->st[0].hist ||
-            !fir8_many_supported(nfirst, p->st[0].ntb, p->R))
+            !fir8_many_supported(nfirst, p->st[0].ntb, p->R) ||
+            stage0_i8_kind(p, nsamples) != 0)        /* (the matrix-core kernels have no many-stream launch: such a member
+                                                        runs its own chain on the gang's stream -- the same bits as alone) */
             return 1;
     }
-    if (!mixed_hist && stages012_fusable(p, nsamples)) {
+    const int i8kind = mixed_hist ? 0 : stage0_i8_kind(p, nsamples);
+    if (i8kind == 2 && stages01_i8x(p, nsamples) && !stages012_fusable(p, nsamples)) {
+        /* stages 0 and 1 as k_fir_i8x's fused pair: stage 0 on the int8 matrix cores with the NCO in its taps, stage 1 on
+         * its values while they are in LDS.  The stage behind the pair runs in line (no carried tail on this kernel). */
+        Stage &s0 = p->st[0], &s1 = p->st[1];
+        float *dst;
+        if ((rc = pddc_pipeline_fence(p, s)))
+            return rc;
+        if ((rc = stage_dst(1, &dst, true)))
+            return rc;
+        FirI8xArgs q;
+        if ((rc = i8x_prepare(p, mix, true, s, q)))
+            return rc;
+        q.in = d_packed;
+        q.hist = s0.d_hist[s0.cur];
+        q.hist_out = s0.d_hist[s0.cur ^ 1];
+        q.out = dst;
+        q.n_in = (long long)nsamples;
+        q.hist2 = s1.d_hist[s1.cur];
+        q.hist2_out = s1.d_hist[s1.cur ^ 1];
+        if ((rc = stage0_event(p, s, true)))
+            return rc;
+        HIP_TRY(launch_fir_i8x(q, s0.hist, mix, true, s, p->opt.i8x_blocks));
+        if ((rc = stage0_event(p, s, false)))
+            return rc;
+        flip[0] = flip[1] = true;
+        first = 2;
+    } else if (!mixed_hist && stages012_fusable(p, nsamples)) {
         /* stages 0, 1 and 2 in ONE kernel: neither intermediate touches HBM */
         Stage &s0 = p->st[0], &s1 = p->st[1];
         float *dst;
@@ -1821,7 +2068,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         } else if (i == 0 && stage0_fused(p)) {
             /* overlap mode, two-stage plan: stage 1 is held back and rides along with the next batch's stage 0 */
             GenTail mine;
-            bool ov = !g && carry_wanted(1) && p->NT == 256;
+            bool ov = !g && carry_wanted(1) && p->NT == 256 && i8kind != 2;   /* (k_fir_i8x carries no tail: in line) */
             if (ov) {
                 rc = carry_setup(1, &dst, &mine, p->ov_parity == 1, kCarryLdsCap);
                 if (rc < 0)
@@ -1856,8 +2103,19 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                     flip[1] = true;
                     skip_from = 1;
                 }
-            } else if (stage0_on_i8(p, nsamples) && !ov) {
-                /* 129..256 taps, no NCO: the int8 matrix cores (same history, same outputs to 1e-7 of full scale) */
+            } else if (i8kind == 2 && !ov) {
+                /* the NCO in the taps, the wire bytes on the int8 matrix cores (k_fir_i8x; same history as k_fir8) */
+                FirI8xArgs q;
+                if ((rc = i8x_prepare(p, mix, false, s, q)))
+                    return rc;
+                q.in = d_packed;
+                q.hist = h_in;
+                q.hist_out = a.hist_out;
+                q.out = dst;
+                q.n_in = (long long)nsamples;
+                HIP_TRY(launch_fir_i8x(q, st.hist, mix, false, s, p->opt.i8x_blocks));
+            } else if (i8kind == 1 && !ov) {
+                /* 65..256 taps, no NCO: the int8 matrix cores (same history, same outputs to 1e-7 of full scale) */
                 FirI8Args q;
                 q.in = d_packed;
                 q.hist = h_in;
@@ -2668,7 +2926,23 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     a.n_in = (long long)nsamples;
     fill_fir8_args(p, a);
     const bool mix = (p->flags & PDDC_F_MIX) != 0;
-    const bool i8 = !fuse2 && !fuse3 && stage0_on_i8(p, nsamples);     /* what process() would launch for this batch */
+    const int i8kind = stage0_i8_kind(p, nsamples);                    /* what process() would launch for this batch */
+    const bool x2 = !fuse3 && i8kind == 2 && stages01_i8x(p, nsamples);
+    const bool x1 = !fuse3 && !x2 && !fuse2 && i8kind == 2;
+    const bool i8 = !fuse2 && !fuse3 && i8kind == 1;
+    FirI8xArgs qx;
+    if (x1 || x2) {
+        int rc = i8x_prepare(p, mix, x2, s, qx);
+        if (rc)
+            return rc;
+        qx.in = d_packed;
+        qx.hist = a.hist;
+        qx.hist_out = nullptr;
+        qx.out = a.out;
+        qx.n_in = (long long)nsamples;
+        qx.hist2 = p->st[1].d_hist[p->st[1].cur];
+        qx.hist2_out = nullptr;
+    }
     FirI8Args q;
     q.in = d_packed;
     q.hist = a.hist;
@@ -2687,6 +2961,8 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     for (int i = 0; i < iters; ++i) {
         if (fuse3)
             HIP_TRY(launch_fir8_fused3(p->st[0].ntb, p->R, mix, a, s));
+        else if (x1 || x2)
+            HIP_TRY(launch_fir_i8x(qx, p->st[0].hist, mix, x2, s, p->opt.i8x_blocks));
         else if (fuse2)
             HIP_TRY(launch_fir8_fused2(p->st[0].ntb, p->R, mix, a, s));
         else if (i8)

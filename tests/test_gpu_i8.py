@@ -29,11 +29,8 @@ def run(pkg, dev, stages, packed, cuts, monkeypatch=None, no_i8_at=()):
     parts, on = [], []
     for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
         if monkeypatch is not None:
-            if k in no_i8_at:
-                monkeypatch.setenv("PDDC_NO_I8", "1")
-            else:
-                monkeypatch.delenv("PDDC_NO_I8", raising=False)
-        on.append(pipe.on_i8(b - a))
+            pipe.set_option("no_i8", 1 if k in no_i8_at else 0)      # kernel selection is API state, per pipeline
+        on.append(bool(pipe.on_i8(b - a)))
         parts.append(pipe.process(to_dev(packed[6 * a:6 * b], dev)).cpu().numpy().reshape(-1))
     pipe.close()
     return np.concatenate(parts), on
@@ -57,7 +54,7 @@ def test_i8_first_stage_vs_oracle_ragged_batches(pkg, dev, O, ntaps):
 
 def test_i8_and_fp32_kernels_alternate_on_one_stream(pkg, dev, O, monkeypatch):
     """k_fir_i8 and k_fir8 keep the same stream state (256 packed history samples): switching between them batch by
-    batch -- PDDC_NO_I8 read per call -- still gives the oracle's stream, and the two agree with each other to 1e-6."""
+    batch -- option no_i8 flipped between calls -- still gives the oracle's stream, and the two agree with each other to 1e-6."""
     h = load_taps("d8_255")
     sizes = [1 << 16, 8192 * 5 + 24, 1 << 15, 1 << 17, 8192, 1 << 16]
     cuts = np.concatenate([[0], np.cumsum(sizes)])
@@ -146,14 +143,23 @@ def test_i8_binary16_taps_set_taps_and_checkpoint(pkg, dev, O):
     other.close()
 
 
-def test_nco_and_short_filters_keep_the_vector_kernel(pkg, dev):
+def test_which_first_stages_run_where(pkg, dev):
     h = load_taps("d8_255")
     p = pkg.Pipeline([(8, h)], mix=True)
-    assert not p.on_i8(1 << 20)                                  # the mix happens before the filter, in floats
+    assert p.on_i8(1 << 20) == 2                                 # tuned: k_fir_i8x, the NCO folded into the taps
+    p.set_option("i8x", 0)
+    assert p.on_i8(1 << 20) == 0                                 # ... unless switched off: k_fir8 mixes in floats
+    p.close()
+    p = pkg.Pipeline([(8, h)])
+    assert p.on_i8(1 << 20) == 1                                 # untuned, 65..256 taps: k_fir_i8
     p.close()
     p = pkg.Pipeline([(8, load_taps("c320_s1_d8_32"))])
-    assert not p.on_i8(1 << 20)                                  # up to 64 taps: the band would be mostly zeros
+    assert p.on_i8(1 << 20) == 0                                 # untuned, up to 64 taps: the vector kernel streams as well
+    p.set_option("i8x_plain", 1)
+    assert p.on_i8(1 << 20) == 2
     p.close()
     p = pkg.Pipeline([(8, h)], no_fast=True)
     assert not p.on_i8(1 << 20)
     p.close()
+    with pytest.raises(pkg.PddcError):
+        pkg.Pipeline([(8, h)]).set_option("no_such_option", 1)

@@ -1,0 +1,196 @@
+"""GPU tests (-m gpu) of k_fir_i8x (ddc_fir_i8.hip): the tuned decimate-by-8 first stage on the int8 matrix cores with the
+NCO folded into the taps -- y[m] = LO(n0 + 8m) sum_k (h[k] e^{+j theta k}) x_raw[8m - k] -- and the cascade's first two
+stages as its fused pair.  This is the kernel every pipeline of the drop-in API runs behind perseus_set_ddc_center_freq /
+perseus_start_async_input (perseus-sdr.c:556-692).  Bar: max|y - ref| / max|ref| <= 1e-6 against the CPU oracle's
+mix-then-filter definition, through the C ABI, on the stream state k_fir8 keeps (packed history, 64 mixed
+first-stage outputs), so the kernels can alternate batch by batch -- which they do around a retune."""
+import numpy as np
+import pytest
+
+from conftest import load_taps
+
+pytestmark = pytest.mark.gpu
+FIR_TOL = 1e-6
+FREG = 381178347                                   # 7.1 MHz (perseus-sdr.c:584), BASELINE config 3
+TILE = 8192
+
+
+def to_dev(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def lowpass(ntaps, cutoff):
+    k = np.arange(ntaps) - (ntaps - 1) / 2.0
+    h = np.sinc(2 * cutoff * k) * np.hamming(ntaps)
+    return (h / h.sum()).astype(np.float32)
+
+
+def run(pkg, dev, stages, packed, cuts, freg=FREG, mix=True, opts=None, retune_at=None, record=None):
+    pipe = pkg.Pipeline(stages, mix=mix)
+    for k, v in (opts or {}).items():
+        pipe.set_option(k, v)
+    if mix:
+        pipe.set_freg(freg)
+    parts = []
+    for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if retune_at and k in retune_at:
+            pipe.set_freg(retune_at[k])
+        if record is not None:
+            record.append((pipe.on_i8(b - a), pipe.fused_pair(b - a)))
+        parts.append(pipe.process(to_dev(packed[6 * a:6 * b], dev)).cpu().numpy().reshape(-1))
+    pipe.close()
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("ntaps", [9, 32, 33, 48, 64, 65, 100, 127, 128, 160, 255, 256])
+def test_tuned_first_stage_vs_oracle_ragged_batches(pkg, dev, O, ntaps):
+    """Every geometry (32 / 64 / 128 / 256 samples of history; two tap sets per wave up to 64 taps, split over waves
+    above), batches of whole tiles, ragged ones, more tiles than CUs (several tiles per block: the history travels inside
+    LDS), tiny ones (below the history length: k_fir8's path on the same state)."""
+    h = load_taps("d8_255") if ntaps == 255 else load_taps("d8_127") if ntaps == 127 else lowpass(ntaps, 0.05)
+    hist = 32 if ntaps <= 32 else 64 if ntaps <= 64 else 128 if ntaps <= 128 else 256
+    sizes = [TILE * 3, TILE + 8, 264, 8, 128, 256, TILE * 40 + 4096 + 16, TILE * 600, TILE * 2 - 8, TILE * 257]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    packed = O.lcg_bytes(6 * int(cuts[-1]), 2027)
+    ref = O.ddc_chain(packed, [(8, h)], freg=FREG, mix=True)
+    rec = []
+    y = run(pkg, dev, [(8, h)], packed, cuts, record=rec)
+    assert [r[0] for r in rec] == [2 if s >= hist else 0 for s in sizes]
+    assert y.size == ref.size
+    assert O.rel_err(y, ref) <= FIR_TOL, (ntaps, O.rel_err(y, ref))
+
+
+@pytest.mark.parametrize("word", [1, 0x7FFFFFFF, 0xFFFFFFF0, 0x40000000, 123456789])
+def test_tuning_words_at_the_edges(pkg, dev, O, word):
+    h = load_taps("d8_127")
+    ns = TILE * 5 + 808
+    packed = O.lcg_bytes(6 * ns, 11)
+    ref = O.ddc_chain(packed, [(8, h)], freg=word, mix=True)
+    y = run(pkg, dev, [(8, h)], packed, [0, TILE * 2, ns], freg=word)
+    assert O.rel_err(y, ref) <= FIR_TOL, (word, O.rel_err(y, ref))
+
+
+@pytest.mark.parametrize("taps12", [(48, 56), (32, 64), (17, 33), (64, 64)])
+@pytest.mark.parametrize("mix", [True, False])
+def test_fused_pair_vs_oracle(pkg, dev, O, taps12, mix):
+    """Stages 0 and 1 in one kernel: batches of one tile, a few, more tiles than CUs (warm-up tiles in front of every
+    block's range), and a ragged batch in between (unfused path, same state)."""
+    h1, h2 = lowpass(taps12[0], 0.05), lowpass(taps12[1], 0.05)
+    sizes = [TILE, TILE * 3, TILE * 2 + 64, TILE * 300, TILE * 7, 512, TILE * 513]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    packed = O.lcg_bytes(6 * int(cuts[-1]), 4242)
+    ref = O.ddc_chain(packed, [(8, h1), (8, h2)], freg=FREG if mix else 0, mix=mix)
+    rec = []
+    y = run(pkg, dev, [(8, h1), (8, h2)], packed, cuts, mix=mix, opts=None if mix else {"i8x_plain": 1}, record=rec)
+    assert [r[1] for r in rec] == [2 if s % TILE == 0 else 0 for s in sizes], rec
+    assert y.size == ref.size
+    assert O.rel_err(y, ref) <= FIR_TOL, O.rel_err(y, ref)
+
+
+def test_cascade_x320_on_the_matrix_cores_vs_oracle_and_vs_the_vector_kernels(pkg, dev, O):
+    """BASELINE config 3's shape with the drop-in API's tap counts (48 / 56 / 144): pair on k_fir_i8x, the /5 tail in line;
+    against the oracle and against the same plan on the vector kernels (option i8x = 0)."""
+    stages = [(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05)), (5, lowpass(144, 0.08))]
+    sizes = [TILE * 40, TILE * 5, TILE * 320, TILE * 3]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    packed = O.lcg_bytes(6 * int(cuts[-1]), 320)
+    ref = O.ddc_chain(packed, stages, freg=FREG, mix=True)
+    y = run(pkg, dev, stages, packed, cuts)
+    yv = run(pkg, dev, stages, packed, cuts, opts={"i8x": 0})
+    assert y.size == ref.size == yv.size
+    assert O.rel_err(y, ref) <= FIR_TOL, O.rel_err(y, ref)
+    assert O.rel_err(yv, ref) <= FIR_TOL
+    assert O.rel_err(y, yv) <= FIR_TOL
+
+
+def test_retune_between_batches_goes_through_the_vector_kernel_once(pkg, dev, O):
+    """A new tuning word takes effect at a batch boundary, phase-continuously; the batch behind it sees two words in its
+    history window and runs on k_fir8 (which re-mixes its packed history with the old word), the next one is back on the
+    matrix cores with tables for the new word -- single stage and fused pair."""
+    f1, f2, f3 = FREG, 123456789, 0xC0000001
+    for stages in ([(8, load_taps("d8_127"))], [(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05))]):
+        nb = TILE * 6
+        packed = O.lcg_bytes(6 * 6 * nb, 77)
+        ref = O.ddc_chain_retuned(packed, stages, [(0, f1), (2 * nb, f2), (4 * nb, f3)])
+        rec = []
+        y = run(pkg, dev, stages, packed, [k * nb for k in range(7)], freg=f1, retune_at={2: f2, 4: f3}, record=rec)
+        assert [r[0] for r in rec] == [2, 2, 0, 2, 0, 2], rec
+        assert O.rel_err(y, ref) <= FIR_TOL, O.rel_err(y, ref)
+
+
+def test_matrix_and_vector_kernels_alternate_on_one_stream(pkg, dev, O):
+    """option i8x flipped between calls: k_fir_i8x and k_fir8 (single stage and fused pair) continue each other's stream"""
+    import torch
+    for stages in ([(8, load_taps("d8_127"))], [(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05))]):
+        sizes = [TILE * 4, TILE * 9, TILE * 2, TILE * 300, TILE, TILE * 5]
+        cuts = np.concatenate([[0], np.cumsum(sizes)])
+        packed = O.lcg_bytes(6 * int(cuts[-1]), 5)
+        ref = O.ddc_chain(packed, stages, freg=FREG, mix=True)
+        pipe = pkg.Pipeline(stages, mix=True)
+        pipe.set_freg(FREG)
+        parts = []
+        for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            pipe.set_option("i8x", k % 2)
+            assert pipe.on_i8(b - a) == (2 if k % 2 else 0)
+            parts.append(pipe.process(to_dev(packed[6 * a:6 * b], dev)).cpu().numpy().reshape(-1))
+        pipe.close()
+        assert O.rel_err(np.concatenate(parts), ref) <= FIR_TOL
+
+
+def test_checkpoint_resume_and_set_taps_on_the_matrix_core_path(pkg, dev, O):
+    import ctypes as C
+    stages = [(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05))]
+    ns = TILE * 12
+    packed = O.lcg_bytes(6 * ns, 8)
+    ref = O.ddc_chain(packed, stages, freg=FREG, mix=True)
+    a = pkg.Pipeline(stages, mix=True)
+    a.set_freg(FREG)
+    half = TILE * 5
+    y1 = a.process(to_dev(packed[:6 * half], dev)).cpu().numpy().reshape(-1)
+    blob = a.save_state()
+    b = pkg.Pipeline(stages, mix=True)
+    b.restore_state(blob)
+    assert b.fused_pair(ns - half) == 2
+    y2 = b.process(to_dev(packed[6 * half:], dev)).cpu().numpy().reshape(-1)
+    assert O.rel_err(np.concatenate([y1, y2]), ref) <= FIR_TOL
+    # new taps: the tables follow
+    g = lowpass(40, 0.03)
+    pkg.check(pkg.ddc_lib().pddc_pipeline_set_taps(a._h, 0, g.ctypes.data_as(C.POINTER(C.c_float)), g.size))
+    a.reset()
+    y = a.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+    assert O.rel_err(y, O.ddc_chain(packed, [(8, g), stages[1]], freg=FREG, mix=True)) <= FIR_TOL
+    a.close()
+    b.close()
+
+
+def test_untuned_first_stage_on_the_same_kernel(pkg, dev, O):
+    """option i8x_plain: the no-NCO form (contiguous tile ranges, history carried in LDS) gives k_fir_i8's results"""
+    for ntaps in (127, 255, 48):
+        h = load_taps("d8_255") if ntaps == 255 else load_taps("d8_127") if ntaps == 127 else lowpass(ntaps, 0.05)
+        sizes = [TILE * 3 + 8, TILE * 290, 264, TILE * 2]
+        cuts = np.concatenate([[0], np.cumsum(sizes)])
+        packed = O.lcg_bytes(6 * int(cuts[-1]), 6)
+        ref = O.ddc_chain(packed, [(8, h)])
+        y = run(pkg, dev, [(8, h)], packed, cuts, mix=False, opts={"i8x_plain": 1})
+        assert O.rel_err(y, ref) <= FIR_TOL, (ntaps, O.rel_err(y, ref))
+
+
+def test_full_scale_extremes_through_the_tuned_stage(pkg, dev, O):
+    """every sample at +- full scale, taps of one sign at the 64-tap limit (two band products in one accumulator set) and at
+    256 taps (four float partial products)"""
+    rng = np.random.default_rng(5)
+    ns = TILE * 6 + 40
+    v = np.where(rng.random((ns, 2)) < 0.5, -(1 << 23), (1 << 23) - 1).astype(np.int64)
+    v[: ns // 3] = (1 << 23) - 1
+    v[ns // 3: 2 * ns // 3] = -(1 << 23)
+    b = np.zeros((ns, 2, 3), np.uint8)
+    for i in range(3):
+        b[:, :, i] = (v >> (8 * i)) & 0xFF
+    packed = b.reshape(-1)
+    for n in (64, 256):
+        h = (np.ones(n, np.float32) / n * (1 + 1e-3 * np.arange(n))).astype(np.float32)
+        for word in (1 << 29, 3):
+            ref = O.ddc_chain(packed, [(8, h)], freg=word, mix=True)
+            y = run(pkg, dev, [(8, h)], packed, [0, TILE * 2, ns], freg=word)
+            assert O.rel_err(y, ref) <= FIR_TOL, (n, word, O.rel_err(y, ref))

@@ -1,0 +1,215 @@
+"""CPU tests of k_fir_i8x's arithmetic (ddc_fir_i8.hip; operands from pddc_fir_i8x_tables / pddc_fir_i8x_taps2, host
+arithmetic, no GPU).  The kernel folds the NCO into the taps,
+    y[m] = LO(n0 + 8 m) * sum_k (h[k] e^{+j theta k}) x_raw[8 m - k],      theta = 2 pi freg / 2^32,
+so that the int8 matrix cores work on the wire bytes themselves and the phase is applied once per output.  Everything it
+does is integer and exact up to the recombination, so it can be restated in numpy from the tables alone: byte planes,
+digit planes of the cosine and sine tap sets, the band products, their combination in the kernel's two forms (mode 1:
+four partial products meet as floats; mode 2: both band products in one set of integer accumulators), the rotation with
+the exact 32-bit phase, and the fused second stage with its complex taps.  Checked against the oracle's mix-then-filter
+definition (perseus-sdr.c:584 for the tuning word)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_taps
+
+FREG = 381178347              # 7.1 MHz (perseus-sdr.c:584), BASELINE config 3
+
+
+def lowpass(ntaps, cutoff):
+    k = np.arange(ntaps) - (ntaps - 1) / 2.0
+    h = np.sinc(2 * cutoff * k) * np.hamming(ntaps)
+    return (h / h.sum()).astype(np.float32)
+
+
+def tables(pkg, h, hist, mix, freg):
+    L = pkg.ddc_lib()
+    ks = (120 + hist + 63) // 64
+    ntab = 1 if not mix else (3 if hist <= 64 else 2)
+    tab = np.zeros(ntab * 4 * ks * 64 * 16, np.int8)
+    sc, ct = C.c_float(), (C.c_float * 2)()
+    h = np.ascontiguousarray(h, np.float32)
+    n = pkg.check(L.pddc_fir_i8x_tables(h.ctypes.data_as(C.POINTER(C.c_float)), h.size, hist, int(mix), freg,
+                                        tab.ctypes.data, tab.nbytes, C.byref(sc), ct))
+    assert n == ntab
+    return tab.reshape(ntab, 4, ks, 64, 16), sc.value, (ct[0], ct[1])
+
+
+def band(tab):
+    """one table -> the integer Toeplitz band T[16][64 ksteps] (digits recombined)"""
+    ks = tab.shape[1]
+    T = np.zeros((4, 16, 64 * ks), np.int64)
+    for k in range(ks):
+        for lane in range(64):
+            T[:, lane & 15, 64 * k + 16 * (lane >> 4):64 * k + 16 * (lane >> 4) + 16] = tab[:, k, lane, :]
+    return T
+
+
+def byte_planes(packed, hist, K):
+    b = packed.reshape(-1, 2, 3).astype(np.int64)
+    pl = np.stack([b[:, :, 0] - 128, b[:, :, 1] - 128, np.where(b[:, :, 2] >= 128, b[:, :, 2] - 256, b[:, :, 2])])
+    zero = np.array([-128, -128, 0], np.int64)[:, None, None]            # the planes of a zero sample
+    return np.concatenate([np.broadcast_to(zero, (3, hist, 2)), pl, np.broadcast_to(zero, (3, K + 128, 2))], axis=1)
+
+
+def plane_products(T, X):
+    """the nine plane products of one band with one component's planes X[i][c] -> the float the kernel recombines"""
+    acc = np.zeros((4, 16), np.int64)
+    for i in range(3):
+        for j in range(4):
+            if i + j >= 2:
+                acc[i + j - 2] += T[j] @ X[i]
+    return acc
+
+
+def recombine(acc):
+    a = acc.astype(np.float32)
+    return ((a[0] * np.float32(65536.0) + a[1] * np.float32(16777216.0)) +
+            (a[2] * np.float32(4294967296.0) + a[3] * np.float32(1099511627776.0)))
+
+
+def lo(freg, n, off=0):
+    ph = (np.asarray(n, np.uint64) * np.uint64(freg) + np.uint64(off)) & np.uint64(0xFFFFFFFF)
+    th = 2.0 * np.pi * ph.astype(np.float64) / 4294967296.0
+    return np.cos(th).astype(np.float32), (-np.sin(th)).astype(np.float32)      # nco_lo's c, s: LO = c + j s
+
+
+def restated_first_stage(tabs, scale, ct, hist, packed, mix):
+    """u[m] (before the rotation) of a batch that starts a stream, as the kernel forms it"""
+    Ts = [band(t) for t in tabs]
+    K = Ts[0].shape[2]
+    xp = byte_planes(packed, hist, K)
+    n_out = packed.size // 48
+    u = np.zeros((n_out, 2), np.float32)
+    scale = np.float32(scale)
+    for col in range((n_out + 15) // 16):
+        X = xp[:, 128 * col:128 * col + K, :]
+        XI, XQ = X[:, :, 0], X[:, :, 1]
+        if not mix:
+            y = [recombine(plane_products(Ts[0], Xc)) * scale + np.float32(ct[c]) for c, Xc in enumerate((XI, XQ))]
+        elif len(Ts) == 3:                                       # mode 2: one set of integer accumulators per component
+            aI = plane_products(Ts[0], XI) + plane_products(Ts[2], XQ)
+            aQ = plane_products(Ts[1], XI) + plane_products(Ts[0], XQ)
+            assert max(np.abs(aI).max(), np.abs(aQ).max()) < 1 << 24
+            y = [recombine(aI) * scale + np.float32(ct[0]), recombine(aQ) * scale + np.float32(ct[1])]
+        else:                                                    # mode 1: four float partial products
+            P = [[recombine(plane_products(Ts[t], Xc)) * scale for Xc in (XI, XQ)] for t in range(2)]
+            y = [(P[0][0] - P[1][1]) + np.float32(ct[0]), (P[1][0] + P[0][1]) + np.float32(ct[1])]
+        m = min(16, n_out - 16 * col)
+        u[16 * col:16 * col + m, 0] = y[0][:m]
+        u[16 * col:16 * col + m, 1] = y[1][:m]
+    return u
+
+
+def rotate(u, freg, step, off=0, n0=0):
+    c, s = lo(freg, n0 + step * np.arange(u.shape[0], dtype=np.uint64), off)
+    return np.stack([u[:, 0] * c - u[:, 1] * s, u[:, 0] * s + u[:, 1] * c], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("ntaps,hist", [(127, 128), (255, 256), (100, 128), (48, 64), (64, 64), (32, 32), (17, 32)])
+def test_restated_nco_first_stage_matches_the_oracle(pkg, O, ntaps, hist):
+    h = load_taps("d8_127") if ntaps == 127 else load_taps("d8_255") if ntaps == 255 else lowpass(ntaps, 0.05)
+    packed = O.lcg_bytes(6 * 8 * 600, 9)
+    ref = O.ddc_chain(packed, [(8, h)], freg=FREG, mix=True)
+    tabs, scale, ct = tables(pkg, h, hist, True, FREG)
+    assert tabs.shape[0] == (3 if hist <= 64 else 2)
+    y = rotate(restated_first_stage(tabs, scale, ct, hist, packed, True), FREG, 8).reshape(-1)
+    assert y.size == ref.size and O.rel_err(y, ref) <= 3e-7, O.rel_err(y, ref)
+
+
+def test_tables_hold_the_rotated_taps_and_their_negative(pkg):
+    h = lowpass(56, 0.05)
+    tabs, scale, ct = tables(pkg, h, 64, True, FREG)
+    E = 30 - int(np.ceil(np.log2(np.abs(h).max())))
+    th = 2 * np.pi * ((np.arange(56, dtype=np.uint64) * np.uint64(FREG)) & np.uint64(0xFFFFFFFF)).astype(np.float64) / 2.0 ** 32
+    want_c = np.rint(np.ldexp(h.astype(np.float64), E) * np.cos(th)).astype(np.int64)
+    want_s = np.rint(np.ldexp(h.astype(np.float64), E) * np.sin(th)).astype(np.int64)
+    for t, want in ((0, want_c), (1, want_s), (2, -want_s)):
+        T = band(tabs[t])
+        H = np.array([sum(int(T[j, 0, 64 - k]) << (8 * j) for j in range(4)) for k in range(56)])   # row 0: tt = c = hist - k
+        assert np.abs(H - want).max() <= 1, t                                                    # (rint vs llround on exact halves)
+    unit = np.ldexp(1.0, -E) / 8388607.0
+    assert abs(scale - unit) <= 1e-7 * unit
+    assert abs(ct[0] - float(want_c.sum() - want_s.sum()) * 32896.0 * unit) <= 1e-6 * abs(ct[0]) + 1e-9
+    assert abs(ct[1] - float(want_c.sum() + want_s.sum()) * 32896.0 * unit) <= 1e-6 * abs(ct[1]) + 1e-9
+
+
+def test_without_the_nco_the_table_is_k_fir_i8s(pkg):
+    h = load_taps("d8_127")
+    tabs, scale, ct = tables(pkg, h, 128, False, 0)
+    L = pkg.ddc_lib()
+    old = np.zeros(4 * 4 * 64 * 16, np.int8)
+    sc, c0 = C.c_float(), C.c_float()
+    pkg.check(L.pddc_fir_i8_table(h.ctypes.data_as(C.POINTER(C.c_float)), h.size, 128, old.ctypes.data, old.nbytes,
+                                  C.byref(sc), C.byref(c0)))
+    assert np.array_equal(tabs[0].reshape(-1), old)
+    assert abs(scale - sc.value) <= 1e-7 * scale and abs(ct[0] - c0.value) <= 1e-6 * abs(c0.value) + 1e-12 and ct[0] == ct[1]
+
+
+@pytest.mark.parametrize("mix", [True, False])
+def test_restated_fused_pair_matches_the_oracle(pkg, O, mix):
+    """second stage on the first stage's u values: complex taps g2[k] = h2[k] e^{+j 8 theta k} in descending order, one
+    rotation with the phase of input sample 64 P -- as thread p of the kernel walks its window"""
+    L = pkg.ddc_lib()
+    h1, h2 = lowpass(48, 0.05), lowpass(56, 0.05)
+    freg = FREG if mix else 0
+    packed = O.lcg_bytes(6 * 64 * 150, 3)
+    ref = O.ddc_chain(packed, [(8, h1), (8, h2)], freg=freg, mix=mix)
+    tabs, scale, ct = tables(pkg, h1, 64, mix, freg)
+    u = restated_first_stage(tabs, scale, ct, 64, packed, mix)
+    g = np.zeros(136, np.float32)
+    pkg.check(L.pddc_fir_i8x_taps2(h2.ctypes.data_as(C.POINTER(C.c_float)), h2.size, int(mix), freg,
+                                   g.ctypes.data_as(C.POINTER(C.c_float)), g.size))
+    gre, gim = g[:65].astype(np.float64), g[68:133].astype(np.float64)
+    if not mix:
+        assert not gim.any() and np.array_equal(g[64 - np.arange(56)], h2)
+    up = np.concatenate([np.zeros((64, 2), np.float32), u]).astype(np.float64)           # the porch: zeros at a stream's start
+    nz = u.shape[0] // 8
+    z = np.zeros((nz, 2), np.float32)
+    for P in range(nz):
+        w = up[8 * P:8 * P + 65]                                                          # u[8P - 64 .. 8P]
+        zr = (gre * w[:, 0]).sum() - (gim * w[:, 1]).sum()
+        zi = (gre * w[:, 1]).sum() + (gim * w[:, 0]).sum()
+        z[P] = (zr, zi)
+    if mix:
+        z = rotate(z, freg, 64)
+    assert z.size == ref.size and O.rel_err(z.reshape(-1), ref) <= 3e-7, O.rel_err(z.reshape(-1), ref)
+
+
+def test_extremes_stay_inside_the_accumulators(pkg, O):
+    """mode 2 adds two band products into one accumulator set: taps of one sign at the 64-tap limit, samples at the
+    extremes, a tuning word that keeps cos and sin near 0.7 -- the accumulators stay below 2^24 (exact float conversion)"""
+    h = (np.ones(64, np.float32) / 64 * (1 + 1e-3 * np.arange(64))).astype(np.float32)
+    freg = 1 << 29                                                # 45 degrees per sample
+    ns = 8 * 200
+    v = np.full((ns, 2), (1 << 23) - 1, np.int64)
+    v[ns // 2:] = -(1 << 23)
+    b = np.zeros((ns, 2, 3), np.uint8)
+    for i in range(3):
+        b[:, :, i] = (v >> (8 * i)) & 0xFF
+    packed = b.reshape(-1)
+    tabs, scale, ct = tables(pkg, h, 64, True, freg)
+    y = rotate(restated_first_stage(tabs, scale, ct, 64, packed, True), freg, 8).reshape(-1)
+    ref = O.ddc_chain(packed, [(8, h)], freg=freg, mix=True)
+    assert O.rel_err(y, ref) <= 3e-7, O.rel_err(y, ref)
+
+
+def test_tables_refuse_what_they_cannot_hold(pkg):
+    L = pkg.ddc_lib()
+    buf = np.zeros(3 * 4 * 6 * 1024, np.int8)
+    sc, ct = C.c_float(), (C.c_float * 2)()
+    h = np.zeros(60, np.float32)
+
+    def call(n, hist, mix, nbytes):
+        return L.pddc_fir_i8x_tables(h.ctypes.data_as(C.POINTER(C.c_float)), n, hist, mix, FREG, buf.ctypes.data, nbytes,
+                                     C.byref(sc), ct)
+
+    assert call(60, 64, 1, buf.nbytes) < 0                          # all-zero taps
+    h[5] = 0.25
+    assert call(60, 64, 1, buf.nbytes) == 3
+    assert call(60, 128, 1, buf.nbytes) == 2
+    assert call(60, 64, 0, buf.nbytes) == 1
+    assert call(60, 32, 1, buf.nbytes) < 0                          # more taps than the history reaches
+    assert call(60, 96, 1, buf.nbytes) < 0                          # no such geometry
+    assert call(60, 64, 1, 3 * 4 * 3 * 1024 - 1) < 0                # buffer too small
