@@ -232,7 +232,8 @@ int pddc_fir_i8x_tables(const float *taps, int ntaps, int hist, int mix, uint32_
  * g2[k] = h2[k] e^{+j 8 theta k} (a first-stage output is 8 input samples); 136 floats */
 int pddc_fir_i8x_taps2(const float *taps2, int ntaps2, int mix, uint32_t freg, float *out, size_t out_len);
 /* Kernel selection is API state, not environment: name = "no_i8", "i8_128", "i8x", "i8x_pair", "i8x_plain", "i8x_blocks",
- * "no_fuse2", "fuse3" (the PDDC_* environment variables of the same names are read once, when the pipeline is created).
+ * "i8x_chunk", "i8x_layout", "i8x_pair_max_log2", "no_fuse2", "fuse3" (the PDDC_* environment variables of the same names
+ * are read once, when the pipeline is created).
  * PDDC_ESTATE while overlap mode holds a tail back (fence first), PDDC_EINVAL for an unknown name.                  */
 int pddc_pipeline_set_option(pddc_pipeline *p, const char *name, int value);
 int pddc_pipeline_get_option(const pddc_pipeline *p, const char *name, int *value);

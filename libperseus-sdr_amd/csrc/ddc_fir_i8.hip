@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace pddc {
@@ -433,28 +434,32 @@ hipError_t launch_fir_i8(const FirI8Args &a, int hist, hipStream_t s)
  *   2  NCO, <= 64 taps   waves = component x half, each holds the two tap sets it needs (c and -s, or s and c: 96
  *                        registers at 3 k-steps) and adds both band products into the SAME int32 accumulators: u leaves
  *                        the wave complete, one rounding
- * Walk: block b owns the contiguous tiles [b T / G, (b + 1) T / G); the HIST samples in front of a tile are the last
- * ones of the tile before it, so the loaders copy them from the previous plane set inside LDS (8..32 lanes, 6 x 8 bytes
- * each) instead of re-reading them from HBM; only a block's first tile loads them.
- * FUSE2 (modes 0 and 2): the tile's 1024 first-stage values u stay in LDS behind a 64-entry porch that holds the last 64 of
- * the tile before (copied there by two otherwise idle waves while the other two filter); thread p of waves 0/1 computes
- * second-stage output p of the tile, z = LO(n0 + 64 P) sum_k (h2[k] e^{+j 8 theta k}) u[8 P - k], from float4 reads of
- * both rails (packed FMAs, taps through the scalar cache) and stores it; still ONE barrier per tile.  A block whose
- * range does not start the batch first runs the tile in front of it silently (only the columns the porch needs).    */
+ * Walk: the batch is cut into chunks of C tiles and block b takes chunks b, b + G, b + 2 G, ...  C = 1 is k_fir_i8's
+ * tile-interleaved walk -- all CUs read one compact window of the batch, which is what this chip's HBM likes (same
+ * kernel, 2^28 samples: contiguous ranges per block 0.380 ms, interleaved 0.332) --; inside a chunk the HIST samples in
+ * front of a tile are the last ones of the tile before it and come over from the previous plane set inside LDS, only a
+ * chunk's first tile loads them.
+ * FUSE2 (modes 0 and 2): the tile's 1024 first-stage values u stay in LDS behind a 64-entry porch that holds the 64 values
+ * in front of the tile; thread p of waves 0/1 computes second-stage output p of the tile,
+ *     z = LO(n0 + 64 P) sum_k (h2[k] e^{+j 8 theta k}) u[8 P - k],
+ * from float4 reads of both rails (packed FMAs, taps through the scalar cache) and stores it; still ONE barrier per tile.
+ * Inside a chunk the porch is the previous tile's tail (copied by the two waves that do not filter); a chunk's first tile
+ * computes it itself: four more columns in front of the tile (one extra pass of the matrix waves 2/3 over 512 + HIST more
+ * samples, loaded by 72 loader lanes) -- no tile depends on another block, no warm-up tile; the batch's first tile takes
+ * the stream's second-stage history (the 64 mixed first-stage outputs k_fir8's fused pair keeps too) instead.        */
 namespace i8x {
-using i8::NLT;
-using i8::NMW;
 using i8::plane_bytes;
 using i8::swz;
-static_assert(NMW == 4 && NLT == 512, "k_fir_i8x is written for 4 matrix waves + 8 loader waves");
 constexpr int TILE = 8192;
 constexpr int kTaps2Len = 68;                  /* floats per rail of the second stage's tap table (65 used) */
 
 template <int HIST, int MODE, bool FUSE2>
 struct Geo {
-    static constexpr int SPAN = TILE + HIST, PLANE = SPAN + 16 * ((SPAN + 127) / 128);
+    static constexpr int EXTRA = FUSE2 ? 512 : 0;                   /* samples in front of the history: the porch's columns */
+    static constexpr int FRONT = EXTRA + HIST;
+    static constexpr int SPAN = TILE + FRONT, PLANE = SPAN + 16 * ((SPAN + 127) / 128);
     static constexpr int KSTEPS = (120 + HIST + 63) / 64;
-    static constexpr int HG = HIST / 8;                              /* history groups of 8 samples */
+    static constexpr int HG = HIST / 8, FG = FRONT / 8;              /* history groups of 8 samples; with the extra ones */
     static constexpr int NARR = MODE == 1 ? 4 : 2;
     static constexpr int PORCH = FUSE2 ? 64 : 0;
     static constexpr int AS = 20 * ((1024 + PORCH) / 16);            /* floats per output array (16 values per 20) */
@@ -464,6 +469,30 @@ struct Geo {
     static_assert(MODE != 2 || HIST <= 64, "two tap sets per wave only fit at 3 k-steps");
     static_assert(!(FUSE2 && MODE == 1), "the fused second stage reads complete u values");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(FG <= 128, "front groups are loaded by the first loader waves");
+};
+
+/* a block's tile sequence: chunk b, b + G, ... of C tiles each */
+struct Cursor {
+    long long chunk;
+    int k;
+};
+struct Walk {
+    long long ntiles, G;
+    int C;
+    __device__ __forceinline__ long long tile(const Cursor &c) const
+    {
+        const long long t = c.chunk * C + c.k;
+        return t < ntiles ? t : -1;
+    }
+    __device__ __forceinline__ Cursor next(Cursor c) const
+    {
+        if (++c.k == C) {
+            c.k = 0;
+            c.chunk += G;
+        }
+        return c;
+    }
 };
 
 /* 8 samples (48 bytes) -> 8 bytes in each of the six planes at (swizzled) position `at` */
@@ -497,27 +526,29 @@ __device__ __forceinline__ void issue_group(const FirI8xArgs &a, long long t, in
     }
 }
 
-/* one loader step: the loads of tile `tn` (if any) go out group by group BETWEEN the conversions of the tile that has
- * arrived (k_fir_i8's pacing); then the history groups come over from the plane set of the tile before */
-template <int HIST, int PLANE>
-__device__ __forceinline__ void load_and_convert(const FirI8xArgs &a, long long tn, bool have_next, uint4 (&nxt)[2][3],
-                                                 const uint4 (&cur)[2][3], uint8_t *plane, const uint8_t *prev, int lt)
+/* the groups in front of a chunk's first tile t: front group g (0 .. FG) = samples 8192 t - FRONT + 8 g ..; groups below
+ * `g0` are not needed (no porch columns: not FUSE2, or the batch's first tile).  From the stream's history for t = 0. */
+template <int HIST, int FRONT>
+__device__ __forceinline__ void issue_front(const FirI8xArgs &a, long long t, int g, uint4 (&r)[3])
 {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int g = lt + NLT * q;
-        if (have_next)
-            issue_group(a, tn, g, nxt[q]);
-        __builtin_amdgcn_sched_barrier(0);
-        put_planes(cur[q], plane, PLANE, swz(HIST + 8 * g));
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (lt < HIST / 8) {
-        const int src = swz(TILE + 8 * lt), dst = swz(8 * lt);
-#pragma unroll
-        for (int pl = 0; pl < 6; ++pl)
-            *reinterpret_cast<uint2 *>(plane + pl * PLANE + dst) = *reinterpret_cast<const uint2 *>(prev + pl * PLANE + src);
-    }
+    const long long b = t * TILE - FRONT + 8LL * g;
+    const uint4 *p = b < 0 ? reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.hist) + (b + HIST) * 6)
+                           : reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + b * 6);
+    r[0] = p[0];
+    r[1] = p[1];
+    r[2] = p[2];
+}
+
+/* A float2 store whose data registers stay untouched for two more issue slots.  Measured on MI355X (ROCm 7.2): when a wave
+ * stores (global_store_dwordx2) while ANOTHER wave on its SIMD is issuing matrix instructions, and the wave's next vector
+ * instruction overwrites one of the store's data registers, the last quarter of the wave (lanes 48..63) now and then stores
+ * the new value of that register -- once per few thousand tiles with post waves beside two matrix waves, never seen without
+ * a matrix wave beside the storing one.  hipcc pads only stores of more than 64 bits; the pad has to sit inside the statement,
+ * or the scheduler moves vector instructions in front of it.                                                           */
+__device__ __forceinline__ void store_f2_padded(float2 *p, float x, float y)
+{
+    const f32x2 v = { x, y };
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 /* y = sum_s acc[s] 256^(s+2) as floats */
@@ -528,63 +559,383 @@ __device__ __forceinline__ float recombine(const v4i_t (&acc)[4], int v)
 }
 } // namespace i8x
 
-template <int HIST, int MODE, bool FUSE2>
-__global__ __launch_bounds__(64 * i8::NMW + i8::NLT, 1) void k_fir_i8x(FirI8xArgs a, long long ntiles)
+/* Who does what (LAYOUT).  The matrix waves' chain per tile -- operand reads, matrix instructions, recombination, and then
+ * the tile's finish (rotation and stores, or the second stage) -- was the longest in the block: the loaders sat in the
+ * barrier for a third to a half of every tile while waves 0..3 finished it (in-kernel clock probe: tuned 48 taps, matrix pass
+ * 2800 cycles + finish 2700 against 3650..4300 of loader work; the finish is slow because its stores queue behind the
+ * loaders' loads in the CU's one memory pipeline).
+ *   0  matrix waves 0..3 finish their tile themselves, behind its barrier (k_fir_i8's scheme)
+ *   1  the LOADERS finish the tile before while the matrix waves work on this one: every wave of the block then has about
+ *      the same work per tile; stores from a loader wave sit beside a matrix wave's instructions on its SIMD and need the
+ *      padded form (store_f2_padded)
+ *   2  TWO matrix waves (0, 1: one component -- or tap set -- each, all four column blocks) and two FINISHING waves (2, 3:
+ *      the tile before, while the matrix waves work on this one).  Waves w, w + 4, w + 8 share a SIMD
+ *      (tools/ubench/wave_simd.hip): the finishing waves have no matrix wave beside them (packed fp32 is safe there) and,
+ *      without tap operands, the registers to keep a second stage's LDS reads in flight
+ * (Tried: matrix and dedicated post waves on two SIMDs, six loader waves with the vector port to themselves on the other
+ * two -- a matrix instruction holds its SIMD's vector issue port for 8 of its 16 cycles, which costs the loaders beside it
+ * 0.05 ms per 2^28 samples -- but six loader waves stream worse than eight: 0.39 ms for every form.)                 */
+template <int LAYOUT>
+struct Roles {
+    static constexpr int NLT = 512;                            /* loader threads */
+    static constexpr int NPT = LAYOUT == 0 ? 256 : LAYOUT == 1 ? 512 : 128;       /* threads that finish a tile */
+    static constexpr int NQ = 2;                               /* main groups per loader thread and tile */
+};
+
+template <int HIST, int MODE, bool FUSE2, int LAYOUT>
+__global__ __launch_bounds__(768, 1) void k_fir_i8x(FirI8xArgs a, long long ntiles, int C)
 {
     using namespace i8x;
     using G = Geo<HIST, MODE, FUSE2>;
-    constexpr int PLANE = G::PLANE, KSTEPS = G::KSTEPS, AS = G::AS, NARR = G::NARR, PORCH = G::PORCH;
+    using R = Roles<LAYOUT>;
+    constexpr int PLANE = G::PLANE, KSTEPS = G::KSTEPS, AS = G::AS, NARR = G::NARR, PORCH = G::PORCH, EXTRA = G::EXTRA,
+                  FRONT = G::FRONT, NLT = R::NLT, NPT = R::NPT, NQ = R::NQ;
     constexpr bool MIX = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_i8x[];
     /* [2 buffers][2 components][3 planes][PLANE], then [2 buffers][NARR][AS] first-stage values */
     float *arr_base = reinterpret_cast<float *>(lds_i8x + 12 * PLANE);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long nblk = gridDim.x, blk = blockIdx.x;
-    const long long t0 = blk * ntiles / nblk, t1 = (blk + 1) * ntiles / nblk;
-    const long long ts = (FUSE2 && t0 > 0) ? t0 - 1 : t0;          /* the tile in front primes the second stage's history */
-    if (wave >= NMW) {
-        /* ---- loaders (waves 4..11) */
-        const int lt = tid - 64 * NMW;
-        if (blk == 0 && a.hist_out) {                    /* the next call's history: the batch's last HIST samples */
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* (an SGPR: role branches are uniform) */
+    const Walk wk{ ntiles, (long long)gridDim.x, C };
+    Cursor cur{ (long long)blockIdx.x, 0 };
+    const uint32_t n0lo = (uint32_t)a.n0;
+    const long long n_out = a.n_in >> 3;
+
+    /* ---- finishing a tile whose values are in `arr` (after its barrier): non-FUSE2 combine, rotate, store float2 (thread
+     * pt of NPT); FUSE2 the second stage and the porch copy.  GUARD: the batch's last tile (ragged end, hist2_out). */
+    /* (u + j v) (c + j s) in place.  NO packed fp32 in code that loader waves run (this TU is compiled without the SLP
+     * vectoriser, and the finishing code below uses no 2-vectors): on MI355X a v_pk_fma_f32 / v_pk_mul_f32 result consumed
+     * one or two instructions later came out wrong in lanes 48..63 now and then -- only in waves that share their SIMD with
+     * a wave issuing matrix instructions (tools/i8x_debug.py, 20..27 of 40 runs of 600 tiles; none with plain v_fma_f32) */
+    auto rotate = [](float &u, float &v, float c, float s) __attribute__((always_inline)) {
+        const float x = __builtin_fmaf(-v, s, u * c), y = __builtin_fmaf(v, c, u * s);
+        u = x;
+        v = y;
+    };
+    auto put_f2 = [&](float2 *p, float x, float y) __attribute__((always_inline)) {
+        if (LAYOUT == 0)
+            *p = make_float2(x, y);
+        else
+            store_f2_padded(p, x, y);
+    };
+    auto post_store = [&](long long t, const float *arr, int pt, auto guard_c) __attribute__((always_inline)) {
+        constexpr bool GUARD = decltype(guard_c)::value;
+        float2 *dst = reinterpret_cast<float2 *>(a.out) + t * 1024;
+        const long long left = n_out - t * 1024;
+#pragma unroll
+        for (int o4 = 0; o4 < 1024 / NPT; ++o4) {
+            const int o = pt + NPT * o4;
+            const int q = 20 * (o >> 4) + (o & 15);
+            float uI, uQ;
+            if (MODE == 1) {
+                uI = (arr[q] - arr[3 * AS + q]) + a.ct[0];
+                uQ = (arr[2 * AS + q] + arr[AS + q]) + a.ct[1];
+            } else {
+                uI = arr[q];
+                uQ = arr[AS + q];
+            }
+            if (MIX) {
+                float c, s;
+                nco_lo((n0lo + 8u * (uint32_t)(t * 1024 + o)) * a.freg + a.phase_off, c, s);
+                rotate(uI, uQ, c, s);
+            }
+            if (!GUARD || o < left)
+                put_f2(dst + o, uI, uQ);
+        }
+    };
+    /* second stage, output p of the tile from u[8 p - 64 .. 8 p] (array positions 8 p .. 8 p + 64 behind the porch); the tap
+     * tables are in descending order, gre[i] = Re g2[64 - i], so that a float4 of u meets a float4 of taps.
+     * WHOLE: one thread forms the complex output.  Otherwise a PAIR of neighbouring lanes forms it: lane `comp` = 0 the real
+     * part gr * uI - gi * uQ, lane 1 the imaginary part gr * uQ + gi * uI (the same code on swapped rails), one quad
+     * permute brings the halves together for the rotation, and each lane stores its own float.                        */
+    auto post_stage2 = [&](long long t, const float *arr, int p) __attribute__((always_inline)) {
+        constexpr bool WHOLE = true;
+        const float *uA = arr, *uB = arr + AS;
+        const f32x2 PDDC_CONSTANT *gre = (const f32x2 PDDC_CONSTANT *)a.taps2;
+        const f32x2 PDDC_CONSTANT *gim = (const f32x2 PDDC_CONSTANT *)(a.taps2 + kTaps2Len);
+        f32x2 ra_[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, ib_[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
+        f32x2 ia_[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, rb_[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
+        /* (hipcc waits for every float4 pair: sixteen exposed LDS latencies, 4200 cycles per tile on the clock probe -- the
+         * reason why LAYOUT 1 gives this work to waves that can keep the reads in flight) */
+        constexpr int S2B = LAYOUT == 2 ? 8 : 1;  /* (matrix waves: no registers for more -- batches of 4 spill 12, of 8 47) */
+#pragma unroll
+        for (int jb = 0; jb < 16; jb += S2B) {
+            float4 xA[S2B], xB[S2B];
+#pragma unroll
+            for (int jj = 0; jj < S2B; ++jj) {
+                const int op = 8 * p + 4 * (jb + jj), q = 20 * (op >> 4) + (op & 15);
+                xA[jj] = *reinterpret_cast<const float4 *>(uA + q);
+                xB[jj] = *reinterpret_cast<const float4 *>(uB + q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 0; jj < S2B; ++jj) {
+                const int j = jb + jj;
+                const f32x2 xa[2] = { { xA[jj].x, xA[jj].y }, { xA[jj].z, xA[jj].w } },
+                            xb[2] = { { xB[jj].x, xB[jj].y }, { xB[jj].z, xB[jj].w } };
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const f32x2 gr = gre[2 * j + e];
+                    ra_[e] = __builtin_elementwise_fma(gr, xa[e], ra_[e]);
+                    if (WHOLE)
+                        rb_[e] = __builtin_elementwise_fma(gr, xb[e], rb_[e]);
+                    if (MIX) {
+                        const f32x2 gi = gim[2 * j + e];
+                        ib_[e] = __builtin_elementwise_fma(gi, xb[e], ib_[e]);
+                        if (WHOLE)
+                            ia_[e] = __builtin_elementwise_fma(gi, xa[e], ia_[e]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int op = 8 * p + 64, q = 20 * (op >> 4) + (op & 15);
+        const float g0r = a.taps2[64], g0i = a.taps2[kTaps2Len + 64];
+        const float x0A = uA[q], x0B = uB[q];
+        const uint32_t ph = (n0lo + 64u * (uint32_t)(t * 128 + p)) * a.freg + a.phase_off;
+        if (WHOLE) {
+            float zr = ((ra_[0].x + ra_[0].y) + (ra_[1].x + ra_[1].y)) + g0r * x0A;
+            float zi = ((rb_[0].x + rb_[0].y) + (rb_[1].x + rb_[1].y)) + g0r * x0B;
+            if (MIX) {
+                zr -= ((ib_[0].x + ib_[0].y) + (ib_[1].x + ib_[1].y)) + g0i * x0B;
+                zi += ((ia_[0].x + ia_[0].y) + (ia_[1].x + ia_[1].y)) + g0i * x0A;
+                float c, s;
+                nco_lo(ph, c, s);
+                const float yr = zr * c - zi * s, yi = zr * s + zi * c;
+                zr = yr;
+                zi = yi;
+            }
+            put_f2(reinterpret_cast<float2 *>(a.out) + t * 128 + p, zr, zi);
+        }
+    };
+    /* the same output by a PAIR of neighbouring loader lanes (LAYOUT 1): lane `comp` = 0 the real part gr * uI - gi * uQ,
+     * lane 1 the imaginary part gr * uQ + gi * uI -- the same code on swapped rails --, scalar FMAs (see rotate()), the
+     * window's LDS reads in batches that are in flight before the first FMA (these waves have the registers the matrix waves
+     * lack), one quad permute brings the halves together for the rotation, each lane stores its own float.  A wave takes
+     * outputs of ONE parity (B: p = 2 (32 h + i) + B for lane pair i of wave 2 h + B): the window of output p starts at
+     * array position 8 p = 16 a + 8 B, so with the parity fixed every read is the lane's base 20 a plus a constant (the 16
+     * values of a block lie 20 floats apart), and the taps stay wave-uniform (scalar loads).                           */
+    auto post_stage2_pair = [&](long long t, const float *arr, int h, int lane_, auto parity_c) __attribute__((always_inline)) {
+        constexpr int B = decltype(parity_c)::value;
+        const int comp = lane_ & 1, ap = 32 * h + (lane_ >> 1), p = 2 * ap + B;
+        const float *uA = arr + comp * AS + 20 * ap, *uB = arr + (comp ^ 1) * AS + 20 * ap;
+        const float PDDC_CONSTANT *gre = (const float PDDC_CONSTANT *)a.taps2;
+        const float PDDC_CONSTANT *gim = (const float PDDC_CONSTANT *)(a.taps2 + kTaps2Len);
+        float s1[4] = { 0.f, 0.f, 0.f, 0.f }, s2[4] = { 0.f, 0.f, 0.f, 0.f };
+        constexpr int NB = 4;
+#pragma unroll
+        for (int jb = 0; jb < 16; jb += NB) {
+            float4 xA[NB], xB[NB];
+#pragma unroll
+            for (int jj = 0; jj < NB; ++jj) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int m = jb + jj + 2 * B, q = 4 * m + 4 * (m >> 2);          /* float4 m of the lane's blocks */
+                xA[jj] = *reinterpret_cast<const float4 *>(uA + q);
+                if (MIX)
+                    xB[jj] = *reinterpret_cast<const float4 *>(uB + q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 0; jj < NB; ++jj) {
+                const int i = 4 * (jb + jj);
+                const float *xa = &xA[jj].x, *xb = &xB[jj].x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[e] = __builtin_fmaf(gre[i + e], xa[e], s1[e]);
+                    if (MIX)
+                        s2[e] = __builtin_fmaf(gim[i + e], xb[e], s2[e]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        constexpr int ml = 16 + 2 * B, ql = 4 * ml + 4 * (ml >> 2);
+        float z = ((s1[0] + s1[1]) + (s1[2] + s1[3])) + gre[64] * uA[ql];
+        if (MIX) {
+            const float w = ((s2[0] + s2[1]) + (s2[2] + s2[3])) + gim[64] * uB[ql];
+            z = comp ? z + w : z - w;
+            const float other = __builtin_bit_cast(
+                float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, z), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
+            const float zr = comp ? other : z, zi = comp ? z : other;
+            float c, s;
+            nco_lo((n0lo + 64u * (uint32_t)(t * 128 + p)) * a.freg + a.phase_off, c, s);
+            z = comp ? __builtin_fmaf(zi, c, zr * s) : __builtin_fmaf(-zi, s, zr * c);
+        }
+        float *dst = a.out + 2 * (t * 128 + p) + comp;
+        asm volatile("global_store_dword %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(z) : "memory");
+    };
+    auto post_porch = [&](long long t, const float *arr, float *other, int c, bool chain, auto guard_c) __attribute__((always_inline)) {
+        constexpr bool GUARD = decltype(guard_c)::value;
+        const int comp = c >> 6, e = c & 63;
+        const int qs = 20 * (64 + (e >> 4)) + (e & 15), qd = 20 * (e >> 4) + (e & 15);
+        if (chain)                                           /* inside a chunk the tile's last 64 values are the next one's porch */
+            other[comp * AS + qd] = arr[comp * AS + qs];
+        if (GUARD && t == ntiles - 1 && a.hist2_out && comp == 0) {
+            /* ... and the batch's last 64 the next call's second-stage history: mixed floats, y = u LO */
+            float uI = arr[qs], uQ = arr[AS + qs];
+            if (MIX) {
+                float c, s;
+                nco_lo((n0lo + 8u * (uint32_t)(t * 1024 + 960 + e)) * a.freg + a.phase_off, c, s);
+                rotate(uI, uQ, c, s);
+            }
+            put_f2(static_cast<float2 *>(a.hist2_out) + e, uI, uQ);
+        }
+    };
+    /* `next_first`: the tile behind t starts a chunk (it makes its own porch, or takes the stream's history); pt: the
+     * finishing thread, 0 .. NPT */
+    auto post = [&](long long t, float *arr, float *other, bool next_first, int pt, auto guard_c) __attribute__((always_inline)) {
+        const int pw = __builtin_amdgcn_readfirstlane(pt >> 6);
+        if (!FUSE2) {
+            post_store(t, arr, pt, guard_c);
+        } else if (LAYOUT == 0) {
+            if (pw < 2)
+                post_stage2(t, arr, pt);
+            else
+                post_porch(t, arr, other, pt - 128, !next_first, guard_c);
+        } else if (LAYOUT == 2) {
+            post_stage2(t, arr, pt);
+            post_porch(t, arr, other, pt, !next_first, guard_c);
+        } else {
+            if (pw < 4) {
+                if (pw & 1)
+                    post_stage2_pair(t, arr, pw >> 1, pt & 63, std::integral_constant<int, 1>{});
+                else
+                    post_stage2_pair(t, arr, pw >> 1, pt & 63, std::integral_constant<int, 0>{});
+            }
+            else if (pw < 6)
+                post_porch(t, arr, other, pt - 256, !next_first, guard_c);
+        }
+    };
+    if (wave >= 4) {
+        /* ---- loaders (waves 4..11): main groups two tiles ahead in two register sets, front groups one tile ahead;
+         * LAYOUT 1: they also finish the tile before the one the matrix waves are working on */
+        const int lt = tid - 256;
+        if (blockIdx.x == 0 && a.hist_out) {             /* the next call's history: the batch's last HIST samples */
             const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + (a.n_in - HIST) * 6);
             if (lt < HIST * 6 / 16)
                 static_cast<uint4 *>(a.hist_out)[lt] = src[lt];
         }
-        uint4 ra[2][3], rb[2][3];
-        issue_group(a, ts, lt, ra[0]);
-        issue_group(a, ts, lt + NLT, ra[1]);
-        if (lt < G::HG) {
-            /* this block's first tile takes the samples in front of it from memory: the stream's history or the batch */
-            const long long b = ts * TILE - HIST + 8LL * lt;
-            const uint4 *p = b < 0 ? reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.hist) + (b + HIST) * 6)
-                                   : reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + b * 6);
-            const uint4 rh[3] = { p[0], p[1], p[2] };
-            put_planes(rh, lds_i8x, PLANE, swz(8 * lt));
+        /* front groups a chunk's first tile t needs: all FG with the porch columns (FUSE2, t > 0), else the last HG */
+        auto front_lo = [&](long long t) __attribute__((always_inline)) { return FUSE2 && t > 0 ? 0 : G::FG - G::HG; };
+        uint4 ra[NQ][3], rb[NQ][3], rf[3];
+        Cursor c0 = cur, c1 = wk.next(c0), c2 = wk.next(c1);
+        long long t = wk.tile(c0), t1 = wk.tile(c1), t2 = wk.tile(c2), tp = -1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            issue_group(a, t, lt + NLT * q, ra[q]);
+        if (lt < G::FG && lt >= front_lo(t)) {
+            issue_front<HIST, FRONT>(a, t, lt, rf);
+            put_planes(rf, lds_i8x, PLANE, swz(8 * lt));
         }
-        put_planes(ra[0], lds_i8x, PLANE, swz(HIST + 8 * lt));
-        put_planes(ra[1], lds_i8x, PLANE, swz(HIST + 8 * (lt + NLT)));
-        long long t = ts;
-        if (t + 1 < t1) {
-            issue_group(a, t + 1, lt, ra[0]);
-            issue_group(a, t + 1, lt + NLT, ra[1]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            put_planes(ra[q], lds_i8x, PLANE, swz(FRONT + 8 * (lt + NLT * q)));
+        if (t1 >= 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                issue_group(a, t1, lt + NLT * q, ra[q]);
         }
         __syncthreads();
+        /* one step: tile `tn` (already in `cur_r`) goes into plane set `dst` while the matrix waves work on `src`; the loads
+         * of the tile after it (`tnn`, if any) go out group by group BETWEEN the conversions (k_fir_i8's pacing) */
+        auto step = [&](long long tn, bool tn_first, long long tnn, uint4 (&nxt)[NQ][3], const uint4 (&cur_r)[NQ][3], uint8_t *dst,
+                        const uint8_t *src) {
+            const bool ff = tn_first && lt < G::FG && lt >= front_lo(tn);
+            if (ff)
+                issue_front<HIST, FRONT>(a, tn, lt, rf);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int g = lt + NLT * q;
+                if (tnn >= 0)
+                    issue_group(a, tnn, g, nxt[q]);
+                __builtin_amdgcn_sched_barrier(0);
+                put_planes(cur_r[q], dst, PLANE, swz(FRONT + 8 * g));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ff) {
+                put_planes(rf, dst, PLANE, swz(8 * lt));
+            } else if (!tn_first && lt < G::HG) {
+                /* inside a chunk: the history comes over from the plane set of the tile before */
+                const int s_at = swz(FRONT + TILE - HIST + 8 * lt), d_at = swz(EXTRA + 8 * lt);
+#pragma unroll
+                for (int pl = 0; pl < 6; ++pl)
+                    *reinterpret_cast<uint2 *>(dst + pl * PLANE + d_at) = *reinterpret_cast<const uint2 *>(src + pl * PLANE + s_at);
+            }
+        };
+        float *arr0 = arr_base, *arr1 = arr_base + NARR * AS;
+        int lastbuf;
         for (;;) {
-            /* tile t is computed from plane set 0; t + 1 (in ra) goes to set 1, t + 2 starts towards rb */
-            if (t + 1 < t1)
-                load_and_convert<HIST, PLANE>(a, t + 2, t + 2 < t1, rb, ra, lds_i8x + 6 * PLANE, lds_i8x, lt);
+            /* the matrix waves compute tile t from plane set 0 into value set 0; t1 (in ra) goes to plane set 1, t2 starts
+             * towards rb; the tile before t (values in set 1) is finished */
+            if (t1 >= 0)
+                step(t1, c1.k == 0, t2, rb, ra, lds_i8x + 6 * PLANE, lds_i8x);
+            if (LAYOUT == 1 && tp >= 0)
+                post(tp, arr1, arr0, c0.k == 0, lt, std::false_type{});
             __syncthreads();
-            if (++t >= t1)
+            lastbuf = 0;
+            if (t1 < 0)
                 break;
-            if (t + 1 < t1)
-                load_and_convert<HIST, PLANE>(a, t + 2, t + 2 < t1, ra, rb, lds_i8x, lds_i8x + 6 * PLANE, lt);
+            tp = t;
+            c0 = c1;
+            c1 = c2;
+            c2 = wk.next(c2);
+            t = t1;
+            t1 = t2;
+            t2 = wk.tile(c2);
+            if (t1 >= 0)
+                step(t1, c1.k == 0, t2, ra, rb, lds_i8x, lds_i8x + 6 * PLANE);
+            if (LAYOUT == 1)
+                post(tp, arr0, arr1, c0.k == 0, lt, std::false_type{});
             __syncthreads();
-            if (++t >= t1)
+            lastbuf = 1;
+            if (t1 < 0)
                 break;
+            tp = t;
+            c0 = c1;
+            c1 = c2;
+            c2 = wk.next(c2);
+            t = t1;
+            t1 = t2;
+            t2 = wk.tile(c2);
         }
+        if (LAYOUT == 1)
+            post(t, lastbuf ? arr1 : arr0, lastbuf ? arr0 : arr1, true, lt, std::true_type{});
         return;
     }
-    /* ---- matrix waves (0..3) */
+    if (LAYOUT == 2 && wave >= 2) {
+        /* ---- finishing waves (LAYOUT 2): tile t - 1 is finished while the matrix waves work on tile t */
+        const int pt = tid - 128;
+        if (FUSE2 && blockIdx.x == 0 && pt < 64) {
+            /* the batch's first tile: the stream's second-stage history -- the 64 first-stage outputs in front of this batch,
+             * mixed floats -- taken back into the frame of this call's u values: u = y conj(LO) */
+            const float2 y = static_cast<const float2 *>(a.hist2)[pt];
+            float uI = y.x, uQ = y.y;
+            if (MIX) {
+                float c, s;
+                nco_lo((n0lo + 8u * (uint32_t)(pt - 64)) * a.freg + a.phase_off, c, s);
+                uI = y.x * c + y.y * s;
+                uQ = y.y * c - y.x * s;
+            }
+            const int q = 20 * (pt >> 4) + (pt & 15);
+            arr_base[q] = uI;
+            arr_base[AS + q] = uQ;
+        }
+        __syncthreads();
+        int buf = 0;
+        long long t = wk.tile(cur), tprev = -1;
+        while (t >= 0) {
+            const bool first = cur.k == 0;
+            cur = wk.next(cur);
+            if (tprev >= 0)
+                post(tprev, arr_base + (buf ^ 1) * NARR * AS, arr_base + buf * NARR * AS, first, pt, std::false_type{});
+            __syncthreads();
+            tprev = t;
+            t = wk.tile(cur);
+            buf ^= 1;
+        }
+        post(tprev, arr_base + (buf ^ 1) * NARR * AS, arr_base + buf * NARR * AS, true, pt, std::true_type{});
+        return;
+    }
+    /* ---- matrix waves (0..3; LAYOUT 2: 0 and 1, both halves of the columns each) */
     const int w0 = wave & 1, half = wave >> 1;
     const int n = lane & 15, kq = lane >> 4;
     const v4i_t *atab = static_cast<const v4i_t *>(a.atab);
@@ -603,10 +954,9 @@ __global__ __launch_bounds__(64 * i8::NMW + i8::NLT, 1) void k_fir_i8x(FirI8xArg
                     A1[ks][j] = atab[tab1 * G::TABV + (j * KSTEPS + ks) * 64 + lane];
             }
     }
-    const uint32_t n0lo = (uint32_t)a.n0;
-    if (FUSE2 && ts == 0 && tid < 64) {
-        /* the stream's second-stage history: the 64 first-stage outputs in front of this batch (mixed floats, the state
-         * k_fir8's fused pair keeps too), taken back into the frame of this call's u values: u = y conj(LO) */
+    if (LAYOUT != 2 && FUSE2 && blockIdx.x == 0 && tid < 64) {
+        /* the batch's first tile: the stream's second-stage history -- the 64 first-stage outputs in front of this batch,
+         * mixed floats -- taken back into the frame of this call's u values: u = y conj(LO) */
         const float2 y = static_cast<const float2 *>(a.hist2)[tid];
         float uI = y.x, uQ = y.y;
         if (MIX) {
@@ -619,179 +969,105 @@ __global__ __launch_bounds__(64 * i8::NMW + i8::NLT, 1) void k_fir_i8x(FirI8xArg
         arr_base[q] = uI;
         arr_base[AS + q] = uQ;
     }
-    const long long n_out = a.n_in >> 3;
-    __syncthreads();
-    int buf = 0;
-    for (long long t = ts; t < t1; ++t, buf ^= 1) {
-        const bool silent = FUSE2 && t < t0;
-        const uint8_t *pb = lds_i8x + buf * 6 * PLANE;
-        float *arr = arr_base + buf * NARR * AS;
+    /* one band pass of this wave over 16 columns whose operand bytes start at plane position `pos` (per lane: + 16 kq + 64 ks) */
+    auto band = [&](const uint8_t *pb, int pos, float *dst) __attribute__((always_inline)) {
+        if (MODE == 1) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            if (FUSE2 && silent && !(half == 1 && cb == 1))
-                continue;                                 /* the porch needs the tile's last 64 values only */
-            const int col = 16 * (2 * half + cb) + n;
-            float *dst = arr + 20 * (col + PORCH / 16) + 4 * kq;
-            if (MODE == 1) {
-#pragma unroll
-                for (int comp = 0; comp < 2; ++comp) {
-                    v4i_t acc[4];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        acc[s] = v4i_t{ 0, 0, 0, 0 };
-#pragma unroll
-                    for (int ks = 0; ks < KSTEPS; ++ks) {
-                        const int at = swz(128 * col + 64 * ks + 16 * kq);
-                        v4i_t B[3];
-#pragma unroll
-                        for (int i = 0; i < 3; ++i)
-                            B[i] = *reinterpret_cast<const v4i_t *>(pb + (3 * comp + i) * PLANE + at);
-#pragma unroll
-                        for (int i = 0; i < 3; ++i)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (i + j >= 2)
-                                    acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks][j], B[i], acc[i + j - 2], 0, 0, 0);
-                    }
-                    float4 y;
-                    float *yp = &y.x;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        yp[v] = recombine(acc, v) * a.scale;
-                    *reinterpret_cast<float4 *>(dst + (2 * w0 + comp) * AS) = y;
-                }
-            } else {
+            for (int comp = 0; comp < 2; ++comp) {
                 v4i_t acc[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
                     acc[s] = v4i_t{ 0, 0, 0, 0 };
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
-                    const int at = swz(128 * col + 64 * ks + 16 * kq);
-                    if (MODE == 0) {
-                        v4i_t B[3];
+                    const int at = swz(pos + 64 * ks);
+                    v4i_t B[3];
 #pragma unroll
-                        for (int i = 0; i < 3; ++i)
-                            B[i] = *reinterpret_cast<const v4i_t *>(pb + (3 * w0 + i) * PLANE + at);
+                    for (int i = 0; i < 3; ++i)
+                        B[i] = *reinterpret_cast<const v4i_t *>(pb + (3 * comp + i) * PLANE + at);
 #pragma unroll
-                        for (int i = 0; i < 3; ++i)
+                    for (int i = 0; i < 3; ++i)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (i + j >= 2)
-                                    acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks][j], B[i], acc[i + j - 2], 0, 0, 0);
-                    } else {
-                        v4i_t BI[3], BQ[3];
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            BI[i] = *reinterpret_cast<const v4i_t *>(pb + i * PLANE + at);
-                            BQ[i] = *reinterpret_cast<const v4i_t *>(pb + (3 + i) * PLANE + at);
-                        }
-#pragma unroll
-                        for (int i = 0; i < 3; ++i)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (i + j >= 2) {
-                                    acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks][j], BI[i], acc[i + j - 2], 0, 0, 0);
-                                    acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1[MODE == 2 ? ks : 0][j], BQ[i], acc[i + j - 2], 0, 0, 0);
-                                }
-                    }
+                        for (int j = 0; j < 4; ++j)
+                            if (i + j >= 2)
+                                acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks][j], B[i], acc[i + j - 2], 0, 0, 0);
                 }
-                /* this lane: column `col`, rows 4 kq + v -> values 16 col + 4 kq + v of the tile, four consecutive ones */
                 float4 y;
                 float *yp = &y.x;
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
-                    yp[v] = recombine(acc, v) * a.scale + a.ct[w0];
-                *reinterpret_cast<float4 *>(dst + w0 * AS) = y;
-            }
-        }
-        __syncthreads();                 /* ONE barrier per tile: the next tile's planes are written, this tile's values are in LDS */
-        if (!FUSE2) {
-            float2 *dst = reinterpret_cast<float2 *>(a.out) + t * 1024;
-            const long long left = n_out - t * 1024;
-            for (int o = tid; o < 1024; o += 64 * NMW) {
-                const int q = 20 * (o >> 4) + (o & 15);
-                float uI, uQ;
-                if (MODE == 1) {
-                    uI = (arr[q] - arr[3 * AS + q]) + a.ct[0];
-                    uQ = (arr[2 * AS + q] + arr[AS + q]) + a.ct[1];
-                } else {
-                    uI = arr[q];
-                    uQ = arr[AS + q];
-                }
-                if (MIX) {
-                    float c, s;
-                    nco_lo((n0lo + 8u * (uint32_t)(t * 1024 + o)) * a.freg + a.phase_off, c, s);
-                    const float yI = uI * c - uQ * s, yQ = uI * s + uQ * c;
-                    uI = yI;
-                    uQ = yQ;
-                }
-                if (o < left)
-                    dst[o] = make_float2(uI, uQ);
-            }
-        } else if (tid < 128) {
-            /* second stage: output p of the tile from u[8 p - 64 .. 8 p] (array positions 8 p .. 8 p + 64 behind the porch);
-             * the tap tables are in descending order, gre[i] = Re g2[64 - i], so that a float4 of u meets a float4 of taps */
-            if (!silent) {
-                const int p = tid;
-                const float *uIp = arr, *uQp = arr + AS;
-                const f32x2 PDDC_CONSTANT *gre = (const f32x2 PDDC_CONSTANT *)a.taps2;
-                const f32x2 PDDC_CONSTANT *gim = (const f32x2 PDDC_CONSTANT *)(a.taps2 + kTaps2Len);
-                f32x2 rr[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, ii[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
-                f32x2 ir[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, ri[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int op = 8 * p + 4 * j, q = 20 * (op >> 4) + (op & 15);
-                    const float4 xI = *reinterpret_cast<const float4 *>(uIp + q);
-                    const float4 xQ = *reinterpret_cast<const float4 *>(uQp + q);
-                    const f32x2 xi[2] = { { xI.x, xI.y }, { xI.z, xI.w } }, xq[2] = { { xQ.x, xQ.y }, { xQ.z, xQ.w } };
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const f32x2 gr = gre[2 * j + e];
-                        rr[e] = __builtin_elementwise_fma(gr, xi[e], rr[e]);
-                        ri[e] = __builtin_elementwise_fma(gr, xq[e], ri[e]);
-                        if (MIX) {
-                            const f32x2 gi = gim[2 * j + e];
-                            ii[e] = __builtin_elementwise_fma(gi, xq[e], ii[e]);
-                            ir[e] = __builtin_elementwise_fma(gi, xi[e], ir[e]);
-                        }
-                    }
-                }
-                const int op = 8 * p + 64, q = 20 * (op >> 4) + (op & 15);
-                const float g0r = a.taps2[64], g0i = a.taps2[kTaps2Len + 64];
-                const float x0I = uIp[q], x0Q = uQp[q];
-                float zr = ((rr[0].x + rr[0].y) + (rr[1].x + rr[1].y)) + g0r * x0I;
-                float zi = ((ri[0].x + ri[0].y) + (ri[1].x + ri[1].y)) + g0r * x0Q;
-                if (MIX) {
-                    zr -= ((ii[0].x + ii[0].y) + (ii[1].x + ii[1].y)) + g0i * x0Q;
-                    zi += ((ir[0].x + ir[0].y) + (ir[1].x + ir[1].y)) + g0i * x0I;
-                    float c, s;
-                    nco_lo((n0lo + 64u * (uint32_t)(t * 128 + p)) * a.freg + a.phase_off, c, s);
-                    const float yr = zr * c - zi * s, yi = zr * s + zi * c;
-                    zr = yr;
-                    zi = yi;
-                }
-                reinterpret_cast<float2 *>(a.out)[t * 128 + p] = make_float2(zr, zi);
+                    yp[v] = recombine(acc, v) * a.scale;
+                *reinterpret_cast<float4 *>(dst + (2 * w0 + comp) * AS) = y;
             }
         } else {
-            /* waves 2, 3: the tile's last 64 values become the porch of the other set */
-            const int idx = tid - 128, comp = idx >> 6, e = idx & 63;
-            const int qs = 20 * (64 + (e >> 4)) + (e & 15), qd = 20 * (e >> 4) + (e & 15);
-            float *other = arr_base + (buf ^ 1) * NARR * AS;
-            other[comp * AS + qd] = arr[comp * AS + qs];
-            if (t == ntiles - 1 && a.hist2_out && comp == 0) {
-                /* ... and the next call's second-stage history: mixed floats, y = u LO */
-                float uI = arr[qs], uQ = arr[AS + qs];
-                if (MIX) {
-                    float c, s;
-                    nco_lo((n0lo + 8u * (uint32_t)(t * 1024 + 960 + e)) * a.freg + a.phase_off, c, s);
-                    const float yI = uI * c - uQ * s, yQ = uI * s + uQ * c;
-                    uI = yI;
-                    uQ = yQ;
+            v4i_t acc[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc[s] = v4i_t{ 0, 0, 0, 0 };
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const int at = swz(pos + 64 * ks);
+                if (MODE == 0) {
+                    v4i_t B[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        B[i] = *reinterpret_cast<const v4i_t *>(pb + (3 * w0 + i) * PLANE + at);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (i + j >= 2)
+                                acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks][j], B[i], acc[i + j - 2], 0, 0, 0);
+                } else {
+                    v4i_t BI[3], BQ[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        BI[i] = *reinterpret_cast<const v4i_t *>(pb + i * PLANE + at);
+                        BQ[i] = *reinterpret_cast<const v4i_t *>(pb + (3 + i) * PLANE + at);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (i + j >= 2) {
+                                acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks][j], BI[i], acc[i + j - 2], 0, 0, 0);
+                                acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1[MODE == 2 ? ks : 0][j], BQ[i], acc[i + j - 2], 0, 0, 0);
+                            }
                 }
-                static_cast<float2 *>(a.hist2_out)[e] = make_float2(uI, uQ);
             }
+            /* this lane: its column, rows 4 kq + v -> four consecutive values */
+            float4 y;
+            float *yp = &y.x;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                yp[v] = recombine(acc, v) * a.scale + a.ct[w0];
+            *reinterpret_cast<float4 *>(dst + w0 * AS) = y;
         }
+    };
+    __syncthreads();
+    int buf = 0;
+    long long t = wk.tile(cur);
+    while (t >= 0) {
+        const bool first = cur.k == 0;
+        cur = wk.next(cur);
+        const uint8_t *pb = lds_i8x + buf * 6 * PLANE;
+        float *arr = arr_base + buf * NARR * AS, *arr_o = arr_base + (buf ^ 1) * NARR * AS;
+        if (FUSE2 && first && t > 0 && (LAYOUT == 2 || half == 1)) {
+            /* a chunk's first tile computes its own porch: columns -4 .. -1 in lanes 12..15; the other lanes repeat column -4
+             * (same operand bytes, same results, same address: the whole wave runs the matrix instructions) */
+            const int colx = n < 12 ? -4 : n - 16;
+            band(pb, EXTRA + 128 * colx + 16 * kq, arr + 20 * (colx + 4) + 4 * kq);
+        }
+#pragma unroll
+        for (int cb = 0; cb < (LAYOUT == 2 ? 4 : 2); ++cb) {
+            const int col = 16 * (LAYOUT == 2 ? cb : 2 * half + cb) + n;
+            band(pb, EXTRA + 128 * col + 16 * kq, arr + 20 * (col + PORCH / 16) + 4 * kq);
+        }
+        __syncthreads();                 /* ONE barrier per tile: the next tile's planes are written, this tile's values are in LDS */
+        if (LAYOUT == 0)                 /* ... and these waves finish it themselves */
+            post(t, arr, arr_o, cur.k == 0, tid, std::true_type{});
+        t = wk.tile(cur);
+        buf ^= 1;
     }
 }
 
@@ -896,8 +1172,8 @@ void fir_i8x_taps2(const float *taps2, int ntaps2, bool mix, uint32_t freg, floa
     }
 }
 
-template <int HIST, int MODE, bool FUSE2>
-static hipError_t launch_fir_i8x_t(const FirI8xArgs &a, int max_blocks, hipStream_t s)
+template <int HIST, int MODE, bool FUSE2, int LAYOUT>
+static hipError_t launch_fir_i8x_l(const FirI8xArgs &a, int max_blocks, int chunk, hipStream_t s)
 {
     using G = i8x::Geo<HIST, MODE, FUSE2>;
     const long long ntiles = (a.n_in + i8x::TILE - 1) / i8x::TILE;
@@ -909,33 +1185,48 @@ static hipError_t launch_fir_i8x_t(const FirI8xArgs &a, int max_blocks, hipStrea
         hipError_t e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess)
             return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_i8x<HIST, MODE, FUSE2>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_i8x<HIST, MODE, FUSE2, LAYOUT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
         if (e != hipSuccess)
             return e;
         cus[dev & 63] = v > 0 ? v : 256;
     }
-    long long grid = ntiles < cus[dev & 63] ? ntiles : cus[dev & 63];
-    if (max_blocks > 0 && grid > max_blocks)
-        grid = max_blocks;
-    hipLaunchKernelGGL((k_fir_i8x<HIST, MODE, FUSE2>), dim3((unsigned)grid), dim3(64 * i8::NMW + i8::NLT), G::LDS_BYTES, s, a,
-                       ntiles);
+    /* chunks of C tiles go round the blocks: C = 1 (tile-interleaved) unless asked otherwise; never more than a block's
+     * fair share, so that every CU has work */
+    long long nblk = cus[dev & 63];
+    if (max_blocks > 0 && nblk > max_blocks)
+        nblk = max_blocks;
+    long long C = chunk > 0 ? chunk : FUSE2 ? 4 : 1;
+    if (C > (ntiles + nblk - 1) / nblk)
+        C = (ntiles + nblk - 1) / nblk;
+    const long long nchunks = (ntiles + C - 1) / C;
+    const long long grid = nchunks < nblk ? nchunks : nblk;
+    hipLaunchKernelGGL((k_fir_i8x<HIST, MODE, FUSE2, LAYOUT>), dim3((unsigned)grid), dim3(768), G::LDS_BYTES, s, a, ntiles, (int)C);
     return hipGetLastError();
 }
 
+template <int HIST, int MODE, bool FUSE2>
+static hipError_t launch_fir_i8x_t(const FirI8xArgs &a, int max_blocks, int chunk, int layout, hipStream_t s)
+{
+    return layout == 0   ? launch_fir_i8x_l<HIST, MODE, FUSE2, 0>(a, max_blocks, chunk, s)
+           : layout == 1 ? launch_fir_i8x_l<HIST, MODE, FUSE2, 1>(a, max_blocks, chunk, s)
+                         : launch_fir_i8x_l<HIST, MODE, FUSE2, 2>(a, max_blocks, chunk, s);
+}
+
 template <int HIST>
-static hipError_t launch_fir_i8x_h(const FirI8xArgs &a, bool mix, bool fuse2, int max_blocks, hipStream_t s)
+static hipError_t launch_fir_i8x_h(const FirI8xArgs &a, bool mix, bool fuse2, int max_blocks, int chunk, int layout, hipStream_t s)
 {
     constexpr int MM = HIST <= 64 ? 2 : 1;
     if (!mix)
-        return fuse2 ? launch_fir_i8x_t<HIST, 0, true>(a, max_blocks, s) : launch_fir_i8x_t<HIST, 0, false>(a, max_blocks, s);
+        return fuse2 ? launch_fir_i8x_t<HIST, 0, true>(a, max_blocks, chunk, layout, s) : launch_fir_i8x_t<HIST, 0, false>(a, max_blocks, chunk, layout, s);
     if (!fuse2)
-        return launch_fir_i8x_t<HIST, MM, false>(a, max_blocks, s);
+        return launch_fir_i8x_t<HIST, MM, false>(a, max_blocks, chunk, layout, s);
     if constexpr (MM == 2)
-        return launch_fir_i8x_t<HIST, 2, true>(a, max_blocks, s);
+        return launch_fir_i8x_t<HIST, 2, true>(a, max_blocks, chunk, layout, s);
     else
         return hipErrorInvalidValue;
 }
+
 
 bool fir_i8x_supported(int hist, bool mix, bool fuse2)
 {
@@ -944,7 +1235,7 @@ bool fir_i8x_supported(int hist, bool mix, bool fuse2)
     return !(fuse2 && mix && hist > 64);
 }
 
-hipError_t launch_fir_i8x(const FirI8xArgs &a, int hist, bool mix, bool fuse2, hipStream_t s, int max_blocks)
+hipError_t launch_fir_i8x(const FirI8xArgs &a, int hist, bool mix, bool fuse2, hipStream_t s, int max_blocks, int chunk, int layout)
 {
     if (a.n_in <= 0)
         return hipSuccess;
@@ -954,13 +1245,13 @@ hipError_t launch_fir_i8x(const FirI8xArgs &a, int hist, bool mix, bool fuse2, h
         return hipErrorInvalidValue;
     switch (hist) {
     case 32:
-        return launch_fir_i8x_h<32>(a, mix, fuse2, max_blocks, s);
+        return launch_fir_i8x_h<32>(a, mix, fuse2, max_blocks, chunk, layout, s);
     case 64:
-        return launch_fir_i8x_h<64>(a, mix, fuse2, max_blocks, s);
+        return launch_fir_i8x_h<64>(a, mix, fuse2, max_blocks, chunk, layout, s);
     case 128:
-        return launch_fir_i8x_h<128>(a, mix, fuse2, max_blocks, s);
+        return launch_fir_i8x_h<128>(a, mix, fuse2, max_blocks, chunk, layout, s);
     default:
-        return launch_fir_i8x_h<256>(a, mix, fuse2, max_blocks, s);
+        return launch_fir_i8x_h<256>(a, mix, fuse2, max_blocks, chunk, layout, s);
     }
 }
 

@@ -179,6 +179,11 @@ struct pddc_pipeline {
         int i8x_pair = 1;         /* ... and the cascade's first two stages as its fused pair (0: unfused, or k_fir8)  */
         int i8x_plain = 0;        /* untuned first stages on k_fir_i8x too (LDS-carried history; 0: k_fir_i8 / k_fir8) */
         int i8x_blocks = 0;       /* persistent grid override of k_fir_i8x (0: one block per CU)                       */
+        int i8x_chunk = 0;        /* tiles per chunk of its walk (0: 1, fused pair 4)                                    */
+        int i8x_layout = 1;       /* which waves finish a tile (ddc_fir_i8.hip "Who does what"): 0 the matrix waves, 1 the
+                                     loaders (measured best), 2 two matrix + two finishing waves                        */
+        int i8x_pair_max_log2 = 26;   /* the fused pair up to 2^26-sample batches: 3.2x k_fir8's pair at 2^22, 1.6x at
+                                         2^24, level at 2^26, 9 % behind at 2^28 (profiles/r04)                         */
         int no_fuse2 = 0, fuse3 = 0;
     } opt;
     /* k_fir_i8x's operands follow the tuning word: they are rebuilt on the host when the word, the taps or the form
@@ -941,6 +946,9 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
         p->opt.i8x_pair = env_int("PDDC_I8X_PAIR", 1);
         p->opt.i8x_plain = env_int("PDDC_I8X_PLAIN", 0);
         p->opt.i8x_blocks = env_int("PDDC_I8X_BLOCKS", 0);
+        p->opt.i8x_chunk = env_int("PDDC_I8X_CHUNK", 0);
+        p->opt.i8x_layout = env_int("PDDC_I8X_LAYOUT", 1);
+        p->opt.i8x_pair_max_log2 = env_int("PDDC_I8X_PAIR_MAX_LOG2", 26);
         p->opt.no_fuse2 = getenv("PDDC_NO_FUSE2") ? 1 : 0;
         p->opt.fuse3 = env_int("PDDC_FUSE3", 0);
     }
@@ -1156,6 +1164,9 @@ static int *option_field(pddc_pipeline *p, const char *name)
         int *f;
     } tab[] = { { "no_i8", &p->opt.no_i8 },       { "i8_128", &p->opt.i8_128 },         { "i8x", &p->opt.i8x },
                 { "i8x_pair", &p->opt.i8x_pair }, { "i8x_plain", &p->opt.i8x_plain },   { "i8x_blocks", &p->opt.i8x_blocks },
+                { "i8x_chunk", &p->opt.i8x_chunk },
+                { "i8x_layout", &p->opt.i8x_layout },
+                { "i8x_pair_max_log2", &p->opt.i8x_pair_max_log2 },
                 { "no_fuse2", &p->opt.no_fuse2 }, { "fuse3", &p->opt.fuse3 } };
     for (const auto &t : tab)
         if (!strcmp(t.n, name))
@@ -1412,6 +1423,8 @@ static bool stages01_i8x(const pddc_pipeline *p, size_t nsamples)
         return false;
     if (!fir_i8x_supported(s0.hist, (p->flags & PDDC_F_MIX) != 0, true))
         return false;
+    if (p->opt.i8x_pair_max_log2 < 40 && nsamples > ((size_t)1 << (p->opt.i8x_pair_max_log2 < 0 ? 0 : p->opt.i8x_pair_max_log2)))
+        return false;
     return nsamples > 0 && nsamples % 8192 == 0 && s0.consumed % 8 == 0 && s1.consumed % 8 == 0;
 }
 
@@ -1477,7 +1490,7 @@ static int i8x_prepare(pddc_pipeline *p, bool mix, bool fuse2, hipStream_t s, Fi
 
 extern "C" int pddc_pipeline_uses_fused_pair(const pddc_pipeline *p, size_t nsamples)
 {
-    return p && (stages01_i8x(p, nsamples) ? 2 : stages01_fusable(p, nsamples) ? 1 : 0);
+    return !p ? 0 : stages01_i8x(p, nsamples) ? 2 : stages01_fusable(p, nsamples) ? 1 : 0;
 }
 
 /* The whole cascade in one kernel: behind the fused pair, stage 2 -- a plain decimator at 1/64 of the input rate --
@@ -1927,7 +1940,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         q.hist2_out = s1.d_hist[s1.cur ^ 1];
         if ((rc = stage0_event(p, s, true)))
             return rc;
-        HIP_TRY(launch_fir_i8x(q, s0.hist, mix, true, s, p->opt.i8x_blocks));
+        HIP_TRY(launch_fir_i8x(q, s0.hist, mix, true, s, p->opt.i8x_blocks, p->opt.i8x_chunk, p->opt.i8x_layout));
         if ((rc = stage0_event(p, s, false)))
             return rc;
         flip[0] = flip[1] = true;
@@ -2113,7 +2126,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                 q.hist_out = a.hist_out;
                 q.out = dst;
                 q.n_in = (long long)nsamples;
-                HIP_TRY(launch_fir_i8x(q, st.hist, mix, false, s, p->opt.i8x_blocks));
+                HIP_TRY(launch_fir_i8x(q, st.hist, mix, false, s, p->opt.i8x_blocks, p->opt.i8x_chunk, p->opt.i8x_layout));
             } else if (i8kind == 1 && !ov) {
                 /* 65..256 taps, no NCO: the int8 matrix cores (same history, same outputs to 1e-7 of full scale) */
                 FirI8Args q;
@@ -2962,7 +2975,7 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
         if (fuse3)
             HIP_TRY(launch_fir8_fused3(p->st[0].ntb, p->R, mix, a, s));
         else if (x1 || x2)
-            HIP_TRY(launch_fir_i8x(qx, p->st[0].hist, mix, x2, s, p->opt.i8x_blocks));
+            HIP_TRY(launch_fir_i8x(qx, p->st[0].hist, mix, x2, s, p->opt.i8x_blocks, p->opt.i8x_chunk, p->opt.i8x_layout));
         else if (fuse2)
             HIP_TRY(launch_fir8_fused2(p->st[0].ntb, p->R, mix, a, s));
         else if (i8)

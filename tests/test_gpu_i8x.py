@@ -194,3 +194,56 @@ def test_full_scale_extremes_through_the_tuned_stage(pkg, dev, O):
             ref = O.ddc_chain(packed, [(8, h)], freg=word, mix=True)
             y = run(pkg, dev, [(8, h)], packed, [0, TILE * 2, ns], freg=word)
             assert O.rel_err(y, ref) <= FIR_TOL, (n, word, O.rel_err(y, ref))
+
+
+def test_every_walk_gives_the_same_bits(pkg, dev, O):
+    """The chunk size of the round-robin walk (option i8x_chunk: 1 = tile-interleaved, large = contiguous ranges) and the
+    grid size change which tiles take their history from memory and which from LDS, and which tiles compute their own
+    porch for the fused second stage -- never a bit of the output.  The layout (option i8x_layout: which waves load,
+    multiply and finish a tile) leaves the single stage's bits alone too; the fused second stage sums in another order in
+    layout 1 (scalar FMAs on the loader waves), so layouts are compared with the oracle's tolerance there."""
+    for stages in ([(8, load_taps("d8_127"))], [(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05))]):
+        sizes = [TILE * 300, TILE * 7, TILE * 1030]
+        cuts = np.concatenate([[0], np.cumsum(sizes)])
+        packed = O.lcg_bytes(6 * int(cuts[-1]), 12)
+        ref = O.ddc_chain(packed, stages, freg=FREG, mix=True)
+        first = None
+        for lay in (0, 1, 2):
+            base = None
+            for opts in ({}, {"i8x_chunk": 1}, {"i8x_chunk": 2}, {"i8x_chunk": 3}, {"i8x_chunk": 100000}, {"i8x_blocks": 7, "i8x_chunk": 5},
+                         {"i8x_blocks": 1}):
+                y = run(pkg, dev, stages, packed, cuts, opts=dict(opts, i8x_layout=lay))
+                if base is None:
+                    base = y
+                    assert O.rel_err(y, ref) <= FIR_TOL, (lay, O.rel_err(y, ref))
+                assert np.array_equal(y.view(np.uint32), base.view(np.uint32)), (lay, opts)
+            if first is None:
+                first = base
+            elif len(stages) == 1:
+                assert np.array_equal(base.view(np.uint32), first.view(np.uint32)), lay
+            else:
+                assert O.rel_err(base, first) <= FIR_TOL
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_layouts_stay_clean_under_repetition(pkg, dev, O, layout):
+    """Sporadic faults need repetition to show (the packed-fp32 / store hazards beside matrix waves): the same
+    600-tile batch twenty times per layout, single stage (both NCO forms) and fused pair, every output against the first
+    run's bits and the first run against the oracle."""
+    import torch
+    for stages in ([(8, load_taps("d8_127"))], [(8, lowpass(48, 0.05))], [(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05))]):
+        ns = TILE * 600
+        packed = O.lcg_bytes(6 * ns, 2027)
+        ref = O.ddc_chain(packed, stages, freg=FREG, mix=True)
+        d_in = to_dev(packed, dev)
+        first = None
+        for rep in range(20):
+            pipe = pkg.Pipeline(stages, mix=True)
+            pipe.set_option("i8x_layout", layout)
+            pipe.set_freg(FREG)
+            y = pipe.process(d_in).cpu().numpy().reshape(-1)
+            pipe.close()
+            if first is None:
+                first = y
+                assert O.rel_err(y, ref) <= FIR_TOL
+            assert np.array_equal(y.view(np.uint32), first.view(np.uint32)), (layout, len(stages), rep)

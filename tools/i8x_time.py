@@ -45,7 +45,16 @@ def timeit(stages, opts, ns, steps=30, mix=True):
     pipe.fence(st)
     e1.record()
     torch.cuda.synchronize()
+    L = pkg.ddc_lib()
+    if hasattr(L, "pddc_i8x_probe_dump") and os.environ.get("I8X_PROBE"):
+        L.pddc_i8x_probe_dump()                  # (timing builds with -DI8X_PROBE: clears what the warm-up left)
+        pipe.process_ptr(d_in.data_ptr(), ns, out.data_ptr(), out.shape[0], st)
+        torch.cuda.synchronize()
+        print("probe of one launch:", flush=True)
+        L.pddc_i8x_probe_dump()
     kind = (pipe.on_i8(ns), pipe.fused_pair(ns))
+    k0 = pipe.time_stage0(d_in.data_ptr(), ns, out.data_ptr(), steps, st)
+    kind = kind + (round(k0, 4),)
     pipe.close()
     del d_in, out
     return e0.elapsed_time(e1) / steps, kind
@@ -53,6 +62,69 @@ def timeit(stages, opts, ns, steps=30, mix=True):
 
 if __name__ == "__main__":
     ns = 1 << 28
+    if len(sys.argv) > 2 and sys.argv[1] == "one":
+        # one case, for profilers: python3 tools/i8x_time.py one <case> [opt=value ...]
+        allc = {
+            "d8_127+nco": ([(8, taps("d8_127"))], True), "d8_255+nco": ([(8, taps("d8_255"))], True),
+            "d8_48+nco": ([(8, lowpass(48, 0.05))], True), "d8_127": ([(8, taps("d8_127"))], False),
+            "pair": ([(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05))], True),
+            "c320api": ([(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05)), (5, lowpass(144, 0.08))], True),
+        }
+        stages, mix = allc[sys.argv[2]]
+        opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in sys.argv[3:]}
+        for rnd in range(2):
+            ms, kind = timeit(stages, opts, ns, mix=mix, steps=20)
+            print(f"{sys.argv[2]} {opts} round {rnd}: {ms:.4f} ms {ns / ms / 1e6:8.1f} GS/s kernels {kind}", flush=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sizes":
+        # where does the matrix-core path pay?  whole-step time by batch size, i8x layouts against the vector kernels
+        pair = [(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05))]
+        casc = pair + [(5, lowpass(144, 0.08))]
+        for name, stages in (("d8_48+nco", [(8, lowpass(48, 0.05))]), ("d8_127+nco", [(8, taps("d8_127"))]),
+                             ("d8_255+nco", [(8, taps("d8_255"))]), ("pair 48/56", pair), ("x320 48/56/144", casc)):
+            for lg in (18, 20, 22, 24, 26, 28):
+                n = 1 << lg
+                row = []
+                for label, opts in (("vec", {"i8x": 0}), ("L0", {"i8x_layout": 0}), ("L1", {"i8x_layout": 1}), ("L2", {"i8x_layout": 2}),
+                                    ("L2c8", {"i8x_layout": 2, "i8x_chunk": 8})):
+                    if label == "L2c8" and len(stages) < 2:
+                        continue
+                    ms, kind = timeit(stages, opts, n, steps=200 if lg <= 24 else 30)
+                    row.append(f"{label} {ms * 1e3:8.1f} us")
+                print(f"{name:16s} 2^{lg}: " + " | ".join(row), flush=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "layouts":
+        pair = [(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05))]
+        for rnd in range(2):
+            for name, stages, mix, extra in (("d8_127 plain", [(8, taps("d8_127"))], False, {"i8x_plain": 1}),
+                                             ("d8_127+nco", [(8, taps("d8_127"))], True, {}),
+                                             ("d8_255+nco", [(8, taps("d8_255"))], True, {}),
+                                             ("d8_48+nco", [(8, lowpass(48, 0.05))], True, {}),
+                                             ("pair 48/56", pair, True, {}),
+                                             ("pair 48/56 C=8", pair, True, {"i8x_chunk": 8}),
+                                             ("pair 48/56 C=2", pair, True, {"i8x_chunk": 2})):
+                for lay in (0, 1, 2):
+                    opts = dict(extra)
+                    opts["i8x_layout"] = lay
+                    ms, kind = timeit(stages, opts, ns, mix=mix)
+                    print(f"layout {lay} {name:16s} round {rnd}: {ms:.4f} ms {ns / ms / 1e6:8.1f} GS/s kernels {kind}", flush=True)
+            for name, stages, mix in (("d8_127 k_fir_i8", [(8, taps("d8_127"))], False), ("pair 48/56 k_fir8", pair, True)):
+                ms, kind = timeit(stages, {"i8x": 0}, ns, mix=mix)
+                print(f"reference {name:16s} round {rnd}: {ms:.4f} ms {ns / ms / 1e6:8.1f} GS/s kernels {kind}", flush=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "chunks":
+        pair = [(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05)), (5, lowpass(144, 0.08))]
+        for rnd in range(2):
+            for C in (1, 2, 4, 8, 16, 100000):
+                for name, stages, mix, extra in (("d8_127 plain", [(8, taps("d8_127"))], False, {"i8x_plain": 1}),
+                                                 ("d8_127+nco", [(8, taps("d8_127"))], True, {}),
+                                                 ("d8_48+nco", [(8, lowpass(48, 0.05))], True, {}),
+                                                 ("c320 api-like", pair, True, {})):
+                    opts = dict(extra)
+                    opts["i8x_chunk"] = C
+                    ms, kind = timeit(stages, opts, ns, mix=mix)
+                    print(f"C={C:6d} {name:16s} round {rnd}: {ms:.4f} ms {ns / ms / 1e6:8.1f} GS/s kernels {kind}", flush=True)
+        sys.exit(0)
     cases = {
         "d8_127+nco": [(8, taps("d8_127"))],
         "d8_255+nco": [(8, taps("d8_255"))],
@@ -61,6 +133,11 @@ if __name__ == "__main__":
         "c320 api-like 48/56/144": [(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05)), (5, lowpass(144, 0.08))],
         "2M api-like 48/144 (8*5)": [(8, lowpass(48, 0.05)), (5, lowpass(144, 0.08))],
     }
+    for name, h in (("d8_127 no nco", taps("d8_127")), ("d8_255 no nco", taps("d8_255")), ("d8_48 no nco", lowpass(48, 0.05))):
+        for rnd in range(2):
+            for label, opts in (("i8x", {"i8x_plain": 1}), ("default", {}), ("vector", {"no_i8": 1})):
+                ms, kind = timeit([(8, h)], opts, ns, mix=False)
+                print(f"{name:28s} {label:7s} round {rnd}: {ms:.4f} ms  {ns / ms / 1e6:8.1f} GS/s  kernels {kind}", flush=True)
     for name, stages in cases.items():
         for rnd in range(2):
             for label, opts in (("i8x", {}), ("vector", {"i8x": 0})):
