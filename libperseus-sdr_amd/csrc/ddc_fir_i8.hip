@@ -582,8 +582,10 @@ struct Roles {
     static constexpr int NQ = 2;                               /* main groups per loader thread and tile */
 };
 
+/* the block's work; `nblk` blocks walk this stream's tiles, this is block `blk` of them (k_fir_i8x: the grid; k_fir_i8x_many:
+ * the grid's x dimension, one stream per y) */
 template <int HIST, int MODE, bool FUSE2, int LAYOUT>
-__global__ __launch_bounds__(768, 1) void k_fir_i8x(FirI8xArgs a, long long ntiles, int C)
+__device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long ntiles, int C, long long nblk, long long blk)
 {
     using namespace i8x;
     using G = Geo<HIST, MODE, FUSE2>;
@@ -595,8 +597,8 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8x(FirI8xArgs a, long long ntil
     /* [2 buffers][2 components][3 planes][PLANE], then [2 buffers][NARR][AS] first-stage values */
     float *arr_base = reinterpret_cast<float *>(lds_i8x + 12 * PLANE);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* (an SGPR: role branches are uniform) */
-    const Walk wk{ ntiles, (long long)gridDim.x, C };
-    Cursor cur{ (long long)blockIdx.x, 0 };
+    const Walk wk{ ntiles, nblk, C };
+    Cursor cur{ blk, 0 };
     const uint32_t n0lo = (uint32_t)a.n0;
     const long long n_out = a.n_in >> 3;
 
@@ -809,7 +811,7 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8x(FirI8xArgs a, long long ntil
         /* ---- loaders (waves 4..11): main groups two tiles ahead in two register sets, front groups one tile ahead;
          * LAYOUT 1: they also finish the tile before the one the matrix waves are working on */
         const int lt = tid - 256;
-        if (blockIdx.x == 0 && a.hist_out) {             /* the next call's history: the batch's last HIST samples */
+        if (blk == 0 && a.hist_out) {             /* the next call's history: the batch's last HIST samples */
             const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + (a.n_in - HIST) * 6);
             if (lt < HIST * 6 / 16)
                 static_cast<uint4 *>(a.hist_out)[lt] = src[lt];
@@ -904,7 +906,7 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8x(FirI8xArgs a, long long ntil
     if (LAYOUT == 2 && wave >= 2) {
         /* ---- finishing waves (LAYOUT 2): tile t - 1 is finished while the matrix waves work on tile t */
         const int pt = tid - 128;
-        if (FUSE2 && blockIdx.x == 0 && pt < 64) {
+        if (FUSE2 && blk == 0 && pt < 64) {
             /* the batch's first tile: the stream's second-stage history -- the 64 first-stage outputs in front of this batch,
              * mixed floats -- taken back into the frame of this call's u values: u = y conj(LO) */
             const float2 y = static_cast<const float2 *>(a.hist2)[pt];
@@ -954,7 +956,7 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8x(FirI8xArgs a, long long ntil
                     A1[ks][j] = atab[tab1 * G::TABV + (j * KSTEPS + ks) * 64 + lane];
             }
     }
-    if (LAYOUT != 2 && FUSE2 && blockIdx.x == 0 && tid < 64) {
+    if (LAYOUT != 2 && FUSE2 && blk == 0 && tid < 64) {
         /* the batch's first tile: the stream's second-stage history -- the 64 first-stage outputs in front of this batch,
          * mixed floats -- taken back into the frame of this call's u values: u = y conj(LO) */
         const float2 y = static_cast<const float2 *>(a.hist2)[tid];
@@ -1040,7 +1042,7 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8x(FirI8xArgs a, long long ntil
             float *yp = &y.x;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                yp[v] = recombine(acc, v) * a.scale + a.ct[w0];
+                yp[v] = recombine(acc, v) * a.scale + (w0 ? a.ct[1] : a.ct[0]);
             *reinterpret_cast<float4 *>(dst + w0 * AS) = y;
         }
     };
@@ -1069,6 +1071,39 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8x(FirI8xArgs a, long long ntil
         t = wk.tile(cur);
         buf ^= 1;
     }
+}
+
+template <int HIST, int MODE, bool FUSE2, int LAYOUT>
+__global__ __launch_bounds__(768, 1) void k_fir_i8x(FirI8xArgs a, long long ntiles, int C)
+{
+    fir_i8x_block<HIST, MODE, FUSE2, LAYOUT>(a, ntiles, C, (long long)gridDim.x, (long long)blockIdx.x);
+}
+
+/* several streams, one launch (the gang: receivers that share a GPU): blockIdx.y is the stream, every record its own --
+ * buffers, history, tuning word, tap tables; the same block body, so the same bits as a launch of its own */
+template <int HIST, int MODE, bool FUSE2, int LAYOUT>
+__global__ __launch_bounds__(768, 1) void k_fir_i8x_many(FirI8xMany m, long long ntiles, int C)
+{
+    /* this stream's record, field by field through the scalar cache (indexing the by-value array puts a copy on the stack) */
+    const FirI8xArgs PDDC_CONSTANT &r = ((const FirI8xArgs PDDC_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr())[blockIdx.y];
+    (void)m;
+    FirI8xArgs a;
+    a.in = r.in;
+    a.hist = r.hist;
+    a.hist_out = r.hist_out;
+    a.out = r.out;
+    a.atab = r.atab;
+    a.n_in = r.n_in;
+    a.scale = r.scale;
+    a.ct[0] = r.ct[0];
+    a.ct[1] = r.ct[1];
+    a.n0 = r.n0;
+    a.freg = r.freg;
+    a.phase_off = r.phase_off;
+    a.taps2 = r.taps2;
+    a.hist2 = r.hist2;
+    a.hist2_out = r.hist2_out;
+    fir_i8x_block<HIST, MODE, FUSE2, LAYOUT>(a, ntiles, C, (long long)gridDim.x, (long long)blockIdx.x);
 }
 
 /* ---- host side: the tap operands ------------------------------------------------------------------------------------ */
@@ -1173,7 +1208,8 @@ void fir_i8x_taps2(const float *taps2, int ntaps2, bool mix, uint32_t freg, floa
 }
 
 template <int HIST, int MODE, bool FUSE2, int LAYOUT>
-static hipError_t launch_fir_i8x_l(const FirI8xArgs &a, int max_blocks, int chunk, hipStream_t s)
+static hipError_t launch_fir_i8x_l(const FirI8xArgs &a, int max_blocks, int chunk, hipStream_t s, const FirI8xMany *many = nullptr,
+                                   int nmany = 0)
 {
     using G = i8x::Geo<HIST, MODE, FUSE2>;
     const long long ntiles = (a.n_in + i8x::TILE - 1) / i8x::TILE;
@@ -1189,11 +1225,17 @@ static hipError_t launch_fir_i8x_l(const FirI8xArgs &a, int max_blocks, int chun
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
         if (e != hipSuccess)
             return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_i8x_many<HIST, MODE, FUSE2, LAYOUT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        if (e != hipSuccess)
+            return e;
         cus[dev & 63] = v > 0 ? v : 256;
     }
     /* chunks of C tiles go round the blocks: C = 1 (tile-interleaved) unless asked otherwise; never more than a block's
      * fair share, so that every CU has work */
     long long nblk = cus[dev & 63];
+    if (many && nmany > 1)
+        nblk = (nblk + nmany - 1) / nmany;        /* the streams of a round share the CUs */
     if (max_blocks > 0 && nblk > max_blocks)
         nblk = max_blocks;
     long long C = chunk > 0 ? chunk : FUSE2 ? 4 : 1;
@@ -1201,16 +1243,25 @@ static hipError_t launch_fir_i8x_l(const FirI8xArgs &a, int max_blocks, int chun
         C = (ntiles + nblk - 1) / nblk;
     const long long nchunks = (ntiles + C - 1) / C;
     const long long grid = nchunks < nblk ? nchunks : nblk;
-    hipLaunchKernelGGL((k_fir_i8x<HIST, MODE, FUSE2, LAYOUT>), dim3((unsigned)grid), dim3(768), G::LDS_BYTES, s, a, ntiles, (int)C);
+    if (many)
+        hipLaunchKernelGGL((k_fir_i8x_many<HIST, MODE, FUSE2, LAYOUT>), dim3((unsigned)grid, (unsigned)nmany), dim3(768), G::LDS_BYTES, s,
+                           *many, ntiles, (int)C);
+    else
+        hipLaunchKernelGGL((k_fir_i8x<HIST, MODE, FUSE2, LAYOUT>), dim3((unsigned)grid), dim3(768), G::LDS_BYTES, s, a, ntiles, (int)C);
     return hipGetLastError();
 }
 
+struct I8xManyRef {
+    const FirI8xMany *m = nullptr;
+    int n = 0;
+};
+static thread_local I8xManyRef t_many;       /* (set by launch_fir_i8x_many around its dispatch through the same switch) */
 template <int HIST, int MODE, bool FUSE2>
 static hipError_t launch_fir_i8x_t(const FirI8xArgs &a, int max_blocks, int chunk, int layout, hipStream_t s)
 {
-    return layout == 0   ? launch_fir_i8x_l<HIST, MODE, FUSE2, 0>(a, max_blocks, chunk, s)
-           : layout == 1 ? launch_fir_i8x_l<HIST, MODE, FUSE2, 1>(a, max_blocks, chunk, s)
-                         : launch_fir_i8x_l<HIST, MODE, FUSE2, 2>(a, max_blocks, chunk, s);
+    return layout == 0   ? launch_fir_i8x_l<HIST, MODE, FUSE2, 0>(a, max_blocks, chunk, s, t_many.m, t_many.n)
+           : layout == 1 ? launch_fir_i8x_l<HIST, MODE, FUSE2, 1>(a, max_blocks, chunk, s, t_many.m, t_many.n)
+                         : launch_fir_i8x_l<HIST, MODE, FUSE2, 2>(a, max_blocks, chunk, s, t_many.m, t_many.n);
 }
 
 template <int HIST>
@@ -1253,6 +1304,20 @@ hipError_t launch_fir_i8x(const FirI8xArgs &a, int hist, bool mix, bool fuse2, h
     default:
         return launch_fir_i8x_h<256>(a, mix, fuse2, max_blocks, chunk, layout, s);
     }
+}
+
+hipError_t launch_fir_i8x_many(const FirI8xMany &m, int n, int hist, bool mix, bool fuse2, hipStream_t s, int max_blocks, int chunk,
+                               int layout)
+{
+    if (n < 1 || n > kFir8ManyMax)
+        return hipErrorInvalidValue;
+    for (int i = 1; i < n; ++i)
+        if (m.a[i].n_in != m.a[0].n_in)
+            return hipErrorInvalidValue;
+    t_many = I8xManyRef{ &m, n };
+    const hipError_t e = launch_fir_i8x(m.a[0], hist, mix, fuse2, s, max_blocks, chunk, layout);
+    t_many = I8xManyRef{};
+    return e;
 }
 
 } // namespace pddc

@@ -178,6 +178,11 @@ struct FirI8xArgs {
     void        *hist2_out = nullptr;
 };
 constexpr int kFirI8xTaps2Len = 2 * 68;
+/* n streams (same geometry and batch length), one launch: blockIdx.y is the stream (the gang) */
+struct FirI8xMany {
+    FirI8xArgs a[kFir8ManyMax];
+};
+static_assert(sizeof(FirI8xMany) <= 4000, "FirI8xMany must fit the kernel-argument segment");
 int    fir_i8x_mode(int hist, bool mix);                 /* 0: no NCO, 1: NCO split over waves, 2: NCO, both tap sets per wave */
 size_t fir_i8x_table_bytes(int hist, bool mix);
 /* host: the tap operand(s) for `ntaps` <= hist taps, NCO word freg when mix; false if the taps are all zero */
@@ -188,6 +193,8 @@ void fir_i8x_taps2(const float *taps2, int ntaps2, bool mix, uint32_t freg, floa
 bool fir_i8x_supported(int hist, bool mix, bool fuse2);
 /* max_blocks: persistent grid (0 = one block per CU); chunk: tiles per chunk of the round-robin walk (0 = 1, or 4 for the
  * fused pair; large = contiguous ranges per block) */
+hipError_t launch_fir_i8x_many(const FirI8xMany &m, int n, int hist, bool mix, bool fuse2, hipStream_t s, int max_blocks = 0,
+                               int chunk = 0, int layout = 1);
 /* layout: which waves do what (ddc_fir_i8.hip "Who does what"): 0 a matrix wave on every SIMD, 1 matrix and post waves on
  * two SIMDs, loaders on the other two */
 hipError_t launch_fir_i8x(const FirI8xArgs &a, int hist, bool mix, bool fuse2, hipStream_t s, int max_blocks = 0, int chunk = 0,

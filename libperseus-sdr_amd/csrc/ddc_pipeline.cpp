@@ -211,10 +211,14 @@ static constexpr size_t kI8xTaps2Off = 60 * 1024;
 
 /* what one member's process() leaves for the gang: kind 0 = nothing recorded */
 struct GangRec {
-    int kind = 0;                 /* 1: the packed /8 first stage alone (launch_fir8), 2: the fused pair          */
+    int kind = 0;                 /* 1: the packed /8 first stage alone (launch_fir8), 2: the fused pair; 3: k_fir_i8x
+                                     (the tuned first stage on the matrix cores, alone or as its fused pair: `fuse2`)  */
     int ntb = 0, R = 4;
     bool mix = false;
     Fir8Args a;
+    FirI8xArgs ax;                /* kind 3 */
+    int hist = 0, chunk = 0, layout = 1, blocks = 0;
+    bool fuse2 = false;
     GenTail tail;                 /* nblocks == 0: the plan ends with the first-stage kernel                       */
 };
 
@@ -1363,7 +1367,7 @@ static size_t words_in_window(const pddc_pipeline *p)
  * no NCO: the wire bytes on the int8 matrix cores), 2 k_fir_i8x (the same with the NCO folded into the taps -- every tuned
  * first stage of 1..256 taps whose history window was mixed with the word in force: the one batch behind a retune goes
  * through k_fir8, which re-mixes its packed history with the old word; the two share the stream state).          */
-static int stage0_i8_kind(const pddc_pipeline *p, size_t nsamples)
+static int stage0_i8_kind_raw(const pddc_pipeline *p, size_t nsamples)
 {
     const Stage &s0 = p->st[0];
     if (!stage0_fused(p) || p->opt.no_i8 || nsamples < (size_t)s0.hist || s0.ntaps > s0.hist)
@@ -1379,6 +1383,34 @@ static int stage0_i8_kind(const pddc_pipeline *p, size_t nsamples)
      * 0.3464-0.3483 ms (three alternating rounds on one box), 2^30 equal -- and it is the more accurate of the two
      * (8e-8 against 2.9e-7).  Option i8_128 = 0 forces the vector kernel (development). */
     return s0.hist == 256 || p->opt.i8_128 ? 1 : 0;
+}
+
+/* can stages 0 and 1 run as k_fir_i8x's fused pair (given that stage 0 runs on it)?  stage 1 a plain decimate-by-8 of <= 64
+ * taps, whole tiles of 8192 samples, batches up to 2^i8x_pair_max_log2 (beyond that k_fir8's pair streams better) */
+static bool i8x_pair_ok(const pddc_pipeline *p, size_t nsamples)
+{
+    if (p->nstages < 2 || !p->opt.i8x_pair || p->opt.no_fuse2)
+        return false;
+    const Stage &s0 = p->st[0], &s1 = p->st[1];
+    if (s1.decim != 8 || s1.interp != 1 || s1.ntb != 8 || s1.hist != 64 || s1.ntaps > 64)
+        return false;
+    if (!fir_i8x_supported(s0.hist, (p->flags & PDDC_F_MIX) != 0, true))
+        return false;
+    if (p->opt.i8x_pair_max_log2 < 40 && nsamples > ((size_t)1 << (p->opt.i8x_pair_max_log2 < 0 ? 0 : p->opt.i8x_pair_max_log2)))
+        return false;
+    return nsamples > 0 && nsamples % 8192 == 0 && s0.consumed % 8 == 0 && s1.consumed % 8 == 0;
+}
+
+static bool stages01_fusable(const pddc_pipeline *p, size_t nsamples);
+/* ... with one more rule for cascades: where this batch cannot take k_fir_i8x's fused pair (not whole 8192-sample tiles, or
+ * larger than the pair is good for) but CAN take k_fir8's (tiles of 4096), the vector pair wins over matrix-core stage 0 +
+ * a second-stage kernel of its own */
+static int stage0_i8_kind(const pddc_pipeline *p, size_t nsamples)
+{
+    const int k = stage0_i8_kind_raw(p, nsamples);
+    if (k == 2 && p->nstages >= 2 && !i8x_pair_ok(p, nsamples) && stages01_fusable(p, nsamples))
+        return 0;
+    return k;
 }
 
 int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples) { return p ? stage0_i8_kind(p, nsamples) : 0; }
@@ -1416,16 +1448,7 @@ static bool stages01_fusable(const pddc_pipeline *p, size_t nsamples)
  * of <= 64 taps -- on its values while they are still in LDS; whole tiles of 8192 samples */
 static bool stages01_i8x(const pddc_pipeline *p, size_t nsamples)
 {
-    if (p->nstages < 2 || !p->opt.i8x_pair || p->opt.no_fuse2 || stage0_i8_kind(p, nsamples) != 2)
-        return false;
-    const Stage &s0 = p->st[0], &s1 = p->st[1];
-    if (s1.decim != 8 || s1.interp != 1 || s1.ntb != 8 || s1.hist != 64 || s1.ntaps > 64)
-        return false;
-    if (!fir_i8x_supported(s0.hist, (p->flags & PDDC_F_MIX) != 0, true))
-        return false;
-    if (p->opt.i8x_pair_max_log2 < 40 && nsamples > ((size_t)1 << (p->opt.i8x_pair_max_log2 < 0 ? 0 : p->opt.i8x_pair_max_log2)))
-        return false;
-    return nsamples > 0 && nsamples % 8192 == 0 && s0.consumed % 8 == 0 && s1.consumed % 8 == 0;
+    return stage0_i8_kind(p, nsamples) == 2 && i8x_pair_ok(p, nsamples);
 }
 
 /* k_fir_i8x's operands for the word in force (rebuilt and uploaded in stream order when word, taps, form or stream changed)
@@ -1906,16 +1929,18 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
     if (g) {
         g->kind = 0;
         g->tail = GenTail{};
-        const int nfirst = stages01_fusable(p, nsamples) ? 2 : 1;
+        const int i8k = mixed_hist ? 0 : stage0_i8_kind(p, nsamples);
+        if (i8k == 1)
+            return 1;            /* (k_fir_i8 has no many-stream launch: this member runs its own chain on the gang's stream --
+                                    the same bits as alone, which the vector kernel of a shared launch would not give) */
+        const int nfirst = (i8k == 2 ? stages01_i8x(p, nsamples) : stages01_fusable(p, nsamples)) ? 2 : 1;
         const int last = p->nstages - 1;
         const bool tail_ok = p->nstages == nfirst ||
                              (p->nstages == nfirst + 1 && p->st[last].interp == 1 && n_in[p->nstages] > 0);
         if (mixed_hist || !stage0_fused(p) || p->NT != 256 || p->overlap || p->carry_pending ||
             p->time_stage0 || p->fail_at_stage >= 0 || (p->flags & (PDDC_F_OUT_PACKED24 | PDDC_F_NO_FAST)) ||
             stages012_fusable(p, nsamples) || !tail_ok || n_in[1] == 0 || nsamples < (size_t)p->st[0].hist ||
-            !fir8_many_supported(nfirst, p->st[0].ntb, p->R) ||
-            stage0_i8_kind(p, nsamples) != 0)        /* (the matrix-core kernels have no many-stream launch: such a member
-                                                        runs its own chain on the gang's stream -- the same bits as alone) */
+            (i8k != 2 && !fir8_many_supported(nfirst, p->st[0].ntb, p->R)))
             return 1;
     }
     const int i8kind = mixed_hist ? 0 : stage0_i8_kind(p, nsamples);
@@ -1928,6 +1953,10 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
             return rc;
         if ((rc = stage_dst(1, &dst, true)))
             return rc;
+        GenTail mine;
+        const bool gtail = g && p->nstages == 3;
+        if (gtail && (rc = carry_setup(2, &dst, &mine, false, 160u * 1024u)))
+            return rc;                                      /* (1: no shape for this tail -- nothing touched yet) */
         FirI8xArgs q;
         if ((rc = i8x_prepare(p, mix, true, s, q)))
             return rc;
@@ -1940,11 +1969,26 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         q.hist2_out = s1.d_hist[s1.cur ^ 1];
         if ((rc = stage0_event(p, s, true)))
             return rc;
-        HIP_TRY(launch_fir_i8x(q, s0.hist, mix, true, s, p->opt.i8x_blocks, p->opt.i8x_chunk, p->opt.i8x_layout));
+        if (g) {
+            g->kind = 3;
+            g->mix = mix;
+            g->ax = q;
+            g->hist = s0.hist;
+            g->fuse2 = true;
+            g->chunk = p->opt.i8x_chunk;
+            g->layout = p->opt.i8x_layout;
+            g->blocks = p->opt.i8x_blocks;
+            if (gtail) {
+                g->tail = mine;
+                flip[2] = true;
+            }
+        } else {
+            HIP_TRY(launch_fir_i8x(q, s0.hist, mix, true, s, p->opt.i8x_blocks, p->opt.i8x_chunk, p->opt.i8x_layout));
+        }
         if ((rc = stage0_event(p, s, false)))
             return rc;
         flip[0] = flip[1] = true;
-        first = 2;
+        first = gtail ? 3 : 2;
     } else if (!mixed_hist && stages012_fusable(p, nsamples)) {
         /* stages 0, 1 and 2 in ONE kernel: neither intermediate touches HBM */
         Stage &s0 = p->st[0], &s1 = p->st[1];
@@ -2105,7 +2149,29 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                 a.tail = p->carry_tail;
             if ((rc = stage0_event(p, s, true)))
                 return rc;
-            if (g) {
+            if (g && i8kind == 2) {
+                FirI8xArgs q;
+                if ((rc = i8x_prepare(p, mix, false, s, q)))
+                    return rc;
+                q.in = d_packed;
+                q.hist = h_in;
+                q.hist_out = a.hist_out;
+                q.out = dst;
+                q.n_in = (long long)nsamples;
+                g->kind = 3;
+                g->mix = mix;
+                g->ax = q;
+                g->hist = st.hist;
+                g->fuse2 = false;
+                g->chunk = p->opt.i8x_chunk;
+                g->layout = p->opt.i8x_layout;
+                g->blocks = p->opt.i8x_blocks;
+                if (gtail) {
+                    g->tail = mine;
+                    flip[1] = true;
+                    skip_from = 1;
+                }
+            } else if (g) {
                 g->kind = 1;
                 g->ntb = st.ntb;
                 g->R = p->R;
@@ -2637,23 +2703,32 @@ int pddc_gang_push_async(pddc_gang *g, pddc_gang_item *items, int n, size_t nsam
         if (!open[i])
             continue;
         Fir8Many fm;
+        FirI8xMany xm;
         GenTailMany tm;
         int k = 0;
         bool any_tail = false;
+        const bool x = rec[i].kind == 3;
         for (int j = i; j < n; ++j) {
-            if (!open[j] || rec[j].kind != rec[i].kind || rec[j].ntb != rec[i].ntb || rec[j].R != rec[i].R ||
-                rec[j].mix != rec[i].mix ||
-                rec[j].a.n_in != rec[i].a.n_in || (rec[j].tail.nblocks > 0) != (rec[i].tail.nblocks > 0) ||
-                rec[j].tail.kind != rec[i].tail.kind || rec[j].tail.D != rec[i].tail.D ||
-                rec[j].tail.ntaps != rec[i].tail.ntaps)
+            if (!open[j] || rec[j].kind != rec[i].kind || rec[j].mix != rec[i].mix ||
+                (rec[j].tail.nblocks > 0) != (rec[i].tail.nblocks > 0) || rec[j].tail.kind != rec[i].tail.kind ||
+                rec[j].tail.D != rec[i].tail.D || rec[j].tail.ntaps != rec[i].tail.ntaps)
                 continue;
-            fm.a[k] = rec[j].a;
+            if (x ? (rec[j].hist != rec[i].hist || rec[j].fuse2 != rec[i].fuse2 || rec[j].ax.n_in != rec[i].ax.n_in)
+                  : (rec[j].ntb != rec[i].ntb || rec[j].R != rec[i].R || rec[j].a.n_in != rec[i].a.n_in))
+                continue;
+            if (x)
+                xm.a[k] = rec[j].ax;
+            else
+                fm.a[k] = rec[j].a;
             tm.t[k] = rec[j].tail;
             any_tail = any_tail || rec[j].tail.nblocks > 0;
             open[j] = false;
             ++k;
         }
-        HIP_TRY(launch_fir8_many(rec[i].kind, rec[i].ntb, rec[i].R, rec[i].mix, fm, k, s));
+        if (x)
+            HIP_TRY(launch_fir_i8x_many(xm, k, rec[i].hist, rec[i].mix, rec[i].fuse2, s, rec[i].blocks, rec[i].chunk, rec[i].layout));
+        else
+            HIP_TRY(launch_fir8_many(rec[i].kind, rec[i].ntb, rec[i].R, rec[i].mix, fm, k, s));
         if (any_tail)
             HIP_TRY(launch_gen_tail_many(tm, k, s));
         if (n_ganged)

@@ -226,3 +226,18 @@ def test_gang_members_in_overlap_mode_run_chains_of_their_own(pkg, O, dev):
         assert np.array_equal(np.concatenate(r.out).view(np.uint32), solo.view(np.uint32)), i
         r.close()
     gang.close()
+
+
+@pytest.mark.parametrize("name", ["d8_127", "d8_255"])
+def test_untuned_long_first_stages_keep_their_bits_in_a_gang(pkg, O, dev, name):
+    """Without the NCO a 65..256-tap first stage runs on k_fir_i8, which has no many-stream launch: in a round of several
+    such a member runs its own chain on the gang's stream -- the bits of a push of its own, which the vector kernel of a
+    shared launch would not give (1e-7 apart)."""
+    stages = [(8, load_taps(name))]
+    seeds = [5, 6, 7]
+    ys = run_gang(pkg, [stages] * 3, seeds, SIZES, max(SIZES), mix=False)
+    for i in range(3):
+        solo = run_solo(pkg, stages, seeds[i], SIZES, max(SIZES), mix=False)
+        assert np.array_equal(ys[i].view(np.uint32), solo.view(np.uint32)), i
+    ref = O.ddc_chain(O.lcg_bytes(6 * sum(SIZES), seeds[0]), stages)
+    assert O.rel_err(ys[0], ref) <= FIR_TOL

@@ -644,7 +644,7 @@ def test_fused_stage_pair_vs_oracle(pkg, dev, O, monkeypatch, R, mix):
         assert pipe.fused_pair(7 * tile) and not pipe.fused_pair(8 * 64)
         parts, used = [], []
         for a, b in zip(cuts[:-1], cuts[1:]):
-            used.append(pipe.fused_pair(b - a))
+            used.append(bool(pipe.fused_pair(b - a)))
             parts.append(pipe.process(to_dev(packed[6 * a:6 * b], dev)).cpu().numpy().reshape(-1))
         assert used == [True, False, True, True]
         y = np.concatenate(parts)
