@@ -100,8 +100,8 @@ def parse(argv=None):
                     help="rule: input at the start of the arena, output probed at +8 (first come), +32, +48, +64 GiB;\n"
                          "full: three input slots x every output slot (the map; use --arena-gib 192)")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="cascades: keep the stages behind the fused pair in line on the one stream instead of running them on\n"
-                         "the pipeline's side stream under the next batch's pair (pddc_pipeline_set_overlap)")
+                    help="cascades: run the stage behind the fused pair in line, as a kernel of its own, instead of holding it\n"
+                         "back as extra thread blocks of the NEXT batch's first-stage launch (pddc_pipeline_set_overlap)")
     ap.add_argument("--gather-timeout", type=float, default=240.0,
                     help="watchdog for the gather leg: past this the line is printed without it")
     return ap.parse_args(argv)
@@ -403,8 +403,8 @@ def run_rank(a):
     if stages is not None:
         # configuration (taps, NCO word, plan) comes from rank 0 over RCCL: a few KB, once
         pipe = grp.make_pipeline(pkg, stages, wl["freg"], wl["mix"], a.taps_fp16)
-        # a cascade behind the fused pair: its tail (1/64 of the samples) runs on the pipeline's side stream under the
-        # NEXT step's pair; the K timed steps end with a fence, so all K tails are inside the timed region
+        # a cascade behind the fused pair: its tail (1/64 of the samples) is held back and rides along with the NEXT step's
+        # first-stage launch as extra thread blocks; the K timed steps end with a fence, so all K tails are inside the timed region
         overlap = len(stages) > 2 and pipe.fused_pair(ns) and not a.no_overlap
         if overlap:
             pipe.set_overlap(True)
@@ -749,8 +749,8 @@ def run_rank(a):
                                  else "binary16 VALUES held in fp32 registers (PDDC_F_TAPS_FP16)") if a.taps_fp16 else
                                 ("fp32 values as four int8 digit planes, 2^-31 of the largest tap (k_fir_i8)"
                                  if pipe is not None and pipe.on_i8(ns) else "fp32")),
-                       "overlap": ("stages behind the fused pair run on the pipeline's side stream under the next step's "
-                                   "pair (pddc_pipeline_set_overlap); the timed region ends with a fence") if overlap else None},
+                       "overlap": ("the stage behind the fused pair is carried by the next step's first-stage launch as extra "
+                                   "thread blocks (pddc_pipeline_set_overlap); the timed region ends with a fence") if overlap else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,

@@ -284,7 +284,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
  * of a double-buffered workspace meanwhile).  One stream, no events.  The price is one batch of latency in what
  * `stream` holds: behind process() k, the outputs up to batch k-1 are complete; pddc_pipeline_fence(p, stream) launches
  * the tail that is still held back -- call it before the last output is read, and before save_state / set_taps /
- * set_overlap.  The output buffer given to process() k must stay valid until the launch of k+1 (or the fence).
+ * set_overlap / set_workspace / set_option (they answer PDDC_ESTATE while a tail is held back).  The output buffer given to process() k must stay valid until the launch of k+1 (or the fence).
  * Batches that do not take the fused pair (not whole tiles) fence by themselves and run in line; push_host* fence every
  * batch (they are PCIe-bound).  Call set_overlap BEFORE pddc_pipeline_workspace_size / _set_workspace: the workspace
  * then holds stage 2's input twice.  No reference counterpart (the FPGA's stages all run at once).              */

@@ -337,11 +337,12 @@ class Pipeline:
         check(ddc_lib().pddc_pipeline_place_buffers(self._h, d_in, max_nsamples, stream))
 
     def set_overlap(self, enable: bool = True):
-        """stages behind the fused pair on a side stream, under the next batch's pair (see perseus_ddc.h)"""
+        """the last stage (behind k_fir8's fused pair or first stage) is held back and rides along with the NEXT batch's
+        first-stage launch as extra thread blocks; fence() launches what is still held back (see perseus_ddc.h)"""
         check(ddc_lib().pddc_pipeline_set_overlap(self._h, 1 if enable else 0))
 
     def fence(self, stream: int = 0):
-        """`stream` waits for every tail the overlap mode has queued"""
+        """launches the tail overlap mode still holds back on `stream` (call before reading the last output)"""
         check(ddc_lib().pddc_pipeline_fence(self._h, stream))
 
     def max_output(self, n: int) -> int:

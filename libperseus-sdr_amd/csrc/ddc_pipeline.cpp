@@ -1632,6 +1632,8 @@ extern "C" size_t pddc_pipeline_workspace_size(const pddc_pipeline *p, size_t ma
 
 extern "C" int pddc_pipeline_set_workspace(pddc_pipeline *p, void *d_ws, size_t nbytes, size_t max_nsamples)
 {
+    if (p && p->carry_pending)
+        return fail(PDDC_ESTATE, "overlap mode holds a tail back that reads the present buffers: pddc_pipeline_fence(p, stream) first");
     if (!p)
         return fail(PDDC_EINVAL, "null pipeline");
     if (d_ws && (((uintptr_t)d_ws & 255) || nbytes < pddc_pipeline_workspace_size(p, max_nsamples)))
@@ -1832,6 +1834,13 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
     auto stage_dst = [&](int i, float **dst, bool reads_packed) -> int {
         if (i + 1 < p->nstages) {
             (void)reads_packed;
+            /* growing the buffer frees it: a tail that overlap mode still holds back may read it (its input half or its
+             * output side) -- it goes out first */
+            if (p->carry_pending && !p->st[i + 1].buf_in_ws && !(p->st[i + 1].d_buf && p->st[i + 1].buf_cap >= n_in[i + 1] + 8)) {
+                int rf = pddc_pipeline_fence(p, s);
+                if (rf)
+                    return rf;
+            }
             int r = ensure_buf(p->st[i + 1], n_in[i + 1] + 8);
             if (r)
                 return r;
@@ -1870,6 +1879,11 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                     return fail(PDDC_ECAPACITY, "overlap mode: the workspace was set before pddc_pipeline_set_overlap, "
                                                 "or for smaller batches (it needs two halves for the last stage)");
             } else if (sl.buf_alt_cap < n_in[ti] + 8) {
+                if (p->carry_pending) {                 /* (the held-back tail may read the half that is about to be freed) */
+                    int rf = pddc_pipeline_fence(p, s);
+                    if (rf)
+                        return rf;
+                }
                 HIP_TRY(hipDeviceSynchronize());
                 if (sl.d_buf_alt)
                     HIP_TRY(hipFree(sl.d_buf_alt));
@@ -2336,7 +2350,8 @@ static int prep_slot(pddc_pipeline *p, pddc_pipeline::HostSlot &sl, size_t nsamp
     const size_t max_out = pddc_pipeline_max_output(p, nsamples) + 1;
     if (sl.in_cap < nsamples || sl.out_cap < max_out) {
         if (sl.used)                          /* growing a slot: its last batch must be out first */
-            HIP_TRY(hipEventSynchronize(sl.ev_wait ? sl.ev_wait : sl.ev_out));
+            if (sl.ev_wait)                     /* (nullptr: known complete) */
+                HIP_TRY(hipEventSynchronize(sl.ev_wait));
         if (sl.in_cap < nsamples) {
             if (sl.d_in)
                 HIP_TRY(hipFree(sl.d_in));
@@ -2359,6 +2374,17 @@ static int prep_slot(pddc_pipeline *p, pddc_pipeline::HostSlot &sl, size_t nsamp
 
 /* A pipeline's pushes are ordered by the stream they go through: its own, or a gang's.  Changing from one to the other
  * (the number of receivers that stream together changed) waits for what is still in flight on the old one.        */
+/* A slot's ticket may wait for an event of the gang round it went out with.  Once the gang's stream has been synchronised
+ * that batch is complete; the event itself goes on being re-recorded by rounds this pipeline is not in (or is destroyed with
+ * the gang), so the slot forgets it: ev_wait == nullptr means "complete".                                            */
+static void forget_gang_events(pddc_pipeline *p, const pddc_gang *g)
+{
+    for (auto &sl : p->slot)
+        for (int i = 0; i < 4; ++i)
+            if (sl.ev_wait && sl.ev_wait == g->ev[i])
+                sl.ev_wait = nullptr;
+}
+
 static int leave_gang(pddc_pipeline *p)
 {
     pddc_gang *g = p->gang;
@@ -2368,6 +2394,7 @@ static int leave_gang(pddc_pipeline *p)
     HIP_TRY(hipStreamSynchronize(g->stream));
     g->members.erase(std::remove(g->members.begin(), g->members.end(), p), g->members.end());
     p->gang = nullptr;
+    forget_gang_events(p, g);
     return PDDC_OK;
 }
 
@@ -2473,6 +2500,8 @@ int pddc_pipeline_ticket_done(pddc_pipeline *p, int ticket)
     if (!p->slot[ticket].used)
         return fail(PDDC_ESTATE, "nothing was pushed on ticket %d", ticket);
     HIP_TRY(hipSetDevice(p->device));
+    if (!p->slot[ticket].ev_wait)
+        return 1;                             /* complete (it went out with a gang this pipeline has left since) */
     hipError_t e = hipEventQuery(p->slot[ticket].ev_wait);
     if (e == hipSuccess)
         return 1;
@@ -2488,7 +2517,8 @@ int pddc_pipeline_wait_ticket(pddc_pipeline *p, int ticket)
     if (!p->slot[ticket].used)
         return fail(PDDC_ESTATE, "nothing was pushed on ticket %d", ticket);
     HIP_TRY(hipSetDevice(p->device));
-    HIP_TRY(hipEventSynchronize(p->slot[ticket].ev_wait));
+    if (p->slot[ticket].ev_wait)
+        HIP_TRY(hipEventSynchronize(p->slot[ticket].ev_wait));
     return PDDC_OK;
 }
 
@@ -2570,8 +2600,10 @@ int pddc_gang_destroy(pddc_gang *g)
             (void)hipStreamSynchronize(g->s_gen);
         if (g->stream)
             (void)hipStreamSynchronize(g->stream);
-        for (pddc_pipeline *p : g->members)
+        for (pddc_pipeline *p : g->members) {
             p->gang = nullptr;                /* their next push goes through their own stream again */
+            forget_gang_events(p, g);         /* (both streams are idle: what their tickets waited for is complete) */
+        }
         g->members.clear();
     }
     for (int i = 0; i < 4; ++i) {

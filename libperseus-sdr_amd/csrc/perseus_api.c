@@ -745,9 +745,13 @@ static void *helper_fn(void *arg)
 static pddc_gang *g_gang[MAX_GANG_GPUS];
 static int g_gang_off = 0;
 
+/* (only free-running sources: a gang round holds every member's lock while it prepares the batches, and a PACED source
+ * sleeps there up to a batch period -- its receiver keeps the helper path, which sleeps under its own lock alone and
+ * delivers at its own due time) */
 static int gang_candidate(const perseus_descr *d)
 {
-    return d->gpu_source && d->gpu_dev >= 0 && d->gpu_dev < MAX_GANG_GPUS && d->cfg.mode == PERSEUS_AMD_MODE_DDC;
+    return d->gpu_source && d->gpu_dev >= 0 && d->gpu_dev < MAX_GANG_GPUS && d->cfg.mode == PERSEUS_AMD_MODE_DDC &&
+           !d->cfg.pace;
 }
 
 /* the receivers sub[0..m) (ascending, all on GPU `dev`): up to `depth` rounds of one batch each */

@@ -144,13 +144,17 @@ def test_fused_cascade_checkpoint_and_retune(pkg, dev, O, monkeypatch):
 
 
 # ------------------------------------------------------------------ overlap mode (the tail under the next batch's pair)
+@pytest.mark.parametrize("i8x", [1, 0])
 @pytest.mark.parametrize("plan", ["8*8*5", "8*8*10", "8*8*4*5", "8*10", "8*5", "8*7", "10*5", "5*4"])
-def test_overlap_mode_is_bit_identical_and_fenced(pkg, dev, O, plan):
+def test_overlap_mode_is_bit_identical_and_fenced(pkg, dev, O, plan, i8x):
     """pddc_pipeline_set_overlap: the last stage -- behind the fused pair, or behind an unfused /8 first stage -- rides
     along with the NEXT batch's launch (extra thread blocks of the first stage's grid).  Same arithmetic, same order per stage -- so the outputs are bit-identical to the
     in-line pipeline, whatever mix of whole-tile batches (carried) and odd ones (in line, fenced by the library) the
     stream is cut into; a retune in between; outputs read only behind pddc_pipeline_fence.  (The four-stage plan is
-    not carried: it must simply still be right with the mode switched on.)"""
+    not carried: it must simply still be right with the mode switched on.)  i8x = 1: tuned first stages take k_fir_i8x where
+    the batch allows (whole 8192-sample tiles: no tail is carried then, it runs in line); i8x = 0: the vector kernels
+    throughout, every whole-tile batch carried.  The second size list grows the batch right behind a carried one: the
+    buffers a held-back tail reads must not be freed under it."""
     import torch
     pl = plans()
     pl["8*8*4*5"] = pl["8*8*4"] + [(5, lowpass(41, 0.08))]
@@ -160,34 +164,35 @@ def test_overlap_mode_is_bit_identical_and_fenced(pkg, dev, O, plan):
     pl["10*5"] = [(10, lowpass(69, 0.04)), (5, lowpass(144, 0.08))]          # 1.6 MS/s: k_firp reads the packed samples and carries
     pl["5*4"] = [(5, lowpass(41, 0.08)), (4, lowpass(33, 0.1))]
     stages = pl[plan]
-    sizes = [8, 8, 3, 0.25, 16, 1, 1, 1, 0.5, 40, 8]
-    cuts = [0]
-    for t in sizes:
-        cuts.append(cuts[-1] + int(t * TILE))
-    d_in = pkg.synth_lcg(6 * cuts[-1], 777, 0, dev)
-    st = torch.cuda.current_stream(dev).cuda_stream
-    outs = {}
-    for mode in ("inline", "overlap"):
-        pipe = pkg.Pipeline(stages, mix=True)
-        pipe.set_freg(381178347)
-        if mode == "overlap":
-            pipe.set_overlap(True)
-        bufs = []
-        for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
-            if k == 5:
-                pipe.set_freg(123456789)
-            o = torch.zeros((pipe.max_output(b - a) + 1, 2), dtype=torch.float32, device=dev)
-            n = pipe.process_ptr(d_in[6 * a:6 * b].data_ptr(), b - a, o.data_ptr(), o.shape[0], st)
-            bufs.append((o, n))
-        pipe.fence(st)
-        torch.cuda.synchronize()
-        outs[mode] = torch.cat([o[:n] for o, n in bufs])
-        pipe.close()
-    assert outs["inline"].shape == outs["overlap"].shape and outs["inline"].shape[0] > 0
-    assert torch.equal(outs["inline"], outs["overlap"])
-    packed = d_in.cpu().numpy()
-    ref = O.ddc_chain_retuned(packed, stages, [(0, 381178347), (cuts[5], 123456789)])
-    assert O.rel_err(outs["overlap"].cpu().numpy().reshape(-1), ref) <= FIR_TOL
+    for sizes in ([8, 8, 3, 0.25, 16, 1, 1, 1, 0.5, 40, 8], [8, 8, 32, 8, 3, 3, 96, 3, 3, 3]):
+        cuts = [0]
+        for t in sizes:
+            cuts.append(cuts[-1] + int(t * TILE))
+        d_in = pkg.synth_lcg(6 * cuts[-1], 777, 0, dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        outs = {}
+        for mode in ("inline", "overlap"):
+            pipe = pkg.Pipeline(stages, mix=True)
+            pipe.set_option("i8x", i8x)
+            pipe.set_freg(381178347)
+            if mode == "overlap":
+                pipe.set_overlap(True)
+            bufs = []
+            for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+                if k == 5:
+                    pipe.set_freg(123456789)
+                o = torch.zeros((pipe.max_output(b - a) + 1, 2), dtype=torch.float32, device=dev)
+                n = pipe.process_ptr(d_in[6 * a:6 * b].data_ptr(), b - a, o.data_ptr(), o.shape[0], st)
+                bufs.append((o, n))
+            pipe.fence(st)
+            torch.cuda.synchronize()
+            outs[mode] = torch.cat([o[:n] for o, n in bufs])
+            pipe.close()
+        assert outs["inline"].shape == outs["overlap"].shape and outs["inline"].shape[0] > 0
+        assert torch.equal(outs["inline"], outs["overlap"])
+        packed = d_in.cpu().numpy()
+        ref = O.ddc_chain_retuned(packed, stages, [(0, 381178347), (cuts[5], 123456789)])
+        assert O.rel_err(outs["overlap"].cpu().numpy().reshape(-1), ref) <= FIR_TOL
 
 
 def test_overlap_mode_with_a_caller_workspace_and_checkpoint(pkg, dev, O):
