@@ -136,6 +136,10 @@ def ddc_lib() -> C.CDLL:
     L.pddc_pipeline_set_option.restype = C.c_int
     L.pddc_pipeline_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
     L.pddc_pipeline_get_option.restype = C.c_int
+    L.pddc_set_tunable.argtypes = [C.c_char_p, C.c_int]
+    L.pddc_set_tunable.restype = C.c_int
+    L.pddc_get_tunable.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    L.pddc_get_tunable.restype = C.c_int
     L.pddc_pipeline_check.argtypes = [vp, vp]
     L.pddc_pipeline_check.restype = C.c_int
     L.pddc_arena_place.argtypes = [vp, sz, sz, sz, sz, sz, C.POINTER(sz), C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -228,6 +232,17 @@ def ddc_lib() -> C.CDLL:
         getattr(L, name).restype = C.c_int
     _ddc = L
     return L
+
+
+def set_tunable(name: str, value: int):
+    """process-wide development knob of the launchers (pddc_set_tunable)"""
+    check(ddc_lib().pddc_set_tunable(name.encode(), int(value)))
+
+
+def get_tunable(name: str) -> int:
+    v = C.c_int(0)
+    check(ddc_lib().pddc_get_tunable(name.encode(), C.byref(v)))
+    return int(v.value)
 
 
 def check(rc: int) -> int:

@@ -9,9 +9,28 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace pddc {
 
 enum InFmt { IN_PACKED24 = 0, IN_F32C = 1 };
+
+/* Process-wide development knobs of the launchers and of the host plumbing.  The environment (PDDC_<NAME>) is looked at
+ * ONCE, the first time tunables() is called; afterwards they change only through set_tunable (pddc_set_tunable: tests,
+ * tools).  Nothing on the data path calls getenv.  -1 / 0 = the built-in choice.                                      */
+struct Tunables {
+    std::atomic<int> fir8_dyn_pct{ -1 };      /* share of a k_fir8 launch's tiles that go out in dynamic chunks (-1: default) */
+    std::atomic<int> fir8_chunk{ 0 };         /* tiles per dynamic chunk (0: default)                                  */
+    std::atomic<int> gen_shape_nt{ 0 }, gen_shape_p{ 0 };   /* k_fir_generic block shape override (PDDC_GEN_SHAPE=NT,P) */
+    std::atomic<int> no_firp{ 0 };            /* 1: plain decimators by 4/5/10 on k_fir_generic instead of k_firp      */
+    std::atomic<int> firp_packed_p{ 0 };
+    std::atomic<int> unpack_blocks{ 512 };
+    std::atomic<int> debug{ 0 };              /* allocation / placement messages on stderr                             */
+    std::atomic<int> push_three_streams{ 0 }, gang_copy_out{ 0 }, gang_gen_inline{ 0 }, gang_solo{ 0 };
+};
+Tunables &tunables();
+bool set_tunable(const char *name, int value);       /* false: no such knob */
+bool get_tunable(const char *name, int *value);
 
 /* A THIRD stage fused behind the decimate-by-8 pair (launch_fir8_fused3): a plain decimate-by-d FIR on the second
  * stage's outputs, which then never reach HBM either -- the whole cascade is ONE streaming pass (x320 = 8*8*5:
@@ -316,9 +335,6 @@ hipError_t launch_synth_lcg(void *dst, size_t nbytes, uint32_t seed, uint64_t by
                             hipStream_t s);
 
 
-#ifdef PDDC_CLOCK_PROBE
-void fir8_probe_dump();
-#endif
 
 } // namespace pddc
 #endif

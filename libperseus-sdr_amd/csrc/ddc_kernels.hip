@@ -69,7 +69,77 @@
 #define PDDC_PRIO_F 2
 #endif
 
+#include <cstring>
+#include <mutex>
+
 namespace pddc {
+
+Tunables &tunables()
+{
+    static Tunables t;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        auto env = [](const char *name, std::atomic<int> &v) {
+            if (const char *e = getenv(name))
+                v.store(atoi(e));
+        };
+        auto flag = [](const char *name, std::atomic<int> &v) {
+            if (getenv(name))
+                v.store(1);
+        };
+        env("PDDC_FIR8_DYN_PCT", t.fir8_dyn_pct);
+        env("PDDC_FIR8_CHUNK", t.fir8_chunk);
+        if (const char *e = getenv("PDDC_GEN_SHAPE")) {
+            int a = 0, b = 0;
+            if (sscanf(e, "%d,%d", &a, &b) == 2) {
+                t.gen_shape_nt.store(a);
+                t.gen_shape_p.store(b);
+            }
+        }
+        flag("PDDC_NO_FIRP", t.no_firp);
+        env("PDDC_FIRP_PACKED_P", t.firp_packed_p);
+        env("PDDC_UNPACK_BLOCKS", t.unpack_blocks);
+        flag("PDDC_DEBUG", t.debug);
+        flag("PDDC_PUSH_THREE_STREAMS", t.push_three_streams);
+        flag("PDDC_GANG_COPY_OUT", t.gang_copy_out);
+        flag("PDDC_GANG_GEN_INLINE", t.gang_gen_inline);
+        flag("PDDC_GANG_SOLO", t.gang_solo);
+    });
+    return t;
+}
+
+static std::atomic<int> *tunable_by_name(const char *name)
+{
+    Tunables &t = tunables();
+    const struct {
+        const char *n;
+        std::atomic<int> *v;
+    } tab[] = { { "fir8_dyn_pct", &t.fir8_dyn_pct },   { "fir8_chunk", &t.fir8_chunk },       { "gen_shape_nt", &t.gen_shape_nt },
+                { "gen_shape_p", &t.gen_shape_p },     { "no_firp", &t.no_firp },             { "firp_packed_p", &t.firp_packed_p },
+                { "unpack_blocks", &t.unpack_blocks }, { "debug", &t.debug },                 { "push_three_streams", &t.push_three_streams },
+                { "gang_copy_out", &t.gang_copy_out }, { "gang_gen_inline", &t.gang_gen_inline }, { "gang_solo", &t.gang_solo } };
+    if (name)
+        for (const auto &e : tab)
+            if (!strcmp(e.n, name))
+                return e.v;
+    return nullptr;
+}
+
+bool set_tunable(const char *name, int value)
+{
+    std::atomic<int> *v = tunable_by_name(name);
+    if (v)
+        v->store(value);
+    return v != nullptr;
+}
+
+bool get_tunable(const char *name, int *value)
+{
+    std::atomic<int> *v = tunable_by_name(name);
+    if (v && value)
+        *value = v->load();
+    return v != nullptr;
+}
 
 static constexpr int kFused3MaxChunks = 2048;      /* seam slots / flag words of a fused-cascade launch */
 static constexpr int kPend3 = 4;                   /* open seams a block of the fused cascade may carry along */
@@ -289,7 +359,7 @@ hipError_t launch_unpack24(const void *d_in, long long ns, void *d_out, bool to_
     }
     const long long ngroups = (ns + 7) >> 3;
     long long blocks = (ngroups + 255) / 256;
-    static const int cap = getenv("PDDC_UNPACK_BLOCKS") ? atoi(getenv("PDDC_UNPACK_BLOCKS")) : 512;   /* 2 per CU measured best (0.66 vs 0.70 ms) */
+    const int cap = tunables().unpack_blocks.load();                       /* 512: 2 per CU measured best (0.66 vs 0.70 ms) */
     if (blocks > cap)
         blocks = cap;
     const dim3 grid((unsigned)blocks), blk(256);
@@ -986,50 +1056,6 @@ __device__ __forceinline__ void fir_window(const float *base, const float PDDC_C
     }
 }
 
-#ifdef PDDC_CLOCK_PROBE
-/* development: per-block 100 MHz wall-clock (s_memrealtime) and shader-clock (s_memtime)
- * stamps plus the hardware placement, to see the engine clock the kernel ran at and how
- * evenly the persistent blocks finish (make HIPFLAGS+=-DPDDC_CLOCK_PROBE; the report is
- * printed by pddc_pipeline_time_stage0, PDDC_PROBE_VERBOSE=1 lists every block)          */
-struct ProbeRec { unsigned long long w0, w1, c0, c1; unsigned hw, xcc; };
-__device__ ProbeRec g_probe[4096];
-void fir8_probe_dump()
-{
-    static ProbeRec h[4096];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe), sizeof(h)) != hipSuccess)
-        return;
-    int nb = 0;
-    while (nb < 4096 && h[nb].w1 != 0)
-        ++nb;
-    if (nb == 0)
-        return;
-    unsigned long long t0 = ~0ull, t1 = 0;
-    for (int b = 0; b < nb; ++b) {
-        if (h[b].w0 < t0) t0 = h[b].w0;
-        if (h[b].w1 > t1) t1 = h[b].w1;
-    }
-    static double dur[4096], st[4096], en[4096];
-    for (int b = 0; b < nb; ++b) {
-        st[b] = (h[b].w0 - t0) / 100.0;
-        en[b] = (h[b].w1 - t0) / 100.0;
-        dur[b] = en[b] - st[b];
-    }
-    if (getenv("PDDC_PROBE_VERBOSE"))
-        for (int b = 0; b < nb; ++b)
-            fprintf(stderr, "[blk] %d xcc %u se %u sh %u cu %u simd %u wave %u  start %.1f end %.1f\n", b, h[b].xcc & 15,
-                    (h[b].hw >> 13) & 7, (h[b].hw >> 12) & 1, (h[b].hw >> 8) & 15, (h[b].hw >> 4) & 3, h[b].hw & 15,
-                    st[b], en[b]);
-    auto srt = [&](double *v) { for (int i = 1; i < nb; ++i) { double x = v[i]; int j = i - 1; while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; } v[j + 1] = x; } };
-    const double mhz = (double)(h[0].c1 - h[0].c0) / ((double)(h[0].w1 - h[0].w0) / 100.0);
-    srt(st); srt(en); srt(dur);
-    fprintf(stderr, "[probe] %d blocks, span %.1f us, block 0 at %.0f MHz\n", nb, (t1 - t0) / 100.0, mhz);
-    fprintf(stderr, "[probe] start  min %.1f  p50 %.1f  p90 %.1f  max %.1f us\n", st[0], st[nb / 2], st[nb * 9 / 10], st[nb - 1]);
-    fprintf(stderr, "[probe] end    min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f us\n", en[0], en[nb / 10], en[nb / 2], en[nb * 9 / 10], en[nb - 1]);
-    for (int b = 0; b < nb; ++b)
-        h[b] = ProbeRec{};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe), h, sizeof(h));
-}
-#endif
 
 /* The same sliding window with the loops exchanged: tap block j outermost, the R groups
  * that meet it (ub = r + NTB-1-j) held in VGPRs and shifted by one group per step.  Only one
@@ -1100,8 +1126,8 @@ __device__ __forceinline__ void fir_window_tap_outer(const float *base, const fl
  *              C  the last NTB groups become the next tile's history (copied by
  *                 the very threads that overwrite them in the next U, so no
  *                 third barrier is needed).                                */
-/* (PDDC_ABLATE_LOADS / _FIR / _STORES: timing-only builds with one part of the kernel removed,
- * tools/ablate.sh; their outputs are garbage.)                                              */
+/* (The ablation builds -- loads / FIR / stores removed --, the in-kernel clock probe and the 128-thread variant that the
+ * measurements in DESIGN.md 5 come from are not in this file: tools/ubench/fir8_probe_and_ablations.patch.)          */
 /* NT = threads per block.  256 (4 waves: two per plane) is the default; 128 (R = 8 only: one wave per
  * plane, half the tile, half the LDS) lets four independent blocks share a CU instead of two.       */
 /* SL3 > 0 (FUSE3): a third stage (plain decimate-by-d3 FIR, struct Fir8Stage3) runs on the second stage's outputs in LDS
@@ -1150,13 +1176,10 @@ struct Fir8Sched {
 
 static Fir8Sched fir8_schedule(int ntiles, int R, bool fused, int NT = 256, int group = 0)
 {
-    /* read per launch (two getenv calls against a launch of several microseconds), so a
-     * test can switch schedules inside one process */
-    const char *e = getenv("PDDC_FIR8_DYN_PCT");
-    const int v = e ? atoi(e) : -1;
+    /* (process-wide knobs, pddc_set_tunable: a test can switch schedules inside one process) */
+    const int v = tunables().fir8_dyn_pct.load();
     const int dyn_pct = v < 0 ? -1 : (v > 100 ? 100 : v);
-    e = getenv("PDDC_FIR8_CHUNK");
-    const int chunk = e ? atoi(e) : 0;
+    const int chunk = tunables().fir8_chunk.load();
     Fir8Sched sc;
     /* 128-thread blocks: four per CU, tiles half as long (chunks of twice as many) */
     /* small batches (BASELINE config 5's low end): one block per tile up to one block per CU, then about three tiles
@@ -1510,10 +1533,6 @@ void fir8_set_grid_blocks(int nblocks) { g_fir8_blocks = nblocks > 0 ? nblocks :
 
 bool fir8_nt_supported(int ntb, int R, int NT)
 {
-#ifdef PDDC_EXPERIMENT_NT128
-    if (NT == 128 && R == 8 && (ntb == 8 || ntb == 16 || ntb == 32))
-        return true;
-#endif
     (void)ntb;
     (void)R;
     return NT == 256;
@@ -1523,22 +1542,8 @@ hipError_t launch_fir8(int ntb, int R, InFmt fmt, bool mix, const Fir8Args &a, h
 {
     if (fmt == IN_F32C && mix)
         return hipErrorInvalidValue;
-#ifdef PDDC_EXPERIMENT_NT128
-    /* 128-thread blocks (four independent blocks per CU instead of two) -- measured, not faster: 127 taps
-     * 0.377 vs 0.367 ms, and at 255 taps only three such blocks fit the LDS (0.613 vs 0.482 ms); kept
-     * behind this macro for the record, not instantiated in the product build          */
-    if (NT == 128) {
-        if (fmt != IN_PACKED24 || R != 8)
-            return hipErrorInvalidValue;
-        if (ntb == 8) return launch_fir8_t<8, 8, 128>(fmt, mix, a, s);
-        if (ntb == 16) return launch_fir8_t<16, 8, 128>(fmt, mix, a, s);
-        if (ntb == 32) return launch_fir8_t<32, 8, 128>(fmt, mix, a, s);
-        return hipErrorInvalidValue;
-    }
-#else
     if (NT != 256)
         return hipErrorInvalidValue;
-#endif
 #define PDDC_CASE(N, RR)                                                                          \
     if (ntb == N && R == RR)                                                                      \
         return launch_fir8_t<N, RR>(fmt, mix, a, s)
@@ -1593,9 +1598,7 @@ static GenShape pick_generic_shape(long long n_out, int D, int ntaps, int ncu)
                                      { 256, 2 }, { 128, 2 }, { 64, 2 }, { 256, 1 }, { 64, 1 } };
     GenShape g;
     double best = -1.0;
-    int force_nt = 0, force_p = 0;                     /* development: PDDC_GEN_SHAPE=NT,P */
-    if (const char *e = getenv("PDDC_GEN_SHAPE"))
-        (void)sscanf(e, "%d,%d", &force_nt, &force_p);
+    const int force_nt = tunables().gen_shape_nt.load(), force_p = tunables().gen_shape_p.load();   /* development */
     for (const auto &sh : shapes) {
         const int nt = sh[0], pp = sh[1];
         if (force_nt ? (nt != force_nt || pp != force_p) : ((D & 1) ? (pp == 2 || pp == 4) : pp == 3))
@@ -1771,7 +1774,7 @@ size_t firp_lds_bytes(int D, int ntaps)
 
 bool firp_supported(int D, int ntaps)
 {
-    if (getenv("PDDC_NO_FIRP"))
+    if (tunables().no_firp.load())
         return false;
     if (!(D == 4 || D == 5 || D == 10) || ntaps < 1)
         return false;
@@ -1844,7 +1847,7 @@ hipError_t launch_firp(int infmt, bool mix, const void *in, const void *hist, in
     a.nbq = firp_nbq(D, ntaps);
     a.mx = mx ? *mx : GenMixArgs{};
     /* development: PDDC_FIRP_PACKED_P=1 gives the packed /10 first stage tiles of 256 outputs (one per lane) */
-    static const int pp = getenv("PDDC_FIRP_PACKED_P") ? atoi(getenv("PDDC_FIRP_PACKED_P")) : 0;
+    const int pp = tunables().firp_packed_p.load();
     if (D == 10 && infmt == IN_PACKED24 && pp == 1) {
         a.nbq = (ntaps + D - 1) / D;
         return launch_firp_t<10, 1>(infmt, mix, a, ntaps, s);

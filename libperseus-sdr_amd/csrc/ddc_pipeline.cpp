@@ -1023,7 +1023,7 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
         pddc_pipeline_destroy(p);
         return rc;
     }
-    if (getenv("PDDC_DEBUG"))
+    if (tunables().debug.load())
         fprintf(stderr, "[pddc] pipeline %p sched %p taps_blk %p %p\n", (void *)p, (void *)p->d_sched,
                 (void *)p->st[0].d_taps_blk, (void *)p->st[1].d_taps_blk);
     *out = p;
@@ -1188,6 +1188,20 @@ int pddc_pipeline_set_option(pddc_pipeline *p, const char *name, int value)
     if (!f)
         return fail(PDDC_EINVAL, "unknown option '%s'", name ? name : "(null)");
     *f = value;
+    return PDDC_OK;
+}
+
+int pddc_set_tunable(const char *name, int value)
+{
+    if (!set_tunable(name, value))
+        return fail(PDDC_EINVAL, "unknown tunable '%s'", name ? name : "(null)");
+    return PDDC_OK;
+}
+
+int pddc_get_tunable(const char *name, int *value)
+{
+    if (!value || !get_tunable(name, value))
+        return fail(PDDC_EINVAL, "unknown tunable '%s'", name ? name : "(null)");
     return PDDC_OK;
 }
 
@@ -1603,7 +1617,7 @@ static int ensure_buf(Stage &s, size_t need, const void * = nullptr, size_t = 0)
     s.buf_cap = 0;
     HIP_TRY(hipMalloc(&s.d_buf, sizeof(float) * 2 * cap));
     s.buf_cap = cap;
-    if (getenv("PDDC_DEBUG"))
+    if (tunables().debug.load())
         fprintf(stderr, "[pddc] stage buffer %p (%zu samples) hist %p %p\n", (void *)s.d_buf, cap, s.d_hist[0],
                 s.d_hist[1]);
     return PDDC_OK;
@@ -1703,7 +1717,7 @@ int pddc_pipeline_place_buffers(pddc_pipeline *p, const void *d_packed, size_t m
                 HIP_TRY(hipFree(s.d_buf));
             s.d_buf = static_cast<float *>(ptr);
             s.buf_cap = cap;
-            if (getenv("PDDC_DEBUG"))
+            if (tunables().debug.load())
                 fprintf(stderr, "[pddc] stage %d buffer placed: probe %.3f ms (slowest candidate %.3f)\n", i, fast, slow);
         }
         src = s.d_buf;
@@ -2438,7 +2452,7 @@ static int push_async(pddc_pipeline *p, const void *h_packed, bool synth, uint32
      * and the copy out then all go on ONE stream.  The three-stream form below costs two cross-stream event hops per
      * batch, ~18 us each on this runtime (profiles/r03/d_side_stream_overlap_delay.txt) -- more than the kernels of a
      * 2^22-sample batch take.  Two slots still alternate, so the host fills / reads one while the GPU works on the other. */
-    const bool one_stream = synth && !getenv("PDDC_PUSH_THREE_STREAMS");
+    const bool one_stream = synth && !tunables().push_three_streams.load();
     hipStream_t st_in = one_stream ? p->own_stream : p->s_in;
     hipStream_t st_out = one_stream ? p->own_stream : p->s_out;
     /* H2D (or the generator): the slot's input buffer is free once the kernels of its previous batch are done */
@@ -2550,7 +2564,7 @@ static float *direct_out(pddc_pipeline::HostSlot &sl, void *h_out)
         sl.h_out_seen = h_out;
         sl.h_out_dev = nullptr;
         hipPointerAttribute_t at;
-        if (!getenv("PDDC_GANG_COPY_OUT") && hipPointerGetAttributes(&at, h_out) == hipSuccess &&
+        if (!tunables().gang_copy_out.load() && hipPointerGetAttributes(&at, h_out) == hipSuccess &&
             at.type == hipMemoryTypeHost && at.devicePointer && ((uintptr_t)at.devicePointer & 15) == 0)
             sl.h_out_dev = static_cast<float *>(at.devicePointer);
         else
@@ -2682,7 +2696,7 @@ int pddc_gang_push_async(pddc_gang *g, pddc_gang_item *items, int n, size_t nsam
          * goes to a stream of its own and runs BESIDE the kernels of the round before, which the main stream is still
          * working on when this round is queued (a free-running source keeps two rounds in flight).  The main stream
          * meets an event that is long complete.                                                                  */
-        if (n > 1 && !getenv("PDDC_GANG_GEN_INLINE")) {
+        if (n > 1 && !tunables().gang_gen_inline.load()) {
             hipEvent_t seen[PDDC_GANG_MAX];
             int nseen = 0;
             for (int i = 0; i < n; ++i) {
@@ -2718,7 +2732,7 @@ int pddc_gang_push_async(pddc_gang *g, pddc_gang_item *items, int n, size_t nsam
         direct[i] = (p->flags & PDDC_F_OUT_PACKED24) ? nullptr : direct_out(sl, items[i].h_out);
         void *dst = direct[i] ? direct[i] : sl.d_out;
         const size_t cap = direct[i] ? items[i].out_capacity : sl.out_cap;
-        p->gang_rec = n > 1 && !getenv("PDDC_GANG_SOLO") ? &rec[i] : nullptr;
+        p->gang_rec = n > 1 && !tunables().gang_solo.load() ? &rec[i] : nullptr;
         int rc = p->gang_rec ? pddc_pipeline_process(p, sl.d_in, nsamples, dst, cap, &items[i].n_out, s) : 1;
         p->gang_rec = nullptr;
         open[i] = rc == PDDC_OK && rec[i].kind != 0;
@@ -3097,9 +3111,6 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     *avg_ms = ms / (float)iters;
-#ifdef PDDC_CLOCK_PROBE
-    fir8_probe_dump();
-#endif
     return PDDC_OK;
 }
 

@@ -47,3 +47,18 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def tune(pkg):
+    """set process-wide launcher knobs (pddc_set_tunable) for one test; restored afterwards"""
+    saved = {}
+
+    def _set(name, value):
+        if name not in saved:
+            saved[name] = pkg.get_tunable(name)
+        pkg.set_tunable(name, value)
+
+    yield _set
+    for k, v in saved.items():
+        pkg.set_tunable(k, v)

@@ -104,3 +104,30 @@ def test_product_does_not_reference_oracle():
                 assert "liboracle" not in txt and "perseus_oracle" not in txt and "from oracle" not in txt, f
     ldd = subprocess.check_output(["ldd", os.path.join(pk, "libperseus_ddc.so")], text=True)
     assert "oracle" not in ldd
+
+
+def test_no_getenv_on_the_data_path():
+    """Kernel selection is API state (pddc_pipeline_set_option, pddc_set_tunable): the library looks at the environment when
+    a pipeline is created and once for the process-wide launcher knobs -- never inside process(), a push or a gang round.
+    Source-level check: every getenv in the kernels' host code sits in one of those two places (the GPU suite counts
+    the calls of a running stream: tests/test_gpu_api.py::test_a_running_stream_never_calls_getenv)."""
+    import re
+    csrc = os.path.join(ROOT, "libperseus-sdr_amd", "csrc")
+    allowed = {"ddc_pipeline.cpp": ["pddc_pipeline_create"], "ddc_kernels.hip": ["tunables"], "ddc_fir_i8.hip": [],
+               "fir8_block.inc": [], "ddc_multi.cpp": None}          # (None: not on the DSP data path -- communicator set-up)
+    for name, funcs in allowed.items():
+        src = open(os.path.join(csrc, name)).read()
+        if funcs is None:
+            continue
+        # walk the file; remember the last function header seen at column 0
+        current = None
+        for line in src.split("\n"):
+            m = re.match(r"^[A-Za-z_].*?\b([A-Za-z_0-9]+)\s*\([^;]*$", line)
+            if m and not line.startswith(("static constexpr", "typedef", "#")):
+                current = m.group(1)
+            if "getenv(" in line and not line.lstrip().startswith(("*", "/*", "//")):
+                assert current in funcs, (name, current, line.strip())
+    for forbidden in ("PDDC_ABLATE_", "PDDC_CLOCK_PROBE", "PDDC_EXPERIMENT_NT128", "I8X_PROBE", "I8X_ABL_"):
+        for name in ("ddc_kernels.hip", "fir8_block.inc", "ddc_fir_i8.hip", "ddc_pipeline.cpp", "ddc_kernels.h"):
+            src = open(os.path.join(csrc, name)).read()
+            assert ("#ifdef " + forbidden) not in src and ("defined(" + forbidden) not in src, (name, forbidden)

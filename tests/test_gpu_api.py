@@ -455,3 +455,19 @@ def test_gang_membership_churn_leaves_the_other_receivers_streams_intact(L, pkg,
     print(f"{churns[0]} stop/start cycles of receivers 2..7 beside two streams of {nbuf} buffers; receiver 0 shared "
           f"{ganged} batches")
     assert ganged > 0
+
+
+def test_a_running_stream_never_calls_getenv(pkg, dev, tmp_path):
+    """Kernel selection is API state: with an interposed getenv (LD_PRELOAD) counting every PDDC_* look-up, a stream of
+    process() calls, device-source pushes and gang rounds -- with a retune and an option change in between -- makes none;
+    the environment is read when a pipeline is created and once for the process-wide knobs."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = str(tmp_path / "getenv_count.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", so, os.path.join(here, "getenv_count.c"), "-ldl"])
+    env = dict(os.environ, LD_PRELOAD=so)
+    out = subprocess.run([sys.executable, os.path.join(here, "getenv_stream.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("GETENV_CALLS")]
+    assert line and int(line[0].split()[1]) == 0, out.stdout[-500:]

@@ -41,14 +41,12 @@ def plans():
 @pytest.mark.parametrize("plan", ["8*8*5", "8*8*10", "8*8*4"])
 @pytest.mark.parametrize("mix", [False, True])
 @pytest.mark.parametrize("sched", ["3,-1,0", "7,0,0", "5,100,0", "4,50,5", "512,-1,0"])
-def test_fused_cascade_vs_oracle(pkg, dev, O, monkeypatch, plan, mix, sched):
+def test_fused_cascade_vs_oracle(pkg, dev, O, monkeypatch, tune, plan, mix, sched):
     blocks, dyn, chunk = sched.split(",")
-    monkeypatch.setenv("PDDC_FUSE3", "1")                # the one-kernel cascade is opt-in (slower than pair + tail)
-    monkeypatch.setenv("PDDC_FIR8_BLOCKS", blocks)
-    if int(dyn) >= 0:
-        monkeypatch.setenv("PDDC_FIR8_DYN_PCT", dyn)
-    if int(chunk) > 0:
-        monkeypatch.setenv("PDDC_FIR8_CHUNK", chunk)
+    monkeypatch.setenv("PDDC_FUSE3", "1")                # the one-kernel cascade is opt-in (slower than pair + tail); read at create
+    monkeypatch.setenv("PDDC_FIR8_BLOCKS", blocks)       # (read when a pipeline is created)
+    tune("fir8_dyn_pct", int(dyn))
+    tune("fir8_chunk", int(chunk))
     stages = plans()[plan]
     # batches in tiles; 0.25 = a batch that is not whole tiles (unfused path on the same state)
     sizes = [3, 37, 5, 0.25, 1, 64, 12, 0.5, 23]

@@ -163,3 +163,78 @@ def test_which_first_stages_run_where(pkg, dev):
     p.close()
     with pytest.raises(pkg.PddcError):
         pkg.Pipeline([(8, h)]).set_option("no_such_option", 1)
+
+
+def _tone_packed(ns, f_cyc_per_sample, amp=(1 << 23) - 1):
+    """a full-scale complex tone as exact 24-bit integers (what the ADC side would deliver), packed"""
+    n = np.arange(ns, dtype=np.float64)
+    v = np.stack([np.rint(amp * np.cos(2 * np.pi * f_cyc_per_sample * n)), np.rint(amp * np.sin(2 * np.pi * f_cyc_per_sample * n))],
+                 axis=1).astype(np.int64)
+    b = np.zeros((ns, 2, 3), np.uint8)
+    for i in range(3):
+        b[:, :, i] = (v >> (8 * i)) & 0xFF
+    return b.reshape(-1)
+
+
+def _floor(y, ref, skip):
+    """(max |y - ref| absolute, highest residual spur in dBFS: Hann-windowed spectrum, a full-scale tone = 0 dBFS)"""
+    r = (y.astype(np.float64) - ref.astype(np.float64)).reshape(-1, 2)[skip:]
+    c = r[:, 0] + 1j * r[:, 1]
+    n = 1 << int(np.log2(c.size))
+    w = np.hanning(n)
+    spec = np.abs(np.fft.fft(c[:n] * w)) / w.sum()
+    return float(np.abs(r).max()), 20 * np.log10(max(spec.max(), 1e-300))
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+@pytest.mark.parametrize("design", ["d8_255", "kaiser120"])
+def test_int8_path_numeric_floor_in_dbfs(pkg, dev, O, design, fp16):
+    """The floor of the int8 matrix-core path measured ABSOLUTELY, not relative to max|ref|: a full-scale tone far out of
+    band (the output is the filter's stop band, -80 .. -120 dB: whatever the kernel adds shows) and a one-signed full-scale
+    DC (every term of every plane product with the same sign) through the 255-tap fixture and a 120-dB Kaiser design.
+    max |y - oracle| <= 2e-7 of full scale for both, and no residual spur of the tone case above -150 dBFS -- with the
+    host-built table and with binary16-stored taps (oracle on the same binary16 values)."""
+    from scipy.signal import firwin
+    h = load_taps("d8_255") if design == "d8_255" else firwin(255, 0.8 / 16, window=("kaiser", 0.1102 * (120 - 8.7))).astype(np.float32)
+    if fp16:
+        h = h.astype(np.float16).astype(np.float32)
+    ns = 8192 * 72
+    for name, packed in (("tone", _tone_packed(ns, 0.3137)),
+                         ("dc", _tone_packed(ns, 0.0)[: 6 * ns].reshape(-1, 6).copy().reshape(-1))):
+        if name == "dc":                                          # I = +FS, Q = -FS - 1: both rails one-signed
+            v = np.zeros((ns, 2), np.int64)
+            v[:, 0], v[:, 1] = (1 << 23) - 1, -(1 << 23)
+            b = np.zeros((ns, 2, 3), np.uint8)
+            for i in range(3):
+                b[:, :, i] = (v >> (8 * i)) & 0xFF
+            packed = b.reshape(-1)
+        ref = O.ddc_chain(packed, [(8, h)])
+        pipe = pkg.Pipeline([(8, h)], taps_fp16=fp16)
+        assert pipe.on_i8(ns) == 1
+        y = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+        pipe.close()
+        err, spur = _floor(y, ref, skip=64)
+        assert err <= 2e-7, (design, fp16, name, err)
+        if name == "tone":
+            assert float(np.abs(ref.reshape(-1, 2)[64:]).max()) < 3e-4       # (the tone really is in the stop band)
+            assert spur <= -150.0, (design, fp16, spur)
+
+
+@pytest.mark.parametrize("ntaps", [48, 127, 255])
+def test_tuned_matrix_core_path_numeric_floor_in_dbfs(pkg, dev, O, ntaps):
+    """The same floor for k_fir_i8x (the NCO folded into the taps, one rotation per output): a full-scale tone that the
+    mix leaves far out of band; max |y - oracle| <= 2e-7 absolute, no residual spur above -150 dBFS."""
+    from scipy.signal import firwin
+    h = firwin(ntaps, 0.8 / 16, window=("kaiser", 0.1102 * (100 - 8.7))).astype(np.float32)
+    ns = 8192 * 72
+    freg = 381178347                                              # 7.1 MHz: 0.08875 cycles per sample
+    packed = _tone_packed(ns, 0.08875 + 0.2931)
+    ref = O.ddc_chain(packed, [(8, h)], freg=freg, mix=True)
+    pipe = pkg.Pipeline([(8, h)], mix=True)
+    pipe.set_freg(freg)
+    assert pipe.on_i8(ns) == 2
+    y = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
+    pipe.close()
+    err, spur = _floor(y, ref, skip=64)
+    assert float(np.abs(ref.reshape(-1, 2)[64:]).max()) < 3e-3
+    assert err <= 2e-7 and spur <= -150.0, (ntaps, err, spur)

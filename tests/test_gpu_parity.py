@@ -540,15 +540,16 @@ def test_long_tile_runs_per_block_all_variants(pkg, dev, O, monkeypatch):
 
 
 @pytest.mark.parametrize("dyn,chunk", [("100", "1"), ("100", "3"), ("60", "2"), ("0", "5"), ("100", "64")])
-def test_tile_scheduler_variants(pkg, dev, O, monkeypatch, dyn, chunk):
+def test_tile_scheduler_variants(pkg, dev, O, monkeypatch, tune, dyn, chunk):
     """k_fir8 hands part of the tiles out dynamically (atomic chunk counter, the
     history of a chunk's first tile re-read from global memory, a warm-up tile for
     the fused pair).  Every schedule must give the same stream: all-dynamic with
     single-tile chunks, odd chunk sizes, mostly static, one chunk larger than the
     batch; several launches in a row check that the counters are left at zero."""
-    monkeypatch.setenv("PDDC_FIR8_DYN_PCT", dyn)
-    monkeypatch.setenv("PDDC_FIR8_CHUNK", chunk)
+    tune("fir8_dyn_pct", int(dyn))
+    tune("fir8_chunk", int(chunk))
     monkeypatch.setenv("PDDC_FIR8_BLOCKS", "5")
+    monkeypatch.setenv("PDDC_NO_I8", "1")                # (this is about k_fir8's scheduler: the vector kernels throughout)
     h1, h2 = load_taps("c320_s1_d8_32"), load_taps("c320_s2_d8_64")
     for stages, mix, R in (([(8, load_taps("d8_127"))], False, "4"), ([(8, load_taps("d8_255"))], True, "8"),
                            ([(8, h1), (8, h2)], True, "4"), ([(8, h1), (8, h2)], False, "8")):

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS the timing code that lives outside the product sources: git apply tools/ubench/fir8_probe_and_ablations.patch (revert afterwards)
 # Ablation builds of k_fir8 (NOT valid outputs -- timing only): which part of the kernel costs what.
 # Build here (no GPU needed):   tools/ablate.sh build
 # Run on the GPU box:           gpurun -- bash tools/ablate.sh run

@@ -41,14 +41,16 @@ base = run([(8, h0)])
 print(f"stage 0 alone: {base:.4f} ms")
 for D, nt in ((10, 287), (10, 63), (5, 144), (4, 29), (5, 32), (5, 48), (10, 61)):
     h = (rng.standard_normal(nt) / nt).astype(np.float32)
-    os.environ.pop("PDDC_GEN_SHAPE", None)
+    pkg.set_tunable("gen_shape_nt", 0)
+    pkg.set_tunable("gen_shape_p", 0)
     auto = run([(8, h0), (D, h)]) - base
     row = {"D": D, "ntaps": nt, "auto_us": round(auto * 1e3, 1)}
     for NT in (256, 128, 64):
         for P in (1, 2, 3, 4):
             if (D % 2 == 1 and P in (2, 4)) or (D % 2 == 0 and P == 3):
                 continue
-            os.environ["PDDC_GEN_SHAPE"] = f"{NT},{P}"
+            pkg.set_tunable("gen_shape_nt", NT)
+            pkg.set_tunable("gen_shape_p", P)
             try:
                 row[f"{NT},{P}"] = round((run([(8, h0), (D, h)]) - base) * 1e3, 1)
             except Exception as e:

@@ -1,3 +1,4 @@
+# NEEDS: git apply tools/ubench/fir8_probe_and_ablations.patch, build with -DPDDC_CLOCK_PROBE (revert afterwards)
 """Development: per-block start/end stamps of the fused pair kernel (build with -DPDDC_CLOCK_PROBE as
 libperseus-sdr_amd/probe_ddc.so; run on the GPU box with PDDC_FIR8_BLOCKS=512|768)."""
 import importlib, os, shutil, sys

@@ -21,11 +21,8 @@ for ns in (1 << 22, (1 << 22) + 4096 * 37, 1 << 20):
                 os.environ["PDDC_FIR8_BLOCKS"] = str(blocks)
             else:
                 os.environ.pop("PDDC_FIR8_BLOCKS", None)
-            for k, v in (("PDDC_FIR8_DYN_PCT", dyn), ("PDDC_FIR8_CHUNK", chunk)):
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = str(v)
+            pkg.set_tunable("fir8_dyn_pct", -1 if dyn is None else dyn)       # (process-wide launcher knobs, not environment)
+            pkg.set_tunable("fir8_chunk", 0 if chunk is None else chunk)
             pipe = pkg.Pipeline(stages, mix=True)
             pipe.set_freg(381178347)
             y = torch.cat([pipe.process(d_in[:6 * ns]).clone(), pipe.process(d_in[6 * ns:]).clone()])

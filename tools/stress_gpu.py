@@ -23,12 +23,10 @@ for it in range(n_iter):
     stages = plans[int(rng.integers(0, len(plans)))]
     os.environ["PDDC_FIR8_BLOCKS"] = str(int(rng.choice([1, 2, 3, 5, 16, 512])))
     dyn = int(rng.choice([-1, -1, 0, 10, 20, 50, 100]))          # -1: the library's own default schedule
-    if dyn < 0:
-        os.environ.pop("PDDC_FIR8_DYN_PCT", None)
-        os.environ.pop("PDDC_FIR8_CHUNK", None)
-    else:
-        os.environ["PDDC_FIR8_DYN_PCT"] = str(dyn)
-        os.environ["PDDC_FIR8_CHUNK"] = str(int(rng.choice([1, 2, 3, 4, 8])))
+    chunk_k = int(rng.choice([1, 2, 3, 4, 8])) if dyn >= 0 else 0
+    pkg.set_tunable("fir8_dyn_pct", dyn)                      # (process-wide launcher knobs: API state, not environment)
+    pkg.set_tunable("fir8_chunk", chunk_k)
+    os.environ["PDDC_FIR8_DYN_PCT"], os.environ["PDDC_FIR8_CHUNK"] = str(dyn), str(chunk_k)   # (for the report line below)
     os.environ["PDDC_FIR8_R"] = str(int(rng.choice([4, 8])))
     mix = bool(rng.integers(0, 2))
     freg = int(rng.integers(0, 2**32))
