@@ -61,8 +61,13 @@ def parse(argv=None):
                          "the settled, sustained-load clocks")
     ap.add_argument("--log2n", type=int, default=28, help="log2 complex samples per GPU per step")
     ap.add_argument("--workload", default="d8_127",
-                    choices=["d8_127", "d8_255", "c320", "unpack"],
-                    help="d8_127 = BASELINE configs[1] (default); others are sweep points")
+                    choices=["d8_127", "d8_255", "c320", "c320_fixture", "unpack", "api250k"],
+                    help="d8_127 = BASELINE configs[1] (default); others are sweep points.  c320 = BASELINE config 3 with the\n"
+                         "plan perseus_set_sampling_rate(250000) builds (what the drop-in API ships); c320_fixture = the same\n"
+                         "shape with the committed fixture taps (tests/golden); api250k = the reference's own call sequence\n"
+                         "(perseustest.c:188-404) through libperseus-sdr.so with the on-device source, in a C client")
+    ap.add_argument("--api-batch-log2", type=int, default=0,
+                    help="api250k: GPU batch size of the API stream (0 = the library's own choice: 2^26 for an unpaced on-device source)")
     ap.add_argument("--taps-fp16", action="store_true",
                     help="binary16 taps (BASELINE config 5's fp16 leg).  The 127-/255-tap workloads run on k_fir_i8, which\n"
                          "then holds the taps on the device as binary16 (2 bytes a tap) and quantises them into its\n"
@@ -255,17 +260,27 @@ BASELINE_METRIC = _baseline_metric()
 
 def workload_def(name, pkg=None):
     """-> dict(stages, mix, freg, bytes_per_sample, decim, label)."""
-    if name == "c320":
-        return {"stages": [(8, load_taps("c320_s1_d8_32")), (8, load_taps("c320_s2_d8_64")),
-                           (5, load_taps("c320_s3_d5_161"))],
+    if name in ("c320", "c320_fixture"):
+        if name == "c320":
+            # ONE x320 filter set, benchmarked and shipped: the plan the drop-in API builds for the reference's 250 kS/s
+            # setting (perseus_set_sampling_rate(250000), perseus-sdr.c:776-892; taps: csrc/plan_taps.inc)
+            if pkg is None:
+                pkg = importlib.import_module("libperseus-sdr_amd")
+            stages = [(d, t) for d, t, _l in pkg.api_plan(250000)]
+            origin = "the drop-in API's 250 kS/s plan"
+        else:
+            stages = [(8, load_taps("c320_s1_d8_32")), (8, load_taps("c320_s2_d8_64")), (5, load_taps("c320_s3_d5_161"))]
+            origin = "fixture taps"
+        nt = "/".join(str(len(t)) for _d, t in stages)
+        return {"stages": stages, "ntaps": [int(len(t)) for _d, t in stages],
                 "mix": True, "freg": 381178347,        # 7.1 MHz at 80 MHz (perseus-sdr.c:584)
                 "bytes_per_sample": 6.0 + 8.0 / 320.0, "decim": 320, "kernel_bytes_per_sample": 6.125,
-                "label": "80 MS/s synthetic 24-bit I/Q, NCO mix 7.1 MHz + cascade /320 (8*8*5)"}
+                "label": f"80 MS/s synthetic 24-bit I/Q, NCO mix 7.1 MHz + cascade /320 (8*8*5, {nt} taps: {origin})"}
     if name == "unpack":
         return {"stages": None, "mix": False, "freg": 0, "bytes_per_sample": 14.0, "decim": 1,
                 "kernel_bytes_per_sample": 14.0, "label": "24-bit packed I/Q -> float32 unpack only"}
     h = load_taps(name)
-    return {"stages": [(8, h)], "mix": False, "freg": 0, "bytes_per_sample": 7.0, "decim": 8,
+    return {"stages": [(8, h)], "ntaps": [int(h.size)], "mix": False, "freg": 0, "bytes_per_sample": 7.0, "decim": 8,
             "kernel_bytes_per_sample": 7.0,
             "label": f"80 MS/s synthetic 24-bit I/Q, unpack + {h.size}-tap polyphase decimate-by-8"}
 
@@ -730,7 +745,9 @@ def run_rank(a):
         step_achieved = wl["bytes_per_sample"] * ns / (dt_max / a.steps) / 1e9      # the whole step, gaps and tails included
         klabel = (("k_fir8 (fused cascade: all stages in one launch)" if cascade else
                    "k_fir8 (fused pair + the previous batch's tail as extra blocks of the launch)" if overlap
-                   else "k_fir_i8 (int8 matrix cores on the wire bytes)" if pipe.on_i8(ns)
+                   else "k_fir_i8x (int8 matrix cores, NCO folded into the taps, fused pair)" if pipe.fused_pair(ns) == 2
+                   else "k_fir_i8x (int8 matrix cores, NCO folded into the taps)" if pipe.on_i8(ns) == 2
+                   else "k_fir_i8 (int8 matrix cores on the wire bytes)" if pipe.on_i8(ns) == 1
                    else "k_fir8") if fused else "k_unpack24" if stages is None else "pipeline")
         traffic, traffic_src = traffic_from_profile(a.workload, kernel_source_sig(), a.log2n, a.taps_fp16, klabel)
         if verified is not None:
@@ -741,8 +758,8 @@ def run_rank(a):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt_max / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["label"], "samples_per_gpu_per_step": ns,
+            "dtype": ("i8xi8->i32, f32 out" if (pipe is not None and pipe.on_i8(ns)) else "f32"), "data": "synthetic",
+            "config": {"workload": wl["label"], "samples_per_gpu_per_step": ns, "ntaps": wl.get("ntaps"),
                        "input": "LCG bytes seed 12345+rank, device resident",
                        "sharding": "independent stream per GPU, no data-path collective",
                        "taps": (("binary16 STORAGE: 2 bytes a tap on the device, quantised into int8 digit planes by k_fir_i8's blocks themselves (PDDC_F_TAPS_FP16)" if pipe is not None and pipe.on_i8(ns)
@@ -850,7 +867,8 @@ def gather_leg(a, pkg, grp, dev, stream, ns, d_in, pipe, out_shape_rows, decim, 
             "out_bytes_per_rank_per_step": int(nbytes),
             "root_ingest_GBps": round((world - 1) * nbytes * a.steps / tg / 1e9, 2),
             # xGMI is point to point: each peer reaches rank 0 over its own link
-            "per_link_GBps": round(nbytes * a.steps / tg / 1e9, 2) if world > 1 else 0.0,
+            # (None at one rank: no link carried anything -- a measured zero would be a number)
+            "per_link_GBps": round(nbytes * a.steps / tg / 1e9, 2) if world > 1 else None,
             "root_block_matches_own_output": ok, "all_blocks_match_their_ranks_checksums": blocks_ok}
 
 
@@ -900,6 +918,54 @@ def guarded_gather_legs(a, pkg, shard, grp, dev, stream, ns, d_in, wl, pipe, out
 PARTIAL = {}
 
 
+def run_api250k(a):
+    """The reference's own call sequence (examples/perseustest.c:188-404: init, open, firmware, rate, tuning, start with a
+    callback, stop, close, exit) through the drop-in library, in the C client (libperseus-sdr_amd/perseus_plumbing -B):
+    250 kS/s setting, 7.1 MHz, float32 callback buffers from the GPU (mode ddc), the synthetic LCG stream generated on the
+    device, unpaced.  A "step" is one GPU batch of the stream; the client stamps the callback that completes batch W and
+    the one that completes batch W + K.  This process makes no GPU call (the child owns the device)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "libperseus-sdr_amd", "perseus_plumbing")
+    if not os.path.exists(exe):
+        raise SystemExit(f"{exe} is missing: run __graft_entry__.build()")
+    env = dict(os.environ, PERSEUS_AMD_MODE="ddc", PERSEUS_AMD_PACE="0")
+    if a.api_batch_log2 > 0:
+        env["PERSEUS_AMD_BATCH"] = str(1 << a.api_batch_log2)
+    cmd = [exe, "-s", "250000", "-f", "7100000", "-n", "2", "-b", "6144", "-o", "none", "-a", "-d", "0", "-t", "600",
+           "-B", f"{a.warmup},{a.steps}"]
+    t0 = time.perf_counter()
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - t0
+    line = [l for l in out.stdout.splitlines() if l.startswith("api_bench")]
+    if out.returncode != 0 or not line or "failed" in line[0]:
+        raise SystemExit(f"api250k: client failed (rc {out.returncode}): {out.stdout[-400:]} {out.stderr[-800:]}")
+    kv = dict(t.split("=") for t in line[0].split()[1:])
+    ns = int(kv["batch_samples"])
+    ms = float(kv["ms_per_step"])
+    pkg = importlib.import_module("libperseus-sdr_amd")
+    plan = pkg.api_plan(250000)
+    bps = 6.0 + 8.0 / 320.0
+    achieved = bps * ns / (ms * 1e-3) / 1e9
+    res = {
+        "metric": BASELINE_METRIC, "value": round(ns / ms / 1e3, 1), "unit": "MS/s", "n_gpus": 1, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i8xi8->i32, f32 out" if ns <= (1 << 26) else "f32", "data": "synthetic",
+        "config": {"workload": "drop-in API: perseus_init/open/firmware_download/set_sampling_rate(250000)/set_ddc_center_freq(7.1 MHz)/"
+                               "start_async_input(12288 B, C callback) in libperseus-sdr_amd/perseus_plumbing; on-device LCG source, unpaced, "
+                               "float32 buffers (mode ddc)",
+                   "samples_per_gpu_per_step": ns, "ntaps": [int(t.size) for _d, t, _l in plan],
+                   "api_batch": "the library's choice for an unpaced on-device source" if a.api_batch_log2 <= 0 else "PERSEUS_AMD_BATCH",
+                   "gpu_batches": int(kv["gpu_batches"]), "gpu_source": int(kv["gpu_source"])},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "whole API step (callbacks included): 6 + 8/320 B per ADC sample over the time between the callbacks "
+                               "that complete batch W and batch W + K",
+                     "bytes_per_sample": bps},
+        "cpu_baseline": None, "client_wall_s": round(wall, 2),
+    }
+    print(json.dumps(res), flush=True)
+
+
 def finish(grp, res):
     # RCCL writes its version banner to C stdout, which is block buffered on a pipe and would
     # otherwise come out at process exit -- after the JSON line, on any rank.  Every rank flushes
@@ -931,6 +997,8 @@ def main():
         # file computes an output on the CPU.
         mod, fn = hook.split(":")
         return getattr(importlib.import_module(mod), fn)(a, sys.modules[__name__])
+    if a.workload == "api250k":
+        return run_api250k(a)
     run_rank(a)
 
 

@@ -146,6 +146,8 @@ struct perseus_descr_ds {
     int n_pend;
     int input_done;             /* the source has nothing more to give           */
     int gpu_source;             /* the LCG stream is generated on the device     */
+    int batch_auto;             /* batch_samples was not chosen by the client (PERSEUS_AMD_BATCH, set_config): the library
+                                   picks it for the kind of source when the stream starts (effective_batch)             */
     uint64_t ganged_batches;    /* batches that shared their launches with other receivers of the GPU */
     int gpu_dev;                /* HIP device of the current / last stream, -1: none */
     uint8_t *fifo;              /* ring of decimated bytes awaiting callbacks    */
@@ -238,6 +240,20 @@ static void plan_free(ddc_plan *p)
     p->nstages = 0;
 }
 
+/* the plain decimator stages' taps: shortest equiripple designs for the specification below, made offline
+ * (tools/design_plans.py -> plan_taps.inc); the window designer above remains for the rational stages and as the fallback */
+#include "plan_taps.inc"
+
+static const float *plan_table_taps(int rate, int stage, int decim, int *ntaps)
+{
+    for (size_t k = 0; k < sizeof(kPlanTapTable) / sizeof(kPlanTapTable[0]); k++)
+        if (kPlanTapTable[k].rate == rate && kPlanTapTable[k].stage == stage && kPlanTapTable[k].decim == decim) {
+            *ntaps = kPlanTapTable[k].ntaps;
+            return kPlanTapTable[k].taps;
+        }
+    return NULL;
+}
+
 /* Plans from the 80 MS/s ADC rate to the ten rates of the reference's FPGA
  * images.  Integer ratios are decimator cascades; the four non-integer rates
  * end in a rational L/M polyphase resampler fed at 200/400 kS/s. */
@@ -278,6 +294,12 @@ static int plan_build(ddc_plan *p, int rate)
             }
             if (n > (L > 1 ? PDDC_MAX_TAPS : PDDC_MAX_TAPS_DECIM))
                 n = (L > 1 ? PDDC_MAX_TAPS : PDDC_MAX_TAPS_DECIM) / L * L;
+            /* the same specification met by the shortest equiripple filter (offline design): e.g. 250 kS/s 32 / 41 / 117
+             * taps where the window method needs 48 / 56 / 144 */
+            int nt = 0;
+            const float *tt = L == 1 ? plan_table_taps(rate, i, D, &nt) : NULL;
+            if (tt && nt <= PDDC_MAX_TAPS_DECIM)
+                n = nt;
             p->decim[i] = D;
             p->interp[i] = L;
             p->ntaps[i] = n;
@@ -286,7 +308,10 @@ static int plan_build(ddc_plan *p, int rate)
                 plan_free(p);
                 return 0;
             }
-            kaiser_lowpass(p->taps[i], n, 0.5 * (fpass + fstop) / fproto, atten);
+            if (tt && nt == n)
+                memcpy(p->taps[i], tt, sizeof(float) * (size_t)n);
+            else
+                kaiser_lowpass(p->taps[i], n, 0.5 * (fpass + fstop) / fproto, atten);
             if (L > 1)                               /* zero stuffing divides the gain by L */
                 for (int k = 0; k < n; k++)
                     p->taps[i][k] *= (float)L;
@@ -963,6 +988,8 @@ static void *worker_fn(void *arg)
 /* ---- API ---------------------------------------------------------------------- */
 void perseus_set_debug(int level) { perseus_dbg_level = level; }
 
+static uint32_t effective_batch(const perseus_descr *d);
+
 static void default_config(perseus_descr *d)
 {
     const char *e;
@@ -973,6 +1000,7 @@ static void default_config(perseus_descr *d)
     d->cfg.pace = 1;
     d->cfg.gpu_device = -1;
     d->cfg.batch_samples = 1u << 22;
+    d->batch_auto = 1;
     if ((e = getenv("PERSEUS_AMD_MODE"))) {
         if (strcmp(e, "ddc") == 0)
             d->cfg.mode = PERSEUS_AMD_MODE_DDC;
@@ -994,8 +1022,10 @@ static void default_config(perseus_descr *d)
     }
     if ((e = getenv("PERSEUS_AMD_PACE")))
         d->cfg.pace = atoi(e) != 0;
-    if ((e = getenv("PERSEUS_AMD_BATCH")) && atol(e) >= 8)
+    if ((e = getenv("PERSEUS_AMD_BATCH")) && atol(e) >= 8) {
         d->cfg.batch_samples = (uint32_t)(atol(e) / 8 * 8);
+        d->batch_auto = 0;
+    }
     if ((e = getenv("PERSEUS_AMD_DROP")))
         d->cfg.drop_every = atoi(e);
     if ((e = getenv("PERSEUS_AMD_MAX_BUFFERS")))
@@ -1423,6 +1453,7 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
             return errorset(PERSEUS_DEVCONF, "GPU pipeline creation failed (%d): %s", rc, pddc_last_error());
         }
         pddc_pipeline_set_freg(d->pipe, d->freg);
+        d->cfg.batch_samples = effective_batch(d);             /* (what get_config reports while the stream runs) */
         d->out_cap = pddc_pipeline_max_output(d->pipe, d->cfg.batch_samples) + 8;
         /* the synthetic stream is generated on the GPU (bit-identical to the host loop,
          * pddc_synth_lcg) unless the configuration insists on the CPU generator */
@@ -1522,6 +1553,8 @@ int perseus_amd_set_config(perseus_descr *d, const perseus_amd_config *cfg)
     /* the strings are copied into the descriptor -- unless they already ARE the descriptor's
      * copies (get_config -> modify -> set_config hands them back) */
     const char *fp = cfg->file_path, *fs = cfg->fault_script;
+    if (cfg->batch_samples != d->cfg.batch_samples)
+        d->batch_auto = 0;                      /* the client chose a batch size */
     d->cfg = *cfg;
     if (d->cfg.ep_packet_size == 0)
         d->cfg.ep_packet_size = 512;
@@ -1539,6 +1572,20 @@ int perseus_amd_set_config(perseus_descr *d, const perseus_amd_config *cfg)
     }
     return errornone(0);
 }
+
+/* GPU batch size of the next stream.  The client's choice if it made one; otherwise 2^22 samples (52 ms of signal: a paced,
+ * real-time source must not wait longer for its output; a host-fed one is bound by filling the batch) -- except for a
+ * free-running on-device source, where nothing but the launch chain's fixed cost is amortised by the batch: 2^26 (x320 plan
+ * on one MI355X: 20 us per 2^22-sample batch = 213 GS/s, 112 us per 2^26 = 600 GS/s; 0.4 GB of HBM per slot).           */
+static uint32_t effective_batch(const perseus_descr *d)
+{
+    const int gpu_source = d->cfg.source == PERSEUS_AMD_SRC_LCG && !d->cfg.cpu_source;
+    if (d->batch_auto && !d->cfg.pace && gpu_source && d->cfg.mode != PERSEUS_AMD_MODE_WIRE)
+        return 1u << 26;
+    return d->cfg.batch_samples;
+}
+
+uint32_t perseus_amd_effective_batch(perseus_descr *d) { return d ? effective_batch(d) : 0; }
 
 uint32_t perseus_amd_get_freg(perseus_descr *d) { return d ? d->freg : 0; }
 int perseus_amd_get_sampling_rate(perseus_descr *d) { return d ? d->sample_rate : 0; }

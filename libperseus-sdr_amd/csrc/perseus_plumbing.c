@@ -16,6 +16,8 @@
  *   -t sec    run time (10)                            -m count     stop after count buffers
  *   -o file   output ("perseusdata", "-" = stdout)     -p           float32 output (default int32)
  *   -d level  debug level (3)                          -F fifo      control FIFO (see below)
+ *   -B w,k    bench mode (one receiver, DDC mode): stop after w + k + 1 GPU batches and report the time the callbacks took
+ *             from the end of batch w to the end of batch w + k (stamps taken in the callback): "api_bench ..." line
  *   -N n      open n receivers (1..8, reference PERSEUS_MAX_DESCR; sets PERSEUS_AMD_DEVICES=n unless it is set):
  *             every receiver gets the same settings and its own stream (seed 12345+i); in DDC mode receiver i
  *             runs on GPU i % ngpu and all of them are in flight at once; output files get ".i" appended
@@ -33,13 +35,32 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <sys/time.h>
+#include <time.h>
 #include <unistd.h>
 
 typedef struct {
     FILE *out;
     int ddc;
     unsigned long long buffers, samples;
+    /* -B: time stamps taken in the callback when the delivered samples cross two marks (bench.py --workload api250k) */
+    unsigned long long mark0, mark1;
+    struct timespec t_mark0, t_mark1;
+    int got0, got1;
 } sink;
+
+static inline void sink_marks(sink *s)
+{
+    if (s->mark1 == 0)
+        return;
+    if (!s->got0 && s->samples >= s->mark0) {
+        clock_gettime(CLOCK_MONOTONIC, &s->t_mark0);
+        s->got0 = 1;
+    }
+    if (!s->got1 && s->samples >= s->mark1) {
+        clock_gettime(CLOCK_MONOTONIC, &s->t_mark1);
+        s->got1 = 1;
+    }
+}
 
 /* wire format: I0 I1 I2 Q0 Q1 Q2, 24-bit little endian.  MSB-align into int32. */
 static inline int32_t msb24(const uint8_t *b)
@@ -72,6 +93,7 @@ static int on_buffer_float(void *buf, int buf_size, void *extra)
             fwrite(buf, 1, (size_t)buf_size, s->out);
         s->buffers++;
         s->samples += (unsigned)buf_size / 8;
+        sink_marks(s);
         return 0;
     }
     const uint8_t *b = (const uint8_t *)buf;
@@ -123,12 +145,13 @@ int main(int argc, char **argv)
 {
     int rate = 95000, nb = 6, bs = 1024, dbg = 3, seconds = 10, as_float = 0, test_fe = 1, nrx = 1, multi = 0;
     long max_buffers = 0;
+    int bench_w = -1, bench_k = 0;
     double freq = 7000000.0;
     const char *outname = "perseusdata";
     const char *fifo = NULL;
     pthread_t fifo_tid;
     int c;
-    while ((c = getopt(argc, argv, "s:n:b:d:t:o:f:m:F:N:pah")) != -1) {
+    while ((c = getopt(argc, argv, "s:n:b:d:t:o:f:m:F:N:B:pah")) != -1) {
         switch (c) {
         case 's': rate = atoi(optarg); break;
         case 'n': nb = atoi(optarg); break;
@@ -140,6 +163,12 @@ int main(int argc, char **argv)
         case 'm': max_buffers = atol(optarg); break;
         case 'F': fifo = optarg; break;
         case 'N': nrx = atoi(optarg); multi = 1; break;   /* -N 1: the same loop with one receiver */
+        case 'B':
+            if (sscanf(optarg, "%d,%d", &bench_w, &bench_k) != 2 || bench_w < 0 || bench_k < 1) {
+                fprintf(stderr, "-B wants warm,steps\n");
+                return 2;
+            }
+            break;
         case 'p': as_float = 1; break;
         case 'a': test_fe = 0; break;
         default:
@@ -195,7 +224,7 @@ int main(int argc, char **argv)
                 cfg.max_buffers = (uint64_t)max_buffers;
                 perseus_amd_set_config(rx[i], &cfg);
             }
-            sk[i] = (sink){ NULL, cfg.mode == PERSEUS_AMD_MODE_DDC, 0, 0 };
+            sk[i] = (sink){ NULL, cfg.mode == PERSEUS_AMD_MODE_DDC, 0, 0, 0, 0, { 0, 0 }, { 0, 0 }, 0, 0 };
             if (strcmp(outname, "none") != 0 && strcmp(outname, "-") != 0) {
                 char name[1100];
                 snprintf(name, sizeof(name), "%s.%d", outname, i);
@@ -280,7 +309,24 @@ int main(int argc, char **argv)
         cfg.max_buffers = (uint64_t)max_buffers;
         perseus_amd_set_config(d, &cfg);
     }
-    sink s = { NULL, cfg.mode == PERSEUS_AMD_MODE_DDC, 0, 0 };
+    sink s = { NULL, cfg.mode == PERSEUS_AMD_MODE_DDC, 0, 0, 0, 0, { 0, 0 }, { 0, 0 }, 0, 0 };
+    unsigned long long bench_batch = 0;
+    if (bench_w >= 0) {
+        if (!s.ddc) {
+            fprintf(stderr, "-B needs PERSEUS_AMD_MODE=ddc\n");
+            return 2;
+        }
+        /* the library's own batch size (PERSEUS_AMD_BATCH, or what it picks for this kind of source) */
+        bench_batch = perseus_amd_effective_batch(d);
+        const unsigned long long per_batch = bench_batch * (unsigned long long)rate / 80000000ull;   /* outputs per batch */
+        s.mark0 = per_batch * (unsigned long long)bench_w;
+        s.mark1 = per_batch * (unsigned long long)(bench_w + bench_k);
+        cfg.max_buffers = (per_batch * (unsigned long long)(bench_w + bench_k + 1) * 8 + (unsigned long long)(nb * bs) - 1) /
+                          (unsigned long long)(nb * bs);
+        perseus_amd_set_config(d, &cfg);
+        if (s.mark0 == 0)
+            clock_gettime(CLOCK_MONOTONIC, &s.t_mark0), s.got0 = 1;
+    }
     if (strcmp(outname, "-") == 0)
         s.out = stdout;
     else if (strcmp(outname, "none") != 0)
@@ -319,6 +365,19 @@ int main(int argc, char **argv)
     if (s.out && s.out != stdout)
         fclose(s.out);
     fprintf(stderr, "%llu buffers, %llu samples\n", s.buffers, s.samples);
+    if (bench_w >= 0) {
+        perseus_amd_stats st;
+        perseus_amd_get_stats(d, &st);
+        if (s.got0 && s.got1) {
+            const double ms = 1e3 * (double)(s.t_mark1.tv_sec - s.t_mark0.tv_sec) + 1e-6 * (double)(s.t_mark1.tv_nsec - s.t_mark0.tv_nsec);
+            printf("api_bench batch_samples=%llu warm=%d steps=%d ms_total=%.6f ms_per_step=%.6f adc_MSps=%.1f gpu_batches=%llu "
+                   "ganged=%llu gpu_source=%d\n", bench_batch, bench_w, bench_k, ms, ms / bench_k,
+                   (double)bench_batch * bench_k / ms / 1e3, (unsigned long long)st.batches, (unsigned long long)st.ganged_batches,
+                   st.gpu_source);
+        } else {
+            printf("api_bench failed: the stream ended before the marks (%llu samples of %llu)\n", s.samples, s.mark1);
+        }
+    }
     perseus_close(d);
     perseus_exit();
     fprintf(stderr, "Bye\n");
