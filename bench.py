@@ -67,7 +67,7 @@ def parse(argv=None):
                          "shape with the committed fixture taps (tests/golden); api250k = the reference's own call sequence\n"
                          "(perseustest.c:188-404) through libperseus-sdr.so with the on-device source, in a C client")
     ap.add_argument("--api-batch-log2", type=int, default=0,
-                    help="api250k: GPU batch size of the API stream (0 = the library's own choice: 2^26 for an unpaced on-device source)")
+                    help="api250k: GPU batch size of the API stream (0 = the library's own choice: 2^24 for an unpaced on-device source)")
     ap.add_argument("--taps-fp16", action="store_true",
                     help="binary16 taps (BASELINE config 5's fp16 leg).  The 127-/255-tap workloads run on k_fir_i8, which\n"
                          "then holds the taps on the device as binary16 (2 bytes a tap) and quantises them into its\n"
@@ -375,7 +375,7 @@ def traffic_from_profile(workload, kernel_sig, log2n, taps_fp16, kernel_in_use=N
 def kernel_source_sig():
     import hashlib
     h = hashlib.sha256()
-    for f in ("ddc_kernels.hip", "ddc_kernels.h", "fir8_block.inc"):
+    for f in ("ddc_kernels.hip", "ddc_kernels.h", "fir8_block.inc", "ddc_fir_i8.hip", "ddc_dev.h"):
         h.update(open(os.path.join(ROOT, "libperseus-sdr_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -487,6 +487,7 @@ def run_rank(a):
 
         def out_view(k):
             if ws_bytes:                                          # the workspace goes where the output goes
+                pipe.fence(stream)                                # (a tail still held back reads the present one)
                 pipe.set_workspace(arena[k * slot + in_span:].data_ptr(), ws_bytes, ns)
             at = k * slot + in_span + ws_span
             return arena[at:at + out_bytes].view(torch.float32).view(out_rows, 2)

@@ -99,7 +99,7 @@ int perseus_amd_get_config(perseus_descr *descr, perseus_amd_config *cfg);
 int perseus_amd_set_config(perseus_descr *descr, const perseus_amd_config *cfg);
 
 /* The GPU batch size the next stream will use: cfg.batch_samples if the client chose one (set_config, PERSEUS_AMD_BATCH);
- * otherwise the library's pick for the kind of source -- 2^22 samples, or 2^26 for a free-running (unpaced) on-device source */
+ * otherwise the library's pick for the kind of source -- 2^22 samples, or 2^24 for a free-running (unpaced) on-device source */
 uint32_t perseus_amd_effective_batch(perseus_descr *descr);
 
 /* state introspection (for tests and tools) */

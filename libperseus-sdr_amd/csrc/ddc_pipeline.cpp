@@ -2453,20 +2453,24 @@ static int push_async(pddc_pipeline *p, const void *h_packed, bool synth, uint32
      * batch, ~18 us each on this runtime (profiles/r03/d_side_stream_overlap_delay.txt) -- more than the kernels of a
      * 2^22-sample batch take.  Two slots still alternate, so the host fills / reads one while the GPU works on the other. */
     const bool one_stream = synth && !tunables().push_three_streams.load();
-    hipStream_t st_in = one_stream ? p->own_stream : p->s_in;
+    /* ... except that from 2^24 samples on the GENERATOR of this batch goes to the side stream: it writes 6 bytes per
+     * sample -- as much as the whole cascade reads -- and with two batches in flight it then runs beside the kernels of the
+     * batch before (one event hop of ~18 us against 24 us of generator at 2^24, 94 us at 2^26) */
+    const bool gen_aside = one_stream && nsamples >= ((size_t)1 << 24);
+    hipStream_t st_in = one_stream && !gen_aside ? p->own_stream : p->s_in;
     hipStream_t st_out = one_stream ? p->own_stream : p->s_out;
     /* H2D (or the generator): the slot's input buffer is free once the kernels of its previous batch are done */
-    if (sl.used && !one_stream)
+    if (sl.used && (!one_stream || gen_aside))
         HIP_TRY(hipStreamWaitEvent(st_in, sl.ev_comp, 0));
     if (synth)
         HIP_TRY(launch_synth_lcg(sl.d_in, nsamples * 6, seed, byte_offset, st_in));
     else
         HIP_TRY(hipMemcpyAsync(sl.d_in, h_packed, nsamples * 6, hipMemcpyHostToDevice, st_in));
-    if (!one_stream) {
+    if (!one_stream || gen_aside) {
         HIP_TRY(hipEventRecord(sl.ev_in, st_in));
         /* kernels: after this batch has arrived and the slot's previous output has left */
         HIP_TRY(hipStreamWaitEvent(p->own_stream, sl.ev_in, 0));
-        if (sl.used)
+        if (sl.used && !one_stream)
             HIP_TRY(hipStreamWaitEvent(p->own_stream, sl.ev_out, 0));
     }
     size_t n_out = 0;

@@ -1575,13 +1575,15 @@ int perseus_amd_set_config(perseus_descr *d, const perseus_amd_config *cfg)
 
 /* GPU batch size of the next stream.  The client's choice if it made one; otherwise 2^22 samples (52 ms of signal: a paced,
  * real-time source must not wait longer for its output; a host-fed one is bound by filling the batch) -- except for a
- * free-running on-device source, where nothing but the launch chain's fixed cost is amortised by the batch: 2^26 (x320 plan
- * on one MI355X: 20 us per 2^22-sample batch = 213 GS/s, 112 us per 2^26 = 600 GS/s; 0.4 GB of HBM per slot).           */
+ * free-running on-device source, where the batch only has to amortise the launch chain's fixed cost: 2^24.  Measured
+ * through the C client, 250 kS/s plan, one receiver (bench.py --workload api250k): 2^22 80 GS/s of ADC-rate input, 2^24
+ * 255, 2^26 200, 2^28 214 -- beyond 2^24 the delivery thread's two copies of every output byte (GPU batch -> ring ->
+ * transfer buffer, 5 GB/s of callback payload) bound the stream, not the GPU.                                          */
 static uint32_t effective_batch(const perseus_descr *d)
 {
     const int gpu_source = d->cfg.source == PERSEUS_AMD_SRC_LCG && !d->cfg.cpu_source;
     if (d->batch_auto && !d->cfg.pace && gpu_source && d->cfg.mode != PERSEUS_AMD_MODE_WIRE)
-        return 1u << 26;
+        return 1u << 24;
     return d->cfg.batch_samples;
 }
 

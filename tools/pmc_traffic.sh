@@ -5,7 +5,7 @@
 OUT=${1:-gpurun_out/pmc_traffic}
 mkdir -p $OUT
 export TMPDIR=/tmp
-for W in d8_127 d8_255 c320 unpack; do
+for W in d8_127 d8_255 c320 c320_fixture unpack; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/${W}_$C -- python3 bench.py --no-cpu --out-candidates 1 --workload $W --steps 5 --warmup 1 > $OUT/${W}_$C.log 2>&1
   done
@@ -13,8 +13,8 @@ done
 python3 - $OUT <<'PY'
 import csv, glob, json, sys
 out = sys.argv[1]
-kern = {"d8_127": "k_fir_i8", "d8_255": "k_fir_i8", "c320": "k_fir8", "unpack": "k_unpack24"}
-alg = {"d8_127": 7.0, "d8_255": 7.0, "c320": 6.125, "unpack": 14.0}      # bytes per input sample of that kernel
+kern = {"d8_127": "k_fir_i8", "d8_255": "k_fir_i8", "c320": "k_fir8", "c320_fixture": "k_fir8", "unpack": "k_unpack24"}
+alg = {"d8_127": 7.0, "d8_255": 7.0, "c320": 6.125, "c320_fixture": 6.125, "unpack": 14.0}      # bytes per input sample of that kernel
 res = {}
 for w, k in kern.items():
     v = {}
@@ -30,7 +30,7 @@ for w, k in kern.items():
         print(f"{w:8s} {k:12s} corrected HBM bytes per launch {res[w]:.4e}   algorithmic {alg[w] * 2**28:.4e}")
 import hashlib, subprocess
 h = hashlib.sha256()
-for f in ("ddc_kernels.hip", "ddc_kernels.h", "fir8_block.inc"):
+for f in ("ddc_kernels.hip", "ddc_kernels.h", "fir8_block.inc", "ddc_fir_i8.hip", "ddc_dev.h"):
     h.update(open("libperseus-sdr_amd/csrc/" + f, "rb").read())
 try:
     commit = subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
