@@ -122,10 +122,12 @@ def test_eight_receivers_share_one_gpu_and_overlap(L, pkg, O, monkeypatch):
     print(f"8 receivers on one GPU: {wall8 * 1e3:.1f} ms first-to-last callback; one alone: "
           f"{min(walls) * 1e3:.1f} ms; ratio {wall8 / min(walls):.2f}")
     # Eight times the samples and eight times the (GIL-serialized) Python callbacks of one receiver.  Round 2: 94 ms vs
-    # 8.3 ms, 11x.  Now ~22 ms vs ~10.5 ms: the C client, with no interpreter in the loop, shows the library's own
-    # share -- eight receivers in 1.6x to 2.1x the time of one -- and asserts it there
-    # (test_plumbing_client_eight_receivers_on_the_gpu_path); here 4800 callbacks of ~3 us ride along.
-    assert wall8 < 3.5 * min(walls), (walls8, walls)             # (seen: 2.06 .. 2.38; the single receiver follows the host's speed)
+    # 8.3 ms, 11x; round 3: ~22 ms vs ~10.5 ms.  Round 4: the single receiver's batches run on k_fir_i8x (x320 step at 2^22
+    # samples 40 -> 20 us) and its 600 callbacks now take 2.3 ms -- the Python callback (~4 us) is all that is left on
+    # either side, so eight receivers with 4800 callbacks take about eight times as long (~20 ms).  What the library itself
+    # adds shows in the C client (test_plumbing_client_eight_receivers_on_the_gpu_path, tools/api_receivers.sh: one
+    # receiver 135 GS/s of ADC-rate input, eight 225); here only: not worse than eight streams one after the other.
+    assert wall8 < 12.0 * min(walls), (walls8, walls)
 
 
 # ------------------------------------------------------------------ N4: retune while streaming
@@ -302,10 +304,12 @@ def test_unpaced_plumbing_client_is_kernel_bound_not_source_bound(pkg, dev):
 
 def test_plumbing_client_eight_receivers_on_the_gpu_path(pkg, dev):
     """The C client with -N 8 in DDC mode: eight pipelines on one GPU, all in flight at once, no Python in the loop.
-    Their batches go out as ONE launch chain (gang submission): eight receivers take about twice the time of one --
-    1.6x to 2.5x over the boxes seen, the one receiver being a latency chain whose speed varies with the host (40-82 GS/s)
-    and the eight being bound by the GPU (235-265 GS/s); round 2: a chain per receiver, 11x.  Asserted: under 3.3x
-    (the aggregate is more than 2.4 times one receiver's rate) and more than 150 GS/s for the eight."""
+    Their batches go out as ONE launch chain (gang submission).  Round 3: one receiver 40-82 GS/s of ADC-rate input (a
+    latency chain of vector kernels at 2^22-sample batches), eight 235-265.  Round 4: the tuned first stages run on
+    k_fir_i8x and an unpaced on-device source gets 2^24-sample batches: ONE receiver 135-142 GS/s; the eight stay at
+    225-265 -- what bounds them is the one delivery thread, which copies every output byte twice on its way into the
+    callback buffers (5-6 GB/s of payload), not the GPU.  Asserted: more than 150 GS/s for the eight, more than 80 for the
+    one, and the eight together ahead of the one by half again."""
     import re
     exe = os.path.join(os.path.dirname(pkg.SDR_LIB), "perseus_plumbing")
     env = dict(os.environ, PERSEUS_AMD_PACE="0", PERSEUS_AMD_MODE="ddc")
@@ -332,9 +336,7 @@ def test_plumbing_client_eight_receivers_on_the_gpu_path(pkg, dev):
     adc8, adc1 = float(m8.group(4)), float(m1.group(4))
     print("plumbing -N 8:", m8.group(0))
     print(f"plumbing -N 1: {adc1:.0f} MS/s of ADC-rate input; eight receivers take {8 * adc1 / adc8:.2f}x the time of one")
-    # (one receiver is a latency chain whose speed follows the host: 49-82 GS/s over the boxes seen; the eight are bound
-    # by the GPU: 235-265 GS/s)
-    assert adc8 > 2.4 * adc1 and adc8 > 150000.0, (adc8, adc1)
+    assert adc8 > 1.5 * adc1 and adc8 > 150000.0 and adc1 > 80000.0, (adc8, adc1)
 
 
 def test_large_api_batches_start_at_once_and_run_faster(pkg, dev):
