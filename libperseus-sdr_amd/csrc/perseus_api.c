@@ -256,15 +256,18 @@ static const float *plan_table_taps(int rate, int stage, int decim, int *ntaps)
 
 /* Plans from the 80 MS/s ADC rate to the ten rates of the reference's FPGA
  * images.  Integer ratios are decimator cascades; the four non-integer rates
- * end in a rational L/M polyphase resampler fed at 200/400 kS/s. */
+ * end in a rational L/M polyphase resampler fed at 250 kS/s. */
 static int plan_build(ddc_plan *p, int rate)
 {
     static const struct { int rate, n, d[4], l[4]; } tab[] = {
         { 2000000, 2, { 8, 5, 0, 0 },   { 1, 1, 0, 0 } },  { 1600000, 2, { 10, 5, 0, 0 },  { 1, 1, 0, 0 } },
-        { 1000000, 2, { 8, 10, 0, 0 },  { 1, 1, 0, 0 } },  { 500000, 3, { 8, 4, 5, 0 },    { 1, 1, 1, 0 } },
+        { 1000000, 2, { 8, 10, 0, 0 },  { 1, 1, 0, 0 } },  { 500000, 3, { 8, 8, 5, 0 },    { 1, 1, 2, 0 } },   /* (the fused pair to 1.25 MS/s, then x2/5: 8 * 4 * 5 cannot fuse) */
         { 250000, 3, { 8, 8, 5, 0 },    { 1, 1, 1, 0 } },  { 125000, 3, { 8, 8, 10, 0 },   { 1, 1, 1, 0 } },
-        { 192000, 4, { 8, 5, 5, 25 },   { 1, 1, 1, 12 } }, { 96000, 4, { 8, 10, 5, 25 },   { 1, 1, 1, 12 } },
-        { 48000, 4, { 8, 10, 5, 25 },   { 1, 1, 1, 6 } },  { 95000, 4, { 8, 10, 5, 40 },   { 1, 1, 1, 19 } },
+        /* the non-integer ratios, all from 250 kS/s -- behind the SAME two decimate-by-8 stages as the 250 / 125 kS/s plans,
+         * which run as one fused kernel (6.125 B per ADC sample instead of 8.3 for 8 * 10 * 5 or 8 * 5 * 5: round 3
+         * 480-600 GS/s at 2^28 samples, now 690-815) -- x96/125, x48/125, x24/125 and x19/50 */
+        { 192000, 4, { 8, 8, 5, 125 },  { 1, 1, 1, 96 } }, { 96000, 4, { 8, 8, 5, 125 },   { 1, 1, 1, 48 } },
+        { 48000, 4, { 8, 8, 5, 125 },   { 1, 1, 1, 24 } }, { 95000, 4, { 8, 8, 5, 50 },    { 1, 1, 1, 19 } },
     };
     plan_free(p);
     for (size_t t = 0; t < sizeof(tab) / sizeof(tab[0]); t++) {
