@@ -746,8 +746,8 @@ def run_rank(a):
         step_achieved = wl["bytes_per_sample"] * ns / (dt_max / a.steps) / 1e9      # the whole step, gaps and tails included
         klabel = (("k_fir8 (fused cascade: all stages in one launch)" if cascade else
                    "k_fir8 (fused pair + the previous batch's tail as extra blocks of the launch)" if overlap
-                   else "k_fir_i8x (int8 matrix cores, NCO folded into the taps, fused pair)" if pipe.fused_pair(ns) == 2
-                   else "k_fir_i8x (int8 matrix cores, NCO folded into the taps)" if pipe.on_i8(ns) == 2
+                   else "k_fir_i8x (int8 matrix cores on the wire bytes%s, fused pair)" % (", NCO folded into the taps" if wl["mix"] else "") if pipe.fused_pair(ns) == 2
+                   else "k_fir_i8x (int8 matrix cores on the wire bytes%s)" % (", NCO folded into the taps" if wl["mix"] else "") if pipe.on_i8(ns) == 2
                    else "k_fir_i8 (int8 matrix cores on the wire bytes)" if pipe.on_i8(ns) == 1
                    else "k_fir8") if fused else "k_unpack24" if stages is None else "pipeline")
         traffic, traffic_src = traffic_from_profile(a.workload, kernel_source_sig(), a.log2n, a.taps_fp16, klabel)
@@ -765,7 +765,7 @@ def run_rank(a):
                        "sharding": "independent stream per GPU, no data-path collective",
                        "taps": (("binary16 STORAGE: 2 bytes a tap on the device, quantised into int8 digit planes by k_fir_i8's blocks themselves (PDDC_F_TAPS_FP16)" if pipe is not None and pipe.on_i8(ns)
                                  else "binary16 VALUES held in fp32 registers (PDDC_F_TAPS_FP16)") if a.taps_fp16 else
-                                ("fp32 values as four int8 digit planes, 2^-31 of the largest tap (k_fir_i8)"
+                                ("fp32 values as four int8 digit planes, 2^-31 of the largest tap (k_fir_i8 / k_fir_i8x)"
                                  if pipe is not None and pipe.on_i8(ns) else "fp32")),
                        "overlap": ("the stage behind the fused pair is carried by the next step's first-stage launch as extra "
                                    "thread blocks (pddc_pipeline_set_overlap); the timed region ends with a fence") if overlap else None},

@@ -362,7 +362,7 @@ bool fir_i8_build_table(const float *taps, int ntaps, int hist, int8_t *table, f
                     table[(((size_t)j * ksteps + ks) * 64 + l) * 16 + jj] = (tt >= 1 && tt <= hist) ? dig[j][hist - tt] : 0;
                 }
     /* sample = (v24 << 8) / (INT_MAX - 256): the reference's float (perseustest.c:466-502) */
-    const double unit = std::ldexp(1.0, -E) * 256.0 / 2147483391.0;
+    const double unit = std::ldexp(1.0, -E) / 8388607.0;          /* (= 256 / 2147483392: the float the reference divides by) */
     *scale = (float)unit;
     *cterm = (float)((double)hsum * 32896.0 * unit);               /* planes 0 and 1 are stored minus 128: 128 + 128*256 */
     return true;
@@ -1294,6 +1294,8 @@ hipError_t launch_fir_i8x(const FirI8xArgs &a, int hist, bool mix, bool fuse2, h
         return hipErrorInvalidValue;
     if (fuse2 && ((a.n_in % i8x::TILE) || !a.taps2 || !a.hist2))
         return hipErrorInvalidValue;
+    if (layout < 0)              /* by form: the loaders finish the tile where the finish is heavy (four partial products, the second stage) */
+        layout = (fuse2 || (mix && hist > 64)) ? 1 : 0;
     switch (hist) {
     case 32:
         return launch_fir_i8x_h<32>(a, mix, fuse2, max_blocks, chunk, layout, s);

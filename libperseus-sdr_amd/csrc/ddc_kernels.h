@@ -213,11 +213,11 @@ bool fir_i8x_supported(int hist, bool mix, bool fuse2);
 /* max_blocks: persistent grid (0 = one block per CU); chunk: tiles per chunk of the round-robin walk (0 = 1, or 4 for the
  * fused pair; large = contiguous ranges per block) */
 hipError_t launch_fir_i8x_many(const FirI8xMany &m, int n, int hist, bool mix, bool fuse2, hipStream_t s, int max_blocks = 0,
-                               int chunk = 0, int layout = 1);
+                               int chunk = 0, int layout = -1);
 /* layout: which waves do what (ddc_fir_i8.hip "Who does what"): 0 a matrix wave on every SIMD, 1 matrix and post waves on
  * two SIMDs, loaders on the other two */
 hipError_t launch_fir_i8x(const FirI8xArgs &a, int hist, bool mix, bool fuse2, hipStream_t s, int max_blocks = 0, int chunk = 0,
-                          int layout = 1);
+                          int layout = -1 /* by form */);
 
 /* k_fir8 with packed input does not scale the unpacked integers (value * 256): the taps of
  * that stage must be uploaded multiplied by this, RN(1/8388607) / 256 -- the factor that

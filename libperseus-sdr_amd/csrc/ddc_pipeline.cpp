@@ -177,11 +177,14 @@ struct pddc_pipeline {
         int i8_128 = 1;           /* 65..128 taps without NCO on k_fir_i8 (0: k_fir8)                                 */
         int i8x = 1;              /* tuned first stages (PDDC_F_MIX) on k_fir_i8x (0: k_fir8)                         */
         int i8x_pair = 1;         /* ... and the cascade's first two stages as its fused pair (0: unfused, or k_fir8)  */
-        int i8x_plain = 0;        /* untuned first stages on k_fir_i8x too (LDS-carried history; 0: k_fir_i8 / k_fir8) */
+        int i8x_plain = 1;        /* untuned first stages on k_fir_i8x too (0: k_fir_i8 for 65..256 taps, k_fir8 below): at
+                                     2^28 samples 32/48 taps 0.319 against k_fir8's 0.339 ms, 255 taps 0.334 against k_fir_i8's
+                                     0.343; at 2^22 5.9 against 12.9 us (profiles/r04)                                  */
         int i8x_blocks = 0;       /* persistent grid override of k_fir_i8x (0: one block per CU)                       */
         int i8x_chunk = 0;        /* tiles per chunk of its walk (0: 1, fused pair 4)                                    */
-        int i8x_layout = 1;       /* which waves finish a tile (ddc_fir_i8.hip "Who does what"): 0 the matrix waves, 1 the
-                                     loaders (measured best), 2 two matrix + two finishing waves                        */
+        int i8x_layout = -1;      /* which waves finish a tile (ddc_fir_i8.hip "Who does what"): 0 the matrix waves, 1 the
+                                     loaders, 2 two matrix + two finishing waves; -1: by form (0 without the NCO and for
+                                     tuned stages up to 64 taps, 1 for 65..256 tuned taps and for the fused pair)        */
         int i8x_pair_max_log2 = 26;   /* the fused pair up to 2^26-sample batches: 3.2x k_fir8's pair at 2^22, 1.6x at
                                          2^24, level at 2^26, 9 % behind at 2^28 (profiles/r04)                         */
         int no_fuse2 = 0, fuse3 = 0;
@@ -217,7 +220,7 @@ struct GangRec {
     bool mix = false;
     Fir8Args a;
     FirI8xArgs ax;                /* kind 3 */
-    int hist = 0, chunk = 0, layout = 1, blocks = 0;
+    int hist = 0, chunk = 0, layout = -1, blocks = 0;
     bool fuse2 = false;
     GenTail tail;                 /* nblocks == 0: the plan ends with the first-stage kernel                       */
 };
@@ -948,10 +951,10 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
         p->opt.i8_128 = env_int("PDDC_I8_128", 1);
         p->opt.i8x = env_int("PDDC_I8X", 1);
         p->opt.i8x_pair = env_int("PDDC_I8X_PAIR", 1);
-        p->opt.i8x_plain = env_int("PDDC_I8X_PLAIN", 0);
+        p->opt.i8x_plain = env_int("PDDC_I8X_PLAIN", 1);
         p->opt.i8x_blocks = env_int("PDDC_I8X_BLOCKS", 0);
         p->opt.i8x_chunk = env_int("PDDC_I8X_CHUNK", 0);
-        p->opt.i8x_layout = env_int("PDDC_I8X_LAYOUT", 1);
+        p->opt.i8x_layout = env_int("PDDC_I8X_LAYOUT", -1);
         p->opt.i8x_pair_max_log2 = env_int("PDDC_I8X_PAIR_MAX_LOG2", 26);
         p->opt.no_fuse2 = getenv("PDDC_NO_FUSE2") ? 1 : 0;
         p->opt.fuse3 = env_int("PDDC_FUSE3", 0);

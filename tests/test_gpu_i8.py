@@ -24,8 +24,9 @@ def lowpass(ntaps, cutoff):
     return (h / h.sum()).astype(np.float32)
 
 
-def run(pkg, dev, stages, packed, cuts, monkeypatch=None, no_i8_at=()):
+def run(pkg, dev, stages, packed, cuts, monkeypatch=None, no_i8_at=(), plain=0):
     pipe = pkg.Pipeline(stages)
+    pipe.set_option("i8x_plain", plain)          # (0: round 3's k_fir_i8, what this file is about; 1: k_fir_i8x's plain form)
     parts, on = [], []
     for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
         if monkeypatch is not None:
@@ -36,8 +37,9 @@ def run(pkg, dev, stages, packed, cuts, monkeypatch=None, no_i8_at=()):
     return np.concatenate(parts), on
 
 
+@pytest.mark.parametrize("plain", [0, 1])
 @pytest.mark.parametrize("ntaps", [65, 100, 127, 128, 129, 160, 200, 255, 256])
-def test_i8_first_stage_vs_oracle_ragged_batches(pkg, dev, O, ntaps):
+def test_i8_first_stage_vs_oracle_ragged_batches(pkg, dev, O, ntaps, plain):
     """Tap counts over the kernel's whole range; batches of whole tiles (8192), ragged ones, one of a single group of 8
     behind the history length, and tiny ones (< 256 samples: k_fir8's generic history path on the same state)."""
     h = load_taps("d8_255") if ntaps == 255 else load_taps("d8_127") if ntaps == 127 else lowpass(ntaps, 0.05)
@@ -46,7 +48,7 @@ def test_i8_first_stage_vs_oracle_ragged_batches(pkg, dev, O, ntaps):
     cuts = np.concatenate([[0], np.cumsum(sizes)])
     packed = O.lcg_bytes(6 * int(cuts[-1]), 2026)
     ref = O.ddc_chain(packed, [(8, h)])
-    y, on = run(pkg, dev, [(8, h)], packed, cuts)
+    y, on = run(pkg, dev, [(8, h)], packed, cuts, plain=plain)
     assert on == [s >= hist for s in sizes]
     assert y.size == ref.size
     assert O.rel_err(y, ref) <= FIR_TOL, (ntaps, O.rel_err(y, ref))
@@ -151,19 +153,23 @@ def test_which_first_stages_run_where(pkg, dev):
     assert p.on_i8(1 << 20) == 0                                 # ... unless switched off: k_fir8 mixes in floats
     p.close()
     p = pkg.Pipeline([(8, h)])
-    assert p.on_i8(1 << 20) == 1                                 # untuned, 65..256 taps: k_fir_i8
+    assert p.on_i8(1 << 20) == 2                                 # untuned: k_fir_i8x's plain form (round 4)
+    p.set_option("i8x_plain", 0)
+    assert p.on_i8(1 << 20) == 1                                 # ... or round 3's k_fir_i8 (65..256 taps)
+    p.close()
+    p = pkg.Pipeline([(8, h)], taps_fp16=True)
+    assert p.on_i8(1 << 20) == 1                                 # binary16 tap STORAGE: k_fir_i8 quantises them itself
     p.close()
     p = pkg.Pipeline([(8, load_taps("c320_s1_d8_32"))])
-    assert p.on_i8(1 << 20) == 0                                 # untuned, up to 64 taps: the vector kernel streams as well
-    p.set_option("i8x_plain", 1)
-    assert p.on_i8(1 << 20) == 2
+    assert p.on_i8(1 << 20) == 2                                 # short untuned stages too
+    p.set_option("i8x_plain", 0)
+    assert p.on_i8(1 << 20) == 0                                 # ... or the vector kernel
     p.close()
     p = pkg.Pipeline([(8, h)], no_fast=True)
     assert not p.on_i8(1 << 20)
     p.close()
     with pytest.raises(pkg.PddcError):
         pkg.Pipeline([(8, h)]).set_option("no_such_option", 1)
-
 
 def _tone_packed(ns, f_cyc_per_sample, amp=(1 << 23) - 1):
     """a full-scale complex tone as exact 24-bit integers (what the ADC side would deliver), packed"""
@@ -210,7 +216,7 @@ def test_int8_path_numeric_floor_in_dbfs(pkg, dev, O, design, fp16):
             packed = b.reshape(-1)
         ref = O.ddc_chain(packed, [(8, h)])
         pipe = pkg.Pipeline([(8, h)], taps_fp16=fp16)
-        assert pipe.on_i8(ns) == 1
+        assert pipe.on_i8(ns) == (1 if fp16 else 2)            # binary16 STORAGE is k_fir_i8's; otherwise k_fir_i8x's plain form
         y = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
         pipe.close()
         err, spur = _floor(y, ref, skip=64)

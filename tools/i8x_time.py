@@ -76,6 +76,29 @@ if __name__ == "__main__":
             ms, kind = timeit(stages, opts, ns, mix=mix, steps=20)
             print(f"{sys.argv[2]} {opts} round {rnd}: {ms:.4f} ms {ns / ms / 1e6:8.1f} GS/s kernels {kind}", flush=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "plainsizes":
+        # untuned first stages of every length: the vector kernel (k_fir8), k_fir_i8 (65..256 taps) and k_fir_i8x's plain form
+        for name, h in (("d8_32", taps("c320_s1_d8_32")), ("d8_48", lowpass(48, 0.05)), ("d8_127", taps("d8_127")), ("d8_255", taps("d8_255"))):
+            for lg in (20, 22, 24, 26, 28):
+                n = 1 << lg
+                row = []
+                for label, opts in (("vec", {"no_i8": 1}), ("i8", {"i8x_plain": 0}), ("x L0", {"i8x_plain": 1, "i8x_layout": 0}),
+                                    ("x L1", {"i8x_plain": 1, "i8x_layout": 1})):
+                    ms, kind = timeit([(8, h)], opts, n, steps=200 if lg <= 24 else 30, mix=False)
+                    row.append(f"{label}({kind[0]}) {ms * 1e3:8.1f} us")
+                print(f"{name:8s} 2^{lg}: " + " | ".join(row), flush=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "plain":
+        # verdict item 5: does carrying the history inside LDS (chunks of C > 1 tiles) pay for the untuned long stages?
+        for rnd in range(3):
+            for name in ("d8_127", "d8_255"):
+                ms, kind = timeit([(8, taps(name))], {}, ns, mix=False)
+                print(f"{name} k_fir_i8            round {rnd}: {ms:.4f} ms  kernel {kind[2]}", flush=True)
+                for lay in (0, 1):
+                    for C in (1, 2, 4):
+                        ms, kind = timeit([(8, taps(name))], {"i8x_plain": 1, "i8x_layout": lay, "i8x_chunk": C}, ns, mix=False)
+                        print(f"{name} k_fir_i8x L{lay} C={C}    round {rnd}: {ms:.4f} ms  kernel {kind[2]}", flush=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sizes":
         # where does the matrix-core path pay?  whole-step time by batch size, i8x layouts against the vector kernels
         pair = [(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05))]
