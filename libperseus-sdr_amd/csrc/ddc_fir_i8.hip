@@ -7,8 +7,8 @@
  *                   y[m] = LO(n0 + 8 m) * sum_k (h[k] e^{+j theta k}) x_raw[8 m - k],   theta = 2 pi freg / 2^32,
  *               i.e. complex taps on the raw integer planes (four real band products instead of one) and ONE float
  *               rotation per output, with the exact 32-bit phase; optionally a second decimate-by-8 stage fused behind
- *               it (the cascades' pair: the 1 B/sample intermediate never reaches HBM); blocks walk contiguous tile
- *               ranges and carry the filter history from tile to tile inside LDS.
+ *               it (the cascades' pair: the 1 B/sample intermediate never reaches HBM).  Tiles are handed round the
+ *               blocks in chunks of C (1: tile-interleaved, what streams best; the pair: 4), NOTEBOOK.md R4.2.
  *
  * Reference anchors: the samples are the 24-bit wire format of examples/perseustest.c:449-455, the tuning word is
  * perseus-sdr.c:584; the arithmetic itself has no reference source (FPGA bitstreams), DESIGN.md 3.
@@ -49,13 +49,10 @@ namespace pddc {
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 namespace i8 {
-#ifndef PDDC_I8_WIDE
-#define PDDC_I8_WIDE 1
-#endif
 /* MFMA waves + loader threads per block.  The loaders (global loads, byte de-interleave, plane writes) are the half the
  * kernel sits on, the matrix work has room: 8 + 256 (4 loader waves) 0.3608 ms, 4 + 512 0.3454 ms for 255 taps,
  * 0.3378 -> 0.3250 ms for 127 (same-box A/B, tools/ab_libs.sh). */
-constexpr int NMW = PDDC_I8_WIDE == 2 ? 2 : PDDC_I8_WIDE == 1 ? 4 : 8, NLT = PDDC_I8_WIDE == 2 ? 640 : PDDC_I8_WIDE == 1 ? 512 : 256,
+constexpr int NMW = 4, NLT = 512,
               NB = 8 / NMW;
 /* HIST = 256 (129..256 taps) or 128 (65..128 taps): history samples in front of the batch = the filter's reach */
 template <int HIST>

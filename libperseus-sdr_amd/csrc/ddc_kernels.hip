@@ -14,9 +14,10 @@
  *                (+ a fused second /8 stage, + the previous batch's last stage as extra
  *                blocks of the launch; k_fir8_many: up to eight streams, one launch;
  *                body in fir8_block.inc)
- *   k_fir_i8     the same filter for 65..256 taps without the NCO on the INT8 matrix
- *                cores: the wire bytes are the operand planes, the taps four planes of
- *                balanced base-256 digits, int32 accumulation is exact.
+ *   k_fir_i8, k_fir_i8x   the same filter on the INT8 matrix cores, with or without the NCO,
+ *                optionally with the second /8 stage fused: ddc_fir_i8.hip.  Those are what
+ *                a decimate-by-8 first stage runs on unless the pipeline's options say
+ *                otherwise; k_fir8 keeps the pair with the carried tail above 2^26 samples.
  *   k_firp       register-blocked decimators by 4, 5, 10 (packed first stages, float2 tails).
  *   k_fir_generic  any-D decimating FIR on float2 (later cascade stages).
  *   k_resample     rational L/M polyphase resampler (non-integer rates).
@@ -52,7 +53,7 @@
  *   - optional fused second decimate-by-8 stage on the tile's outputs (NTB2)
  *   No fp32 MFMA here: 9 flop/B, a banded single-filter FIR wastes a third to a half of a
  *   matrix op and fp32 MFMA has the vector unit's own peak.  The INT8 matrix cores are another
- *   matter for this data: k_fir_i8 below.
+ *   matter for this data: ddc_fir_i8.hip.
  */
 #include "ddc_kernels.h"
 #include "ddc_dev.h"
@@ -60,17 +61,11 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
-
-
-#ifndef PDDC_PRIO_U
-#define PDDC_PRIO_U 0
-#endif
-#ifndef PDDC_PRIO_F
-#define PDDC_PRIO_F 2
-#endif
-
 #include <cstring>
 #include <mutex>
+
+/* wave issue priority of k_fir8's phases: unpack 0, FIR 2 (+3 % at 255 taps, NOTEBOOK.md rounds 1-3, 5 (v)) */
+static constexpr int PDDC_PRIO_U = 0, PDDC_PRIO_F = 2;
 
 namespace pddc {
 
@@ -1061,10 +1056,7 @@ __device__ __forceinline__ void fir_window(const float *base, const float PDDC_C
  * that meet it (ub = r + NTB-1-j) held in VGPRs and shifted by one group per step.  Only one
  * tap block is live at a time (8 SGPRs + the next s_load) instead of R of them: the R=8
  * kernels otherwise keep 64 tap SGPRs live and spill (119 v_readlane per tile at 255 taps).  */
-#ifndef PDDC_TAP_OUTER_R8
-#define PDDC_TAP_OUTER_R8 1
-#endif
-static constexpr bool kTapOuterR8 = PDDC_TAP_OUTER_R8 != 0;
+static constexpr bool kTapOuterR8 = true;
 template <int NTB, int R, int PAR, bool PADDED = true>
 __device__ __forceinline__ void fir_window_tap_outer(const float *base, const float PDDC_CONSTANT *hb,
                                                      f32x2 (&acc)[R][FirAcc<NTB>::N])
