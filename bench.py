@@ -23,7 +23,7 @@ kernel's average duration measured with HIP events on the launch stream;
 `roofline.copy_ceiling_GBps` is a device-to-device copy of the same number of bytes
 measured in this run.  `placement`: input, a cascade's inter-stage workspace and the output
 are cut from one arena at the pair of 8 GiB slots where they run fastest against each other
-(different HBM extent classes; every pair's probe time is in the line).
+(different HBM extent classes; every pair's probe time is in the line; NOTEBOOK.md rounds 1-3 5 (o)-(r)).
 `verified` is a parity check of the LAST timed step's output
 against the CPU oracle on windows placed at the tile scheduler's seams (outside the
 timed region).  `cpu_baseline` times the oracle's float path (oracle/perseus_oracle.c
@@ -523,7 +523,7 @@ def run_rank(a):
                 for o in range(nslot):
                     probe(i, o)
         else:
-            # The rule read off those maps (some twenty leases, profiles/r0[23]/*placement*): with the
+            # The rule read off those maps (some twenty leases, profiles/r0[23]/*placement*, NOTEBOOK.md rounds 1-3 5 (u)): with the
             # input at the START of one allocation, the extent class it lies in reaches 32, 48 or 64 GiB up; the slot
             # right behind the input is nearly always in it ("first come"), and +32, +48 or +64 GiB nearly always in another one.
             # So: four probes.  Only if none of them gains (a workload that does not care, or a layout not seen yet)
@@ -841,7 +841,7 @@ def gather_leg(a, pkg, grp, dev, stream, ns, d_in, pipe, out_shape_rows, decim, 
         grp.comm.gather_async(o.data_ptr(), nbytes, rptr, 0, stream)
 
     # untimed: both buffers once, then enough back-to-back steps for sustained clocks (the legs before this one end in
-    # verification and host work; the first dozen launches after an idle spell run up to 40 % slow, DESIGN.md 5 DVFS)
+    # verification and host work; the first dozen launches after an idle spell run up to 40 % slow, NOTEBOOK.md rounds 1-3 5 DVFS)
     for k in range(200 + a.warmup):         # the same count on every rank: each step is a collective
         gstep(k)
     grp.comm.gather_wait()

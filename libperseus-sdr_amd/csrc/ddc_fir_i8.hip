@@ -27,7 +27,7 @@ namespace pddc {
 /* ======================================================================== */
 /* k_fir_i8 : 129..256 taps, decimate by 8, packed input, no NCO -- int8 MFMA */
 /* ======================================================================== */
-/* The 255-tap first stage is the one configuration that is bound by vector issue, not by HBM: 17 G
+/* The 255-tap first stage is the one configuration that is bound by vector issue, not by HBM (NOTEBOOK.md rounds 1-3 5 (v)): 17 G
  * multiply-adds per 2^28 samples on a power-capped clock.  fp32 MFMA has the vector unit's own peak; int8 MFMA has
  * thirty times that, and this data fits it exactly: a 24-bit sample is three bytes, a tap quantised to 2^-E (E = 30 -
  * ceil(log2 max|h|), i.e. 31 significant bits on the largest tap) is four balanced base-256 digits, every digit x

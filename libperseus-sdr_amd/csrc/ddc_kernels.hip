@@ -25,7 +25,7 @@
  *   k_hist_update  carries the FIR history between batches (generic path).
  *   k_synth_lcg    device-side synthetic source.
  *
- * k_fir8 design (DESIGN.md "Kernels"):
+ * k_fir8 design (NOTEBOOK.md rounds 1-3 section 4):
  *   - persistent grid (2 blocks per CU); a block = 256 threads = 4 waves; tile = 1024*R
  *     input samples; two-level schedule: a static run of tiles per block, then
  *     dynamic chunks from an atomic counter (the two blocks of a CU run unevenly)
@@ -1119,7 +1119,7 @@ __device__ __forceinline__ void fir_window_tap_outer(const float *base, const fl
  *                 the very threads that overwrite them in the next U, so no
  *                 third barrier is needed).                                */
 /* (The ablation builds -- loads / FIR / stores removed --, the in-kernel clock probe and the 128-thread variant that the
- * measurements in DESIGN.md 5 come from are not in this file: tools/ubench/fir8_probe_and_ablations.patch.)          */
+ * measurements in NOTEBOOK.md rounds 1-3 5 come from are not in this file: tools/ubench/fir8_probe_and_ablations.patch.)          */
 /* NT = threads per block.  256 (4 waves: two per plane) is the default; 128 (R = 8 only: one wave per
  * plane, half the tile, half the LDS) lets four independent blocks share a CU instead of two.       */
 /* SL3 > 0 (FUSE3): a third stage (plain decimate-by-d3 FIR, struct Fir8Stage3) runs on the second stage's outputs in LDS

@@ -764,7 +764,7 @@ int pddc_arena_place(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_
     hipError_t e = hipSuccess;
     int n = 0;
     /* The probes compare times a few per cent apart, so they must all see the same clocks: after idle the chip boosts
-     * for a few launches and then undershoots for some tens of milliseconds (DVFS) -- a first-come slot
+     * for a few launches and then undershoots for some tens of milliseconds (NOTEBOOK.md rounds 1-3 5, DVFS) -- a first-come slot
      * timed during the boost and the others after it once ranked a slow slot first.  So: ~40 ms of untimed launches
      * up front, and every probe queued back to back with no host wait inside (6 untimed, 12 timed).          */
     for (int r = 0; r < 100 && e == hipSuccess; ++r)
@@ -1603,7 +1603,7 @@ extern "C" int pddc_pipeline_check(pddc_pipeline *p, void *stream)
 }
 
 /* the stage's input buffer, grown when a batch is larger than any seen before (synchronising).  Plain allocations: WHERE
- * a buffer lies in HBM matters to the kernel that writes it, but a search for a good place is the
+ * a buffer lies in HBM matters to the kernel that writes it (NOTEBOOK.md rounds 1-3 5 (o)-(r)), but a search for a good place is the
  * host's decision and never happens inside process(): pddc_pipeline_place_buffers, or pddc_pipeline_set_workspace.  */
 static int ensure_buf(Stage &s, size_t need, const void * = nullptr, size_t = 0)
 {

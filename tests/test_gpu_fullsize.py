@@ -186,7 +186,7 @@ def test_the_placement_rule_finds_a_fast_pair_in_a_handful_of_probes(pkg, O, dev
             os.environ["PDDC_NO_I8"] = "1"
         try:
             pipe = pkg.Pipeline(wl["stages"])
-            assert pipe.on_i8(NS) == (not vector)
+            assert bool(pipe.on_i8(NS)) == (not vector)
             rows = pipe.max_output(NS) + 8
             o_sl, fc, best, npr = C.c_size_t(), C.c_float(), C.c_float(), C.c_int()
             if vector:

@@ -164,8 +164,27 @@ def test_checkpoint_resume_and_set_taps_on_the_matrix_core_path(pkg, dev, O):
     b.close()
 
 
+def test_plain_form_agrees_with_k_fir_i8(pkg, dev, O):
+    """Two independent kernels, one arithmetic: the untuned form of k_fir_i8x (the default) and round 3's k_fir_i8 (option
+    i8x_plain = 0) build their operand tables with the same quantisation and accumulate the same exact integers; only
+    the order of the last float additions may differ.  Asserted: they agree to 3e-8 of full scale (a quarter ulp of the
+    fp32 recombination), far inside what either is allowed against the oracle."""
+    for name in ("d8_127", "d8_255"):
+        h = load_taps(name)
+        n = TILE * 40 + 264
+        packed = O.lcg_bytes(6 * n, 11)
+        rec = []
+        y_new = run(pkg, dev, [(8, h)], packed, [0, n], mix=False, opts={"i8x_plain": 1}, record=rec)
+        y_old = run(pkg, dev, [(8, h)], packed, [0, n], mix=False, opts={"i8x_plain": 0}, record=rec)
+        assert [int(k) for k, _ in rec] == [2, 1]
+        ref = O.ddc_chain(packed, [(8, h)])
+        scale = np.abs(ref).max()
+        assert np.abs(y_new - y_old).max() <= 3e-8 * scale, np.abs(y_new - y_old).max() / scale
+        assert O.rel_err(y_new, ref) <= 2e-7 and O.rel_err(y_old, ref) <= 2e-7
+
+
 def test_untuned_first_stage_on_the_same_kernel(pkg, dev, O):
-    """option i8x_plain: the no-NCO form (contiguous tile ranges, history carried in LDS) gives k_fir_i8's results"""
+    """the no-NCO form of k_fir_i8x against the oracle, ragged batches, 48 / 127 / 255 taps"""
     for ntaps in (127, 255, 48):
         h = load_taps("d8_255") if ntaps == 255 else load_taps("d8_127") if ntaps == 127 else lowpass(ntaps, 0.05)
         sizes = [TILE * 3 + 8, TILE * 290, 264, TILE * 2]

@@ -1,4 +1,4 @@
-# PCIe-inclusive rate of the host-buffer path (never the bench's `value`):
+# PCIe-inclusive rate of the host-buffer path (never the bench's `value`; NOTEBOOK.md rounds 1-3 5):
 # synchronous push_host from pageable memory vs push_host_async, pinned, two batches in flight.
 import sys, os, importlib, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Does a kernel's speed depend on WHERE its buffers lie in HBM?  (It does: DESIGN.md 5(u), profiles/r02/i_placement_*.txt,
+"""Does a kernel's speed depend on WHERE its buffers lie in HBM?  (It does: NOTEBOOK.md rounds 1-3 5(u), profiles/r02/i_placement_*.txt,
 profiles/r03/f_placement_rule.txt.)  One script for the experiments that led to the placement rule; every mode times the
 real pipeline (2^28 samples a launch, HIP events, untimed launches first) on explicit (input, output) addresses.
 

@@ -23,6 +23,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rates", default="")
 ap.add_argument("--no-fast", action="store_true")
 ap.add_argument("--overlap", action="store_true", help="pddc_pipeline_set_overlap: the last stage rides along with the next batch's launch")
+ap.add_argument("--opt", action="append", default=[], help="pipeline option name=value (pddc_pipeline_set_option), repeatable")
 a = ap.parse_args()
 
 L = pkg.sdr_lib()
@@ -50,6 +51,9 @@ for rate in want:
     stages = [(dec[i], taps[i], it[i]) for i in range(n)]
     pipe = pkg.Pipeline(stages, mix=True, no_fast=a.no_fast)
     pipe.set_freg(381178347)
+    for o in a.opt:
+        k, v = o.split("=")
+        pipe.set_option(k, int(v))
     if a.overlap:
         pipe.set_overlap(True)
     out = torch.empty((pipe.max_output(ns) + 8, 2), dtype=torch.float32, device=dev)
@@ -65,7 +69,7 @@ for rate in want:
     r = {"rate": rate, "plan": "*".join(f"{dec[i]}" + (f"(x{it[i]})" if it[i] > 1 else "") for i in range(n)),
          "ntaps": [nt[i] for i in range(n)], "ms_per_2^%d" % a.log2n: round(ms, 4), "GS_per_s": round(ns / ms / 1e6, 1),
          "stage0_reads_packed": pipe.stage0_reads_packed, "fused8": pipe.fused, "fused_pair": pipe.fused_pair(ns),
-         "overlap": a.overlap}
+         "on_i8": pipe.on_i8(ns), "overlap": a.overlap, "opts": a.opt}
     res.append(r)
     print(json.dumps(r), flush=True)
     pipe.close()

@@ -15,6 +15,9 @@ python tools/plan_rates.py --log2n 28 --overlap > $OUT/plan_rates_overlap.txt 2>
 python tools/plan_rates.py --log2n 22 > $OUT/plan_rates_2p22.txt 2>&1
 python tools/i8x_time.py sizes > $OUT/i8x_sizes.txt 2>&1
 python tools/i8x_time.py layouts > $OUT/i8x_layouts.txt 2>&1
+python tools/i8x_time.py chunks > $OUT/i8x_chunks.txt 2>&1
+python tools/i8x_time.py plain > $OUT/i8x_plain.txt 2>&1
+python tools/i8x_time.py plainsizes > $OUT/i8x_plainsizes.txt 2>&1
 bash tools/pmc_i8x.sh $OUT/pmc_i8x_pair "c320api i8x_pair_max_log2=28" > /dev/null 2>&1
 bash tools/pmc_i8x.sh $OUT/pmc_i8x_127nco d8_127+nco > /dev/null 2>&1
 bash tools/pmc_i8x.sh $OUT/pmc_i8x_48nco d8_48+nco > /dev/null 2>&1

@@ -1,4 +1,4 @@
-// Prototype / feasibility measurement: the long first-stage FIR (255 taps, decimate by 8, no NCO) on the
+// Prototype / feasibility measurement (NOTEBOOK.md rounds 1-3 5 (v)): the long first-stage FIR (255 taps, decimate by 8, no NCO) on the
 // INT8 matrix cores.  A 24-bit sample IS three int8 planes -- the wire bytes themselves (I0 I1 I2 Q0 Q1 Q2) -- and taps
 // quantised to 32-bit integers are four balanced base-256 digits; v_mfma_i32_32x32x32_i8 forms the byte-plane products
 // EXACTLY in int32, the planes are recombined once per output.  The only error is the tap quantisation (2^-31 of the

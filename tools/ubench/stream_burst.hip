@@ -80,7 +80,7 @@ int main()
     uint4 *in, *out;
     CHECK(hipMalloc(&in, ns * 6));
     // SPACER_GIB=n: n GiB of other allocations between the input and the output, so that the two land in
-    // different HBM extent classes; the default, 0, is the first-come placement
+    // different HBM extent classes (NOTEBOOK.md rounds 1-3 5 (o)); the default, 0, is the first-come placement
     if (const char *e = getenv("SPACER_GIB")) {
         for (int k = 0; k < atoi(e); k += 8) {
             void *sp;

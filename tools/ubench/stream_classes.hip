@@ -1,4 +1,4 @@
-// Which pairs of streams feel the HBM "extent classes" ?  One 160 GiB arena, 8 GiB slots; stream A
+// Which pairs of streams feel the HBM "extent classes" (NOTEBOOK.md rounds 1-3 5 (o)-(r))?  One 160 GiB arena, 8 GiB slots; stream A
 // in slot 0, stream B in every slot; three kernels over 1 GiB per stream: read A + write B (the DDC's case), read A +
 // read B, write A + write B.  Prints ms per launch for every slot of B.
 #include <hip/hip_runtime.h>
