@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64 * i8::NMW + i8::NLT, 1) void k_fir_i8(FirI8Args 
         for (int o = tid; o < 1024; o += 64 * NMW) {
             const int q = 20 * (o >> 4) + (o & 15);
             if (o < left)
-                dst[o] = make_float2(osum[q], osum[OS + q]);
+                __builtin_nontemporal_store(f32x2{ osum[q], osum[OS + q] }, reinterpret_cast<f32x2 *>(dst + o));
         }
     }
 }
@@ -509,7 +509,9 @@ __device__ __forceinline__ void put_planes(const uint4 (&r)[3], uint8_t *plane, 
 #undef PDDC_PL
 }
 
-/* the loads of group g = lt + 512 q (q = 0, 1) of tile t: batch samples 8192 t + 8 g .. + 8, zeros behind the batch */
+/* the loads of group g = lt + 512 q (q = 0, 1) of tile t: batch samples 8192 t + 8 g .. + 8, zeros behind the batch.
+ * (Plain loads: a lane's three 16-byte loads share their cache lines with its neighbours' -- as NONTEMPORAL loads the lines
+ * are fetched again and again: 0.3205 -> 0.4293 ms for the untuned 127-tap stage, same box, tools/ab_i8x.sh.)          */
 __device__ __forceinline__ void issue_group(const FirI8xArgs &a, long long t, int g, uint4 (&r)[3])
 {
     const long long b = t * TILE + 8LL * g;
@@ -541,11 +543,14 @@ __device__ __forceinline__ void issue_front(const FirI8xArgs &a, long long t, in
  * instruction overwrites one of the store's data registers, the last quarter of the wave (lanes 48..63) now and then stores
  * the new value of that register -- once per few thousand tiles with post waves beside two matrix waves, never seen without
  * a matrix wave beside the storing one.  hipcc pads only stores of more than 64 bits; the pad has to sit inside the statement,
- * or the scheduler moves vector instructions in front of it.                                                           */
+ * or the scheduler moves vector instructions in front of it.
+ * All result stores of this file are NONTEMPORAL: the outputs are written once and read by another kernel much later, and
+ * keeping them out of the L2's way is worth 5.7 % on the untuned 127-tap stage (same box, two rounds: 0.3383 / 0.3359 ->
+ * 0.3191 / 0.3166 ms), 2 % on the tuned 48-tap one, nothing where the matrix work bounds (tools/ab_i8x.sh).           */
 __device__ __forceinline__ void store_f2_padded(float2 *p, float x, float y)
 {
     const f32x2 v = { x, y };
-    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 /* y = sum_s acc[s] 256^(s+2) as floats */
@@ -611,9 +616,10 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
         v = y;
     };
     auto put_f2 = [&](float2 *p, float x, float y) __attribute__((always_inline)) {
-        if (LAYOUT == 0)
-            *p = make_float2(x, y);
-        else
+        if (LAYOUT == 0) {
+            const f32x2 v = { x, y };
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x2 *>(p));
+        } else
             store_f2_padded(p, x, y);
     };
     auto post_store = [&](long long t, const float *arr, int pt, auto guard_c) __attribute__((always_inline)) {
@@ -760,7 +766,7 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
             z = comp ? __builtin_fmaf(zi, c, zr * s) : __builtin_fmaf(-zi, s, zr * c);
         }
         float *dst = a.out + 2 * (t * 128 + p) + comp;
-        asm volatile("global_store_dword %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(z) : "memory");
+        asm volatile("global_store_dword %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(z) : "memory");
     };
     auto post_porch = [&](long long t, const float *arr, float *other, int c, bool chain, auto guard_c) __attribute__((always_inline)) {
         constexpr bool GUARD = decltype(guard_c)::value;

@@ -1427,6 +1427,10 @@ static int stage0_i8_kind(const pddc_pipeline *p, size_t nsamples)
     const int k = stage0_i8_kind_raw(p, nsamples);
     if (k == 2 && p->nstages >= 2 && !i8x_pair_ok(p, nsamples) && stages01_fusable(p, nsamples))
         return 0;
+    /* (Measured and not added: in overlap mode a two-stage plan's tail -- the /5 of 2 MS/s, the /10 of 1 MS/s -- could ride
+     * in k_fir8's launch, which k_fir_i8x, one block of twelve waves per CU, cannot offer.  2^28 samples, same process,
+     * each twice: 8 * 5 vector + carried tail 0.405 / 0.457 ms, k_fir_i8x + tail in line 0.425 / 0.408; 8 * 10 0.452 / 0.407
+     * against 0.4255 / 0.4259: no winner, and the matrix-core path is the steadier one.  tools/plan_rates.py --overlap) */
     return k;
 }
 
