@@ -21,6 +21,7 @@ python tools/i8x_time.py plainsizes > $OUT/i8x_plainsizes.txt 2>&1
 bash tools/pmc_i8x.sh $OUT/pmc_i8x_pair "c320api i8x_pair_max_log2=28" > /dev/null 2>&1
 bash tools/pmc_i8x.sh $OUT/pmc_i8x_127nco d8_127+nco > /dev/null 2>&1
 bash tools/pmc_i8x.sh $OUT/pmc_i8x_48nco d8_48+nco > /dev/null 2>&1
+bash tools/pmc_i8x.sh $OUT/pmc_i8x_plain127 d8_127 > /dev/null 2>&1
 PDDC_BENCH_GATHER_C320=1 python bench.py --no-cpu --gather --steps 20 --warmup 5 > $OUT/bench_gather_1rank.json 2>/dev/null
 bash tools/api_receivers.sh > $OUT/api_receivers.txt 2>&1
 bash tools/bench_repeat.sh 4 > $OUT/bench_repeat_d8_127.txt 2>&1
