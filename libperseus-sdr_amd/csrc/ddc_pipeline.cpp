@@ -2576,10 +2576,16 @@ static float *direct_out(pddc_pipeline::HostSlot &sl, void *h_out)
         sl.h_out_dev = nullptr;
         hipPointerAttribute_t at;
         if (!tunables().gang_copy_out.load() && hipPointerGetAttributes(&at, h_out) == hipSuccess &&
-            at.type == hipMemoryTypeHost && at.devicePointer && ((uintptr_t)at.devicePointer & 15) == 0)
-            sl.h_out_dev = static_cast<float *>(at.devicePointer);
-        else
+            at.type == hipMemoryTypeHost && at.devicePointer && at.hostPointer) {
+            /* (h_out may point INTO a pinned allocation -- perseus_api.c hands out places inside one output buffer --: the
+             * device's view of it is the allocation's plus the same offset, whichever of the two the runtime reports) */
+            uint8_t *dv = static_cast<uint8_t *>(at.devicePointer) +
+                          (static_cast<uint8_t *>(h_out) - static_cast<uint8_t *>(at.hostPointer));
+            if (((uintptr_t)dv & 15) == 0)
+                sl.h_out_dev = reinterpret_cast<float *>(dv);
+        } else {
             (void)hipGetLastError();
+        }
     }
     return sl.h_out_dev;
 }

@@ -86,11 +86,14 @@ typedef struct {
 #define MAX_FAULTS 32
 #define MAX_RETUNES 256
 
+/* one batch's output inside the receiver's pinned output buffer (`fifo`): reserved when the batch is submitted -- the GPU
+ * writes it there itself --, ready once its ticket has been waited for, consumed from the front by the callbacks */
 typedef struct {
     int ticket;                 /* pddc staging slot                             */
-    int k;                      /* batch buffer pair                             */
-    size_t nout;
-} pending_batch;
+    size_t off, len;            /* bytes not yet delivered: fifo[off .. off+len) */
+} out_seg;
+#define MAX_SEG 8
+#define SEG_ALIGN 256u
 
 struct perseus_descr_ds {
     int index;
@@ -136,13 +139,13 @@ struct perseus_descr_ds {
     /* DDC mode */
     ddc_plan plan;
     pddc_pipeline *pipe;
-    /* two pinned batch buffers each way: while the GPU works on one batch (H2D, kernels,
-     * D2H on three streams) the source fills the next (pddc_pipeline_push_host_async)  */
+    /* two pinned input batch buffers: while the GPU works on one batch (H2D, kernels, D2H
+     * on three streams) the source fills the next (pddc_pipeline_push_host_async)       */
     uint8_t *batch_in[2];       /* batch_samples * 6                             */
-    float *batch_out[2];        /* pipeline output of one batch                  */
-    size_t out_cap;             /* in complex samples                            */
-    int cur;                    /* buffer pair the next batch goes into          */
-    pending_batch pend[2];      /* batches in flight, oldest first               */
+    size_t out_cap;             /* a batch's output at most, in complex samples  */
+    int cur;                    /* input buffer the next batch goes into         */
+    out_seg seg[MAX_SEG];       /* outputs in `fifo`, oldest first from seg_head; the last n_pend still on the GPU */
+    int seg_head, seg_n;
     int n_pend;
     int input_done;             /* the source has nothing more to give           */
     int gpu_source;             /* the LCG stream is generated on the device     */
@@ -150,8 +153,13 @@ struct perseus_descr_ds {
                                    picks it for the kind of source when the stream starts (effective_batch)             */
     uint64_t ganged_batches;    /* batches that shared their launches with other receivers of the GPU */
     int gpu_dev;                /* HIP device of the current / last stream, -1: none */
-    uint8_t *fifo;              /* ring of decimated bytes awaiting callbacks    */
-    size_t fifo_rd, fifo_len, fifo_cap;
+    /* The decimated output never moves on the host: `fifo` is ONE pinned buffer, every batch reserves its place in it
+     * when it is submitted (the last kernel or the D2H copy writes there), and a callback gets a pointer INTO it
+     * wherever its buffer's worth of bytes lies in one piece; only a buffer that straddles two batches (or the wrap) is
+     * gathered into the transfer's ring slot first.  (Until round 4 every byte was copied twice, batch buffer -> byte
+     * ring -> ring slot: 5-6 GB/s of payload on the one delivery thread, which bounded the unpaced stream.) */
+    uint8_t *fifo;
+    size_t fifo_len, fifo_cap;  /* ready bytes not yet delivered; size           */
     uint64_t adc_samples;       /* ADC-rate samples handed to the GPU so far     */
     uint64_t batches;
     uint32_t freg_applied;      /* word the last submitted batch was mixed with  */
@@ -422,7 +430,7 @@ static int fault_for(const perseus_descr *d, uint64_t n)     /* n = 1-based tran
 
 /* ---- the dispatcher: what the reference does with one completed transfer
  * (perseus-in.c:187-264), status by status -------------------------------------- */
-static void dispatch(perseus_descr *d, int idx, int status, uint32_t actual)
+static void dispatch(perseus_descr *d, int idx, int status, uint32_t actual, const uint8_t *data)
 {
     if (d->cancelling)
         return;
@@ -433,7 +441,10 @@ static void dispatch(perseus_descr *d, int idx, int status, uint32_t actual)
             if (actual == d->buffersize) {
                 perseus_input_callback cb = d->cb;
                 if (cb) {
-                    cb(d->ring + (size_t)idx * d->buffersize, (int)d->buffersize, d->cb_extra);
+                    /* `data`: the transfer's payload -- its ring slot, or (DDC modes) the bytes where the GPU put them.
+                     * Like the reference's buffers it is the library's and valid until the callback returns
+                     * (perseus-in.c:206-207 resubmits the transfer right after it). */
+                    cb((void *)(data ? data : d->ring + (size_t)idx * d->buffersize), (int)d->buffersize, d->cb_extra);
                     d->delivered++;
                 }
             } else {
@@ -484,7 +495,7 @@ static int next_live_slot(perseus_descr *d)
  * decimated FIFO) and returns the bytes it had; `avail` says how many whole buffers `fill`
  * can still provide without blocking (an out-of-sequence pair needs two).
  * Returns 0 when nothing could be done (no payload, queue dead).                          */
-typedef size_t (*fill_fn)(perseus_descr *d, uint8_t *slot);
+typedef const uint8_t *(*fill_fn)(perseus_descr *d, uint8_t *slot, size_t *got);
 
 static int turn(perseus_descr *d, fill_fn fill, size_t avail)
 {
@@ -502,7 +513,7 @@ static int turn(perseus_descr *d, fill_fn fill, size_t avail)
         /* nothing arrived: no payload is consumed */
         const int sidx = next_live_slot(d);
         d->seq++;
-        dispatch(d, sidx, fault == FAULT_TIMEOUT ? XFER_TIMED_OUT : XFER_ERROR + (fault - FAULT_ERROR), 0);
+        dispatch(d, sidx, fault == FAULT_TIMEOUT ? XFER_TIMED_OUT : XFER_ERROR + (fault - FAULT_ERROR), 0, NULL);
         return 1;
     }
     if (avail == 0)
@@ -513,15 +524,17 @@ static int turn(perseus_descr *d, fill_fn fill, size_t avail)
         if (avail < 2)
             return 0;                                 /* wait until two buffers of payload exist */
         const int a = next_live_slot(d), b = next_live_slot(d);
-        const size_t ga = fill(d, d->ring + (size_t)a * d->buffersize);
-        const size_t gb = fill(d, d->ring + (size_t)b * d->buffersize);
+        size_t ga = 0, gb = 0;
+        const uint8_t *pa = fill(d, d->ring + (size_t)a * d->buffersize, &ga);
+        const uint8_t *pb = fill(d, d->ring + (size_t)b * d->buffersize, &gb);
         d->seq += 2;
-        dispatch(d, b, XFER_COMPLETED, (uint32_t)gb);
-        dispatch(d, a, XFER_COMPLETED, (uint32_t)ga);
+        dispatch(d, b, XFER_COMPLETED, (uint32_t)gb, pb);
+        dispatch(d, a, XFER_COMPLETED, (uint32_t)ga, pa);
         return 1;
     }
     const int sidx = next_live_slot(d);
-    size_t got = fill(d, d->ring + (size_t)sidx * d->buffersize);
+    size_t got = 0;
+    const uint8_t *data = fill(d, d->ring + (size_t)sidx * d->buffersize, &got);
     d->seq++;
     if (got == 0) {                                   /* the source had nothing at all */
         d->source_done = 1;
@@ -529,17 +542,17 @@ static int turn(perseus_descr *d, fill_fn fill, size_t avail)
     }
     if (fault == FAULT_SHORT && got == d->buffersize)
         got = d->buffersize / 2;                      /* the payload was consumed, half of it "arrived" */
-    dispatch(d, sidx, XFER_COMPLETED, (uint32_t)got);
+    dispatch(d, sidx, XFER_COMPLETED, (uint32_t)got, data);
     return 1;
 }
 
 /* ---- wire mode: the source plays the receiver ----------------------------------------- */
-static size_t fill_wire(perseus_descr *d, uint8_t *slot)
+static const uint8_t *fill_wire(perseus_descr *d, uint8_t *slot, size_t *got)
 {
-    const size_t got = source_fill(d, slot, d->buffersize);
-    if (got < d->buffersize)
+    *got = source_fill(d, slot, d->buffersize);
+    if (*got < d->buffersize)
         d->input_done = 1;                            /* bounded source (file) ended */
-    return got;
+    return slot;
 }
 
 static int pump_wire(perseus_descr *d)
@@ -553,28 +566,83 @@ static int pump_wire(perseus_descr *d)
 }
 
 /* ---- DDC mode: ADC-rate batches -> GPU -> FIFO of decimated bytes -> transfers ---------- */
-static size_t fifo_room(const perseus_descr *d) { return d->fifo_cap - d->fifo_len; }
+static size_t seg_align(size_t x) { return (x + SEG_ALIGN - 1) & ~(size_t)(SEG_ALIGN - 1); }
 
-static void fifo_put(perseus_descr *d, const uint8_t *src, size_t n)
+/* where the next batch's output (at most `worst` bytes, in one piece) can go: behind the newest segment, or -- when the
+ * buffer's end is too near -- at its start, below the oldest one.  0: no room until the callbacks have consumed more. */
+static int fifo_reserve(const perseus_descr *d, size_t worst, size_t *off)
 {
-    size_t wr = (d->fifo_rd + d->fifo_len) % d->fifo_cap;
-    const size_t first = n < d->fifo_cap - wr ? n : d->fifo_cap - wr;
-    memcpy(d->fifo + wr, src, first);
-    memcpy(d->fifo, src + first, n - first);
-    d->fifo_len += n;
+    size_t at = 0;
+    if (d->seg_n == MAX_SEG)
+        return 0;
+    if (d->seg_n > 0) {
+        const out_seg *h = &d->seg[d->seg_head], *l = &d->seg[(d->seg_head + d->seg_n - 1) % MAX_SEG];
+        const size_t start = h->off, wr = seg_align(l->off + l->len);
+        if (l->off < h->off) {                        /* the newest already lies below the oldest */
+            if (wr > start || start - wr < worst)
+                return 0;
+            at = wr;
+        } else if (wr <= d->fifo_cap && d->fifo_cap - wr >= worst) {
+            at = wr;
+        } else if (start >= worst) {
+            at = 0;
+        } else {
+            return 0;
+        }
+    } else if (worst > d->fifo_cap) {
+        return 0;
+    }
+    if (off)
+        *off = at;
+    return 1;
 }
 
-static size_t fill_fifo(perseus_descr *d, uint8_t *slot)
+static void seg_push(perseus_descr *d, int ticket, size_t off, size_t len)
+{
+    d->seg[(d->seg_head + d->seg_n) % MAX_SEG] = (out_seg){ ticket, off, len };
+    d->seg_n++;
+    d->n_pend++;
+}
+
+/* drop the oldest segments that are ready and empty */
+static void seg_trim(perseus_descr *d)
+{
+    while (d->seg_n > d->n_pend && d->seg[d->seg_head].len == 0) {
+        d->seg_head = (d->seg_head + 1) % MAX_SEG;
+        d->seg_n--;
+    }
+}
+
+/* the next buffersize ready bytes: where they lie, or gathered into `slot` when they are in two pieces */
+static const uint8_t *fill_fifo(perseus_descr *d, uint8_t *slot, size_t *got)
 {
     const size_t n = d->buffersize;
+    *got = 0;
     if (d->fifo_len < n)
-        return 0;
-    const size_t first = n < d->fifo_cap - d->fifo_rd ? n : d->fifo_cap - d->fifo_rd;
-    memcpy(slot, d->fifo + d->fifo_rd, first);
-    memcpy(slot + first, d->fifo, n - first);
-    d->fifo_rd = (d->fifo_rd + n) % d->fifo_cap;
+        return slot;
+    seg_trim(d);
+    out_seg *h = &d->seg[d->seg_head];
+    const uint8_t *p = slot;
+    if (h->len >= n) {
+        p = d->fifo + h->off;
+        h->off += n;
+        h->len -= n;
+    } else {
+        size_t have = 0;
+        while (have < n) {                            /* (fifo_len >= n: only ready segments are touched) */
+            h = &d->seg[d->seg_head];
+            const size_t t = h->len < n - have ? h->len : n - have;
+            memcpy(slot + have, d->fifo + h->off, t);
+            h->off += t;
+            h->len -= t;
+            have += t;
+            seg_trim(d);
+        }
+    }
+    seg_trim(d);
     d->fifo_len -= n;
-    return n;
+    *got = n;
+    return p;
 }
 
 static size_t out_bytes_per_sample(const perseus_descr *d)
@@ -615,7 +683,7 @@ static size_t batch_prepare(perseus_descr *d)
     return ns;
 }
 
-static void batch_pushed(perseus_descr *d, int rc, size_t ns, size_t n_out, int ticket)
+static void batch_pushed(perseus_descr *d, int rc, size_t ns, size_t n_out, int ticket, size_t off)
 {
     if (rc != PDDC_OK) {
         dbgprintf(0, "GPU pipeline failed (%d: %s); stream stopped", rc, pddc_last_error());
@@ -624,7 +692,7 @@ static void batch_pushed(perseus_descr *d, int rc, size_t ns, size_t n_out, int 
     }
     d->adc_samples += ns;
     d->batches++;
-    d->pend[d->n_pend++] = (pending_batch){ ticket, d->cur, n_out };
+    seg_push(d, ticket, off, n_out * out_bytes_per_sample(d));
     d->cur ^= 1;
 }
 
@@ -635,15 +703,17 @@ static void submit_batch(perseus_descr *d)
     const size_t ns = batch_prepare(d);
     if (ns == 0)
         return;
-    size_t n_out = 0;
+    size_t n_out = 0, off = 0;
     int ticket = -1;
     int rc;
+    if (!fifo_reserve(d, d->out_cap * out_bytes_per_sample(d), &off))
+        return;                                  /* (can_submit said there was room) */
     if (d->gpu_source)
-        rc = pddc_pipeline_push_synth_async(d->pipe, d->cfg.lcg_seed, d->adc_samples * 6, ns, d->batch_out[k],
+        rc = pddc_pipeline_push_synth_async(d->pipe, d->cfg.lcg_seed, d->adc_samples * 6, ns, d->fifo + off,
                                             d->out_cap, &n_out, &ticket);
     else
-        rc = pddc_pipeline_push_host_async(d->pipe, d->batch_in[k], ns, d->batch_out[k], d->out_cap, &n_out, &ticket);
-    batch_pushed(d, rc, ns, n_out, ticket);
+        rc = pddc_pipeline_push_host_async(d->pipe, d->batch_in[k], ns, d->fifo + off, d->out_cap, &n_out, &ticket);
+    batch_pushed(d, rc, ns, n_out, ticket, off);
 }
 
 /* pass 1: keep the GPU fed.  A free-running source has two batches in flight (source, PCIe and
@@ -652,7 +722,7 @@ static int can_submit(const perseus_descr *d)
 {
     const int depth = d->cfg.pace ? 1 : 2;
     const size_t worst = d->out_cap * out_bytes_per_sample(d);
-    return d->n_pend < depth && !d->input_done && !d->source_done && fifo_room(d) >= worst * (size_t)(d->n_pend + 1) &&
+    return d->n_pend < depth && !d->input_done && !d->source_done && fifo_reserve(d, worst, NULL) &&
            !(d->cfg.max_buffers && d->seq >= d->cfg.max_buffers);
 }
 
@@ -674,8 +744,7 @@ static int ddc_collect(perseus_descr *d)
 {
     if (d->n_pend == 0)
         return 0;
-    const pending_batch b = d->pend[0];
-    d->pend[0] = d->pend[1];
+    const out_seg b = d->seg[(d->seg_head + d->seg_n - d->n_pend) % MAX_SEG];      /* the oldest still on the GPU */
     d->n_pend--;
     if (pddc_pipeline_wait_ticket(d->pipe, b.ticket) != PDDC_OK) {
         dbgprintf(0, "GPU pipeline failed (%s); stream stopped", pddc_last_error());
@@ -683,7 +752,7 @@ static int ddc_collect(perseus_descr *d)
         d->source_done = 1;
         return 0;
     }
-    fifo_put(d, (const uint8_t *)d->batch_out[b.k], b.nout * out_bytes_per_sample(d));
+    d->fifo_len += b.len;                        /* its bytes are where they will be delivered from */
     return 1;
 }
 
@@ -817,6 +886,7 @@ static void gang_submit(int dev, const int *sub, int m, int *busy, int *inflight
         pddc_gang_item it[MAX_DESCR];
         int ni = 0;
         perseus_descr *in[MAX_DESCR];
+        size_t off[MAX_DESCR];
         for (int k = 0; k < nm; k++) {
             perseus_descr *d = mem[k];
             if (batch_prepare(d) != ns)
@@ -825,7 +895,9 @@ static void gang_submit(int dev, const int *sub, int m, int *busy, int *inflight
             it[ni].pipe = d->pipe;
             it[ni].seed = d->cfg.lcg_seed;
             it[ni].byte_offset = d->adc_samples * 6;
-            it[ni].h_out = d->batch_out[d->cur];
+            if (!fifo_reserve(d, d->out_cap * out_bytes_per_sample(d), &off[ni]))
+                continue;                                      /* (can_submit said there was room) */
+            it[ni].h_out = d->fifo + off[ni];
             it[ni].out_capacity = d->out_cap;
             in[ni++] = d;
         }
@@ -834,7 +906,7 @@ static void gang_submit(int dev, const int *sub, int m, int *busy, int *inflight
         int shared = 0;
         const int rc = pddc_gang_push_async(g_gang[dev], it, ni, ns, &shared);
         for (int k = 0; k < ni; k++) {
-            batch_pushed(in[k], rc, ns, it[k].n_out, it[k].ticket);
+            batch_pushed(in[k], rc, ns, it[k].n_out, it[k].ticket, off[k]);
             if (rc == PDDC_OK && shared > 1)
                 in[k]->ganged_batches++;
         }
@@ -1355,13 +1427,11 @@ static void free_stream(perseus_descr *d)
     for (int k = 0; k < 2; k++) {
         pddc_host_free(d->batch_in[k]);
         d->batch_in[k] = NULL;
-        pddc_host_free(d->batch_out[k]);
-        d->batch_out[k] = NULL;
     }
-    free(d->fifo);
+    pddc_host_free(d->fifo);
     d->fifo = NULL;
-    d->fifo_rd = d->fifo_len = d->fifo_cap = 0;
-    d->n_pend = 0;
+    d->fifo_len = d->fifo_cap = 0;
+    d->n_pend = d->seg_n = d->seg_head = 0;
     if (d->pipe) {
         pddc_pipeline_destroy(d->pipe);
         d->pipe = NULL;
@@ -1465,10 +1535,10 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
         for (int k = 0; k < 2; k++) {
             if (!d->gpu_source)
                 hrc |= pddc_host_alloc((void **)&d->batch_in[k], (size_t)d->cfg.batch_samples * 6);
-            hrc |= pddc_host_alloc((void **)&d->batch_out[k], d->out_cap * 8);
         }
-        d->fifo_cap = 3 * d->out_cap * 8 + 2 * (size_t)buffersize;
-        d->fifo = (uint8_t *)malloc(d->fifo_cap);
+        /* room for two batches on the GPU, one being delivered, and the piece at the end that a batch does not fit into */
+        d->fifo_cap = 6 * seg_align(d->out_cap * 8) + seg_align(2 * (size_t)buffersize);
+        hrc |= pddc_host_alloc((void **)&d->fifo, d->fifo_cap);
         if (hrc || !d->fifo) {
             free_stream(d);
             return errorset(PERSEUS_NOMEM, "can't allocate the batch buffers");
@@ -1488,9 +1558,9 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
     d->ganged_batches = 0;
     d->n_retunes = 0;
     d->cur = 0;
-    d->n_pend = 0;
+    d->n_pend = d->seg_n = d->seg_head = 0;
     d->input_done = 0;
-    d->fifo_rd = d->fifo_len = 0;
+    d->fifo_len = 0;
     d->source_done = 0;
     d->cancelling = 0;
     gettimeofday(&d->t_start, NULL);
