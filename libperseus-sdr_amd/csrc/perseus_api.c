@@ -142,8 +142,9 @@ struct perseus_descr_ds {
     /* two pinned input batch buffers: while the GPU works on one batch (H2D, kernels, D2H
      * on three streams) the source fills the next (pddc_pipeline_push_host_async)       */
     uint8_t *batch_in[2];       /* batch_samples * 6                             */
+    float *batch_out[2];        /* ring mode only (zc == 0): pipeline output of one batch */
     size_t out_cap;             /* a batch's output at most, in complex samples  */
-    int cur;                    /* input buffer the next batch goes into         */
+    int cur;                    /* buffer pair the next batch goes into          */
     out_seg seg[MAX_SEG];       /* outputs in `fifo`, oldest first from seg_head; the last n_pend still on the GPU */
     int seg_head, seg_n;
     int n_pend;
@@ -158,8 +159,14 @@ struct perseus_descr_ds {
      * wherever its buffer's worth of bytes lies in one piece; only a buffer that straddles two batches (or the wrap) is
      * gathered into the transfer's ring slot first.  (Until round 4 every byte was copied twice, batch buffer -> byte
      * ring -> ring slot: 5-6 GB/s of payload on the one delivery thread, which bounded the unpaced stream.) */
+    /* That needs batches that are large against the transfers (every batch at least two buffers' worth of output: then
+     * eight segments always hold a whole buffer).  A stream of small batches -- a low output rate, or a client that asks
+     * for 8192-sample batches -- keeps the byte ring of rounds 1-3 (zc == 0): batch buffer -> ring -> slot; there the
+     * copies are a few hundred bytes a batch. */
+    int zc;
     uint8_t *fifo;
     size_t fifo_len, fifo_cap;  /* ready bytes not yet delivered; size           */
+    size_t fifo_rd;             /* ring mode: read position                      */
     uint64_t adc_samples;       /* ADC-rate samples handed to the GPU so far     */
     uint64_t batches;
     uint32_t freg_applied;      /* word the last submitted batch was mixed with  */
@@ -568,6 +575,33 @@ static int pump_wire(perseus_descr *d)
 /* ---- DDC mode: ADC-rate batches -> GPU -> FIFO of decimated bytes -> transfers ---------- */
 static size_t seg_align(size_t x) { return (x + SEG_ALIGN - 1) & ~(size_t)(SEG_ALIGN - 1); }
 
+/* ring mode (zc == 0): a byte ring between the batch buffers and the transfers */
+static size_t ring_room(const perseus_descr *d) { return d->fifo_cap - d->fifo_len; }
+
+static void ring_put(perseus_descr *d, const uint8_t *src, size_t n)
+{
+    size_t wr = (d->fifo_rd + d->fifo_len) % d->fifo_cap;
+    const size_t first = n < d->fifo_cap - wr ? n : d->fifo_cap - wr;
+    memcpy(d->fifo + wr, src, first);
+    memcpy(d->fifo, src + first, n - first);
+    d->fifo_len += n;
+}
+
+static const uint8_t *fill_ring(perseus_descr *d, uint8_t *slot, size_t *got)
+{
+    const size_t n = d->buffersize;
+    *got = 0;
+    if (d->fifo_len < n)
+        return slot;
+    const size_t first = n < d->fifo_cap - d->fifo_rd ? n : d->fifo_cap - d->fifo_rd;
+    memcpy(slot, d->fifo + d->fifo_rd, first);
+    memcpy(slot + first, d->fifo, n - first);
+    d->fifo_rd = (d->fifo_rd + n) % d->fifo_cap;
+    d->fifo_len -= n;
+    *got = n;
+    return slot;
+}
+
 /* where the next batch's output (at most `worst` bytes, in one piece) can go: behind the newest segment, or -- when the
  * buffer's end is too near -- at its start, below the oldest one.  0: no room until the callbacks have consumed more. */
 static int fifo_reserve(const perseus_descr *d, size_t worst, size_t *off)
@@ -616,6 +650,8 @@ static void seg_trim(perseus_descr *d)
 /* the next buffersize ready bytes: where they lie, or gathered into `slot` when they are in two pieces */
 static const uint8_t *fill_fifo(perseus_descr *d, uint8_t *slot, size_t *got)
 {
+    if (!d->zc)
+        return fill_ring(d, slot, got);
     const size_t n = d->buffersize;
     *got = 0;
     if (d->fifo_len < n)
@@ -683,6 +719,19 @@ static size_t batch_prepare(perseus_descr *d)
     return ns;
 }
 
+/* where the next batch's output goes: its place in the output buffer, or (ring mode) the batch buffer of the pair;
+ * `off` is what batch_pushed() records for it */
+static void *out_place(perseus_descr *d, size_t *off)
+{
+    if (!d->zc) {
+        *off = (size_t)d->cur;
+        return d->batch_out[d->cur];
+    }
+    if (!fifo_reserve(d, d->out_cap * out_bytes_per_sample(d), off))
+        return NULL;
+    return d->fifo + *off;
+}
+
 static void batch_pushed(perseus_descr *d, int rc, size_t ns, size_t n_out, int ticket, size_t off)
 {
     if (rc != PDDC_OK) {
@@ -706,13 +755,14 @@ static void submit_batch(perseus_descr *d)
     size_t n_out = 0, off = 0;
     int ticket = -1;
     int rc;
-    if (!fifo_reserve(d, d->out_cap * out_bytes_per_sample(d), &off))
+    void *dst = out_place(d, &off);
+    if (!dst)
         return;                                  /* (can_submit said there was room) */
     if (d->gpu_source)
-        rc = pddc_pipeline_push_synth_async(d->pipe, d->cfg.lcg_seed, d->adc_samples * 6, ns, d->fifo + off,
-                                            d->out_cap, &n_out, &ticket);
+        rc = pddc_pipeline_push_synth_async(d->pipe, d->cfg.lcg_seed, d->adc_samples * 6, ns, dst, d->out_cap, &n_out,
+                                            &ticket);
     else
-        rc = pddc_pipeline_push_host_async(d->pipe, d->batch_in[k], ns, d->fifo + off, d->out_cap, &n_out, &ticket);
+        rc = pddc_pipeline_push_host_async(d->pipe, d->batch_in[k], ns, dst, d->out_cap, &n_out, &ticket);
     batch_pushed(d, rc, ns, n_out, ticket, off);
 }
 
@@ -722,7 +772,10 @@ static int can_submit(const perseus_descr *d)
 {
     const int depth = d->cfg.pace ? 1 : 2;
     const size_t worst = d->out_cap * out_bytes_per_sample(d);
-    return d->n_pend < depth && !d->input_done && !d->source_done && fifo_reserve(d, worst, NULL) &&
+    return d->n_pend < depth && !d->input_done && !d->source_done &&
+           /* (no further ahead of the callbacks than the ring was: at most three batches' output waiting, so a retune still
+            * takes effect within a few batches of an unpaced stream) */
+           (d->zc ? d->seg_n - d->n_pend <= 2 && fifo_reserve(d, worst, NULL) : ring_room(d) >= worst * (size_t)(d->n_pend + 1)) &&
            !(d->cfg.max_buffers && d->seq >= d->cfg.max_buffers);
 }
 
@@ -752,7 +805,13 @@ static int ddc_collect(perseus_descr *d)
         d->source_done = 1;
         return 0;
     }
-    d->fifo_len += b.len;                        /* its bytes are where they will be delivered from */
+    if (d->zc) {
+        d->fifo_len += b.len;                    /* its bytes are where they will be delivered from */
+    } else {
+        ring_put(d, (const uint8_t *)d->batch_out[b.off], b.len);
+        d->seg_head = (d->seg_head + 1) % MAX_SEG;                /* (ring mode lists only what is still on the GPU) */
+        d->seg_n--;
+    }
     return 1;
 }
 
@@ -895,9 +954,9 @@ static void gang_submit(int dev, const int *sub, int m, int *busy, int *inflight
             it[ni].pipe = d->pipe;
             it[ni].seed = d->cfg.lcg_seed;
             it[ni].byte_offset = d->adc_samples * 6;
-            if (!fifo_reserve(d, d->out_cap * out_bytes_per_sample(d), &off[ni]))
+            it[ni].h_out = out_place(d, &off[ni]);
+            if (!it[ni].h_out)
                 continue;                                      /* (can_submit said there was room) */
-            it[ni].h_out = d->fifo + off[ni];
             it[ni].out_capacity = d->out_cap;
             in[ni++] = d;
         }
@@ -1427,10 +1486,16 @@ static void free_stream(perseus_descr *d)
     for (int k = 0; k < 2; k++) {
         pddc_host_free(d->batch_in[k]);
         d->batch_in[k] = NULL;
+        pddc_host_free(d->batch_out[k]);
+        d->batch_out[k] = NULL;
     }
-    pddc_host_free(d->fifo);
+    if (d->zc)
+        pddc_host_free(d->fifo);
+    else
+        free(d->fifo);
     d->fifo = NULL;
-    d->fifo_len = d->fifo_cap = 0;
+    d->zc = 0;
+    d->fifo_len = d->fifo_cap = d->fifo_rd = 0;
     d->n_pend = d->seg_n = d->seg_head = 0;
     if (d->pipe) {
         pddc_pipeline_destroy(d->pipe);
@@ -1536,9 +1601,19 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
             if (!d->gpu_source)
                 hrc |= pddc_host_alloc((void **)&d->batch_in[k], (size_t)d->cfg.batch_samples * 6);
         }
-        /* room for two batches on the GPU, one being delivered, and the piece at the end that a batch does not fit into */
-        d->fifo_cap = 6 * seg_align(d->out_cap * 8) + seg_align(2 * (size_t)buffersize);
-        hrc |= pddc_host_alloc((void **)&d->fifo, d->fifo_cap);
+        /* every batch at least two buffers' worth of output (out_cap is the most a batch gives, + 8; the least is within
+         * two samples of that): the callbacks read the output where the GPU puts it */
+        d->zc = d->out_cap > 10 && (d->out_cap - 10) * out_bytes_per_sample(d) >= 2 * (size_t)buffersize;
+        if (d->zc) {
+            /* room for two batches on the GPU, one being delivered, and the piece at the end that a batch does not fit into */
+            d->fifo_cap = 6 * seg_align(d->out_cap * 8) + seg_align(2 * (size_t)buffersize);
+            hrc |= pddc_host_alloc((void **)&d->fifo, d->fifo_cap);
+        } else {
+            for (int k = 0; k < 2; k++)
+                hrc |= pddc_host_alloc((void **)&d->batch_out[k], d->out_cap * 8);
+            d->fifo_cap = 3 * d->out_cap * 8 + 2 * (size_t)buffersize;
+            d->fifo = (uint8_t *)malloc(d->fifo_cap);
+        }
         if (hrc || !d->fifo) {
             free_stream(d);
             return errorset(PERSEUS_NOMEM, "can't allocate the batch buffers");
@@ -1560,7 +1635,7 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
     d->cur = 0;
     d->n_pend = d->seg_n = d->seg_head = 0;
     d->input_done = 0;
-    d->fifo_len = 0;
+    d->fifo_len = d->fifo_rd = 0;
     d->source_done = 0;
     d->cancelling = 0;
     gettimeofday(&d->t_start, NULL);
