@@ -65,7 +65,8 @@ def test_committed_bench_line_schema():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    # dtype: the arithmetic the dominant kernel computes in -- int8 digit/byte planes into int32, float recombination (k_fir_i8x)
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] in ("f32", "i8xi8->i32, f32 out")
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
