@@ -306,10 +306,11 @@ def test_plumbing_client_eight_receivers_on_the_gpu_path(pkg, dev):
     """The C client with -N 8 in DDC mode: eight pipelines on one GPU, all in flight at once, no Python in the loop.
     Their batches go out as ONE launch chain (gang submission).  Round 3: one receiver 40-82 GS/s of ADC-rate input (a
     latency chain of vector kernels at 2^22-sample batches), eight 235-265.  Round 4: the tuned first stages run on
-    k_fir_i8x and an unpaced on-device source gets 2^24-sample batches: ONE receiver 135-142 GS/s; the eight stay at
-    225-265 -- what bounds them is the one delivery thread, which copies every output byte twice on its way into the
-    callback buffers (5-6 GB/s of payload), not the GPU; with the shorter equiripple filters one receiver alone reaches
-    170-220.  Both are bound by that thread, so which of the two is ahead is the box's mood.  Asserted: more than 150 GS/s
+    k_fir_i8x and an unpaced on-device source gets 2^24-sample batches: ONE receiver 135-220 GS/s, the eight 225-265 -- bound
+    by the one delivery thread, which copied every output byte twice on its way into the callback buffers.  Since the
+    callbacks read the output where the GPU put it (perseus_api.c, zero-copy delivery): one receiver 213-234, eight 301-321;
+    what bounds both now is the synthetic source's generator on the GPU, so which of the two is ahead depends on how well the
+    gang's shared launches hide it.  Asserted: more than 150 GS/s
     for the eight, more than 80 for the one, the eight together no more than a fifth behind the one."""
     import re
     exe = os.path.join(os.path.dirname(pkg.SDR_LIB), "perseus_plumbing")
