@@ -92,6 +92,10 @@ typedef struct {
                                  for all of them before it waits for any)           */
     uint64_t ganged_batches;  /* batches of this receiver that shared their kernel launches with other
                                  receivers on the same GPU (pddc_gang_push_async)   */
+    uint64_t buffers_in_place; /* DDC modes: transfers whose callback read the output where the GPU had put it
+                                 (no host copy), */
+    uint64_t buffers_gathered; /* ... and transfers copied into their ring slot first: one that straddles two batches,
+                                 or every one of a stream whose batches are small against the transfers */
 } perseus_amd_stats;
 
 /* valid between perseus_open() and perseus_start_async_input() */

@@ -693,7 +693,8 @@ class AmdStats(C.Structure):
     _fields_ = [("delivered", C.c_uint64), ("dropped", C.c_uint64), ("timeouts", C.c_uint64),
                 ("dead_transfers", C.c_uint64), ("transfers", C.c_uint64), ("bytes_received", C.c_uint64),
                 ("adc_samples", C.c_uint64), ("batches", C.c_uint64), ("gpu_device", C.c_int),
-                ("gpu_source", C.c_int), ("peak_receivers_in_flight", C.c_int), ("ganged_batches", C.c_uint64)]
+                ("gpu_source", C.c_int), ("peak_receivers_in_flight", C.c_int), ("ganged_batches", C.c_uint64),
+                ("buffers_in_place", C.c_uint64), ("buffers_gathered", C.c_uint64)]
 
 
 _sdr = None

@@ -153,6 +153,7 @@ struct perseus_descr_ds {
     int batch_auto;             /* batch_samples was not chosen by the client (PERSEUS_AMD_BATCH, set_config): the library
                                    picks it for the kind of source when the stream starts (effective_batch)             */
     uint64_t ganged_batches;    /* batches that shared their launches with other receivers of the GPU */
+    uint64_t n_in_place, n_gathered;   /* transfers delivered from the output buffer itself / copied into their slot */
     int gpu_dev;                /* HIP device of the current / last stream, -1: none */
     /* The decimated output never moves on the host: `fifo` is ONE pinned buffer, every batch reserves its place in it
      * when it is submitted (the last kernel or the D2H copy writes there), and a callback gets a pointer INTO it
@@ -598,6 +599,7 @@ static const uint8_t *fill_ring(perseus_descr *d, uint8_t *slot, size_t *got)
     memcpy(slot + first, d->fifo, n - first);
     d->fifo_rd = (d->fifo_rd + n) % d->fifo_cap;
     d->fifo_len -= n;
+    d->n_gathered++;
     *got = n;
     return slot;
 }
@@ -663,7 +665,9 @@ static const uint8_t *fill_fifo(perseus_descr *d, uint8_t *slot, size_t *got)
         p = d->fifo + h->off;
         h->off += n;
         h->len -= n;
+        d->n_in_place++;
     } else {
+        d->n_gathered++;
         size_t have = 0;
         while (have < n) {                            /* (fifo_len >= n: only ready segments are touched) */
             h = &d->seg[d->seg_head];
@@ -1631,6 +1635,7 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
     d->adc_samples = 0;
     d->batches = 0;
     d->ganged_batches = 0;
+    d->n_in_place = d->n_gathered = 0;
     d->n_retunes = 0;
     d->cur = 0;
     d->n_pend = d->seg_n = d->seg_head = 0;
@@ -1769,6 +1774,8 @@ int perseus_amd_get_stats(perseus_descr *d, perseus_amd_stats *st)
     st->gpu_device = d->gpu_dev;
     st->gpu_source = d->gpu_source;
     st->ganged_batches = d->ganged_batches;
+    st->buffers_in_place = d->n_in_place;
+    st->buffers_gathered = d->n_gathered;
     st->peak_receivers_in_flight = g_peak_inflight;
     if (!on_worker)
         pthread_mutex_unlock(&d->pump_lock);

@@ -130,6 +130,35 @@ def test_eight_receivers_share_one_gpu_and_overlap(L, pkg, O, monkeypatch):
     assert wall8 < 12.0 * min(walls), (walls8, walls)
 
 
+def test_callbacks_read_the_output_in_place_and_both_delivery_modes_give_the_same_stream(L, pkg, O):
+    """The decimated output is delivered from where the GPU put it: a batch reserves its place in the receiver's pinned
+    output buffer, a callback gets a pointer into it, and only a transfer that straddles two batches is gathered into its
+    ring slot (the reference hands its callbacks library-owned buffers the same way, perseus-in.c:206-207).  A stream
+    whose batches are small against the transfers keeps the byte ring instead.  Same source, same batches, two buffer
+    sizes -- one on either side of that rule: the delivered byte streams are identical, the statistics say which way
+    each went, and the stream equals the oracle."""
+    batch, rate, dtot = 1 << 19, 250000, 320
+    runs = {}
+    for bufsize, nbuf in ((6144, 96), (12288, 48)):              # a batch gives 13.1 KB: more / less than two transfers
+        assert L.perseus_init() == 1
+        d = open_receiver(L, pkg, 0, rate, 7.1e6, mode=1, batch_samples=batch, max_buffers=nbuf)
+        stages = plan_of(L, d)
+        outs, _ = run_all(L, pkg, [d], bufsize=bufsize)
+        st = pkg.AmdStats()
+        L.perseus_amd_get_stats(d, C.byref(st))
+        assert st.delivered == nbuf and st.buffers_in_place + st.buffers_gathered >= nbuf
+        runs[bufsize] = (outs[0], st.buffers_in_place, st.buffers_gathered, st.batches)
+        L.perseus_exit()
+    a, b = runs[6144], runs[12288]
+    assert len(a[0]) == len(b[0]) == 96 * 6144 and a[0] == b[0]
+    assert b[1] == 0 and b[2] >= 48                              # byte ring: every transfer copied
+    # in place: all but the transfers that straddle two batches -- at most one per batch
+    assert a[1] >= 96 - a[3] and a[2] <= a[3] and a[1] >= a[2], a[1:]
+    y = np.frombuffer(a[0], dtype=np.float32)[:2 * 8192]       # (the first transfers, across the first batch boundaries: 1638.4 outputs a batch)
+    ref = O.ddc_chain(O.lcg_bytes(6 * 8192 * dtot, 12345), stages, freg=381178347, mix=True)
+    assert O.rel_err(y, ref[:y.size]) <= FIR_TOL
+
+
 # ------------------------------------------------------------------ N4: retune while streaming
 @pytest.mark.parametrize("mode,rate", [(1, 250000), (2, 2000000), (1, 96000)])
 def test_retune_while_streaming_matches_the_retuned_oracle(L, pkg, O, mode, rate):
