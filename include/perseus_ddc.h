@@ -218,14 +218,17 @@ int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples_in);
  * -- the NCO folded into the taps, y[m] = LO(n0 + 8m) sum_k (h[k] e^{+j theta k}) x_raw[8m - k]: complex taps on the raw
  * integer planes, one float rotation per output -- which every tuned (PDDC_F_MIX) decimate-by-8 first stage of 1..256
  * taps runs on, i.e. every pipeline the drop-in API builds behind perseus_set_ddc_center_freq (perseus-sdr.c:556-619);
- * with a decimate-by-8 second stage of <= 64 taps behind it and whole 8192-sample tiles, both stages are one kernel
+ * with a decimate-by-8 second stage of <= 64 taps behind a first stage of <= 128 and whole 8192-sample tiles, both are one kernel
  * (pddc_pipeline_uses_fused_pair answers 2).  The one batch whose history window straddles a retune takes k_fir8.   */
-/* The operands k_fir_i8x reads, as the library builds them (host arithmetic, no device needed): `mix` = 0 one table of
- * H[k] = round(h[k] 2^E) as pddc_fir_i8_table's; `mix` = 1 the tables of Hc[k] = round(h[k] cos(theta k) 2^E) and
- * Hs[k] = round(h[k] sin(theta k) 2^E), theta k = 2 pi ((k freg) mod 2^32) / 2^32, and for hist <= 64 a third one of -Hs
- * (there a wave adds both of its band products into one set of int32 accumulators).  hist = 32, 64, 128 or 256;
- * 4 * ksteps * 1024 bytes per table, ksteps = (120 + hist + 63) / 64.  ct[0], ct[1]: the byte planes' offset constants of
- * uI = gc * xI - gs * xQ and uQ = gs * xI + gc * xQ.  Returns the number of tables written.                        */
+/* The operands k_fir_i8x reads, as the library builds them (host arithmetic, no device needed), from
+ * Hc[k] = round(h[k] cos(theta k) 2^E) and Hs[k] = round(h[k] sin(theta k) 2^E), theta k = 2 pi ((k freg) mod 2^32) / 2^32
+ * (`mix` = 0: H[k] = round(h[k] 2^E), one table, pddc_fir_i8_table's).  A table is 4 digit planes x ksteps x 64 lanes x 16
+ * bytes in the matrix instruction's lane order.  hist = 32, 64 or 128 with `mix`: TWO tables of paired rows -- rows 0..7 the
+ * band of eight outputs for one tap set, rows 8..15 the band of the same outputs for the other: [Hc ; Hs] meets the I
+ * planes, [-Hs ; Hc] the Q planes, one set of int32 accumulators takes both, rows 0..7 are uI, rows 8..15 uQ;
+ * ksteps = (56 + hist + 63) / 64.  hist = 256 with `mix`: the 16-row tables of Hc and of Hs, ksteps = (120 + hist + 63) / 64
+ * (as without `mix`).  ct[0], ct[1]: the byte planes' offset constants of uI = gc * xI - gs * xQ and
+ * uQ = gs * xI + gc * xQ.  Returns the number of tables written (1 or 2).                                           */
 int pddc_fir_i8x_tables(const float *taps, int ntaps, int hist, int mix, uint32_t freg, int8_t *tables, size_t tables_bytes,
                         float *scale, float *ct /* [2] */);
 /* ... and the fused second stage's taps: out[i] = Re g2[64 - i], out[68 + i] = Im g2[64 - i], i = 0 .. 64,

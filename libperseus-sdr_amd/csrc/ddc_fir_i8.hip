@@ -425,12 +425,17 @@ hipError_t launch_fir_i8(const FirI8Args &a, int hist, hipStream_t s)
  * nco_lo and four multiplies per OUTPUT.  The samples stay the integers of the wire: no per-sample mix, no rounding
  * before the accumulation.  Three forms of one kernel (MODE):
  *   0  no NCO            waves = component x half of the columns, one tap set                    (k_fir_i8's arithmetic)
- *   1  NCO, 65..256 taps waves = tap set (c / s) x half of the columns, BOTH components each: four partial products
+ *   1  NCO, 129..256 taps waves = tap set (c / s) x half of the columns, BOTH components each: four partial products
  *                        P[c|s][I|Q] meet in LDS, uI = P[c][I] - P[s][Q], uQ = P[s][I] + P[c][Q] at the stores
  *                        (two tap sets in one wave would need 2 x 96 registers)
- *   2  NCO, <= 64 taps   waves = component x half, each holds the two tap sets it needs (c and -s, or s and c: 96
- *                        registers at 3 k-steps) and adds both band products into the SAME int32 accumulators: u leaves
- *                        the wave complete, one rounding
+ *   2  NCO, <= 128 taps  ONE operand holds both tap sets: rows 0..7 the band of eight outputs for one set, rows 8..15 the
+ *                        band of the same eight outputs for the other (columns of 8 outputs, 64 samples apart; the band is
+ *                        56 + HIST wide: 2 k-steps up to 64 taps, 3 up to 128).  [c ; s] meets the I planes, [-s ; c] the Q
+ *                        planes, both into the SAME int32 accumulators: rows 0..7 come out as uI, rows 8..15 as uQ --
+ *                        complete, one rounding -- and every wave makes both rails of its columns.  A third fewer matrix
+ *                        instructions than two 16-row bands per rail (the dead corners of a band shrink with its height):
+ *                        same box, 2^28 samples, 48 taps 0.3406 -> 0.3272 ms, 127 taps 0.3865 -> 0.3513 (it replaced a form
+ *                        with both 16-row tables per wave for <= 64 taps and took 65..128 taps over from mode 1)
  * Walk: the batch is cut into chunks of C tiles and block b takes chunks b, b + G, b + 2 G, ...  C = 1 is k_fir_i8's
  * tile-interleaved walk -- all CUs read one compact window of the batch, which is what this chip's HBM likes (same
  * kernel, 2^28 samples: contiguous ranges per block 0.380 ms, interleaved 0.332) --; inside a chunk the HIST samples in
@@ -455,15 +460,16 @@ struct Geo {
     static constexpr int EXTRA = FUSE2 ? 512 : 0;                   /* samples in front of the history: the porch's columns */
     static constexpr int FRONT = EXTRA + HIST;
     static constexpr int SPAN = TILE + FRONT, PLANE = SPAN + 16 * ((SPAN + 127) / 128);
-    static constexpr int KSTEPS = (120 + HIST + 63) / 64;
+    /* the band of a row block: 16 outputs (modes 0, 1) or 8 outputs x the two tap sets (mode 2), 8 samples apart, + HIST */
+    static constexpr int KSTEPS = ((MODE == 2 ? 56 : 120) + HIST + 63) / 64;
     static constexpr int HG = HIST / 8, FG = FRONT / 8;              /* history groups of 8 samples; with the extra ones */
     static constexpr int NARR = MODE == 1 ? 4 : 2;
     static constexpr int PORCH = FUSE2 ? 64 : 0;
     static constexpr int AS = 20 * ((1024 + PORCH) / 16);            /* floats per output array (16 values per 20) */
     static constexpr size_t LDS_BYTES = 12 * (size_t)PLANE + 2 * (size_t)NARR * AS * sizeof(float);
-    static constexpr int NTAB = MODE == 0 ? 1 : MODE == 1 ? 2 : 3;
+    static constexpr int NTAB = MODE == 0 ? 1 : 2;
     static constexpr int TABV = 4 * KSTEPS * 64;                     /* v4i entries per tap table */
-    static_assert(MODE != 2 || HIST <= 64, "two tap sets per wave only fit at 3 k-steps");
+    static_assert(MODE != 2 || HIST <= 128, "two paired tables of 5 k-steps do not fit the registers");
     static_assert(!(FUSE2 && MODE == 1), "the fused second stage reads complete u values");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(FG <= 128, "front groups are loaded by the first loader waves");
@@ -944,19 +950,19 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
     const int w0 = wave & 1, half = wave >> 1;
     const int n = lane & 15, kq = lane >> 4;
     const v4i_t *atab = static_cast<const v4i_t *>(a.atab);
-    /* tap operand(s): mode 0 the one table; mode 1 table w0 (c or s); mode 2 the set that meets the I planes and the one
-     * that meets the Q planes: c and -s for component I, s and c for component Q (tables c, s, -s) */
+    /* tap operand(s): mode 0 the one table; mode 1 table w0 (c or s); mode 2 both paired tables -- [c ; s] meets the I planes,
+     * [-s ; c] the Q planes */
     v4i_t A0[KSTEPS][4];
     v4i_t A1[MODE == 2 ? KSTEPS : 1][4];
     {
-        const int tab0 = MODE == 0 ? 0 : w0, tab1 = w0 == 0 ? 2 : 0;
+        const int tab0 = MODE == 1 ? w0 : 0;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 A0[ks][j] = atab[tab0 * G::TABV + (j * KSTEPS + ks) * 64 + lane];
                 if (MODE == 2)
-                    A1[ks][j] = atab[tab1 * G::TABV + (j * KSTEPS + ks) * 64 + lane];
+                    A1[ks][j] = atab[G::TABV + (j * KSTEPS + ks) * 64 + lane];
             }
     }
     if (LAYOUT != 2 && FUSE2 && blk == 0 && tid < 64) {
@@ -1040,13 +1046,15 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
                             }
                 }
             }
-            /* this lane: its column, rows 4 kq + v -> four consecutive values */
+            /* this lane: its column, rows 4 kq + v -> four consecutive values; mode 2: rows 0..7 are uI, rows 8..15 uQ of the
+             * column's eight outputs */
+            const int rail = MODE == 2 ? kq >> 1 : w0;
             float4 y;
             float *yp = &y.x;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                yp[v] = recombine(acc, v) * a.scale + (w0 ? a.ct[1] : a.ct[0]);
-            *reinterpret_cast<float4 *>(dst + w0 * AS) = y;
+                yp[v] = recombine(acc, v) * a.scale + (rail ? a.ct[1] : a.ct[0]);
+            *reinterpret_cast<float4 *>(dst + rail * AS) = y;
         }
     };
     __syncthreads();
@@ -1057,6 +1065,22 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
         cur = wk.next(cur);
         const uint8_t *pb = lds_i8x + buf * 6 * PLANE;
         float *arr = arr_base + buf * NARR * AS, *arr_o = arr_base + (buf ^ 1) * NARR * AS;
+        if (MODE == 2) {
+            /* columns of 8 outputs, 64 samples apart: 128 of them in a tile, 16 per pass; every matrix wave makes both rails.
+             * Output o = 8 col + 4 (kq & 1) + v lies at array position o + PORCH. */
+            constexpr int NMW = LAYOUT == 2 ? 2 : 4;
+            if (FUSE2 && first && t > 0 && wave == NMW - 1) {
+                /* a chunk's first tile computes its own porch: columns -8 .. -1 in lanes 8..15; the other lanes repeat column
+                 * -8 (same operand bytes, same results, same address: the whole wave runs the matrix instructions) */
+                const int colx = n < 8 ? -8 : n - 16, pp = 64 + 8 * colx + 4 * (kq & 1);
+                band(pb, EXTRA + 64 * colx + 16 * kq, arr + 20 * (pp >> 4) + (pp & 15));
+            }
+#pragma unroll
+            for (int cb = 0; cb < 8 / NMW; ++cb) {
+                const int col = 16 * ((8 / NMW) * wave + cb) + n, pp = PORCH + 8 * col + 4 * (kq & 1);
+                band(pb, EXTRA + 64 * col + 16 * kq, arr + 20 * (pp >> 4) + (pp & 15));
+            }
+        } else {
         if (FUSE2 && first && t > 0 && (LAYOUT == 2 || half == 1)) {
             /* a chunk's first tile computes its own porch: columns -4 .. -1 in lanes 12..15; the other lanes repeat column -4
              * (same operand bytes, same results, same address: the whole wave runs the matrix instructions) */
@@ -1067,6 +1091,7 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
         for (int cb = 0; cb < (LAYOUT == 2 ? 4 : 2); ++cb) {
             const int col = 16 * (LAYOUT == 2 ? cb : 2 * half + cb) + n;
             band(pb, EXTRA + 128 * col + 16 * kq, arr + 20 * (col + PORCH / 16) + 4 * kq);
+        }
         }
         __syncthreads();                 /* ONE barrier per tile: the next tile's planes are written, this tile's values are in LDS */
         if (LAYOUT == 0)                 /* ... and these waves finish it themselves */
@@ -1137,12 +1162,43 @@ static bool i8_fill_table(const long long *H, int hist, int8_t *table)
     return true;
 }
 
-int fir_i8x_mode(int hist, bool mix) { return !mix ? 0 : hist <= 64 ? 2 : 1; }
+/* mode 2: the same digits with the two tap sets of a row block in ONE operand -- rows 0..7 the band of `top` over eight
+ * outputs, rows 8..15 the band of `bot` over the same eight: lane l of k-step ks holds A[row l & 15][k = 16 (l >> 4) + jj],
+ * T[r][c] = H_(r >> 3)[hist - (c - 8 (r & 7))] */
+static bool i8_fill_table_paired(const long long *top, const long long *bot, int hist, int8_t *table)
+{
+    std::vector<int8_t> dig(8 * (size_t)hist);
+    for (int set = 0; set < 2; ++set)
+        for (int k = 0; k < hist; ++k) {
+            long long r = (set ? bot : top)[k];
+            for (int j = 0; j < 4; ++j) {
+                const long long d = j == 3 ? r : ((r + 128) & 255) - 128;
+                if (d < -128 || d > 127)
+                    return false;
+                dig[((size_t)set * 4 + j) * hist + k] = (int8_t)d;
+                r = (r - d) / 256;
+            }
+        }
+    const int ksteps = (56 + hist + 63) / 64;
+    for (int j = 0; j < 4; ++j)
+        for (int ks = 0; ks < ksteps; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int r = l & 15, c = 64 * ks + 16 * (l >> 4) + jj, tt = c - 8 * (r & 7);
+                    table[(((size_t)j * ksteps + ks) * 64 + l) * 16 + jj] =
+                        (tt >= 1 && tt <= hist) ? dig[((size_t)(r >> 3) * 4 + j) * hist + (hist - tt)] : 0;
+                }
+    return true;
+}
+
+int fir_i8x_mode(int hist, bool mix) { return !mix ? 0 : hist <= 128 ? 2 : 1; }
+
+static int fir_i8x_ksteps(int hist, int mode) { return ((mode == 2 ? 56 : 120) + hist + 63) / 64; }
 
 size_t fir_i8x_table_bytes(int hist, bool mix)
 {
-    const int ksteps = (120 + hist + 63) / 64, mode = fir_i8x_mode(hist, mix);
-    return (size_t)(mode == 0 ? 1 : mode == 1 ? 2 : 3) * 4 * ksteps * 64 * 16;
+    const int mode = fir_i8x_mode(hist, mix), ksteps = fir_i8x_ksteps(hist, mode);
+    return (size_t)(mode == 0 ? 1 : 2) * 4 * ksteps * 64 * 16;
 }
 
 bool fir_i8x_build_tables(const float *taps, int ntaps, int hist, bool mix, uint32_t freg, int8_t *tables, float *scale,
@@ -1158,7 +1214,8 @@ bool fir_i8x_build_tables(const float *taps, int ntaps, int hist, bool mix, uint
     const int E = 30 - (int)std::ceil(std::log2(hmax));            /* |H| <= 2^30 for h, a fortiori for h cos, h sin */
     if (exp2)
         *exp2 = E;
-    const size_t tb = (size_t)4 * ((120 + hist + 63) / 64) * 64 * 16;
+    const int mode = fir_i8x_mode(hist, mix);
+    const size_t tb = (size_t)4 * fir_i8x_ksteps(hist, mode) * 64 * 16;
     /* sample = v24 / 8388607 (perseustest.c:466-502); planes 0 and 1 are stored minus 128: V = planes + 32896 */
     const double unit = std::ldexp(1.0, -E) / 8388607.0;
     *scale = (float)unit;
@@ -1178,12 +1235,14 @@ bool fir_i8x_build_tables(const float *taps, int ntaps, int hist, bool mix, uint
         sc += Hc[k];
         ss += Hs[k];
     }
-    if (!i8_fill_table(Hc.data(), hist, tables))
-        return false;
-    if (mix) {
-        if (!i8_fill_table(Hs.data(), hist, tables + tb))
+    if (mode == 2) {
+        /* [c ; s] meets the I planes, [-s ; c] the Q planes, both into the same accumulators: rows 0..7 uI, rows 8..15 uQ */
+        if (!i8_fill_table_paired(Hc.data(), Hs.data(), hist, tables) || !i8_fill_table_paired(Hm.data(), Hc.data(), hist, tables + tb))
             return false;
-        if (fir_i8x_mode(hist, true) == 2 && !i8_fill_table(Hm.data(), hist, tables + 2 * tb))
+    } else {
+        if (!i8_fill_table(Hc.data(), hist, tables))
+            return false;
+        if (mix && !i8_fill_table(Hs.data(), hist, tables + tb))
             return false;
     }
     ct[0] = (float)((double)(sc - ss) * 32896.0 * unit);           /* uI = gc xI - gs xQ */
@@ -1270,7 +1329,7 @@ static hipError_t launch_fir_i8x_t(const FirI8xArgs &a, int max_blocks, int chun
 template <int HIST>
 static hipError_t launch_fir_i8x_h(const FirI8xArgs &a, bool mix, bool fuse2, int max_blocks, int chunk, int layout, hipStream_t s)
 {
-    constexpr int MM = HIST <= 64 ? 2 : 1;
+    constexpr int MM = HIST <= 128 ? 2 : 1;
     if (!mix)
         return fuse2 ? launch_fir_i8x_t<HIST, 0, true>(a, max_blocks, chunk, layout, s) : launch_fir_i8x_t<HIST, 0, false>(a, max_blocks, chunk, layout, s);
     if (!fuse2)
@@ -1286,7 +1345,7 @@ bool fir_i8x_supported(int hist, bool mix, bool fuse2)
 {
     if (hist != 32 && hist != 64 && hist != 128 && hist != 256)
         return false;
-    return !(fuse2 && mix && hist > 64);
+    return !(fuse2 && mix && hist > 128);
 }
 
 hipError_t launch_fir_i8x(const FirI8xArgs &a, int hist, bool mix, bool fuse2, hipStream_t s, int max_blocks, int chunk, int layout)
@@ -1298,7 +1357,7 @@ hipError_t launch_fir_i8x(const FirI8xArgs &a, int hist, bool mix, bool fuse2, h
     if (fuse2 && ((a.n_in % i8x::TILE) || !a.taps2 || !a.hist2))
         return hipErrorInvalidValue;
     if (layout < 0)              /* by form: the loaders finish the tile where the finish is heavy (four partial products, the second stage) */
-        layout = (fuse2 || (mix && hist > 64)) ? 1 : 0;
+        layout = (fuse2 || (mix && hist > 128)) ? 1 : 0;
     switch (hist) {
     case 32:
         return launch_fir_i8x_h<32>(a, mix, fuse2, max_blocks, chunk, layout, s);

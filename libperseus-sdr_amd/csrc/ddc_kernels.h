@@ -186,7 +186,7 @@ struct FirI8xArgs {
     const void *hist;        /* the `hist` packed samples in front of it                        */
     void       *hist_out;    /* receives the batch's last `hist` samples (or NULL; needs n_in >= hist) */
     float      *out;         /* float2 outputs: n_in / 8, or n_in / 64 with the fused second stage */
-    const void *atab;        /* fir_i8x_build_tables: 1 (no NCO), 2 (NCO, hist > 64: c, s) or 3 (NCO, hist <= 64: c, s, -s) tables */
+    const void *atab;        /* fir_i8x_build_tables: 1 table (no NCO) or 2 (NCO; hist > 128: c, s; else the paired [c ; s], [-s ; c]) */
     long long   n_in;        /* samples, multiple of 8 (of 8192 with the fused second stage)     */
     float       scale;       /* integer result -> float                                         */
     float       ct[2];       /* the planes' unsigned -> signed offset times the tap sums, per component of u */
@@ -202,7 +202,7 @@ struct FirI8xMany {
     FirI8xArgs a[kFir8ManyMax];
 };
 static_assert(sizeof(FirI8xMany) <= 4000, "FirI8xMany must fit the kernel-argument segment");
-int    fir_i8x_mode(int hist, bool mix);                 /* 0: no NCO, 1: NCO split over waves, 2: NCO, both tap sets per wave */
+int    fir_i8x_mode(int hist, bool mix);                 /* 0: no NCO, 1: NCO split over waves (129..256 taps), 2: NCO, both tap sets in one operand */
 size_t fir_i8x_table_bytes(int hist, bool mix);
 /* host: the tap operand(s) for `ntaps` <= hist taps, NCO word freg when mix; false if the taps are all zero */
 bool fir_i8x_build_tables(const float *taps, int ntaps, int hist, bool mix, uint32_t freg, int8_t *tables, float *scale,

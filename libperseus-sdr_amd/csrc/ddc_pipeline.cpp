@@ -454,8 +454,7 @@ int pddc_fir_i8x_tables(const float *taps, int ntaps, int hist, int mix, uint32_
         return fail(PDDC_EINVAL, "tables need %zu bytes", fir_i8x_table_bytes(hist, mix != 0));
     if (!fir_i8x_build_tables(taps, ntaps, hist, mix != 0, freg, tables, scale, ct))
         return fail(PDDC_EINVAL, "taps cannot be quantised (all zero, not finite, or more than hist)");
-    const int mode = fir_i8x_mode(hist, mix != 0);
-    return mode == 0 ? 1 : mode == 1 ? 2 : 3;
+    return fir_i8x_mode(hist, mix != 0) == 0 ? 1 : 2;
 }
 
 int pddc_fir_i8x_taps2(const float *taps2, int ntaps2, int mix, uint32_t freg, float *out, size_t out_len)

@@ -71,7 +71,7 @@ def test_tuning_words_at_the_edges(pkg, dev, O, word):
     assert O.rel_err(y, ref) <= FIR_TOL, (word, O.rel_err(y, ref))
 
 
-@pytest.mark.parametrize("taps12", [(48, 56), (32, 64), (17, 33), (64, 64)])
+@pytest.mark.parametrize("taps12", [(48, 56), (32, 64), (17, 33), (64, 64), (127, 56), (100, 40)])
 @pytest.mark.parametrize("mix", [True, False])
 def test_fused_pair_vs_oracle(pkg, dev, O, taps12, mix):
     """Stages 0 and 1 in one kernel: batches of one tile, a few, more tiles than CUs (warm-up tiles in front of every

@@ -3,8 +3,10 @@ arithmetic, no GPU).  The kernel folds the NCO into the taps,
     y[m] = LO(n0 + 8 m) * sum_k (h[k] e^{+j theta k}) x_raw[8 m - k],      theta = 2 pi freg / 2^32,
 so that the int8 matrix cores work on the wire bytes themselves and the phase is applied once per output.  Everything it
 does is integer and exact up to the recombination, so it can be restated in numpy from the tables alone: byte planes,
-digit planes of the cosine and sine tap sets, the band products, their combination in the kernel's two forms (mode 1:
-four partial products meet as floats; mode 2: both band products in one set of integer accumulators), the rotation with
+digit planes of the cosine and sine tap sets, the band products, their combination in the kernel's two forms (mode 1,
+129..256 taps: four partial products meet as floats; mode 2, up to 128 taps: ONE operand holds both tap sets -- rows 0..7
+the band of eight outputs for one set, rows 8..15 for the other -- and [c ; s] on the I planes plus [-s ; c] on the Q planes
+go into one set of integer accumulators: rows 0..7 come out as uI, rows 8..15 as uQ), the rotation with
 the exact 32-bit phase, and the fused second stage with its complex taps.  Checked against the oracle's mix-then-filter
 definition (perseus-sdr.c:584 for the tuning word)."""
 import ctypes as C
@@ -23,10 +25,14 @@ def lowpass(ntaps, cutoff):
     return (h / h.sum()).astype(np.float32)
 
 
+def form(hist, mix):
+    return 0 if not mix else 3 if hist <= 128 else 1
+
+
 def tables(pkg, h, hist, mix, freg):
     L = pkg.ddc_lib()
-    ks = (120 + hist + 63) // 64
-    ntab = 1 if not mix else (3 if hist <= 64 else 2)
+    ks = ((56 if form(hist, mix) == 3 else 120) + hist + 63) // 64
+    ntab = 2 if mix else 1
     tab = np.zeros(ntab * 4 * ks * 64 * 16, np.int8)
     sc, ct = C.c_float(), (C.c_float * 2)()
     h = np.ascontiguousarray(h, np.float32)
@@ -83,16 +89,21 @@ def restated_first_stage(tabs, scale, ct, hist, packed, mix):
     n_out = packed.size // 48
     u = np.zeros((n_out, 2), np.float32)
     scale = np.float32(scale)
+    if mix and hist <= 128:                                      # mode 2: columns of eight outputs, both rails from one pass
+        for col in range((n_out + 7) // 8):
+            X = xp[:, 64 * col:64 * col + K, :]
+            acc = plane_products(Ts[0], X[:, :, 0]) + plane_products(Ts[1], X[:, :, 1])
+            assert np.abs(acc).max() < 1 << 24
+            y = recombine(acc) * scale
+            m = min(8, n_out - 8 * col)
+            u[8 * col:8 * col + m, 0] = (y[:8] + np.float32(ct[0]))[:m]
+            u[8 * col:8 * col + m, 1] = (y[8:] + np.float32(ct[1]))[:m]
+        return u
     for col in range((n_out + 15) // 16):
         X = xp[:, 128 * col:128 * col + K, :]
         XI, XQ = X[:, :, 0], X[:, :, 1]
         if not mix:
             y = [recombine(plane_products(Ts[0], Xc)) * scale + np.float32(ct[c]) for c, Xc in enumerate((XI, XQ))]
-        elif len(Ts) == 3:                                       # mode 2: one set of integer accumulators per component
-            aI = plane_products(Ts[0], XI) + plane_products(Ts[2], XQ)
-            aQ = plane_products(Ts[1], XI) + plane_products(Ts[0], XQ)
-            assert max(np.abs(aI).max(), np.abs(aQ).max()) < 1 << 24
-            y = [recombine(aI) * scale + np.float32(ct[0]), recombine(aQ) * scale + np.float32(ct[1])]
         else:                                                    # mode 1: four float partial products
             P = [[recombine(plane_products(Ts[t], Xc)) * scale for Xc in (XI, XQ)] for t in range(2)]
             y = [(P[0][0] - P[1][1]) + np.float32(ct[0]), (P[1][0] + P[0][1]) + np.float32(ct[1])]
@@ -113,7 +124,7 @@ def test_restated_nco_first_stage_matches_the_oracle(pkg, O, ntaps, hist):
     packed = O.lcg_bytes(6 * 8 * 600, 9)
     ref = O.ddc_chain(packed, [(8, h)], freg=FREG, mix=True)
     tabs, scale, ct = tables(pkg, h, hist, True, FREG)
-    assert tabs.shape[0] == (3 if hist <= 64 else 2)
+    assert tabs.shape[0] == 2
     y = rotate(restated_first_stage(tabs, scale, ct, hist, packed, True), FREG, 8).reshape(-1)
     assert y.size == ref.size and O.rel_err(y, ref) <= 3e-7, O.rel_err(y, ref)
 
@@ -125,10 +136,13 @@ def test_tables_hold_the_rotated_taps_and_their_negative(pkg):
     th = 2 * np.pi * ((np.arange(56, dtype=np.uint64) * np.uint64(FREG)) & np.uint64(0xFFFFFFFF)).astype(np.float64) / 2.0 ** 32
     want_c = np.rint(np.ldexp(h.astype(np.float64), E) * np.cos(th)).astype(np.int64)
     want_s = np.rint(np.ldexp(h.astype(np.float64), E) * np.sin(th)).astype(np.int64)
-    for t, want in ((0, want_c), (1, want_s), (2, -want_s)):
+    # table 0 = [c ; s], table 1 = [-s ; c]: rows 0 and 8 are the bands of the block's first output (tt = c = hist - k)
+    for t, row, want in ((0, 0, want_c), (0, 8, want_s), (1, 0, -want_s), (1, 8, want_c)):
         T = band(tabs[t])
-        H = np.array([sum(int(T[j, 0, 64 - k]) << (8 * j) for j in range(4)) for k in range(56)])   # row 0: tt = c = hist - k
-        assert np.abs(H - want).max() <= 1, t                                                    # (rint vs llround on exact halves)
+        H = np.array([sum(int(T[j, row, 64 - k]) << (8 * j) for j in range(4)) for k in range(56)])
+        assert np.abs(H - want).max() <= 1, (t, row)                                             # (rint vs llround on exact halves)
+    T = band(tabs[0])                                            # rows r and r + 8: the same band, eight samples further on per row
+    assert np.array_equal(T[:, 3, 24:24 + 64], T[:, 0, 0:64]) and np.array_equal(T[:, 11, 24:24 + 64], T[:, 8, 0:64])
     unit = np.ldexp(1.0, -E) / 8388607.0
     assert abs(scale - unit) <= 1e-7 * unit
     assert abs(ct[0] - float(want_c.sum() - want_s.sum()) * 32896.0 * unit) <= 1e-6 * abs(ct[0]) + 1e-9
@@ -178,9 +192,10 @@ def test_restated_fused_pair_matches_the_oracle(pkg, O, mix):
 
 
 def test_extremes_stay_inside_the_accumulators(pkg, O):
-    """mode 2 adds two band products into one accumulator set: taps of one sign at the 64-tap limit, samples at the
-    extremes, a tuning word that keeps cos and sin near 0.7 -- the accumulators stay below 2^24 (exact float conversion)"""
-    h = (np.ones(64, np.float32) / 64 * (1 + 1e-3 * np.arange(64))).astype(np.float32)
+    """mode 2 adds two band products into one accumulator set: taps of one sign at the 128-tap limit, samples at the
+    extremes, a tuning word that keeps cos and sin near 0.7 -- the accumulators stay below 2^24 (exact float conversion;
+    asserted inside restated_first_stage)"""
+    h = (np.ones(128, np.float32) / 128 * (1 + 1e-3 * np.arange(128))).astype(np.float32)
     freg = 1 << 29                                                # 45 degrees per sample
     ns = 8 * 200
     v = np.full((ns, 2), (1 << 23) - 1, np.int64)
@@ -189,8 +204,8 @@ def test_extremes_stay_inside_the_accumulators(pkg, O):
     for i in range(3):
         b[:, :, i] = (v >> (8 * i)) & 0xFF
     packed = b.reshape(-1)
-    tabs, scale, ct = tables(pkg, h, 64, True, freg)
-    y = rotate(restated_first_stage(tabs, scale, ct, 64, packed, True), freg, 8).reshape(-1)
+    tabs, scale, ct = tables(pkg, h, 128, True, freg)
+    y = rotate(restated_first_stage(tabs, scale, ct, 128, packed, True), freg, 8).reshape(-1)
     ref = O.ddc_chain(packed, [(8, h)], freg=freg, mix=True)
     assert O.rel_err(y, ref) <= 3e-7, O.rel_err(y, ref)
 
@@ -207,9 +222,10 @@ def test_tables_refuse_what_they_cannot_hold(pkg):
 
     assert call(60, 64, 1, buf.nbytes) < 0                          # all-zero taps
     h[5] = 0.25
-    assert call(60, 64, 1, buf.nbytes) == 3
+    assert call(60, 64, 1, buf.nbytes) == 2
     assert call(60, 128, 1, buf.nbytes) == 2
+    assert call(60, 256, 1, buf.nbytes) == 2
     assert call(60, 64, 0, buf.nbytes) == 1
     assert call(60, 32, 1, buf.nbytes) < 0                          # more taps than the history reaches
     assert call(60, 96, 1, buf.nbytes) < 0                          # no such geometry
-    assert call(60, 64, 1, 3 * 4 * 3 * 1024 - 1) < 0                # buffer too small
+    assert call(60, 64, 1, 2 * 4 * 2 * 1024 - 1) < 0                # buffer too small
