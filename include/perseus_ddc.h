@@ -231,6 +231,12 @@ int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples_in);
  * uQ = gs * xI + gc * xQ.  Returns the number of tables written (1 or 2).                                           */
 int pddc_fir_i8x_tables(const float *taps, int ntaps, int hist, int mix, uint32_t freg, int8_t *tables, size_t tables_bytes,
                         float *scale, float *ct /* [2] */);
+/* ... the same for the tuned decimate-by-10 first stage (the 1.6 MS/s plan's; hist = 64, columns of 8 outputs 80 samples
+ * apart, 3 k-steps): tt = c - 10 (r & 7); the taps delayed by `delay` = 0 .. 7 samples, g[k] = h[k - delay] e^{+j theta k},
+ * which is how a batch whose first output does not fall on a multiple of 8 samples is put on the loaders' 8-sample groups
+ * (ntaps + delay <= 64).  Two tables of 4 * 3 * 1024 bytes. */
+int pddc_fir_i8x_d10_tables(const float *taps, int ntaps, int delay, uint32_t freg, int8_t *tables, size_t tables_bytes,
+                            float *scale, float *ct /* [2] */);
 /* ... and the fused second stage's taps: out[i] = Re g2[64 - i], out[68 + i] = Im g2[64 - i], i = 0 .. 64,
  * g2[k] = h2[k] e^{+j 8 theta k} (a first-stage output is 8 input samples); 136 floats */
 int pddc_fir_i8x_taps2(const float *taps2, int ntaps2, int mix, uint32_t freg, float *out, size_t out_len);

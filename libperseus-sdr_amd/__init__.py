@@ -130,6 +130,9 @@ def ddc_lib() -> C.CDLL:
     L.pddc_fir_i8x_tables.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_uint32, vp, sz,
                                       C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.pddc_fir_i8x_tables.restype = C.c_int
+    L.pddc_fir_i8x_d10_tables.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_uint32, vp, sz,
+                                          C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.pddc_fir_i8x_d10_tables.restype = C.c_int
     L.pddc_fir_i8x_taps2.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_float), sz]
     L.pddc_fir_i8x_taps2.restype = C.c_int
     L.pddc_pipeline_set_option.argtypes = [vp, C.c_char_p, C.c_int]

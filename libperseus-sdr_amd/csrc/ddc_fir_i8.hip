@@ -455,13 +455,15 @@ using i8::swz;
 constexpr int TILE = 8192;
 constexpr int kTaps2Len = 68;                  /* floats per rail of the second stage's tap table (65 used) */
 
-template <int HIST, int MODE, bool FUSE2>
+/* D: the decimation -- 8, or 10 for the tuned form with paired rows (mode 2): a tile is 1024 outputs = 1024 D samples */
+template <int HIST, int MODE, bool FUSE2, int D = 8>
 struct Geo {
     static constexpr int EXTRA = FUSE2 ? 512 : 0;                   /* samples in front of the history: the porch's columns */
     static constexpr int FRONT = EXTRA + HIST;
-    static constexpr int SPAN = TILE + FRONT, PLANE = SPAN + 16 * ((SPAN + 127) / 128);
-    /* the band of a row block: 16 outputs (modes 0, 1) or 8 outputs x the two tap sets (mode 2), 8 samples apart, + HIST */
-    static constexpr int KSTEPS = ((MODE == 2 ? 56 : 120) + HIST + 63) / 64;
+    static constexpr int TILE_S = 1024 * D;                         /* samples per tile */
+    static constexpr int SPAN = TILE_S + FRONT, PLANE = SPAN + 16 * ((SPAN + 127) / 128);
+    /* the band of a row block: 16 outputs (modes 0, 1) or 8 outputs x the two tap sets (mode 2), D samples apart, + HIST */
+    static constexpr int KSTEPS = ((MODE == 2 ? 7 : 15) * D + HIST + 63) / 64;
     static constexpr int HG = HIST / 8, FG = FRONT / 8;              /* history groups of 8 samples; with the extra ones */
     static constexpr int NARR = MODE == 1 ? 4 : 2;
     static constexpr int PORCH = FUSE2 ? 64 : 0;
@@ -470,6 +472,7 @@ struct Geo {
     static constexpr int NTAB = MODE == 0 ? 1 : 2;
     static constexpr int TABV = 4 * KSTEPS * 64;                     /* v4i entries per tap table */
     static_assert(MODE != 2 || HIST <= 128, "two paired tables of 5 k-steps do not fit the registers");
+    static_assert(D == 8 || (D == 10 && MODE == 2 && !FUSE2), "decimate-by-10: the tuned paired-rows form only");
     static_assert(!(FUSE2 && MODE == 1), "the fused second stage reads complete u values");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(FG <= 128, "front groups are loaded by the first loader waves");
@@ -518,9 +521,10 @@ __device__ __forceinline__ void put_planes(const uint4 (&r)[3], uint8_t *plane, 
 /* the loads of group g = lt + 512 q (q = 0, 1) of tile t: batch samples 8192 t + 8 g .. + 8, zeros behind the batch.
  * (Plain loads: a lane's three 16-byte loads share their cache lines with its neighbours' -- as NONTEMPORAL loads the lines
  * are fetched again and again: 0.3205 -> 0.4293 ms for the untuned 127-tap stage, same box, tools/ab_i8x.sh.)          */
+template <int TILE_S = TILE>
 __device__ __forceinline__ void issue_group(const FirI8xArgs &a, long long t, int g, uint4 (&r)[3])
 {
-    const long long b = t * TILE + 8LL * g;
+    const long long b = t * TILE_S + 8LL * g + a.in_off;
     if (b + 8 <= a.n_in) {
         const uint4 *p = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + b * 6);
         r[0] = p[0];
@@ -533,11 +537,16 @@ __device__ __forceinline__ void issue_group(const FirI8xArgs &a, long long t, in
 
 /* the groups in front of a chunk's first tile t: front group g (0 .. FG) = samples 8192 t - FRONT + 8 g ..; groups below
  * `g0` are not needed (no porch columns: not FUSE2, or the batch's first tile).  From the stream's history for t = 0. */
-template <int HIST, int FRONT>
+template <int HIST, int FRONT, int TILE_S = TILE>
 __device__ __forceinline__ void issue_front(const FirI8xArgs &a, long long t, int g, uint4 (&r)[3])
 {
-    const long long b = t * TILE - FRONT + 8LL * g;
-    const uint4 *p = b < 0 ? reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.hist) + (b + HIST) * 6)
+    const long long b = t * TILE_S - FRONT + 8LL * g + a.in_off;
+    const int hl = a.hist_len ? a.hist_len : HIST;                   /* samples the history buffer holds (in front of a.in) */
+    if (b < -(long long)hl) {                                       /* in front of the history: only zero taps reach there */
+        r[0] = r[1] = r[2] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    const uint4 *p = b < 0 ? reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.hist) + (b + hl) * 6)
                            : reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + b * 6);
     r[0] = p[0];
     r[1] = p[1];
@@ -583,21 +592,24 @@ __device__ __forceinline__ float recombine(const v4i_t (&acc)[4], int v)
  * (Tried: matrix and dedicated post waves on two SIMDs, six loader waves with the vector port to themselves on the other
  * two -- a matrix instruction holds its SIMD's vector issue port for 8 of its 16 cycles, which costs the loaders beside it
  * 0.05 ms per 2^28 samples -- but six loader waves stream worse than eight: 0.39 ms for every form.)                 */
-template <int LAYOUT>
+template <int LAYOUT, int D = 8>
 struct Roles {
     static constexpr int NLT = 512;                            /* loader threads */
     static constexpr int NPT = LAYOUT == 0 ? 256 : LAYOUT == 1 ? 512 : 128;       /* threads that finish a tile */
-    static constexpr int NQ = 2;                               /* main groups per loader thread and tile */
+    static constexpr int NGRP = 128 * D;                       /* main groups of 8 samples per tile */
+    static constexpr int NQ = (NGRP + NLT - 1) / NLT;          /* ... per loader thread (the last round may be partial) */
 };
 
 /* the block's work; `nblk` blocks walk this stream's tiles, this is block `blk` of them (k_fir_i8x: the grid; k_fir_i8x_many:
  * the grid's x dimension, one stream per y) */
-template <int HIST, int MODE, bool FUSE2, int LAYOUT>
+template <int HIST, int MODE, bool FUSE2, int LAYOUT, int D = 8>
 __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long ntiles, int C, long long nblk, long long blk)
 {
     using namespace i8x;
-    using G = Geo<HIST, MODE, FUSE2>;
-    using R = Roles<LAYOUT>;
+    using G = Geo<HIST, MODE, FUSE2, D>;
+    using R = Roles<LAYOUT, D>;
+    constexpr int TILE_S = G::TILE_S, NGRP = R::NGRP;
+    constexpr bool PART = NGRP % R::NLT != 0;                  /* the last round of main groups is a partial one */
     constexpr int PLANE = G::PLANE, KSTEPS = G::KSTEPS, AS = G::AS, NARR = G::NARR, PORCH = G::PORCH, EXTRA = G::EXTRA,
                   FRONT = G::FRONT, NLT = R::NLT, NPT = R::NPT, NQ = R::NQ;
     constexpr bool MIX = MODE != 0;
@@ -608,7 +620,7 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
     const Walk wk{ ntiles, nblk, C };
     Cursor cur{ blk, 0 };
     const uint32_t n0lo = (uint32_t)a.n0;
-    const long long n_out = a.n_in >> 3;
+    const long long n_out = a.n_out ? a.n_out : a.n_in >> 3;
 
     /* ---- finishing a tile whose values are in `arr` (after its barrier): non-FUSE2 combine, rotate, store float2 (thread
      * pt of NPT); FUSE2 the second stage and the porch copy.  GUARD: the batch's last tile (ragged end, hist2_out). */
@@ -646,7 +658,7 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
             }
             if (MIX) {
                 float c, s;
-                nco_lo((n0lo + 8u * (uint32_t)(t * 1024 + o)) * a.freg + a.phase_off, c, s);
+                nco_lo((n0lo + (uint32_t)D * (uint32_t)(t * 1024 + o)) * a.freg + a.phase_off, c, s);
                 rotate(uI, uQ, c, s);
             }
             if (!GUARD || o < left)
@@ -820,9 +832,10 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
         /* ---- loaders (waves 4..11): main groups two tiles ahead in two register sets, front groups one tile ahead;
          * LAYOUT 1: they also finish the tile before the one the matrix waves are working on */
         const int lt = tid - 256;
-        if (blk == 0 && a.hist_out) {             /* the next call's history: the batch's last HIST samples */
-            const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + (a.n_in - HIST) * 6);
-            if (lt < HIST * 6 / 16)
+        if (blk == 0 && a.hist_out) {             /* the next call's history: the batch's last HIST (hist_len) samples */
+            const int hl = a.hist_len ? a.hist_len : HIST;
+            const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + (a.n_in - hl) * 6);
+            if (lt < hl * 6 / 16)
                 static_cast<uint4 *>(a.hist_out)[lt] = src[lt];
         }
         /* front groups a chunk's first tile t needs: all FG with the porch columns (FUSE2, t > 0), else the last HG */
@@ -830,20 +843,24 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
         uint4 ra[NQ][3], rb[NQ][3], rf[3];
         Cursor c0 = cur, c1 = wk.next(c0), c2 = wk.next(c1);
         long long t = wk.tile(c0), t1 = wk.tile(c1), t2 = wk.tile(c2), tp = -1;
+        auto has = [&](int q) __attribute__((always_inline)) { return !PART || q < NQ - 1 || lt + NLT * q < NGRP; };
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            issue_group(a, t, lt + NLT * q, ra[q]);
+            if (has(q))
+                issue_group<TILE_S>(a, t, lt + NLT * q, ra[q]);
         if (lt < G::FG && lt >= front_lo(t)) {
-            issue_front<HIST, FRONT>(a, t, lt, rf);
+            issue_front<HIST, FRONT, TILE_S>(a, t, lt, rf);
             put_planes(rf, lds_i8x, PLANE, swz(8 * lt));
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            put_planes(ra[q], lds_i8x, PLANE, swz(FRONT + 8 * (lt + NLT * q)));
+            if (has(q))
+                put_planes(ra[q], lds_i8x, PLANE, swz(FRONT + 8 * (lt + NLT * q)));
         if (t1 >= 0) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-                issue_group(a, t1, lt + NLT * q, ra[q]);
+                if (has(q))
+                    issue_group<TILE_S>(a, t1, lt + NLT * q, ra[q]);
         }
         __syncthreads();
         /* one step: tile `tn` (already in `cur_r`) goes into plane set `dst` while the matrix waves work on `src`; the loads
@@ -852,12 +869,14 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
                         const uint8_t *src) {
             const bool ff = tn_first && lt < G::FG && lt >= front_lo(tn);
             if (ff)
-                issue_front<HIST, FRONT>(a, tn, lt, rf);
+                issue_front<HIST, FRONT, TILE_S>(a, tn, lt, rf);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int g = lt + NLT * q;
+                if (!has(q))
+                    continue;
                 if (tnn >= 0)
-                    issue_group(a, tnn, g, nxt[q]);
+                    issue_group<TILE_S>(a, tnn, g, nxt[q]);
                 __builtin_amdgcn_sched_barrier(0);
                 put_planes(cur_r[q], dst, PLANE, swz(FRONT + 8 * g));
                 __builtin_amdgcn_sched_barrier(0);
@@ -866,7 +885,7 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
                 put_planes(rf, dst, PLANE, swz(8 * lt));
             } else if (!tn_first && lt < G::HG) {
                 /* inside a chunk: the history comes over from the plane set of the tile before */
-                const int s_at = swz(FRONT + TILE - HIST + 8 * lt), d_at = swz(EXTRA + 8 * lt);
+                const int s_at = swz(FRONT + TILE_S - HIST + 8 * lt), d_at = swz(EXTRA + 8 * lt);
 #pragma unroll
                 for (int pl = 0; pl < 6; ++pl)
                     *reinterpret_cast<uint2 *>(dst + pl * PLANE + d_at) = *reinterpret_cast<const uint2 *>(src + pl * PLANE + s_at);
@@ -1066,19 +1085,19 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
         const uint8_t *pb = lds_i8x + buf * 6 * PLANE;
         float *arr = arr_base + buf * NARR * AS, *arr_o = arr_base + (buf ^ 1) * NARR * AS;
         if (MODE == 2) {
-            /* columns of 8 outputs, 64 samples apart: 128 of them in a tile, 16 per pass; every matrix wave makes both rails.
+            /* columns of 8 outputs, 8 D = 64 (80) samples apart: 128 of them in a tile, 16 per pass; every matrix wave makes both rails.
              * Output o = 8 col + 4 (kq & 1) + v lies at array position o + PORCH. */
             constexpr int NMW = LAYOUT == 2 ? 2 : 4;
             if (FUSE2 && first && t > 0 && wave == NMW - 1) {
                 /* a chunk's first tile computes its own porch: columns -8 .. -1 in lanes 8..15; the other lanes repeat column
                  * -8 (same operand bytes, same results, same address: the whole wave runs the matrix instructions) */
                 const int colx = n < 8 ? -8 : n - 16, pp = 64 + 8 * colx + 4 * (kq & 1);
-                band(pb, EXTRA + 64 * colx + 16 * kq, arr + 20 * (pp >> 4) + (pp & 15));
+                band(pb, EXTRA + 8 * D * colx + 16 * kq, arr + 20 * (pp >> 4) + (pp & 15));
             }
 #pragma unroll
             for (int cb = 0; cb < 8 / NMW; ++cb) {
                 const int col = 16 * ((8 / NMW) * wave + cb) + n, pp = PORCH + 8 * col + 4 * (kq & 1);
-                band(pb, EXTRA + 64 * col + 16 * kq, arr + 20 * (pp >> 4) + (pp & 15));
+                band(pb, EXTRA + 8 * D * col + 16 * kq, arr + 20 * (pp >> 4) + (pp & 15));
             }
         } else {
         if (FUSE2 && first && t > 0 && (LAYOUT == 2 || half == 1)) {
@@ -1101,10 +1120,10 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
     }
 }
 
-template <int HIST, int MODE, bool FUSE2, int LAYOUT>
+template <int HIST, int MODE, bool FUSE2, int LAYOUT, int D = 8>
 __global__ __launch_bounds__(768, 1) void k_fir_i8x(FirI8xArgs a, long long ntiles, int C)
 {
-    fir_i8x_block<HIST, MODE, FUSE2, LAYOUT>(a, ntiles, C, (long long)gridDim.x, (long long)blockIdx.x);
+    fir_i8x_block<HIST, MODE, FUSE2, LAYOUT, D>(a, ntiles, C, (long long)gridDim.x, (long long)blockIdx.x);
 }
 
 /* several streams, one launch (the gang: receivers that share a GPU): blockIdx.y is the stream, every record its own --
@@ -1165,7 +1184,7 @@ static bool i8_fill_table(const long long *H, int hist, int8_t *table)
 /* mode 2: the same digits with the two tap sets of a row block in ONE operand -- rows 0..7 the band of `top` over eight
  * outputs, rows 8..15 the band of `bot` over the same eight: lane l of k-step ks holds A[row l & 15][k = 16 (l >> 4) + jj],
  * T[r][c] = H_(r >> 3)[hist - (c - 8 (r & 7))] */
-static bool i8_fill_table_paired(const long long *top, const long long *bot, int hist, int8_t *table)
+static bool i8_fill_table_paired(const long long *top, const long long *bot, int hist, int8_t *table, int D = 8)
 {
     std::vector<int8_t> dig(8 * (size_t)hist);
     for (int set = 0; set < 2; ++set)
@@ -1179,12 +1198,12 @@ static bool i8_fill_table_paired(const long long *top, const long long *bot, int
                 r = (r - d) / 256;
             }
         }
-    const int ksteps = (56 + hist + 63) / 64;
+    const int ksteps = (7 * D + hist + 63) / 64;
     for (int j = 0; j < 4; ++j)
         for (int ks = 0; ks < ksteps; ++ks)
             for (int l = 0; l < 64; ++l)
                 for (int jj = 0; jj < 16; ++jj) {
-                    const int r = l & 15, c = 64 * ks + 16 * (l >> 4) + jj, tt = c - 8 * (r & 7);
+                    const int r = l & 15, c = 64 * ks + 16 * (l >> 4) + jj, tt = c - D * (r & 7);
                     table[(((size_t)j * ksteps + ks) * 64 + l) * 16 + jj] =
                         (tt >= 1 && tt <= hist) ? dig[((size_t)(r >> 3) * 4 + j) * hist + (hist - tt)] : 0;
                 }
@@ -1201,10 +1220,29 @@ size_t fir_i8x_table_bytes(int hist, bool mix)
     return (size_t)(mode == 0 ? 1 : 2) * 4 * ksteps * 64 * 16;
 }
 
+static bool build_tables_core(const float *taps, int ntaps, int hist, bool mix, uint32_t freg, int8_t *tables, float *scale,
+                              float ct[2], int *exp2, int D, int delay);
+
 bool fir_i8x_build_tables(const float *taps, int ntaps, int hist, bool mix, uint32_t freg, int8_t *tables, float *scale,
                           float ct[2], int *exp2)
 {
-    if (!taps || ntaps < 1 || (hist != 32 && hist != 64 && hist != 128 && hist != 256) || ntaps > hist || !tables)
+    return build_tables_core(taps, ntaps, hist, mix, freg, tables, scale, ct, exp2, 8, 0);
+}
+
+size_t fir_i8x_d10_table_bytes() { return (size_t)2 * 4 * ((70 + kFirI8xD10Hist + 63) / 64) * 64 * 16; }
+
+bool fir_i8x_d10_build_tables(const float *taps, int ntaps, int delay, uint32_t freg, int8_t *tables, float *scale, float ct[2])
+{
+    return build_tables_core(taps, ntaps, kFirI8xD10Hist, true, freg, tables, scale, ct, nullptr, 10, delay);
+}
+
+/* taps h[0 .. ntaps) delayed by `delay` samples: g[k] = h[k - delay] e^{+j theta k} (D = 8: delay = 0) */
+static bool build_tables_core(const float *taps, int ntaps, int hist, bool mix, uint32_t freg, int8_t *tables, float *scale,
+                              float ct[2], int *exp2, int D, int delay)
+{
+    if (!taps || ntaps < 1 || (hist != 32 && hist != 64 && hist != 128 && hist != 256) || delay < 0 || ntaps + delay > hist || !tables)
+        return false;
+    if (D != 8 && !(D == 10 && mix && hist == kFirI8xD10Hist))
         return false;
     double hmax = 0.0;
     for (int k = 0; k < ntaps; ++k)
@@ -1215,15 +1253,16 @@ bool fir_i8x_build_tables(const float *taps, int ntaps, int hist, bool mix, uint
     if (exp2)
         *exp2 = E;
     const int mode = fir_i8x_mode(hist, mix);
-    const size_t tb = (size_t)4 * fir_i8x_ksteps(hist, mode) * 64 * 16;
+    const size_t tb = (size_t)4 * (D == 8 ? fir_i8x_ksteps(hist, mode) : (7 * D + hist + 63) / 64) * 64 * 16;
     /* sample = v24 / 8388607 (perseustest.c:466-502); planes 0 and 1 are stored minus 128: V = planes + 32896 */
     const double unit = std::ldexp(1.0, -E) / 8388607.0;
     *scale = (float)unit;
     std::vector<long long> Hc((size_t)hist, 0), Hs((size_t)hist, 0), Hm((size_t)hist, 0);
     long long sc = 0, ss = 0;
     const double w = 6.283185307179586476925286766559 / 4294967296.0;
-    for (int k = 0; k < ntaps; ++k) {
-        const double hk = std::ldexp((double)taps[k], E);
+    for (int kk = 0; kk < ntaps; ++kk) {
+        const int k = kk + delay;
+        const double hk = std::ldexp((double)taps[kk], E);
         if (mix) {
             const double th = w * (double)(uint32_t)((uint64_t)k * freg);
             Hc[k] = std::llround(hk * std::cos(th));
@@ -1237,7 +1276,8 @@ bool fir_i8x_build_tables(const float *taps, int ntaps, int hist, bool mix, uint
     }
     if (mode == 2) {
         /* [c ; s] meets the I planes, [-s ; c] the Q planes, both into the same accumulators: rows 0..7 uI, rows 8..15 uQ */
-        if (!i8_fill_table_paired(Hc.data(), Hs.data(), hist, tables) || !i8_fill_table_paired(Hm.data(), Hc.data(), hist, tables + tb))
+        if (!i8_fill_table_paired(Hc.data(), Hs.data(), hist, tables, D) ||
+            !i8_fill_table_paired(Hm.data(), Hc.data(), hist, tables + tb, D))
             return false;
     } else {
         if (!i8_fill_table(Hc.data(), hist, tables))
@@ -1269,12 +1309,12 @@ void fir_i8x_taps2(const float *taps2, int ntaps2, bool mix, uint32_t freg, floa
     }
 }
 
-template <int HIST, int MODE, bool FUSE2, int LAYOUT>
+template <int HIST, int MODE, bool FUSE2, int LAYOUT, int D = 8>
 static hipError_t launch_fir_i8x_l(const FirI8xArgs &a, int max_blocks, int chunk, hipStream_t s, const FirI8xMany *many = nullptr,
                                    int nmany = 0)
 {
-    using G = i8x::Geo<HIST, MODE, FUSE2>;
-    const long long ntiles = (a.n_in + i8x::TILE - 1) / i8x::TILE;
+    using G = i8x::Geo<HIST, MODE, FUSE2, D>;
+    const long long ntiles = D == 8 ? (a.n_in + i8x::TILE - 1) / i8x::TILE : (a.n_out + 1023) / 1024;
     int dev = 0;
     (void)hipGetDevice(&dev);
     static int cus[64] = { 0 };
@@ -1283,12 +1323,13 @@ static hipError_t launch_fir_i8x_l(const FirI8xArgs &a, int max_blocks, int chun
         hipError_t e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess)
             return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_i8x<HIST, MODE, FUSE2, LAYOUT>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_i8x<HIST, MODE, FUSE2, LAYOUT, D>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
         if (e != hipSuccess)
             return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_i8x_many<HIST, MODE, FUSE2, LAYOUT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        if (D == 8)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_i8x_many<HIST, MODE, FUSE2, LAYOUT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
         if (e != hipSuccess)
             return e;
         cus[dev & 63] = v > 0 ? v : 256;
@@ -1305,11 +1346,11 @@ static hipError_t launch_fir_i8x_l(const FirI8xArgs &a, int max_blocks, int chun
         C = (ntiles + nblk - 1) / nblk;
     const long long nchunks = (ntiles + C - 1) / C;
     const long long grid = nchunks < nblk ? nchunks : nblk;
-    if (many)
+    if (many && D == 8)
         hipLaunchKernelGGL((k_fir_i8x_many<HIST, MODE, FUSE2, LAYOUT>), dim3((unsigned)grid, (unsigned)nmany), dim3(768), G::LDS_BYTES, s,
                            *many, ntiles, (int)C);
     else
-        hipLaunchKernelGGL((k_fir_i8x<HIST, MODE, FUSE2, LAYOUT>), dim3((unsigned)grid), dim3(768), G::LDS_BYTES, s, a, ntiles, (int)C);
+        hipLaunchKernelGGL((k_fir_i8x<HIST, MODE, FUSE2, LAYOUT, D>), dim3((unsigned)grid), dim3(768), G::LDS_BYTES, s, a, ntiles, (int)C);
     return hipGetLastError();
 }
 
@@ -1368,6 +1409,19 @@ hipError_t launch_fir_i8x(const FirI8xArgs &a, int hist, bool mix, bool fuse2, h
     default:
         return launch_fir_i8x_h<256>(a, mix, fuse2, max_blocks, chunk, layout, s);
     }
+}
+
+hipError_t launch_fir_i8x_d10(const FirI8xArgs &a, hipStream_t s, int max_blocks, int chunk, int layout)
+{
+    if (a.n_out <= 0)
+        return hipSuccess;
+    if ((a.n_in & 7) || (a.in_off & 7) || a.in_off < 0 || !a.in || !a.hist || !a.out || !a.atab || a.taps2 ||
+        (a.hist_out && a.n_in < a.hist_len) ||
+        a.hist_len < 8 || (a.hist_len & 7) || (long long)a.in_off - 7 + 10 * (a.n_out - 1) >= a.n_in)
+        return hipErrorInvalidValue;
+    return layout == 1   ? launch_fir_i8x_l<kFirI8xD10Hist, 2, false, 1, 10>(a, max_blocks, chunk, s)
+           : layout == 2 ? launch_fir_i8x_l<kFirI8xD10Hist, 2, false, 2, 10>(a, max_blocks, chunk, s)
+                         : launch_fir_i8x_l<kFirI8xD10Hist, 2, false, 0, 10>(a, max_blocks, chunk, s);
 }
 
 hipError_t launch_fir_i8x_many(const FirI8xMany &m, int n, int hist, bool mix, bool fuse2, hipStream_t s, int max_blocks, int chunk,

@@ -195,6 +195,10 @@ struct FirI8xArgs {
     const float *taps2 = nullptr;   /* fused second stage: fir_i8x_taps2 (kFirI8xTaps2Len floats, device)  */
     const void  *hist2 = nullptr;   /* the 64 first-stage outputs (float2) in front of the batch           */
     void        *hist2_out = nullptr;
+    /* decimate-by-10 (launch_fir_i8x_d10; zero otherwise): output m of the batch is sum_k g[k] x[in_off + 10 m - k] */
+    long long    n_out = 0;         /* outputs to store (0: n_in / 8)                                       */
+    int          in_off = 0;        /* batch sample the first output's window ends on: a multiple of 8      */
+    int          hist_len = 0;      /* samples the history buffer holds (0: the geometry's `hist`)           */
 };
 constexpr int kFirI8xTaps2Len = 2 * 68;
 /* n streams (same geometry and batch length), one launch: blockIdx.y is the stream (the gang) */
@@ -207,6 +211,14 @@ size_t fir_i8x_table_bytes(int hist, bool mix);
 /* host: the tap operand(s) for `ntaps` <= hist taps, NCO word freg when mix; false if the taps are all zero */
 bool fir_i8x_build_tables(const float *taps, int ntaps, int hist, bool mix, uint32_t freg, int8_t *tables, float *scale,
                           float ct[2], int *exp2 = nullptr);
+/* The tuned decimate-by-10 first stage (the 1.6 MS/s plan's) on the same kernel: paired rows, columns of 8 outputs 80
+ * samples apart, tiles of 10240 samples, hist = 64.  A batch's first output need not sit on a multiple of 8 samples (the
+ * stream's decimation phase: `first` = 0 .. 9), the loaders' groups do: the taps are delayed by `delay` = (-first) mod 8
+ * samples -- g[k] = h[k - delay] e^{+j theta k}, ntaps + delay <= 64 -- and the windows end on in_off = first + delay. */
+constexpr int kFirI8xD10Hist = 64;
+bool fir_i8x_d10_build_tables(const float *taps, int ntaps, int delay, uint32_t freg, int8_t *tables, float *scale, float ct[2]);
+size_t fir_i8x_d10_table_bytes();
+hipError_t launch_fir_i8x_d10(const FirI8xArgs &a, hipStream_t s, int max_blocks = 0, int chunk = 0, int layout = -1);
 /* host: the second stage's taps (<= 64) as the kernel reads them: complex g2[k] = h2[k] e^{+j 8 theta k}, descending */
 void fir_i8x_taps2(const float *taps2, int ntaps2, bool mix, uint32_t freg, float *out /* kFirI8xTaps2Len */);
 bool fir_i8x_supported(int hist, bool mix, bool fuse2);

@@ -206,6 +206,16 @@ struct pddc_pipeline {
         unsigned taps_ver = 0;
         hipStream_t stream = nullptr;
         float scale = 0.0f, ct[2] = { 0.0f, 0.0f };
+        /* the decimate-by-10 form: one table set per delay 0 .. 7 of the taps (a batch's decimation phase), built when first
+         * needed for the present word and taps and kept -- the phases of a stream's batches come round again */
+        struct D10 {
+            void *d = nullptr, *h = nullptr;
+            bool valid = false;
+            uint32_t freg = 0;
+            unsigned taps_ver = 0;
+            hipStream_t stream = nullptr;
+            float scale = 0.0f, ct[2] = { 0.0f, 0.0f };
+        } d10[8];
     } i8x;
     unsigned taps_ver = 1;        /* bumped whenever a stage's taps change */
 };
@@ -455,6 +465,18 @@ int pddc_fir_i8x_tables(const float *taps, int ntaps, int hist, int mix, uint32_
     if (!fir_i8x_build_tables(taps, ntaps, hist, mix != 0, freg, tables, scale, ct))
         return fail(PDDC_EINVAL, "taps cannot be quantised (all zero, not finite, or more than hist)");
     return fir_i8x_mode(hist, mix != 0) == 0 ? 1 : 2;
+}
+
+int pddc_fir_i8x_d10_tables(const float *taps, int ntaps, int delay, uint32_t freg, int8_t *tables, size_t tables_bytes,
+                            float *scale, float *ct)
+{
+    if (!taps || !tables || !scale || !ct)
+        return fail(PDDC_EINVAL, "null argument");
+    if (tables_bytes < fir_i8x_d10_table_bytes())
+        return fail(PDDC_EINVAL, "tables need %zu bytes", fir_i8x_d10_table_bytes());
+    if (!fir_i8x_d10_build_tables(taps, ntaps, delay, freg, tables, scale, ct))
+        return fail(PDDC_EINVAL, "taps cannot be quantised (all zero, not finite, or ntaps + delay > %d)", kFirI8xD10Hist);
+    return 2;
 }
 
 int pddc_fir_i8x_taps2(const float *taps2, int ntaps2, int mix, uint32_t freg, float *out, size_t out_len)
@@ -1088,6 +1110,12 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
         hipEventDestroy(e.first);
         hipEventDestroy(e.second);
     }
+    for (auto &e : p->i8x.d10) {
+        if (e.d)
+            hipFree(e.d);
+        if (e.h)
+            hipHostFree(e.h);
+    }
     for (auto &sl : p->i8x.slot) {
         if (sl.d)
             hipFree(sl.d);
@@ -1433,7 +1461,21 @@ static int stage0_i8_kind(const pddc_pipeline *p, size_t nsamples)
     return k;
 }
 
-int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples) { return p ? stage0_i8_kind(p, nsamples) : 0; }
+/* the tuned decimate-by-10 first stage (the 1.6 MS/s plan's) on k_fir_i8x's paired-rows form: up to 57 taps (the taps are
+ * delayed by up to 7 samples to put a batch's first window on a multiple of 8), one tuning word in the history window */
+static bool stage0_packed_generic(const pddc_pipeline *p);
+static bool i8x_d10_ok(const pddc_pipeline *p)
+{
+    const Stage &s0 = p->st[0];
+    return stage0_packed_generic(p) && (p->flags & PDDC_F_MIX) && p->opt.i8x && !p->opt.no_i8 && s0.decim == 10 && s0.interp == 1 &&
+           s0.ntaps + 7 <= kFirI8xD10Hist && s0.hist >= 8 && s0.hist % 8 == 0 && s0.hist <= kFirI8xD10Hist && s0.i8x_ok &&
+           words_in_window(p) == 1;
+}
+
+int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples)
+{
+    return !p ? 0 : i8x_d10_ok(p) && nsamples >= 8 ? 2 : stage0_i8_kind(p, nsamples);
+}
 
 /* a first stage that is a plain decimator but not the fused decimate-by-8 (e.g. the /10 of the
  * 1.6 MS/s plan): the generic kernel reads the packed samples itself (unpack and mix while it
@@ -1528,6 +1570,38 @@ static int i8x_prepare(pddc_pipeline *p, bool mix, bool fuse2, hipStream_t s, Fi
     q.n0 = p->n0;
     q.freg = word;
     q.phase_off = mix ? p->phase_off : 0u;
+    return PDDC_OK;
+}
+
+static int i8x_d10_prepare(pddc_pipeline *p, int delay, hipStream_t s, FirI8xArgs &q)
+{
+    pddc_pipeline::I8x::D10 &e = p->i8x.d10[delay & 7];
+    const Stage &s0 = p->st[0];
+    if (!(e.valid && e.freg == p->freg && e.taps_ver == p->taps_ver && e.stream == s)) {
+        const size_t nb = fir_i8x_d10_table_bytes();
+        if (!e.d) {
+            HIP_TRY(hipMalloc(&e.d, nb));
+            HIP_TRY(hipHostMalloc(&e.h, nb, hipHostMallocDefault));
+        }
+        if (e.valid)              /* a retune, new taps or another stream: whatever still reads (or copies) the old set must be through */
+            HIP_TRY(hipDeviceSynchronize());
+        e.valid = false;
+        if (!fir_i8x_d10_build_tables(s0.taps.data(), s0.ntaps, delay, p->freg, static_cast<int8_t *>(e.h), &e.scale, e.ct))
+            return fail(PDDC_EINVAL, "k_fir_i8x: the taps cannot be quantised (all zero, or not finite)");
+        HIP_TRY(hipMemcpyAsync(e.d, e.h, nb, hipMemcpyHostToDevice, s));
+        e.freg = p->freg;
+        e.taps_ver = p->taps_ver;
+        e.stream = s;
+        e.valid = true;
+    }
+    q.atab = e.d;
+    q.taps2 = nullptr;
+    q.scale = e.scale;
+    q.ct[0] = e.ct[0];
+    q.ct[1] = e.ct[1];
+    q.n0 = p->n0;
+    q.freg = p->freg;
+    q.phase_off = p->phase_off;
     return PDDC_OK;
 }
 
@@ -2255,7 +2329,26 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                 skip_from = 1;
             }
         } else if (i == 0 && stage0_packed_generic(p)) {
-            if (n_in[1] > 0) {
+            if (n_in[1] > 0 && i8x_d10_ok(p)) {
+                /* the matrix cores: the decimation phase of this batch (its first output's newest sample, 0 .. 9) goes into
+                 * the taps as a delay, so that the windows end on a multiple of 8 samples */
+                const int first = (int)off[0], delay = (8 - (first & 7)) & 7;
+                FirI8xArgs q;
+                if ((rc = i8x_d10_prepare(p, delay, s, q)))
+                    return rc;
+                q.in = d_packed;
+                q.hist = h_in;
+                q.hist_out = nsamples >= (size_t)st.hist ? h_out : nullptr;
+                q.out = static_cast<float *>(dst);
+                q.n_in = (long long)nsamples;
+                q.n_out = (long long)n_in[1];
+                q.in_off = first + delay;
+                q.hist_len = st.hist;
+                q.n0 = p->n0 + (unsigned long long)q.in_off;
+                HIP_TRY(launch_fir_i8x_d10(q, s, p->opt.i8x_blocks, p->opt.i8x_chunk, p->opt.i8x_layout));
+                x = d_packed;                 /* (a batch shorter than the history: the packed history moves on below) */
+                hist_done = q.hist_out != nullptr;
+            } else if (n_in[1] > 0) {
                 if (st.d_taps_firp)           /* register-blocked kernel for /4 /5 /10 */
                     HIP_TRY(launch_firp_packed(d_packed, h_in, st.hist, (long long)off[0], (long long)n_in[1], st.decim,
                                                st.d_taps_firp, st.ntaps, dst, h_out, (long long)nsamples, mix, p->n0,

@@ -266,3 +266,55 @@ def test_layouts_stay_clean_under_repetition(pkg, dev, O, layout):
                 first = y
                 assert O.rel_err(y, ref) <= FIR_TOL
             assert np.array_equal(y.view(np.uint32), first.view(np.uint32)), (layout, len(stages), rep)
+
+
+@pytest.mark.parametrize("ntaps", [51, 57, 20])
+def test_decimate_by_ten_first_stage_on_the_matrix_cores(pkg, dev, O, ntaps):
+    """The 1.6 MS/s plan's first stage (decimate by 10, tuned; perseus-sdr.c:776-892 picks the rate) on k_fir_i8x's paired
+    rows: batches of any multiple of 8 samples, so the decimation phase of a batch's first output walks through 0 .. 9
+    (it goes into the taps as a delay of 0 .. 7 samples); a retune sends the one batch behind it through the vector kernel;
+    with the plan's second stage behind it.  Against the oracle, and the kernel that ran is asserted."""
+    h1, h2 = lowpass(ntaps, 0.04), lowpass(117, 0.08)
+    sizes = [10240 * 3 + 8, 8, 10240 * 260 + 16, 64, 10240 * 2 + 24, 10240 * 5, 1016, 10240 * 300 + 8, 10240 * 7 + 32]
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    packed = O.lcg_bytes(6 * int(cuts[-1]), 77)
+    for stages in ([(10, h1)], [(10, h1), (5, h2)]):
+        rec = []
+        y = run(pkg, dev, stages, packed, cuts, record=rec)
+        assert all(int(k) == 2 for k, _ in rec), rec
+        ref = O.ddc_chain(packed, stages, freg=FREG, mix=True)
+        assert y.size == ref.size and O.rel_err(y, ref) <= FIR_TOL, (len(stages), O.rel_err(y, ref))
+        # the vector kernel on the same stream: the two agree to the tolerance's order, and i8x = 0 really is the other kernel
+        rec0 = []
+        y0 = run(pkg, dev, stages, packed, cuts, opts={"i8x": 0}, record=rec0)
+        assert all(int(k) == 0 for k, _ in rec0)
+        assert O.rel_err(y0, ref) <= FIR_TOL and not np.array_equal(y, y0)
+    # a retune between batches: sample-accurate and phase-continuous, as on every path
+    word2 = O.nco_freg(14.2e6)
+    rec = []
+    y = run(pkg, dev, [(10, h1), (5, h2)], packed, cuts, retune_at={3: word2, 6: FREG}, record=rec)
+    ref = O.ddc_chain_retuned(packed, [(10, h1), (5, h2)], [(0, FREG), (int(cuts[3]), word2), (int(cuts[6]), FREG)])
+    assert O.rel_err(y, ref) <= FIR_TOL, O.rel_err(y, ref)
+    assert [int(k) for k, _ in rec].count(0) >= 1 and [int(k) for k, _ in rec].count(2) >= 5, rec
+
+
+def test_decimate_by_ten_walks_and_checkpoint(pkg, dev, O):
+    """every walk / grid / layout of the decimate-by-10 form gives the same bits, and a checkpoint taken between batches
+    continues them"""
+    h1 = lowpass(51, 0.04)
+    n = 10240 * 70 + 24
+    packed = O.lcg_bytes(6 * 2 * n, 5)
+    outs = []
+    for opts in ({}, {"i8x_layout": 1}, {"i8x_layout": 2}, {"i8x_chunk": 3}, {"i8x_blocks": 7, "i8x_chunk": 2}):
+        outs.append(run(pkg, dev, [(10, h1)], packed, [0, n, 2 * n], opts=opts))
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    a = pkg.Pipeline([(10, h1)], mix=True)
+    a.set_freg(FREG)
+    y1 = a.process(to_dev(packed[:6 * n], dev)).cpu().numpy().reshape(-1)
+    blob = a.save_state()
+    b = pkg.Pipeline([(10, h1)], mix=True)
+    b.restore_state(blob)
+    y2 = b.process(to_dev(packed[6 * n:], dev)).cpu().numpy().reshape(-1)
+    assert np.array_equal(np.concatenate([y1, y2]), outs[0])
+    a.close()
+    b.close()

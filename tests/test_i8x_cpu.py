@@ -229,3 +229,57 @@ def test_tables_refuse_what_they_cannot_hold(pkg):
     assert call(60, 32, 1, buf.nbytes) < 0                          # more taps than the history reaches
     assert call(60, 96, 1, buf.nbytes) < 0                          # no such geometry
     assert call(60, 64, 1, 2 * 4 * 2 * 1024 - 1) < 0                # buffer too small
+
+
+@pytest.mark.parametrize("first", range(10))
+def test_restated_decimate_by_ten_matches_the_oracle_at_every_phase(pkg, O, first):
+    """The tuned decimate-by-10 first stage (the 1.6 MS/s plan's, perseus-sdr.c:776-892 picks the rate) on the paired-rows form:
+    columns of 8 outputs 80 samples apart, tt = c - 10 (r & 7), 3 k-steps, hist = 64.  A batch's first output may sit on any
+    sample 0 .. 9 (the stream's decimation phase), the loaders' groups sit on multiples of 8: the taps are delayed by
+    delay = (-first) mod 8, the windows end on in_off = first + delay, and the rotation takes the phase of THAT sample.
+    Restated from pddc_fir_i8x_d10_tables and compared with the oracle's mix-then-filter on the outputs
+    y[m] = sum_k h[k] (x LO)[first + 10 m - k]."""
+    L = pkg.ddc_lib()
+    h = lowpass(51, 0.04)
+    delay = (8 - first % 8) % 8
+    in_off = first + delay
+    tab = np.zeros(2 * 4 * 3 * 64 * 16, np.int8)
+    sc, ct = C.c_float(), (C.c_float * 2)()
+    assert pkg.check(L.pddc_fir_i8x_d10_tables(h.ctypes.data_as(C.POINTER(C.c_float)), h.size, delay, FREG, tab.ctypes.data,
+                                               tab.nbytes, C.byref(sc), ct)) == 2
+    Ts = [band(t) for t in tab.reshape(2, 4, 3, 64, 16)]
+    K = Ts[0].shape[2]
+    assert K == 192
+    ns = 8 * 500
+    packed = O.lcg_bytes(6 * ns, 21)
+    n_out = (ns - 1 - first) // 10 + 1
+    # planes of [64 zero samples of history | the batch from in_off on]
+    xp = byte_planes(packed[6 * in_off:], 64, K)
+    u = np.zeros((n_out, 2), np.float32)
+    for col in range((n_out + 7) // 8):
+        X = xp[:, 80 * col:80 * col + K, :]
+        acc = plane_products(Ts[0], X[:, :, 0]) + plane_products(Ts[1], X[:, :, 1])
+        assert np.abs(acc).max() < 1 << 24
+        y = recombine(acc) * np.float32(sc.value)
+        m = min(8, n_out - 8 * col)
+        u[8 * col:8 * col + m, 0] = (y[:8] + np.float32(ct[0]))[:m]
+        u[8 * col:8 * col + m, 1] = (y[8:] + np.float32(ct[1]))[:m]
+    # a stream that starts with this batch has zeros in front of sample 0: the window of output 0 reaches back to
+    # in_off - 63 < 0 only through zero taps or zero history, except that byte_planes() started the planes AT in_off:
+    # the first in_off samples of the batch are the history's last -- put them there
+    if in_off:
+        hist = byte_planes(packed[:6 * in_off], 64 - in_off, 0)[:, :64, :]
+        xp[:, :64, :] = hist
+        for col in range(2):                                     # only the first columns reach into the history
+            X = xp[:, 80 * col:80 * col + K, :]
+            acc = plane_products(Ts[0], X[:, :, 0]) + plane_products(Ts[1], X[:, :, 1])
+            y = recombine(acc) * np.float32(sc.value)
+            m = min(8, n_out - 8 * col)
+            u[8 * col:8 * col + m, 0] = (y[:8] + np.float32(ct[0]))[:m]
+            u[8 * col:8 * col + m, 1] = (y[8:] + np.float32(ct[1]))[:m]
+    y = rotate(u, FREG, 10, n0=in_off).reshape(-1)
+    # oracle: mix, then y[m] = sum_k h[k] x[first + 10 m - k]: its decimator gives outputs at 10 m' + 9 - ... -- take the
+    # full-rate filter output and pick the samples
+    full = O.ddc_chain(packed, [(1, h)], freg=FREG, mix=True).reshape(-1, 2)
+    ref = full[first::10][:n_out].reshape(-1)
+    assert y.size == ref.size and O.rel_err(y, ref) <= 3e-7, O.rel_err(y, ref)

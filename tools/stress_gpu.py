@@ -19,7 +19,8 @@ for it in range(n_iter):
     rng = np.random.default_rng(5000 + it)
     g = (rng.standard_normal(12 * 20) / 20).astype(np.float32)
     plans = [[(8, load_taps("d8_127"))], [(8, load_taps("d8_255"))], [(8, h1), (8, h2), (5, h3)], [(8, h1), (8, h2)],
-             [(8, h1), (5, h3[:41]), (25, g, 12)], [(10, h3[:77])], [(8, h2), (4, h1)], [(5, h3), (8, h1)]]
+             [(8, h1), (5, h3[:41]), (25, g, 12)], [(10, h3[:77])], [(8, h2), (4, h1)], [(5, h3), (8, h1)],
+             [(10, h3[:51]), (5, h3)], [(10, h3[:40])], [(8, load_taps("d8_127")), (8, h2)]]
     stages = plans[int(rng.integers(0, len(plans)))]
     os.environ["PDDC_FIR8_BLOCKS"] = str(int(rng.choice([1, 2, 3, 5, 16, 512])))
     dyn = int(rng.choice([-1, -1, 0, 10, 20, 50, 100]))          # -1: the library's own default schedule
