@@ -19,7 +19,7 @@ d["provenance"]["commit"] = head + (" + uncommitted changes under csrc/ (committ
 json.dump(d, open("profiles/pmc_traffic.json", "w"), indent=1)
 PY
 cp profiles/pmc_traffic.json $P/m_pmc_traffic_all_workloads.json
-for t in plan_rates plan_rates_overlap plan_rates_2p22 i8x_sizes i8x_layouts i8x_chunks i8x_plain i8x_plainsizes api_receivers; do
+for t in plan_rates plan_rates_overlap plan_rates_2p22 plan_rates_placed i8x_sizes i8x_layouts i8x_chunks i8x_plain i8x_plainsizes api_receivers; do
   [ -f $F/$t.txt ] && grep -v amdgpu.ids $F/$t.txt > $P/m_$t.txt
 done
 for t in pair 127nco 48nco; do [ -f $F/pmc_i8x_$t/pmc_summary.txt ] && cp $F/pmc_i8x_$t/pmc_summary.txt $P/m_pmc_summary_i8x_$t.txt; done
