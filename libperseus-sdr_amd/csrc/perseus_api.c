@@ -86,14 +86,7 @@ typedef struct {
 #define MAX_FAULTS 32
 #define MAX_RETUNES 256
 
-/* one batch's output inside the receiver's pinned output buffer (`fifo`): reserved when the batch is submitted -- the GPU
- * writes it there itself --, ready once its ticket has been waited for, consumed from the front by the callbacks */
-typedef struct {
-    int ticket;                 /* pddc staging slot                             */
-    size_t off, len;            /* bytes not yet delivered: fifo[off .. off+len) */
-} out_seg;
-#define MAX_SEG 8
-#define SEG_ALIGN 256u
+#include "out_segments.h"      /* out_seg, out_segs: where the output lies between the GPU and the callbacks */
 
 struct perseus_descr_ds {
     int index;
@@ -145,9 +138,7 @@ struct perseus_descr_ds {
     float *batch_out[2];        /* ring mode only (zc == 0): pipeline output of one batch */
     size_t out_cap;             /* a batch's output at most, in complex samples  */
     int cur;                    /* buffer pair the next batch goes into          */
-    out_seg seg[MAX_SEG];       /* outputs in `fifo`, oldest first from seg_head; the last n_pend still on the GPU */
-    int seg_head, seg_n;
-    int n_pend;
+    out_segs os;                /* the batches' outputs, oldest first; the last os.n_pend still on the GPU (out_segments.h) */
     int input_done;             /* the source has nothing more to give           */
     int gpu_source;             /* the LCG stream is generated on the device     */
     int batch_auto;             /* batch_samples was not chosen by the client (PERSEUS_AMD_BATCH, set_config): the library
@@ -165,8 +156,8 @@ struct perseus_descr_ds {
      * for 8192-sample batches -- keeps the byte ring of rounds 1-3 (zc == 0): batch buffer -> ring -> slot; there the
      * copies are a few hundred bytes a batch. */
     int zc;
-    uint8_t *fifo;
-    size_t fifo_len, fifo_cap;  /* ready bytes not yet delivered; size           */
+    uint8_t *fifo;              /* zc: the pinned output buffer (os.cap bytes, os.ready of them deliverable); else the byte ring */
+    size_t fifo_len, fifo_cap;  /* ring mode: bytes in the ring; its size        */
     size_t fifo_rd;             /* ring mode: read position                      */
     uint64_t adc_samples;       /* ADC-rate samples handed to the GPU so far     */
     uint64_t batches;
@@ -574,8 +565,6 @@ static int pump_wire(perseus_descr *d)
 }
 
 /* ---- DDC mode: ADC-rate batches -> GPU -> FIFO of decimated bytes -> transfers ---------- */
-static size_t seg_align(size_t x) { return (x + SEG_ALIGN - 1) & ~(size_t)(SEG_ALIGN - 1); }
-
 /* ring mode (zc == 0): a byte ring between the batch buffers and the transfers */
 static size_t ring_room(const perseus_descr *d) { return d->fifo_cap - d->fifo_len; }
 
@@ -604,84 +593,23 @@ static const uint8_t *fill_ring(perseus_descr *d, uint8_t *slot, size_t *got)
     return slot;
 }
 
-/* where the next batch's output (at most `worst` bytes, in one piece) can go: behind the newest segment, or -- when the
- * buffer's end is too near -- at its start, below the oldest one.  0: no room until the callbacks have consumed more. */
-static int fifo_reserve(const perseus_descr *d, size_t worst, size_t *off)
-{
-    size_t at = 0;
-    if (d->seg_n == MAX_SEG)
-        return 0;
-    if (d->seg_n > 0) {
-        const out_seg *h = &d->seg[d->seg_head], *l = &d->seg[(d->seg_head + d->seg_n - 1) % MAX_SEG];
-        const size_t start = h->off, wr = seg_align(l->off + l->len);
-        if (l->off < h->off) {                        /* the newest already lies below the oldest */
-            if (wr > start || start - wr < worst)
-                return 0;
-            at = wr;
-        } else if (wr <= d->fifo_cap && d->fifo_cap - wr >= worst) {
-            at = wr;
-        } else if (start >= worst) {
-            at = 0;
-        } else {
-            return 0;
-        }
-    } else if (worst > d->fifo_cap) {
-        return 0;
-    }
-    if (off)
-        *off = at;
-    return 1;
-}
+/* the next buffersize deliverable bytes: where they lie, or gathered into `slot` when they are in two pieces */
+static size_t ready_bytes(const perseus_descr *d) { return d->zc ? d->os.ready : d->fifo_len; }
 
-static void seg_push(perseus_descr *d, int ticket, size_t off, size_t len)
-{
-    d->seg[(d->seg_head + d->seg_n) % MAX_SEG] = (out_seg){ ticket, off, len };
-    d->seg_n++;
-    d->n_pend++;
-}
-
-/* drop the oldest segments that are ready and empty */
-static void seg_trim(perseus_descr *d)
-{
-    while (d->seg_n > d->n_pend && d->seg[d->seg_head].len == 0) {
-        d->seg_head = (d->seg_head + 1) % MAX_SEG;
-        d->seg_n--;
-    }
-}
-
-/* the next buffersize ready bytes: where they lie, or gathered into `slot` when they are in two pieces */
 static const uint8_t *fill_fifo(perseus_descr *d, uint8_t *slot, size_t *got)
 {
     if (!d->zc)
         return fill_ring(d, slot, got);
-    const size_t n = d->buffersize;
     *got = 0;
-    if (d->fifo_len < n)
+    if (d->os.ready < d->buffersize)
         return slot;
-    seg_trim(d);
-    out_seg *h = &d->seg[d->seg_head];
-    const uint8_t *p = slot;
-    if (h->len >= n) {
-        p = d->fifo + h->off;
-        h->off += n;
-        h->len -= n;
+    int in_place = 0;
+    const uint8_t *p = oseg_take(&d->os, d->fifo, d->buffersize, slot, &in_place);
+    if (in_place)
         d->n_in_place++;
-    } else {
+    else
         d->n_gathered++;
-        size_t have = 0;
-        while (have < n) {                            /* (fifo_len >= n: only ready segments are touched) */
-            h = &d->seg[d->seg_head];
-            const size_t t = h->len < n - have ? h->len : n - have;
-            memcpy(slot + have, d->fifo + h->off, t);
-            h->off += t;
-            h->len -= t;
-            have += t;
-            seg_trim(d);
-        }
-    }
-    seg_trim(d);
-    d->fifo_len -= n;
-    *got = n;
+    *got = d->buffersize;
     return p;
 }
 
@@ -731,7 +659,7 @@ static void *out_place(perseus_descr *d, size_t *off)
         *off = (size_t)d->cur;
         return d->batch_out[d->cur];
     }
-    if (!fifo_reserve(d, d->out_cap * out_bytes_per_sample(d), off))
+    if (!oseg_reserve(&d->os, d->out_cap * out_bytes_per_sample(d), off))
         return NULL;
     return d->fifo + *off;
 }
@@ -745,7 +673,7 @@ static void batch_pushed(perseus_descr *d, int rc, size_t ns, size_t n_out, int 
     }
     d->adc_samples += ns;
     d->batches++;
-    seg_push(d, ticket, off, n_out * out_bytes_per_sample(d));
+    oseg_push(&d->os, ticket, off, n_out * out_bytes_per_sample(d));
     d->cur ^= 1;
 }
 
@@ -776,10 +704,11 @@ static int can_submit(const perseus_descr *d)
 {
     const int depth = d->cfg.pace ? 1 : 2;
     const size_t worst = d->out_cap * out_bytes_per_sample(d);
-    return d->n_pend < depth && !d->input_done && !d->source_done &&
+    return d->os.n_pend < depth && !d->input_done && !d->source_done &&
            /* (no further ahead of the callbacks than the ring was: at most three batches' output waiting, so a retune still
             * takes effect within a few batches of an unpaced stream) */
-           (d->zc ? d->seg_n - d->n_pend <= 2 && fifo_reserve(d, worst, NULL) : ring_room(d) >= worst * (size_t)(d->n_pend + 1)) &&
+           (d->zc ? d->os.n - d->os.n_pend <= 2 && oseg_reserve(&d->os, worst, NULL)
+                  : ring_room(d) >= worst * (size_t)(d->os.n_pend + 1)) &&
            !(d->cfg.max_buffers && d->seq >= d->cfg.max_buffers);
 }
 
@@ -789,7 +718,7 @@ static int ddc_submit(perseus_descr *d)
     while (can_submit(d)) {
         submit_batch(d);
         did = 1;
-        if (d->n_pend == 0)
+        if (d->os.n_pend == 0)
             break;
     }
     return did;
@@ -799,22 +728,21 @@ static int ddc_submit(perseus_descr *d)
  * submitted in pass 1, so the GPUs are all busy while this thread waits for the first of them) */
 static int ddc_collect(perseus_descr *d)
 {
-    if (d->n_pend == 0)
+    if (d->os.n_pend == 0)
         return 0;
-    const out_seg b = d->seg[(d->seg_head + d->seg_n - d->n_pend) % MAX_SEG];      /* the oldest still on the GPU */
-    d->n_pend--;
+    const out_seg b = oseg_oldest_pending(&d->os);
     if (pddc_pipeline_wait_ticket(d->pipe, b.ticket) != PDDC_OK) {
+        d->os.n_pend--;
         dbgprintf(0, "GPU pipeline failed (%s); stream stopped", pddc_last_error());
         d->input_done = 1;
         d->source_done = 1;
         return 0;
     }
     if (d->zc) {
-        d->fifo_len += b.len;                    /* its bytes are where they will be delivered from */
+        oseg_ready(&d->os);                      /* its bytes are where they will be delivered from */
     } else {
         ring_put(d, (const uint8_t *)d->batch_out[b.off], b.len);
-        d->seg_head = (d->seg_head + 1) % MAX_SEG;                /* (ring mode lists only what is still on the GPU) */
-        d->seg_n--;
+        oseg_pop_pending(&d->os);                /* (ring mode lists only what is still on the GPU) */
     }
     return 1;
 }
@@ -828,11 +756,11 @@ static int ddc_deliver(perseus_descr *d, int budget)
             d->source_done = 1;
             break;
         }
-        if (!turn(d, fill_fifo, d->fifo_len / d->buffersize))
+        if (!turn(d, fill_fifo, ready_bytes(d) / d->buffersize))
             break;
         did = 1;
     }
-    if (d->input_done && d->n_pend == 0 && d->fifo_len < d->buffersize)
+    if (d->input_done && d->os.n_pend == 0 && ready_bytes(d) < d->buffersize)
         d->source_done = 1;
     return did;
 }
@@ -859,7 +787,7 @@ static void submit_one(int i, int *busy, int *inflight)
     pthread_mutex_lock(&d->pump_lock);
     if (d->streaming && !d->cancelling && !d->source_done && d->cfg.mode != PERSEUS_AMD_MODE_WIRE) {
         *busy |= ddc_submit(d);
-        *inflight += d->n_pend > 0;
+        *inflight += d->os.n_pend > 0;
     }
     pthread_mutex_unlock(&d->pump_lock);
 }
@@ -975,7 +903,7 @@ static void gang_submit(int dev, const int *sub, int m, int *busy, int *inflight
         }
     }
     for (int k = m - 1; k >= 0; k--) {
-        *inflight += g_list[sub[k]].n_pend > 0;
+        *inflight += g_list[sub[k]].os.n_pend > 0;
         pthread_mutex_unlock(&g_list[sub[k]].pump_lock);
     }
 }
@@ -1500,7 +1428,7 @@ static void free_stream(perseus_descr *d)
     d->fifo = NULL;
     d->zc = 0;
     d->fifo_len = d->fifo_cap = d->fifo_rd = 0;
-    d->n_pend = d->seg_n = d->seg_head = 0;
+    memset(&d->os, 0, sizeof(d->os));
     if (d->pipe) {
         pddc_pipeline_destroy(d->pipe);
         d->pipe = NULL;
@@ -1610,8 +1538,8 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
         d->zc = d->out_cap > 10 && (d->out_cap - 10) * out_bytes_per_sample(d) >= 2 * (size_t)buffersize;
         if (d->zc) {
             /* room for two batches on the GPU, one being delivered, and the piece at the end that a batch does not fit into */
-            d->fifo_cap = 6 * seg_align(d->out_cap * 8) + seg_align(2 * (size_t)buffersize);
-            hrc |= pddc_host_alloc((void **)&d->fifo, d->fifo_cap);
+            d->os.cap = 6 * oseg_align(d->out_cap * 8) + oseg_align(2 * (size_t)buffersize);
+            hrc |= pddc_host_alloc((void **)&d->fifo, d->os.cap);
         } else {
             for (int k = 0; k < 2; k++)
                 hrc |= pddc_host_alloc((void **)&d->batch_out[k], d->out_cap * 8);
@@ -1638,7 +1566,8 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
     d->n_in_place = d->n_gathered = 0;
     d->n_retunes = 0;
     d->cur = 0;
-    d->n_pend = d->seg_n = d->seg_head = 0;
+    d->os.n_pend = d->os.n = d->os.head = 0;
+    d->os.ready = 0;
     d->input_done = 0;
     d->fifo_len = d->fifo_rd = 0;
     d->source_done = 0;

@@ -570,3 +570,24 @@ def test_introspection_calls_are_safe_inside_the_callback(L, pkg):
         time.sleep(0.002)
     assert L.perseus_stop_async_input(d) == 0
     assert seen == list(range(1, 13))
+
+
+def test_output_segments_against_a_byte_queue(tmp_path):
+    """The delivery path of the DDC modes hands callbacks the decimated output where the GPU put it (csrc/out_segments.h:
+    reserve at submit, ready on arrival, take a buffer's worth from the front -- in place or gathered).  No GPU needed for
+    its logic: tests/out_segments_test.c drives it with random batch lengths and a random interleaving of submit / arrive /
+    deliver against a running byte counter, in the regimes the API can be in -- batches of just over two buffers (the
+    smallest the zero-copy path accepts: one gathered buffer per batch), batches of exactly two, and batches of tens of
+    buffers (the 250 kS/s plan at 2^22 and 2^24 samples).  Reservations never touch live bytes, the stream is intact and in
+    order, it never stalls."""
+    import shutil
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "oseg_test")
+    src = os.path.join(ROOT, "tests", "out_segments_test.c")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "libperseus-sdr_amd", "csrc"), "-o", exe, src],
+                   check=True)
+    for seed, steps, bufsize, worst in ((1, 200000, 6144, 13104), (2, 200000, 6144, 12288), (3, 100000, 12288, 104920),
+                                        (4, 60000, 12288, 419432), (5, 100000, 16320, 33000), (6, 100000, 510, 1100)):
+        p = subprocess.run([exe, str(seed), str(steps), str(bufsize), str(worst)], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and p.stdout.startswith("ok:"), (seed, p.stdout[-300:], p.stderr[-300:])
