@@ -438,7 +438,7 @@ def test_perseus_api_fpga_emulation_mode(pkg, dev, O, monkeypatch):
     assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
     dec, nt = (C.c_int * 4)(), (C.c_int * 4)()
     n = L.perseus_amd_get_plan(d, dec, nt, None)
-    assert list(dec)[:n] == [8, 5]
+    assert list(dec)[:n] == [10, 4]                          # (2 MS/s = 80 MS/s / 40: decimate by 10 on the matrix cores, then by 4)
     taps = [np.zeros(nt[i], np.float32) for i in range(n)]
     arr = (C.POINTER(C.c_float) * 4)(*[t.ctypes.data_as(C.POINTER(C.c_float)) for t in taps], None, None)
     L.perseus_amd_get_plan(d, dec, nt, arr)

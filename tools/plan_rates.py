@@ -25,6 +25,7 @@ ap.add_argument("--no-fast", action="store_true")
 ap.add_argument("--overlap", action="store_true", help="pddc_pipeline_set_overlap: the last stage rides along with the next batch's launch")
 ap.add_argument("--place", action="store_true", help="pddc_pipeline_place_buffers: the pipeline's inter-stage buffers in another HBM extent class than the input")
 ap.add_argument("--arena-gib", type=int, default=0, help="cut input, inter-stage workspace and output from ONE arena of that many GiB and place the workspace/output side by probing the plan itself at every 2 GiB (what bench.py does for its cascade; 0: first-come allocations)")
+ap.add_argument("--alt", action="append", default=[], help="rate:d0,d1,... -- time that stage order for the rate instead of the API's plan (taps designed on the spot by tools/design_plans.py's rule; needs scipy)")
 ap.add_argument("--opt", action="append", default=[], help="pipeline option name=value (pddc_pipeline_set_option), repeatable")
 a = ap.parse_args()
 
@@ -62,6 +63,20 @@ for rate in want:
     L.perseus_amd_get_plan(d, dec, nt, arr)
     L.perseus_amd_get_plan_interp(d, it)
     stages = [(dec[i], taps[i], it[i]) for i in range(n)]
+    for alt in a.alt:
+        r_, order = alt.split(":")
+        if int(r_) == rate:
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            import design_plans as dp
+            ds = [int(x) for x in order.split(",")]
+            fs, fpass, stages = dp.FS, 0.4 * rate, []
+            for i, D in enumerate(ds):
+                fs_out = fs / D
+                h, _, _ = dp.design(fs, fpass, 0.6 * rate if i == len(ds) - 1 else fs_out - fpass, 1)
+                stages.append((D, h, 1))
+                fs = fs_out
+            n = len(ds)
+            dec, nt, it = ds, [int(h.size) for _, h, _ in stages], [1] * n
     pipe = pkg.Pipeline(stages, mix=True, no_fast=a.no_fast)
     pipe.set_freg(381178347)
     for o in a.opt:
@@ -71,13 +86,13 @@ for rate in want:
         pipe.set_overlap(True)
     rows = pipe.max_output(ns) + 8
     out = torch.empty((rows, 2), dtype=torch.float32, device=dev)
-    placed_at = None
+    placed_at, probes = None, None
     if arena is not None:
         # workspace + output as one block, tried at every 2 GiB behind the input; the plan itself is the probe
         ws = (pipe.workspace_size(ns) + 255) & ~255
         need, step = ws + rows * 8, 2 << 30
         first_off = ((6 * ns + step - 1) // step) * step
-        best = None
+        best, probes = None, []
         for off in range(first_off, (a.arena_gib << 30) - need, step):
             base = arena.data_ptr() + off
             pipe.fence(st)
@@ -95,6 +110,7 @@ for rate in want:
             pipe.fence(st)
             torch.cuda.synchronize()
             t = (time.perf_counter() - t0) / 8 * 1e3
+            probes.append(round(t, 4))
             if best is None or t < best[0]:
                 best = (t, off)
         placed_at = best[1]
@@ -122,7 +138,7 @@ for rate in want:
     r = {"rate": rate, "plan": "*".join(f"{dec[i]}" + (f"(x{it[i]})" if it[i] > 1 else "") for i in range(n)),
          "ntaps": [nt[i] for i in range(n)], "ms_per_2^%d" % a.log2n: round(ms, 4), "GS_per_s": round(ns / ms / 1e6, 1), "stage0_kernel_ms": round(s0_ms, 4),
          "stage0_reads_packed": pipe.stage0_reads_packed, "fused8": pipe.fused, "fused_pair": pipe.fused_pair(ns),
-         "on_i8": pipe.on_i8(ns), "overlap": a.overlap, "placed": a.place, "arena_offset_GiB": None if placed_at is None else placed_at / 2**30, "opts": a.opt}
+         "on_i8": pipe.on_i8(ns), "overlap": a.overlap, "placed": a.place, "arena_offset_GiB": None if placed_at is None else placed_at / 2**30, "probe_ms_every_2GiB": probes, "opts": a.opt}
     res.append(r)
     print(json.dumps(r), flush=True)
     pipe.close()
