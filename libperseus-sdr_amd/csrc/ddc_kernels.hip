@@ -18,7 +18,7 @@
  *                optionally with the second /8 stage fused: ddc_fir_i8.hip.  Those are what
  *                a decimate-by-8 first stage runs on unless the pipeline's options say
  *                otherwise; k_fir8 keeps the pair with the carried tail above 2^26 samples.
- *   k_firp       register-blocked decimators by 4, 5, 10 (packed first stages, float2 tails).
+ *   k_firp       register-blocked decimators by 4, 5, 8, 10 (packed first stages, float2 tails).
  *   k_fir_generic  any-D decimating FIR on float2 (later cascade stages).
  *   k_resample     rational L/M polyphase resampler (non-integer rates).
  *   k_pack24       float32 -> 24-bit packed (inverse of the unpack).
@@ -890,6 +890,8 @@ __device__ __forceinline__ void run_tail_block(const GenTail &t, const int bid, 
             firp_block<4, firp_p_of(4), IN_F32C, false>(fa, bid, sd_tail);
         else if (t.D == 5)
             firp_block<5, firp_p_of(5), IN_F32C, false>(fa, bid, sd_tail);
+        else if (t.D == 8)
+            firp_block<8, firp_p_of(8), IN_F32C, false>(fa, bid, sd_tail);
         else
             firp_block<10, firp_p_of(10), IN_F32C, false>(fa, bid, sd_tail);
     } else {
@@ -1751,7 +1753,7 @@ __global__ __launch_bounds__(256) void k_firp(FirpArgs a)
     firp_block<D, P, INFMT, MIX>(a, bid, sdp);
 }
 
-/* which D are built: first stages /10 and /5, tails /4 /5 /10 (the reference's rate plans) */
+/* which D are built: first stages /10 and /5, tails /4 /5 /8 /10 (the reference's rate plans) */
 int firp_nbq(int D, int ntaps)
 {
     const int P = firp_p_of(D);
@@ -1768,7 +1770,7 @@ bool firp_supported(int D, int ntaps)
 {
     if (tunables().no_firp.load())
         return false;
-    if (!(D == 4 || D == 5 || D == 10) || ntaps < 1)
+    if (!(D == 4 || D == 5 || D == 8 || D == 10) || ntaps < 1)
         return false;
     if ((long long)(firp_nbq(D, ntaps) + 256) * firp_p_of(D) * D > 6144)       /* a tile's span: 12 x 2 samples per thread */
         return false;
@@ -1846,6 +1848,7 @@ hipError_t launch_firp(int infmt, bool mix, const void *in, const void *hist, in
     }
     if (D == 4) return launch_firp_t<4>(infmt, mix, a, ntaps, s);
     if (D == 5) return launch_firp_t<5>(infmt, mix, a, ntaps, s);
+    if (D == 8) return launch_firp_t<8>(infmt, mix, a, ntaps, s);      /* (a long decimate-by-8 SECOND stage: 1 MS/s = 10 * 8) */
     if (D == 10) return launch_firp_t<10>(infmt, mix, a, ntaps, s);
     return hipErrorInvalidValue;
 }

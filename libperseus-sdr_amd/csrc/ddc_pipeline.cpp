@@ -70,7 +70,7 @@ struct Stage {
     float *d_taps_blk = nullptr;  /* [ntb][8] block-reversed (fused kernel)     */
     float *d_taps_poly = nullptr; /* rational stage: [L][Kp] polyphase rows g[ph][j] = h[j*L + ph] */
     float *d_taps_seg = nullptr;  /* stage 2 as the fused cascade's third stage: h[k] zero padded to spl*seglen */
-    float *d_taps_firp = nullptr; /* k_firp (plain decimators by 4, 5, 10): (h[k], h[k]) zero padded to firp_taps_len */
+    float *d_taps_firp = nullptr; /* k_firp (plain decimators by 4, 5, 8, 10): (h[k], h[k]) zero padded to firp_taps_len */
     void *d_taps_i8 = nullptr;    /* k_fir_i8 (stage 0, 129..256 taps, /8): the int8 tap operand table, with ...       */
     float i8_scale = 0.0f, i8_cterm = 0.0f;      /* ... the integer -> float scale and the planes' offset constant     */
     void *d_taps_f16 = nullptr;   /* PDDC_F_TAPS_FP16: instead of that table the taps as binary16 values (1 KB with padding) -- the only
@@ -2349,7 +2349,7 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                 x = d_packed;                 /* (a batch shorter than the history: the packed history moves on below) */
                 hist_done = q.hist_out != nullptr;
             } else if (n_in[1] > 0) {
-                if (st.d_taps_firp)           /* register-blocked kernel for /4 /5 /10 */
+                if (st.d_taps_firp)           /* register-blocked kernel for /4 /5 /8 /10 */
                     HIP_TRY(launch_firp_packed(d_packed, h_in, st.hist, (long long)off[0], (long long)n_in[1], st.decim,
                                                st.d_taps_firp, st.ntaps, dst, h_out, (long long)nsamples, mix, p->n0,
                                                p->freg, p->phase_off, p->freg_applied, p->lo_c, p->lo_s, p->lo_c_applied,

@@ -271,7 +271,8 @@ static int plan_build(ddc_plan *p, int rate)
          * one (k_fir_i8x<.., D = 10>), writes 0.8 instead of 1 byte per ADC sample between the stages and leaves the second
          * stage a fifth fewer samples -- 2^28 samples, buffers placed: 0.389 -> 0.369 ms (690 -> 727 GS/s) */
         { 2000000, 2, { 10, 4, 0, 0 },  { 1, 1, 0, 0 } },  { 1600000, 2, { 10, 5, 0, 0 },  { 1, 1, 0, 0 } },
-        { 1000000, 2, { 8, 10, 0, 0 },  { 1, 1, 0, 0 } },  { 500000, 3, { 8, 8, 5, 0 },    { 1, 1, 2, 0 } },   /* (the fused pair to 1.25 MS/s, then x2/5: 8 * 4 * 5 cannot fuse) */
+        { 1000000, 2, { 10, 8, 0, 0 },  { 1, 1, 0, 0 } },  /* (likewise: 10 * 8 instead of 8 * 10) */
+        { 500000, 3, { 8, 8, 5, 0 },    { 1, 1, 2, 0 } },   /* (the fused pair to 1.25 MS/s, then x2/5: 8 * 4 * 5 cannot fuse) */
         { 250000, 3, { 8, 8, 5, 0 },    { 1, 1, 1, 0 } },  { 125000, 3, { 8, 8, 10, 0 },   { 1, 1, 1, 0 } },
         /* the non-integer ratios, all from 250 kS/s -- behind the SAME two decimate-by-8 stages as the 250 / 125 kS/s plans,
          * which run as one fused kernel (6.125 B per ADC sample instead of 8.3 for 8 * 10 * 5 or 8 * 5 * 5: round 3
