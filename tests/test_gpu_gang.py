@@ -30,6 +30,7 @@ def plans():
         "8": [(8, load_taps("d8_255"))],                                    # the first stage alone (255 taps)
         "8*7": [(8, h1), (7, lowpass(57, 0.06))],                           # tail on the generic decimator
         "10*5": [(10, lowpass(97, 0.04)), (5, lowpass(81, 0.08))],          # not gang-able: first stage is not /8
+        "10*5m": [(10, lowpass(51, 0.04)), (5, lowpass(117, 0.08))],        # 1.6 MS/s: /10 on the matrix cores (k_fir_i8x<.., 10>), a chain of its own
         "8*8*4*5": [(8, h1), (8, h2), (4, lowpass(33, 0.1)), (5, lowpass(41, 0.08))],   # not gang-able: two stages behind
     }
 
@@ -119,14 +120,14 @@ def test_gang_round_is_bit_identical_to_pushes_of_its_own(pkg, O, dev, plan, n):
 
 
 def test_gang_with_different_plans_retunes_and_members_that_cannot_share(pkg, O, dev):
-    """Eight receivers at five rates in one round: the ones with the same kernels share a launch, the two whose plan is
-    not a /8 first stage + one decimator run as chains of their own on the gang's stream; receiver 1 is retuned twice
+    """Eight receivers at six rates in one round: the ones with the same kernels share a launch, the three whose plan is
+    not a /8 first stage + one decimator run as chains of their own (one of them with its /10 first stage on the matrix cores) on the gang's stream; receiver 1 is retuned twice
     while streaming (the new word at the batch boundary, phase-continuous).  Every stream equals its solo run."""
     P = plans()
-    names = ["8*8*5", "8*8*5", "8*10", "10*5", "8*8*5", "8*10", "8*8*4*5", "8*8*10"]
+    names = ["8*8*5", "8*8*5", "8*10", "10*5", "8*8*5", "10*5m", "8*8*4*5", "8*8*10"]
     seeds = [31 + i for i in range(8)]
     retune = {2: 123456789, 4: 3000000000}
-    ys = run_gang(pkg, [P[k] for k in names], seeds, SIZES, max(SIZES), retune=retune, expect_ganged=[6] * len(SIZES))
+    ys = run_gang(pkg, [P[k] for k in names], seeds, SIZES, max(SIZES), retune=retune, expect_ganged=[5] * len(SIZES))
     for i, k in enumerate(names):
         solo = run_solo(pkg, P[k], seeds[i], SIZES, max(SIZES), retune=retune if i == 1 else None)
         assert np.array_equal(ys[i].view(np.uint32), solo.view(np.uint32)), (i, k)
