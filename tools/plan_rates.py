@@ -26,6 +26,7 @@ ap.add_argument("--overlap", action="store_true", help="pddc_pipeline_set_overla
 ap.add_argument("--place", action="store_true", help="pddc_pipeline_place_buffers: the pipeline's inter-stage buffers in another HBM extent class than the input")
 ap.add_argument("--arena-gib", type=int, default=0, help="cut input, inter-stage workspace and output from ONE arena of that many GiB and place the workspace/output side by probing the plan itself at every 2 GiB (what bench.py does for its cascade; 0: first-come allocations)")
 ap.add_argument("--alt", action="append", default=[], help="rate:d0,d1,... -- time that stage order for the rate instead of the API's plan (taps designed on the spot by tools/design_plans.py's rule; needs scipy)")
+ap.add_argument("--warm-s", type=float, default=1.0, help="run every plan that long before it is timed (a pipeline's freshly allocated inter-stage buffers are slow for their first second)")
 ap.add_argument("--opt", action="append", default=[], help="pipeline option name=value (pddc_pipeline_set_option), repeatable")
 a = ap.parse_args()
 
@@ -126,6 +127,12 @@ for rate in want:
         pipe.process_ptr(d_in.data_ptr(), ns, out.data_ptr(), out.shape[0], st)
     pipe.fence(st)
     torch.cuda.synchronize()
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < a.warm_s:
+        for _ in range(20):
+            pipe.process_ptr(d_in.data_ptr(), ns, out.data_ptr(), out.shape[0], st)
+        pipe.fence(st)
+        torch.cuda.synchronize()
     pipe.time_stage0_inline(True)
     t0 = time.perf_counter()
     for _ in range(a.iters):
