@@ -745,8 +745,8 @@ def run_rank(a):
         achieved = bps * ns / (kern_ms * 1e-3) / 1e9
         step_achieved = wl["bytes_per_sample"] * ns / (dt_max / a.steps) / 1e9      # the whole step, gaps and tails included
         klabel = (("k_fir8 (fused cascade: all stages in one launch)" if cascade else
-                   "k_fir8 (fused pair + the previous batch's tail as extra blocks of the launch)" if overlap
-                   else "k_fir_i8x (int8 matrix cores on the wire bytes%s, fused pair)" % (", NCO folded into the taps" if wl["mix"] else "") if pipe.fused_pair(ns) == 2
+                   "k_fir_i8x (int8 matrix cores on the wire bytes%s, fused pair; the tail in line)" % (", NCO folded into the taps" if wl["mix"] else "") if pipe.fused_pair(ns) == 2
+                   else "k_fir8 (fused pair + the previous batch's tail as extra blocks of the launch)" if overlap
                    else "k_fir_i8x (int8 matrix cores on the wire bytes%s)" % (", NCO folded into the taps" if wl["mix"] else "") if pipe.on_i8(ns) == 2
                    else "k_fir_i8 (int8 matrix cores on the wire bytes)" if pipe.on_i8(ns) == 1
                    else "k_fir8") if fused else "k_unpack24" if stages is None else "pipeline")
