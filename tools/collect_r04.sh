@@ -19,7 +19,7 @@ d["provenance"]["commit"] = head + (" + uncommitted changes under csrc/ (committ
 json.dump(d, open("profiles/pmc_traffic.json", "w"), indent=1)
 PY
 cp profiles/pmc_traffic.json $P/m_pmc_traffic_all_workloads.json
-for t in plan_rates plan_rates_overlap plan_rates_2p22 i8x_sizes i8x_layouts i8x_chunks i8x_plain i8x_plainsizes api_receivers; do
+for t in plan_rates plan_rates_overlap plan_rates_2p22 plan_rates_place_buffers i8x_sizes i8x_layouts i8x_chunks i8x_plain i8x_plainsizes api_receivers; do
   [ -f $F/$t.txt ] && grep -v amdgpu.ids $F/$t.txt > $P/m_$t.txt
 done
 (echo "# tools/plan_rates.py --log2n 28 --arena-gib 64: input, inter-stage workspace and output cut from ONE arena, the workspace/output side tried at every 2 GiB behind the input with the plan itself as the probe (probe_ms_every_2GiB in the lines); two runs on one box"; echo "## placed, run 1"; grep -v amdgpu $F/plan_rates_placed.txt; echo "## placed, run 2"; grep -v amdgpu $F/plan_rates_placed_b.txt) > $P/n_plan_rates_placed.txt

@@ -13,6 +13,7 @@ bash tools/r04_bench.sh $OUT/legs > $OUT/bench_legs.txt 2>&1
 python tools/plan_rates.py --log2n 28 > $OUT/plan_rates.txt 2>&1
 python tools/plan_rates.py --log2n 28 --overlap > $OUT/plan_rates_overlap.txt 2>&1
 python tools/plan_rates.py --log2n 22 --warm-s 0.2 > $OUT/plan_rates_2p22.txt 2>&1
+python tools/plan_rates.py --log2n 28 --place > $OUT/plan_rates_place_buffers.txt 2>&1
 python tools/plan_rates.py --log2n 28 --arena-gib 64 > $OUT/plan_rates_placed.txt 2>&1
 python tools/plan_rates.py --log2n 28 --arena-gib 64 > $OUT/plan_rates_placed_b.txt 2>&1
 python tools/i8x_time.py sizes > $OUT/i8x_sizes.txt 2>&1
