@@ -2345,7 +2345,11 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                 q.in_off = first + delay;
                 q.hist_len = st.hist;
                 q.n0 = p->n0 + (unsigned long long)q.in_off;
+                if ((rc = stage0_event(p, s, true)))
+                    return rc;
                 HIP_TRY(launch_fir_i8x_d10(q, s, p->opt.i8x_blocks, p->opt.i8x_chunk, p->opt.i8x_layout));
+                if ((rc = stage0_event(p, s, false)))
+                    return rc;
                 x = d_packed;                 /* (a batch shorter than the history: the packed history moves on below) */
                 hist_done = q.hist_out != nullptr;
             } else if (n_in[1] > 0) {
