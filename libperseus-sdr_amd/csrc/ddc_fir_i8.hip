@@ -436,6 +436,11 @@ hipError_t launch_fir_i8(const FirI8Args &a, int hist, hipStream_t s)
  *                        instructions than two 16-row bands per rail (the dead corners of a band shrink with its height):
  *                        same box, 2^28 samples, 48 taps 0.3406 -> 0.3272 ms, 127 taps 0.3865 -> 0.3513 (it replaced a form
  *                        with both 16-row tables per wave for <= 64 taps and took 65..128 taps over from mode 1)
+ * The tuned form 2 also DECIMATES BY 10 (template D = 10, hist = 64; the 1.6 / 2 / 1 MS/s plans' first stage,
+ * launch_fir_i8x_d10): columns of 8 outputs 80 samples apart, a band of 70 + 64 samples = 3 k-steps, tiles of 10240 samples =
+ * 1024 outputs, 1280 loader groups (two and a half rounds).  A stream's decimation phase makes a batch's first window end on
+ * any sample 0 .. 9; the loaders' groups sit on multiples of 8, so the taps are delayed by (-first) mod 8 samples (one table
+ * set per delay, built on the host) and the windows end on in_off = first + delay; the rotation takes that sample's phase.
  * Walk: the batch is cut into chunks of C tiles and block b takes chunks b, b + G, b + 2 G, ...  C = 1 is k_fir_i8's
  * tile-interleaved walk -- all CUs read one compact window of the batch, which is what this chip's HBM likes (same
  * kernel, 2^28 samples: contiguous ranges per block 0.380 ms, interleaved 0.332) --; inside a chunk the HIST samples in

@@ -184,9 +184,9 @@ struct pddc_pipeline {
         int i8x_chunk = 0;        /* tiles per chunk of its walk (0: 1, fused pair 4)                                    */
         int i8x_layout = -1;      /* which waves finish a tile (ddc_fir_i8.hip "Who does what"): 0 the matrix waves, 1 the
                                      loaders, 2 two matrix + two finishing waves; -1: by form (0 without the NCO and for
-                                     tuned stages up to 64 taps, 1 for 65..256 tuned taps and for the fused pair)        */
-        int i8x_pair_max_log2 = 26;   /* the fused pair up to 2^26-sample batches: 3.2x k_fir8's pair at 2^22, 1.6x at
-                                         2^24, level at 2^26, 9 % behind at 2^28 (profiles/r04)                         */
+                                     tuned stages up to 128 taps, 1 for 129..256 tuned taps and for the fused pair)      */
+        int i8x_pair_max_log2 = 26;   /* the fused pair up to 2^26-sample batches: 3.6x k_fir8's pair at 2^22, 1.8x at
+                                         2^24, level at 2^26 and 2^28 -- where k_fir8 carries the tail (profiles/r04)   */
         int no_fuse2 = 0, fuse3 = 0;
     } opt;
     /* k_fir_i8x's operands follow the tuning word: they are rebuilt on the host when the word, the taps or the form
