@@ -67,6 +67,43 @@ def test_bench_shape_windows_vs_oracle(pkg, O, dev, name):
     assert v["ok"] and v["max_rel_err"] <= 1e-6, v
 
 
+@pytest.mark.parametrize("rate", [1600000, 2000000, 1000000])
+def test_decimate_by_ten_plans_at_full_size(pkg, O, dev, rate):
+    """The three plans that start with a decimate-by-10 stage (1.6 / 2 / 1 MS/s, perseus-sdr.c:776-892 picks the rate) at the
+    bench's size: 2^28 samples are not a multiple of 10, so the second batch starts in another decimation phase than the
+    first (the phase goes into the matrix kernel's taps as a delay), 26215 tiles of 10240 samples go round 256 blocks, and
+    the last tile is ragged.  Windows at the tile seams a walk could get wrong (first and last tile of the first round, the
+    wrap to the second, the middle, the last tiles) + 20 random ones against the oracle, on the second batch."""
+    import torch
+    b = _bench()
+    shard = importlib.import_module("libperseus-sdr_amd.shard")
+    stages = [(d, t) for d, t, _l in pkg.api_plan(rate)]
+    assert stages[0][0] == 10
+    dtot = int(np.prod([d for d, _ in stages]))
+    wl = {"stages": stages, "mix": True, "freg": 381178347, "decim": dtot}
+    d_in = pkg.synth_lcg(6 * NS, 12345, 0, dev)
+    pipe = pkg.Pipeline(stages, mix=True)
+    pipe.set_freg(wl["freg"])
+    assert pipe.on_i8(NS) == 2
+    out = torch.empty((pipe.max_output(NS) + 8, 2), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    n = 0
+    for _ in range(2):
+        n = pipe.process_ptr(d_in.data_ptr(), NS, out.data_ptr(), out.shape[0], st)
+    torch.cuda.synchronize()
+    ntiles = -(-(NS // 10) // 1024)
+    sched = {"tile": 10240, "nblocks": 256, "S": 1, "K": 1, "ntiles": ntiles}      # k_fir_i8x's walk: tile t -> block t mod 256
+
+    def fetch(a0, b0):
+        idx = torch.arange(6 * a0, 6 * b0, device=dev, dtype=torch.int64) % (6 * NS)
+        return d_in[idx].cpu().numpy()
+
+    v = b.verify_last_output(O, shard, fetch, lambda j0, j1: out[j0:j1].cpu().numpy(), NS, wl, NS, sched)
+    pipe.close()
+    assert v["n_outputs"] == n and v["windows"] >= 24
+    assert v["ok"] and v["max_rel_err"] <= 1e-6, v
+
+
 def test_first_batch_from_zero_history_at_full_size(pkg, O, dev):
     v, _, _ = _run(pkg, O, dev, "d8_127", steps=1)
     assert v["ok"], v
