@@ -104,6 +104,50 @@ def test_decimate_by_ten_plans_at_full_size(pkg, O, dev, rate):
     assert v["ok"] and v["max_rel_err"] <= 1e-6, v
 
 
+@pytest.mark.parametrize("case", ["tuned127", "tuned48", "pair_2p26"])
+def test_tuned_matrix_core_stages_at_full_size(pkg, O, dev, case):
+    """k_fir_i8x's tuned forms at the bench's size (the bench workloads themselves are untuned or run the vector pair there):
+    127 and 48 taps with the NCO at 2^28 samples (both tap sets in one operand, 32768 tiles round 256 blocks), and the x320
+    plan at 2^26 -- the largest batch whose pair runs on k_fir_i8x (chunks of four tiles, a chunk's first tile making its own
+    porch).  Windows at the walk's seams + 20 random ones against the oracle, on the second batch."""
+    import torch
+    from conftest import load_taps
+    b = _bench()
+    shard = importlib.import_module("libperseus-sdr_amd.shard")
+
+    def lowpass(ntaps, cutoff):
+        k = np.arange(ntaps) - (ntaps - 1) / 2.0
+        h = np.sinc(2 * cutoff * k) * np.hamming(ntaps)
+        return (h / h.sum()).astype(np.float32)
+
+    ns = NS if case != "pair_2p26" else 1 << 26
+    stages = {"tuned127": [(8, load_taps("d8_127"))], "tuned48": [(8, lowpass(48, 0.05))],
+              "pair_2p26": [(d, t) for d, t, _l in pkg.api_plan(250000)]}[case]
+    dtot = int(np.prod([d for d, _ in stages]))
+    wl = {"stages": stages, "mix": True, "freg": 381178347, "decim": dtot}
+    d_in = pkg.synth_lcg(6 * ns, 12345, 0, dev)
+    pipe = pkg.Pipeline(stages, mix=True)
+    pipe.set_freg(wl["freg"])
+    assert pipe.on_i8(ns) == 2 and pipe.fused_pair(ns) == (2 if case == "pair_2p26" else 0)
+    out = torch.empty((pipe.max_output(ns) + 8, 2), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    n = 0
+    for _ in range(2):
+        n = pipe.process_ptr(d_in.data_ptr(), ns, out.data_ptr(), out.shape[0], st)
+    torch.cuda.synchronize()
+    C = 4 if case == "pair_2p26" else 1
+    sched = {"tile": 8192, "nblocks": 256, "S": C, "K": C, "ntiles": ns // 8192}
+
+    def fetch(a0, b0):
+        idx = torch.arange(6 * a0, 6 * b0, device=dev, dtype=torch.int64) % (6 * ns)
+        return d_in[idx].cpu().numpy()
+
+    v = b.verify_last_output(O, shard, fetch, lambda j0, j1: out[j0:j1].cpu().numpy(), ns, wl, ns, sched)
+    pipe.close()
+    assert v["n_outputs"] == n and v["windows"] >= 24
+    assert v["ok"] and v["max_rel_err"] <= 1e-6, v
+
+
 def test_first_batch_from_zero_history_at_full_size(pkg, O, dev):
     v, _, _ = _run(pkg, O, dev, "d8_127", steps=1)
     assert v["ok"], v
