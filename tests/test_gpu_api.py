@@ -159,6 +159,30 @@ def test_callbacks_read_the_output_in_place_and_both_delivery_modes_give_the_sam
     assert O.rel_err(y, ref[:y.size]) <= FIR_TOL
 
 
+@pytest.mark.parametrize("rate", [48000, 95000, 96000, 125000, 192000, 250000, 500000, 1000000, 1600000, 2000000])
+def test_every_rate_of_the_reference_through_the_api_vs_oracle(L, pkg, O, rate):
+    """perseus_set_sampling_rate's ten rates (perseus-sdr.c:776-811), each through the whole drop-in path -- open, firmware,
+    rate, centre frequency, start, callbacks, stop -- with the library's own batch size and delivery (the output read in
+    place): the delivered stream is the oracle's mix-then-decimate of the same synthetic ADC stream through the plan the
+    library reports."""
+    assert L.perseus_init() == 1
+    nbuf = 24
+    d = open_receiver(L, pkg, 0, rate, 7.1e6, mode=1, max_buffers=nbuf)
+    stages = plan_of(L, d)
+    outs, _ = run_all(L, pkg, [d], bufsize=6144)
+    st = pkg.AmdStats()
+    L.perseus_amd_get_stats(d, C.byref(st))
+    assert st.delivered == nbuf and st.dropped == 0 and len(outs[0]) == nbuf * 6144
+    assert st.buffers_in_place + st.buffers_gathered == nbuf
+    y = np.frombuffer(outs[0], dtype=np.float32)[:2 * 2048]
+    num = int(np.prod([max(l, 1) for _, _, l in stages]))
+    den = int(np.prod([dd for dd, _, _ in stages]))
+    n_in = ((2048 + 64) * den // num + 4096) // 8 * 8
+    ref = O.ddc_chain(O.lcg_bytes(6 * n_in, 12345), stages, freg=O.nco_freg(7.1e6), mix=True)
+    assert ref.size >= y.size and O.rel_err(y, ref[:y.size]) <= FIR_TOL, (rate, O.rel_err(y, ref[:y.size]))
+    L.perseus_exit()
+
+
 # ------------------------------------------------------------------ N4: retune while streaming
 @pytest.mark.parametrize("mode,rate", [(1, 250000), (2, 2000000), (1, 96000)])
 def test_retune_while_streaming_matches_the_retuned_oracle(L, pkg, O, mode, rate):
