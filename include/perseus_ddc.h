@@ -128,31 +128,17 @@ int pddc_free(void *d_ptr);
  * pddc_pipeline_place_buffers does this for a pipeline's own inter-stage buffers (process() never searches).         */
 int pddc_malloc_apart(void **d_ptr, size_t nbytes, const void *d_partner, size_t partner_bytes, int max_candidates,
                       float *ms_best, float *ms_worst);
-/* The dependable form of the same search: ONE large allocation of the caller's (tens of GiB up; 288 GB of HBM make it
- * affordable), cut into slots of slot_bytes; slot k holds an input region [0, in_bytes) and an output side at
- * [out_offset, out_offset + out_bytes).  Every pair (input in one of n_in_slots evenly spread slots, output side in any
- * slot) is timed with a read+write probe stream; *in_slot / *out_slot are the fastest pair, ms_table (optional,
- * n_in_slots x (arena_bytes / slot_bytes) floats) every time.  The arena's contents are overwritten: search first, fill
- * later.  Separate allocations 8 GiB apart sometimes never leave an extent class; inside one allocation the classes
- * alternate every 32-64 GiB and about two thirds of all pairs are fast (bench.py does this search with the real
- * kernel as its probe; tests/test_gpu_parity.py checks that both agree).                                           */
-int pddc_arena_search(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t in_bytes, size_t out_offset,
-                      size_t out_bytes, int n_in_slots, size_t *in_slot, size_t *out_slot, float *ms_table,
-                      float *ms_best, float *ms_worst);
-/* The cheap form, from what those searches showed on some twenty leases: with the input at the START of one allocation
- * (slot 0), its extent class reaches 32, 48 or 64 GiB up -- the slot right behind it is nearly always in it (the "first come"
- * case) and +32, +48 or +64 GiB nearly always in another one (leases with the other classes at +24 / +40 / +72 GiB exist).  Probes the output side at those four places on `stream`
- * (0.1 s), looks at the remaining slots only if none gains 3 %, returns the fastest in *out_slot with the first-come
- * and the chosen probe times and the number of probes made.  An arena of 80 GiB (ten 8-GiB slots) is enough.
- * Let a freshly allocated arena rest for a second or two before probing it: during the first second behind an
- * allocation of that size the chip sometimes runs EVERY pair 4-5 % slower for some tenths of a second (bench.py waits
- * 3 s; profiles/r03/n_slow_state_investigation.txt).                                                              */
-int pddc_arena_place(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t in_bytes, size_t out_offset,
-                     size_t out_bytes, size_t *out_slot, float *ms_first_come, float *ms_best, int *nprobes, void *stream);
-/* The same with the pipeline's OWN first-stage kernel as the probe (one fused stage: the kernel reads the batch at the
- * arena's start and writes its nsamples / 8 outputs at out_offset of the candidate slot; stream state is not advanced).
- * Which slots are fast depends on the kernel's access pattern: the probe stream of pddc_arena_place models the vector
- * kernels, the matrix-core kernel (k_fir_i8) ranks the slots differently.  Fill the input BEFORE the call.            */
+/* Where in ONE large allocation of the caller's (tens of GiB; 288 GB of HBM make it affordable) does a pipeline's write
+ * side go?  The arena is cut into slots of slot_bytes; the packed batch lies at the arena's start (fill it BEFORE the
+ * call), the write side at out_offset of a slot.  The probe is the pipeline's OWN first kernel: one fused stage writes its
+ * nsamples / D outputs there; a cascade's inter-stage workspace (pddc_pipeline_workspace_size bytes) is set there with
+ * pddc_pipeline_set_workspace and stays at the chosen slot -- the caller puts the output behind it.  Probed: the slot
+ * right behind the input ("first come"), +32 / +48 / +64 GiB, every slot only if none of those gains 3 %; 0.1-0.2 s.
+ * *ms_first_come / *ms_best: the kernel's time at slot 1 and at the returned slot.  Stream state is not advanced.
+ * Worth 1-8 % (which slots are fast is a property of the process's physical layout, found, not modelled); a host that
+ * does not care skips it.  This is the one placement entry point for caller-owned memory: rounds 2-4 also had
+ * pddc_arena_search / pddc_arena_place, which ranked the slots with a read+write MODEL stream -- on one box in a dozen it
+ * ranked them opposite to the kernel it stood for, so they are gone.  (No reference counterpart.)                  */
 int pddc_pipeline_arena_place(pddc_pipeline *p, void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t nsamples,
                               size_t out_offset, size_t *out_slot, float *ms_first_come, float *ms_best, int *nprobes,
                               void *stream);

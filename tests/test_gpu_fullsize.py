@@ -170,144 +170,72 @@ def test_window_check_catches_a_broken_seam(pkg, O, dev):
     assert not v["ok"]
 
 
-def test_arena_search_agrees_with_the_kernel(pkg, O, dev):
-    """pddc_arena_search (include/perseus_ddc.h) ranks (input slot, output slot) pairs of one large allocation with a
-    read+write probe stream.  The pair it returns must be a fast one for the real kernel too: k_fir8 (127 taps, 2^28
-    samples) timed on the helper's best pair is within 3 % of the best of a dozen pairs timed directly, and when the
-    kernel sees both speeds (>= 4 % apart) the helper's worst pair is one of the slow ones."""
+@pytest.mark.perf
+def test_placement_probes_with_the_kernel_itself(pkg, O, dev, perf_record):
+    """pddc_pipeline_arena_place (include/perseus_ddc.h), the one placement entry point: input at the start of ONE
+    allocation, the write side probed with the pipeline's OWN first kernel right behind it (first come) and at +32 / +48 /
+    +64 GiB, every slot only if none of those gains.  Three pipelines: the matrix-core kernel (127 taps, 2^28 samples), the
+    vector kernel (option no_i8) and the x320 cascade (its workspace goes to the chosen slot).  What is asserted is what
+    cannot depend on the box: the call's own bookkeeping, the result still being right at the chosen place, and that the
+    kernel at the returned slot is not GROSSLY (25 %) slower than at the best of all slots.  The times themselves are
+    recorded (gpurun_out/perf_record.jsonl): which slots are fast is a property of the lease (round 4's review)."""
     import ctypes as C
     import torch
     b = _bench()
     L = pkg.ddc_lib()
-    wl = b.workload_def("d8_127")
     free_b, _ = torch.cuda.mem_get_info(dev)
-    gib = min(176, (free_b - (16 << 30)) >> 30)
-    if gib < 32:
-        pytest.skip("less than 32 GiB free")
-    slot, in_bytes, out_off = 8 << 30, 6 * NS, 2 << 30
-    pipe = pkg.Pipeline(wl["stages"])
-    rows = pipe.max_output(NS) + 8
-    arena = torch.empty(gib << 30, dtype=torch.uint8, device=dev)
-    _rest_behind_a_large_allocation(dev)
-    nslot = (gib << 30) // slot
-    i_sl, o_sl, best, worst = C.c_size_t(), C.c_size_t(), C.c_float(), C.c_float()
-    table = (C.c_float * (2 * nslot))()
-    pkg.check(L.pddc_arena_search(arena.data_ptr(), gib << 30, slot, in_bytes, out_off, rows * 8, 2, C.byref(i_sl),
-                                  C.byref(o_sl), table, C.byref(best), C.byref(worst)))
-    tab = np.array(table[:]).reshape(2, nslot)
-    in_slots = [0, nslot // 2]
-    assert i_sl.value in in_slots and o_sl.value < nslot and 0 < best.value <= worst.value
-    assert abs(tab.min() - best.value) < 1e-6 and abs(tab.max() - worst.value) < 1e-6
-    st = torch.cuda.current_stream(dev).cuda_stream
-    for k in in_slots:                                   # search first, fill later
-        pkg.check(L.pddc_synth_lcg(arena.data_ptr() + k * slot, in_bytes, 12345, 0, st))
-
-    def kernel_ms(i, o):
-        a, c = arena.data_ptr() + i * slot, arena.data_ptr() + o * slot + out_off
-        for _ in range(30):
-            pipe.process_ptr(a, NS, c, rows, st)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(24):
-            pipe.process_ptr(a, NS, c, rows, st)
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / 24
-
-    for _ in range(150):
-        pipe.process_ptr(arena.data_ptr(), NS, arena.data_ptr() + out_off, rows, st)
-    direct = {(i, o): kernel_ms(i, o) for i in in_slots for o in range(0, nslot, max(1, nslot // 6))}
-    # single readings can fall into a phase in which the chip runs EVERY launch 4-5 % slower for tens of milliseconds
-    # (profiles/r03/n_per_step_20runs.txt): what is compared is read twice, the smaller reading counts
-    t_best = min(kernel_ms(i_sl.value, o_sl.value) for _ in range(2))
-    wi, wo = divmod(int(tab.argmax()), nslot)
-    t_worst = min(kernel_ms(in_slots[wi], wo) for _ in range(2))
-    slowest = max(direct, key=direct.get)
-    direct[slowest] = min(direct[slowest], kernel_ms(*slowest))
-    lo, hi = min(direct.values()), max(direct.values())
-    print(f"probe best pair in{i_sl.value}/out{o_sl.value}: kernel {t_best:.4f} ms; probe worst pair: kernel {t_worst:.4f} ms; "
-          f"direct {lo:.4f} .. {hi:.4f} ms over {len(direct)} pairs; probe {best.value:.3f} .. {worst.value:.3f} ms")
-    assert t_best <= 1.05 * lo
-    if hi > 1.06 * lo:
-        assert t_worst > 1.02 * t_best
-    # the result is still right at the chosen place
-    n = pipe.process_ptr(arena.data_ptr() + i_sl.value * slot, NS, arena.data_ptr() + o_sl.value * slot + out_off, rows, st)
-    y = np.empty((4096, 2), np.float32)
-    pkg.check(L.pddc_memcpy_d2h(y.ctypes.data, arena.data_ptr() + o_sl.value * slot + out_off + 8 * (n - 4096), y.nbytes, st))
-    pkg.check(L.pddc_stream_sync(st))
-    assert np.isfinite(y).all() and np.abs(y).max() > 0
-    pipe.close()
-    del arena
-    torch.cuda.empty_cache()
-
-
-def test_the_placement_rule_finds_a_fast_pair_in_a_handful_of_probes(pkg, O, dev):
-    """Input at the start of ONE 80 GiB allocation, the output side probed right behind it (first come) and at +32 / +48 /
-    +64 GiB, every slot only if none of those gains.  Two forms: pddc_pipeline_arena_place probes with the pipeline's own
-    kernel, pddc_arena_place with a read+write stream that models the vector kernels.  Each is judged by the real kernel
-    it is meant for (127 taps, 2^28 samples: the matrix-core kernel by default, the vector kernel under PDDC_NO_I8): the
-    slot it returns is within 4 % of the best of ALL slots."""
-    import ctypes as C
-    import torch
-    b = _bench()
-    L = pkg.ddc_lib()
-    wl = b.workload_def("d8_127")
-    free_b, _ = torch.cuda.mem_get_info(dev)
-    gib = min(80, (free_b - (16 << 30)) >> 30)
-    if gib < 72:
-        pytest.skip("less than 72 GiB free")
+    gib = min(72, (free_b - (16 << 30)) >> 30)                # a quarter of the HBM at most
+    if gib < 48:
+        pytest.skip("less than 48 GiB free")
     slot, in_bytes, out_off = 8 << 30, 6 * NS, 2 << 30
     arena = torch.empty(gib << 30, dtype=torch.uint8, device=dev)
     _rest_behind_a_large_allocation(dev)
     nslot = (gib << 30) // slot
     st = torch.cuda.current_stream(dev).cuda_stream
     pkg.check(L.pddc_synth_lcg(arena.data_ptr(), in_bytes, 12345, 0, st))
-    for vector in (False, True):
-        if vector:
-            os.environ["PDDC_NO_I8"] = "1"
-        try:
-            pipe = pkg.Pipeline(wl["stages"])
-            assert bool(pipe.on_i8(NS)) == (not vector)
-            rows = pipe.max_output(NS) + 8
-            o_sl, fc, best, npr = C.c_size_t(), C.c_float(), C.c_float(), C.c_int()
-            if vector:
-                pkg.check(L.pddc_arena_place(arena.data_ptr(), gib << 30, slot, in_bytes, out_off, rows * 8, C.byref(o_sl),
-                                             C.byref(fc), C.byref(best), C.byref(npr), st))
-            else:
-                pkg.check(L.pddc_pipeline_arena_place(pipe._h, arena.data_ptr(), gib << 30, slot, NS, out_off, C.byref(o_sl),
-                                                      C.byref(fc), C.byref(best), C.byref(npr), st))
-            assert 1 <= o_sl.value < nslot and 0 < best.value <= fc.value and 4 <= npr.value <= nslot
+    for name, wlname, opts in (("matrix", "d8_127", {}), ("vector", "d8_127", {"no_i8": 1}), ("cascade", "c320_fixture", {})):
+        wl = b.workload_def(wlname)
+        pipe = pkg.Pipeline(wl["stages"], mix=wl["mix"])
+        if wl["mix"]:
+            pipe.set_freg(wl["freg"])
+        for k, v in opts.items():
+            pipe.set_option(k, v)
+        cascade = len(wl["stages"]) > 1
+        ws = (pipe.workspace_size(NS) + 255) & ~255 if cascade else 0
+        rows = pipe.max_output(NS) + 8
+        o_sl, fc, best, npr = C.c_size_t(), C.c_float(), C.c_float(), C.c_int()
+        pkg.check(L.pddc_pipeline_arena_place(pipe._h, arena.data_ptr(), gib << 30, slot, NS, out_off, C.byref(o_sl),
+                                              C.byref(fc), C.byref(best), C.byref(npr), st))
+        assert 1 <= o_sl.value < nslot and 0 < best.value <= fc.value and 4 <= npr.value <= nslot
 
-            def kernel_ms(o):
-                c = arena.data_ptr() + o * slot + out_off
-                for _ in range(30):
-                    pipe.process_ptr(arena.data_ptr(), NS, c, rows, st)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(24):
-                    pipe.process_ptr(arena.data_ptr(), NS, c, rows, st)
-                e1.record()
-                e1.synchronize()
-                return e0.elapsed_time(e1) / 24
+        def kernel_ms(o):
+            side = arena.data_ptr() + o * slot + out_off
+            if cascade:
+                pipe.set_workspace(side, ws, NS)
+            return pipe.time_stage0(arena.data_ptr(), NS, side + ws, 24, st)
 
-            for _ in range(150):
-                pipe.process_ptr(arena.data_ptr(), NS, arena.data_ptr() + out_off, rows, st)
-            direct = {o: kernel_ms(o) for o in range(1, nslot)}
-            lo, hi = min(direct.values()), max(direct.values())
-            print(f"{'stream probe, vector kernel' if vector else 'kernel probe, matrix-core kernel'}: slot {o_sl.value} after "
-                  f"{npr.value} probes (probe {best.value:.4f} ms, first come {fc.value:.4f}); kernel there "
-                  f"{direct[o_sl.value]:.4f} ms, first come {direct[1]:.4f}, all slots {lo:.4f} .. {hi:.4f}")
-            chosen_ms = direct[o_sl.value]
-            if chosen_ms > 1.04 * lo:
-                # the chip has phases in which EVERY launch is 4-5 % slower for some tens of milliseconds
-                # (profiles/r03/n_per_step_20runs.txt); `lo` is a minimum over nine readings, this was one: read it again
-                chosen_ms = min(chosen_ms, kernel_ms(o_sl.value), kernel_ms(o_sl.value))
-            # Four probes of nine slots can miss a LONE fast slot (one box in a dozen shows such a map: one slot at 0.339 ms,
-            # eight at 0.365): then the rule must at least not have done worse than the first-come buffers it started from.
-            lone = sum(1 for v in direct.values() if v <= 1.04 * lo) == 1
-            assert chosen_ms <= 1.04 * lo or (lone and chosen_ms <= 1.01 * direct[1]), (chosen_ms, lo, direct)
-            pipe.close()
-        finally:
-            os.environ.pop("PDDC_NO_I8", None)
+        kernel_ms(1)
+        direct = {o: kernel_ms(o) for o in range(1, nslot)}
+        lo, hi = min(direct.values()), max(direct.values())
+        perf_record(f"placement_{name}", round(direct[o_sl.value], 4), unit="ms", slot=o_sl.value, probes=npr.value,
+                    probe_best=round(best.value, 4), probe_first_come=round(fc.value, 4),
+                    all_slots={str(o): round(v, 4) for o, v in direct.items()})
+        assert direct[o_sl.value] <= 1.25 * lo, (direct[o_sl.value], lo, hi)
+        # the result is still right at the chosen place (the whole chain, from zero history)
+        side = arena.data_ptr() + o_sl.value * slot + out_off
+        if cascade:
+            pipe.set_workspace(side, ws, NS)
+        pipe.reset()
+        n = pipe.process_ptr(arena.data_ptr(), NS, side + ws, rows, st)
+        y = np.empty((min(n, 2048), 2), np.float32)
+        pkg.check(L.pddc_memcpy_d2h(y.ctypes.data, side + ws, y.nbytes, st))
+        pkg.check(L.pddc_stream_sync(st))
+        dtot = int(np.prod([d for d, _ in wl["stages"]]))
+        x = np.empty(6 * y.shape[0] * dtot, np.uint8)
+        pkg.check(L.pddc_memcpy_d2h(x.ctypes.data, arena.data_ptr(), x.nbytes, st))
+        pkg.check(L.pddc_stream_sync(st))
+        ref = O.ddc_chain(x, wl["stages"], freg=wl["freg"], mix=wl["mix"])
+        assert O.rel_err(y.reshape(-1), ref[:y.size]) <= 1e-6, name
+        pipe.close()
     del arena
     torch.cuda.empty_cache()

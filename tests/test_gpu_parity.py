@@ -549,7 +549,6 @@ def test_tile_scheduler_variants(pkg, dev, O, monkeypatch, tune, dyn, chunk):
     tune("fir8_dyn_pct", int(dyn))
     tune("fir8_chunk", int(chunk))
     monkeypatch.setenv("PDDC_FIR8_BLOCKS", "5")
-    monkeypatch.setenv("PDDC_NO_I8", "1")                # (this is about k_fir8's scheduler: the vector kernels throughout)
     h1, h2 = load_taps("c320_s1_d8_32"), load_taps("c320_s2_d8_64")
     for stages, mix, R in (([(8, load_taps("d8_127"))], False, "4"), ([(8, load_taps("d8_255"))], True, "8"),
                            ([(8, h1), (8, h2)], True, "4"), ([(8, h1), (8, h2)], False, "8")):
@@ -559,6 +558,7 @@ def test_tile_scheduler_variants(pkg, dev, O, monkeypatch, tune, dyn, chunk):
         packed = O.lcg_bytes(6 * cuts[-1], 99)
         ref = O.ddc_chain(packed, stages, freg=987654321, mix=mix)
         pipe = pkg.Pipeline(stages, mix=mix)
+        pipe.set_option("no_i8", 1)                      # (this is about k_fir8's scheduler: the vector kernels throughout)
         pipe.set_freg(987654321)
         y = np.concatenate([pipe.process(to_dev(packed[6 * a:6 * b], dev)).cpu().numpy().reshape(-1)
                             for a, b in zip(cuts[:-1], cuts[1:])])
