@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Build-time guard for ddc_fir_i8.o (run by the Makefile right after the compile; a failure deletes the object).
+
+k_fir_i8x's loader / finishing waves share their SIMD with waves that issue matrix instructions.  In that position two
+code shapes gave wrong values in lanes 48..63 on MI355X (NOTEBOOK.md R4.4, R5.2: the product compiled WITH the SLP
+vectoriser delivers 5-6 thousand wrong outputs per 600-tile batch in layout 1, x only, lanes 48..63; the isolated
+instruction sequences are clean -- tools/ubench/mfma_*_hazard.hip -- so the cause is not understood, only avoided):
+  (b) packed fp32 (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) in a wave beside a matrix wave,
+  (a) a result store whose data registers are overwritten at once.
+The source avoids both (no 2-vector arithmetic in the finishing code, -fno-slp-vectorize for the file, store + s_nop in ONE
+asm statement).  A compiler update, a build line without the flag or a new 2-vector expression would bring them back
+silently; this script looks at the machine code instead:
+  * every k_fir_i8x / k_fir_i8x_many instantiation with LAYOUT 1 (loaders finish tiles): no v_pk_*_f32 at all;
+  * LAYOUT 1 and 2: every nontemporal result store (`global_store_dword[x2] ... nt`) is followed by `s_nop`, and no
+    global store at all is followed directly by a vector instruction.
+usage: check_hazard_pads.py ddc_fir_i8.o"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+NAME = re.compile(r"k_fir_i8x(?:_many)?ILi(\d+)ELi(\d)ELb([01])ELi(\d)E")
+
+
+def disassemble(obj):
+    with tempfile.TemporaryDirectory() as t:
+        fat, co = os.path.join(t, "fat.bin"), os.path.join(t, "dev.co")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", obj])
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--unbundle",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"])
+        return subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True)
+
+
+def main(obj):
+    kernels, cur = {}, None
+    for line in disassemble(obj).splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), [])
+        elif cur is not None and line.startswith("\t"):
+            ins = line.strip().split("//")[0].strip()
+            if ins:
+                cur.append(ins)
+    problems, checked = [], 0
+    for name, code in kernels.items():
+        m = NAME.search(name)
+        if not m:
+            continue
+        layout = int(m.group(4))
+        if layout == 0:
+            continue                       # the matrix waves finish their own tiles: no other matrix wave on their SIMD
+        checked += 1
+        if layout == 1:
+            pk = [i for i in code if re.match(r"v_pk_(mul|fma|add)_f32", i)]
+            if pk:
+                problems.append(f"{name}: {len(pk)} packed fp32 instructions in a kernel whose loaders finish tiles beside matrix waves "
+                                f"(first: {pk[0]})")
+        for k, ins in enumerate(code[:-1]):
+            if not ins.startswith("global_store"):
+                continue
+            nxt = code[k + 1]
+            if re.match(r"global_store_dword(x2)? .* nt$", ins) and not nxt.startswith("s_nop"):
+                problems.append(f"{name}: result store without its pad: `{ins}` then `{nxt}`")
+            elif nxt.startswith("v_"):
+                problems.append(f"{name}: a vector instruction directly behind a store: `{ins}` then `{nxt}`")
+    if not checked:
+        problems.append("no k_fir_i8x instantiation with LAYOUT 1 or 2 found: has the kernel been renamed?")
+    for p in problems:
+        print("check_hazard_pads:", p, file=sys.stderr)
+    if not problems:
+        print(f"check_hazard_pads: {checked} k_fir_i8x kernels with finishing waves beside matrix waves: no packed fp32, every result store padded")
+    return 1 if problems else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1]))

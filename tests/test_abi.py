@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -88,6 +89,21 @@ def test_placement_helpers_check_their_arguments_before_touching_a_device(pkg):
     assert L.pddc_malloc_apart(C.byref(p), 0, None, 0, 4, None, None) == pkg.PDDC_EINVAL
     if L.pddc_device_count() == 0:
         assert L.pddc_malloc_apart(C.byref(p), 1 << 20, None, 0, 4, None, None) == pkg.PDDC_ENODEV
+
+
+def test_the_int8_kernel_object_passes_the_hazard_check(pkg):
+    """csrc/check_hazard_pads.py on the object the library was linked from: no packed fp32 in any k_fir_i8x kernel whose
+    loader waves finish tiles beside matrix waves, every result store of a finishing wave padded (the build runs the same
+    check and deletes an object that fails it; this test makes the CPU suite say so too)."""
+    import subprocess
+    obj = os.path.join(pkg.CSRC, "ddc_fir_i8.o")
+    if not os.path.exists(obj):
+        pkg.build()
+    out = subprocess.run([sys.executable, os.path.join(pkg.CSRC, "check_hazard_pads.py"), obj], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "no packed fp32" in out.stdout
+    mk = open(os.path.join(pkg.CSRC, "Makefile")).read()
+    assert "check_hazard_pads.py $@" in mk and "-fno-slp-vectorize -c ddc_fir_i8.hip" in mk
 
 
 def test_product_does_not_reference_oracle():

@@ -246,26 +246,30 @@ def test_every_walk_gives_the_same_bits(pkg, dev, O):
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
 def test_layouts_stay_clean_under_repetition(pkg, dev, O, layout):
-    """Sporadic faults need repetition to show (the packed-fp32 / store hazards beside matrix waves): the same
-    600-tile batch twenty times per layout, single stage (both NCO forms) and fused pair, every output against the first
-    run's bits and the first run against the oracle."""
-    import torch
-    for stages in ([(8, load_taps("d8_127"))], [(8, lowpass(48, 0.05))], [(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05))]):
-        ns = TILE * 600
+    """Sporadic faults need repetition to show (the packed-fp32 / store hazards beside matrix waves; with the
+    SLP vectoriser on, this test's layout 1 fails within the first few runs -- tools/hazard_ab.sh): the same 600-tile
+    batch SIXTY times per layout -- single stage in all three NCO forms (48, 127 and 255 taps), the fused pair, the
+    decimate-by-10 form --, every run against the first run's bits and the first run against the oracle."""
+    cases = ([(8, load_taps("d8_127"))], [(8, lowpass(48, 0.05))], [(8, load_taps("d8_255"))],
+             [(8, lowpass(48, 0.05)), (8, lowpass(56, 0.05))], [(10, lowpass(51, 0.04))])
+    for stages in cases:
+        ns = (TILE if stages[0][0] == 8 else 10240) * 600
         packed = O.lcg_bytes(6 * ns, 2027)
         ref = O.ddc_chain(packed, stages, freg=FREG, mix=True)
         d_in = to_dev(packed, dev)
+        pipe = pkg.Pipeline(stages, mix=True)
+        pipe.set_option("i8x_layout", layout)
+        pipe.set_freg(FREG)
+        assert pipe.on_i8(ns) == 2
         first = None
-        for rep in range(20):
-            pipe = pkg.Pipeline(stages, mix=True)
-            pipe.set_option("i8x_layout", layout)
-            pipe.set_freg(FREG)
+        for rep in range(60):
+            pipe.reset()
             y = pipe.process(d_in).cpu().numpy().reshape(-1)
-            pipe.close()
             if first is None:
                 first = y
                 assert O.rel_err(y, ref) <= FIR_TOL
-            assert np.array_equal(y.view(np.uint32), first.view(np.uint32)), (layout, len(stages), rep)
+            assert np.array_equal(y.view(np.uint32), first.view(np.uint32)), (layout, len(stages), stages[0][0], len(stages[0][1]), rep)
+        pipe.close()
 
 
 @pytest.mark.parametrize("ntaps", [51, 57, 20])
