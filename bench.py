@@ -88,9 +88,10 @@ def parse(argv=None):
                     help="1 = no placement search: input and output as hipMalloc hands them out (anything else: search\n"
                          "for a pair in different HBM extent classes, 0.340 instead of 0.367 ms,\n"
                          "profiles/r02/i_placement_map.txt)")
-    ap.add_argument("--arena-gib", type=int, default=80,
-                    help="size of the allocation the placement cuts its 8 GiB slots from (less if less is free);\n"
-                         "80 GiB hold the four offsets the rule probes")
+    ap.add_argument("--arena-gib", type=int, default=72,
+                    help="size of the allocation the placement cuts its 8 GiB slots from (less if less is free): a quarter of\n"
+                         "the 288 GB at most by default -- a receiver cannot spend more of its HBM on buying 1-8 %%; 72 GiB\n"
+                         "hold the four offsets the rule probes (+8, +32, +48, +64 GiB)")
     ap.add_argument("--arena-rest-s", type=float, default=3.0,
                     help="pause after the arena has been allocated, before the first launch into it.  During the first\n"
                          "second or so behind an 80 GiB allocation the chip sometimes (one process in five) runs every\n"
@@ -98,9 +99,10 @@ def parse(argv=None):
                          "does to freshly handed-out memory, most likely -- and a 20-step timed region can fall into\n"
                          "that; with the pause none of thirty processes did (profiles/r03/n_slow_state_investigation.txt).\n"
                          "A receiver allocates once and streams for hours; 0 switches the pause off")
-    ap.add_argument("--arena-grow-gib", type=int, default=192,
+    ap.add_argument("--arena-grow-gib", type=int, default=0,
                     help="rule placement: if every slot of the first arena runs at the first-come speed (one extent class\n"
-                         "over all of it), allocate this much instead (less if less is free) and look again; 0: never")
+                         "over all of it), allocate this much instead (less if less is free) and look again; 0 (default\n"
+                         "since round 5): never -- such a layout is reported as it is, `value` = the first-come speed")
     ap.add_argument("--placement", default="rule", choices=["rule", "full"],
                     help="rule: input at the start of the arena, output probed at +8 (first come), +32, +48, +64 GiB;\n"
                          "full: three input slots x every output slot (the map; use --arena-gib 192)")
@@ -447,9 +449,9 @@ def run_rank(a):
     # other's way (two write streams even more: tools/ubench/stream_classes.hip).  Buffers allocated one after the
     # other usually land in the same extent, and separate allocations 8 GiB apart do not reliably leave it (one
     # process saw a single class over 200 GiB of them).  Inside ONE large allocation the classes alternate every
-    # 32-64 GiB in every process tried (tools/placement_probe.py --mode matrix), so: one arena (--arena-gib, default 80), cut
+    # 32-64 GiB in every process tried (tools/placement_probe.py --mode matrix), so: one arena (--arena-gib, default 72 = a quarter of the HBM), cut
     # into 8 GiB slots, the input at its start.  The rule (profiles/r03/f_placement_rule.txt; the library's own form is
-    # pddc_arena_place): the slot right behind the input is always in the input's class ("first come"), one of the slots
+    # pddc_pipeline_arena_place): the slot right behind the input is always in the input's class ("first come"), one of the slots
     # at +32 / +48 / +64 GiB nearly always in another (every slot is looked at when none of them gains 3 %) -- four probes of 24 back-to-back steps, the fastest kept, the first-come
     # time reported next to it.  --placement full scans every slot for three input places (1.5 s; what round 2 did).
     # A receiver allocates once and runs for hours; 288 GB of HBM make this affordable.
@@ -756,6 +758,10 @@ def run_rank(a):
         res = {
             "metric": BASELINE_METRIC,
             "value": round(value, 1), "unit": "MS/s",
+            # what the same step does in the buffers as the allocator hands them out (no arena, no probing): from the
+            # first-come probe of the placement (24 back-to-back steps at output slot 1, right behind the input)
+            "value_first_come": (round(world * ns / (placement["first_come_ms"] * 1e-3) / 1e6, 1)
+                                 if placement and placement.get("first_come_ms") else None),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt_max / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

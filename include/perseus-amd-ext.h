@@ -105,6 +105,12 @@ int perseus_amd_set_config(perseus_descr *descr, const perseus_amd_config *cfg);
 /* The GPU batch size the next stream will use: cfg.batch_samples if the client chose one (set_config, PERSEUS_AMD_BATCH);
  * otherwise the library's pick for the kind of source -- 2^22 samples, or 2^24 for a free-running (unpaced) on-device source */
 uint32_t perseus_amd_effective_batch(perseus_descr *descr);
+/* The explicit form of the choice: batch_samples > 0 (a multiple of 8) is the client's batch size from the next stream on,
+ * whatever value is in force now; 0 hands the choice back to the library.  (set_config takes a batch_samples that DIFFERS
+ * from the present value as the client's choice and the same value as "no change"; the effective size of a stream never
+ * writes cfg.batch_samples, so a descriptor that streamed unpaced at 2^24 starts its next, paced stream at 2^22 again.)
+ * Not while streaming (PERSEUS_ASYNCSTARTED). */
+int perseus_amd_set_batch(perseus_descr *descr, uint32_t batch_samples);
 
 /* state introspection (for tests and tools) */
 uint32_t perseus_amd_get_freg(perseus_descr *descr);          /* NCO word, perseus-sdr.c:584 */
@@ -129,6 +135,10 @@ int perseus_amd_get_plan(perseus_descr *descr, int decim[4], int ntaps[4], float
 /* interpolation factor L of each stage (1 = plain decimator; >1 = rational L/decim
  * resampler, used by the 48k/95k/96k/192k plans) */
 int perseus_amd_get_plan_interp(perseus_descr *descr, int interp[4]);
+/* The same for a rate, without a descriptor and without touching the library's global state (no init / exit): the plan
+ * perseus_set_sampling_rate(sps) would select (nearest table rate, perseus-sdr.c:776-811; *rate gets it).  Returns the
+ * number of stages, or PERSEUS_FPGANOTCFGD for a rate the table does not reach.  Does not set perseus_error. */
+int perseus_amd_plan_for_rate(int sps, int *rate, int decim[4], int ntaps[4], int interp[4], float *taps[4]);
 
 #ifdef __cplusplus
 }

@@ -746,33 +746,30 @@ def sdr_lib() -> C.CDLL:
     L.perseus_amd_get_plan.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                        C.POINTER(C.POINTER(C.c_float))]
     L.perseus_amd_get_plan_interp.argtypes = [vp, C.POINTER(C.c_int)]
+    L.perseus_amd_get_plan.restype = C.c_int
+    L.perseus_amd_get_plan_interp.restype = C.c_int
+    L.perseus_amd_plan_for_rate.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                            C.POINTER(C.POINTER(C.c_float))]
+    L.perseus_amd_plan_for_rate.restype = C.c_int
+    L.perseus_amd_effective_batch.argtypes = [vp]
+    L.perseus_amd_effective_batch.restype = C.c_uint32
+    L.perseus_amd_set_batch.argtypes = [vp, C.c_uint32]
+    L.perseus_amd_set_batch.restype = C.c_int
     _sdr = L
     return L
 
 
 def api_plan(rate: int):
     """The decimation plan the drop-in API builds for perseus_set_sampling_rate(rate) (perseus-sdr.c:776-892 selects the
-    rate; the plan and its taps are this library's): [(decim, taps float32, interp)].  Goes through the API's own call
-    sequence (init, open, firmware, rate) in wire mode -- no GPU call -- and closes it again."""
+    rate; the plan and its taps are this library's): [(decim, taps float32, interp)].  perseus_amd_plan_for_rate: no
+    descriptor, no perseus_init / perseus_exit -- receivers the process has open are left alone."""
     import numpy as np
     L = sdr_lib()
-    L.perseus_amd_get_plan.restype = C.c_int
-    L.perseus_amd_get_plan_interp.restype = C.c_int
-    was = L.perseus_set_debug(0)
-    if L.perseus_init() < 1:
-        raise RuntimeError("perseus_init: no receiver")
-    try:
-        d = L.perseus_open(0)
-        if not d or L.perseus_firmware_download(d, None) != 0 or L.perseus_set_sampling_rate(d, int(rate)) != 0:
-            raise RuntimeError("perseus API: " + L.perseus_errorstr().decode(errors="replace"))
-        dec, nt, it = (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)()
-        n = L.perseus_amd_get_plan(d, dec, nt, None)
-        taps = [np.zeros(nt[i], np.float32) for i in range(n)]
-        arr = (C.POINTER(C.c_float) * 4)(*([t.ctypes.data_as(C.POINTER(C.c_float)) for t in taps] + [None] * (4 - n)))
-        L.perseus_amd_get_plan(d, dec, nt, arr)
-        L.perseus_amd_get_plan_interp(d, it)
-        L.perseus_close(d)
-        return [(int(dec[i]), taps[i], int(it[i])) for i in range(n)]
-    finally:
-        L.perseus_exit()
-
+    dec, nt, it = (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)()
+    n = L.perseus_amd_plan_for_rate(int(rate), None, dec, nt, it, None)
+    if n < 0:
+        raise RuntimeError(f"perseus_amd_plan_for_rate({rate}): {n}")
+    taps = [np.zeros(nt[i], np.float32) for i in range(n)]
+    arr = (C.POINTER(C.c_float) * 4)(*([t.ctypes.data_as(C.POINTER(C.c_float)) for t in taps] + [None] * (4 - n)))
+    L.perseus_amd_plan_for_rate(int(rate), None, dec, nt, it, arr)
+    return [(int(dec[i]), taps[i], int(it[i])) for i in range(n)]

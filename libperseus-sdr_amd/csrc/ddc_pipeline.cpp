@@ -207,9 +207,13 @@ struct pddc_pipeline {
         hipStream_t stream = nullptr;
         float scale = 0.0f, ct[2] = { 0.0f, 0.0f };
         /* the decimate-by-10 form: one table set per delay 0 .. 7 of the taps (a batch's decimation phase), built when first
-         * needed for the present word and taps and kept -- the phases of a stream's batches come round again */
+         * needed for the present word and taps and kept -- the phases of a stream's batches come round again.  Two
+         * buffers per delay with a `left` event each, as the slots above: a retune rebuilds a delay's set into the OTHER
+         * buffer and waits for nothing but that buffer's last readers of two retunes ago (the advisor, round 4: this was a
+         * hipDeviceSynchronize per delay -- up to eight device-wide stalls behind one retune) */
         struct D10 {
-            void *d = nullptr, *h = nullptr;
+            I8xSlot buf[2];
+            int cur = 0;
             bool valid = false;
             uint32_t freg = 0;
             unsigned taps_ver = 0;
@@ -945,12 +949,15 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
         hipEventDestroy(e.first);
         hipEventDestroy(e.second);
     }
-    for (auto &e : p->i8x.d10) {
-        if (e.d)
-            hipFree(e.d);
-        if (e.h)
-            hipHostFree(e.h);
-    }
+    for (auto &e : p->i8x.d10)
+        for (auto &b : e.buf) {
+            if (b.d)
+                hipFree(b.d);
+            if (b.h)
+                hipHostFree(b.h);
+            if (b.left)
+                hipEventDestroy(b.left);
+        }
     for (auto &sl : p->i8x.slot) {
         if (sl.d)
             hipFree(sl.d);
@@ -1414,22 +1421,40 @@ static int i8x_d10_prepare(pddc_pipeline *p, int delay, hipStream_t s, FirI8xArg
     const Stage &s0 = p->st[0];
     if (!(e.valid && e.freg == p->freg && e.taps_ver == p->taps_ver && e.stream == s)) {
         const size_t nb = fir_i8x_d10_table_bytes();
-        if (!e.d) {
-            HIP_TRY(hipMalloc(&e.d, nb));
-            HIP_TRY(hipHostMalloc(&e.h, nb, hipHostMallocDefault));
+        if (e.valid) {
+            /* a retune or new taps: the set in use stays where it is for the launches already queued -- an event behind them --
+             * and the new one goes into the other buffer */
+            if (e.stream == s) {
+                HIP_TRY(hipEventRecord(e.buf[e.cur].left, s));
+                e.buf[e.cur].left_valid = true;
+            } else {
+                /* another stream (joining or leaving a gang): whatever reads the old tables there has to be through */
+                HIP_TRY(hipDeviceSynchronize());
+                for (auto &b : e.buf)
+                    b.left_valid = false;
+            }
+            e.cur ^= 1;
         }
-        if (e.valid)              /* a retune, new taps or another stream: whatever still reads (or copies) the old set must be through */
-            HIP_TRY(hipDeviceSynchronize());
+        pddc_pipeline::I8xSlot &b = e.buf[e.cur];
+        if (!b.d) {
+            HIP_TRY(hipMalloc(&b.d, nb));
+            HIP_TRY(hipHostMalloc(&b.h, nb, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&b.left, hipEventDisableTiming));
+        }
+        if (b.left_valid) {
+            HIP_TRY(hipEventSynchronize(b.left));
+            b.left_valid = false;
+        }
         e.valid = false;
-        if (!fir_i8x_d10_build_tables(s0.taps.data(), s0.ntaps, delay, p->freg, static_cast<int8_t *>(e.h), &e.scale, e.ct))
+        if (!fir_i8x_d10_build_tables(s0.taps.data(), s0.ntaps, delay, p->freg, static_cast<int8_t *>(b.h), &e.scale, e.ct))
             return fail(PDDC_EINVAL, "k_fir_i8x: the taps cannot be quantised (all zero, or not finite)");
-        HIP_TRY(hipMemcpyAsync(e.d, e.h, nb, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b.d, b.h, nb, hipMemcpyHostToDevice, s));
         e.freg = p->freg;
         e.taps_ver = p->taps_ver;
         e.stream = s;
         e.valid = true;
     }
-    q.atab = e.d;
+    q.atab = e.buf[e.cur].d;
     q.taps2 = nullptr;
     q.scale = e.scale;
     q.ct[0] = e.ct[0];

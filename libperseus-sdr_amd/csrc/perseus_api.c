@@ -141,8 +141,10 @@ struct perseus_descr_ds {
     out_segs os;                /* the batches' outputs, oldest first; the last os.n_pend still on the GPU (out_segments.h) */
     int input_done;             /* the source has nothing more to give           */
     int gpu_source;             /* the LCG stream is generated on the device     */
-    int batch_auto;             /* batch_samples was not chosen by the client (PERSEUS_AMD_BATCH, set_config): the library
-                                   picks it for the kind of source when the stream starts (effective_batch)             */
+    int batch_auto;             /* batch_samples was not chosen by the client (PERSEUS_AMD_BATCH, set_config, set_batch): the
+                                   library picks it for the kind of source when the stream starts (effective_batch)     */
+    uint32_t batch_eff;         /* the batch size of THIS stream (set by start; cfg.batch_samples stays the client's / the
+                                   default value, so the next stream of this descriptor decides anew)                   */
     uint64_t ganged_batches;    /* batches that shared their launches with other receivers of the GPU */
     uint64_t n_in_place, n_gathered;   /* transfers delivered from the output buffer itself / copied into their slot */
     int gpu_dev;                /* HIP device of the current / last stream, -1: none */
@@ -627,7 +629,7 @@ static size_t out_bytes_per_sample(const perseus_descr *d)
 static size_t batch_prepare(perseus_descr *d)
 {
     const int k = d->cur;
-    size_t ns = d->cfg.batch_samples;
+    size_t ns = d->batch_eff;
     if (!d->gpu_source) {
         size_t got = source_fill(d, d->batch_in[k], ns * 6);
         got -= got % 48;                         /* whole groups of 8 samples */
@@ -865,8 +867,8 @@ static void gang_submit(int dev, const int *sub, int m, int *busy, int *inflight
             if (!d->streaming || d->cancelling || d->source_done || !gang_candidate(d) || !can_submit(d))
                 continue;
             if (nm == 0)
-                ns = d->cfg.batch_samples;
-            if (d->cfg.batch_samples != ns) {                  /* another batch length: a chain of its own */
+                ns = d->batch_eff;
+            if (d->batch_eff != ns) {                  /* another batch length: a chain of its own */
                 submit_batch(d);
                 *busy = 1;
                 continue;
@@ -1527,15 +1529,15 @@ static int start_locked(perseus_descr *d, uint32_t buffersize, perseus_input_cal
             return errorset(PERSEUS_DEVCONF, "GPU pipeline creation failed (%d): %s", rc, pddc_last_error());
         }
         pddc_pipeline_set_freg(d->pipe, d->freg);
-        d->cfg.batch_samples = effective_batch(d);             /* (what get_config reports while the stream runs) */
-        d->out_cap = pddc_pipeline_max_output(d->pipe, d->cfg.batch_samples) + 8;
+        d->batch_eff = effective_batch(d);                     /* (perseus_amd_effective_batch reports it while the stream runs) */
+        d->out_cap = pddc_pipeline_max_output(d->pipe, d->batch_eff) + 8;
         /* the synthetic stream is generated on the GPU (bit-identical to the host loop,
          * pddc_synth_lcg) unless the configuration insists on the CPU generator */
         d->gpu_source = d->cfg.source == PERSEUS_AMD_SRC_LCG && !d->cfg.cpu_source;
         int hrc = 0;
         for (int k = 0; k < 2; k++) {
             if (!d->gpu_source)
-                hrc |= pddc_host_alloc((void **)&d->batch_in[k], (size_t)d->cfg.batch_samples * 6);
+                hrc |= pddc_host_alloc((void **)&d->batch_in[k], (size_t)d->batch_eff * 6);
         }
         /* every batch at least two buffers' worth of output (out_cap is the most a batch gives, + 8; the least is within
          * two samples of that): the callbacks read the output where the GPU puts it */
@@ -1639,8 +1641,11 @@ int perseus_amd_set_config(perseus_descr *d, const perseus_amd_config *cfg)
     /* the strings are copied into the descriptor -- unless they already ARE the descriptor's
      * copies (get_config -> modify -> set_config hands them back) */
     const char *fp = cfg->file_path, *fs = cfg->fault_script;
+    /* A batch size that differs from the present one is the client's choice.  (The same value back -- get_config, change
+     * another field, set_config -- leaves the choice where it was; a client that WANTS the present value, or the library's
+     * pick again, says so with perseus_amd_set_batch.) */
     if (cfg->batch_samples != d->cfg.batch_samples)
-        d->batch_auto = 0;                      /* the client chose a batch size */
+        d->batch_auto = 0;
     d->cfg = *cfg;
     if (d->cfg.ep_packet_size == 0)
         d->cfg.ep_packet_size = 512;
@@ -1673,7 +1678,25 @@ static uint32_t effective_batch(const perseus_descr *d)
     return d->cfg.batch_samples;
 }
 
-uint32_t perseus_amd_effective_batch(perseus_descr *d) { return d ? effective_batch(d) : 0; }
+uint32_t perseus_amd_effective_batch(perseus_descr *d) { return d ? (d->streaming ? d->batch_eff : effective_batch(d)) : 0; }
+
+int perseus_amd_set_batch(perseus_descr *d, uint32_t batch_samples)
+{
+    if (d == NULL)
+        return errorset(PERSEUS_NULLDESCR, "null descriptor");
+    if (d->streaming)
+        return errorset(PERSEUS_ASYNCSTARTED, "cannot reconfigure while streaming");
+    if (batch_samples % 8)
+        return errorset(PERSEUS_ERRPARAM, "batch_samples must be a multiple of 8 (0: the library picks)");
+    if (batch_samples == 0) {
+        d->batch_auto = 1;
+        d->cfg.batch_samples = 1u << 22;
+    } else {
+        d->batch_auto = 0;
+        d->cfg.batch_samples = batch_samples;
+    }
+    return errornone(0);
+}
 
 uint32_t perseus_amd_get_freg(perseus_descr *d) { return d ? d->freg : 0; }
 int perseus_amd_get_sampling_rate(perseus_descr *d) { return d ? d->sample_rate : 0; }
@@ -1742,6 +1765,36 @@ int perseus_amd_get_plan_interp(perseus_descr *d, int interp[4])
     for (int i = 0; i < d->plan.nstages; i++)
         interp[i] = d->plan.interp[i];
     return errornone(d->plan.nstages);
+}
+
+/* The plan perseus_set_sampling_rate(sps) would select -- nearest table rate, the midpoint to the lower one, as
+ * perseus-sdr.c:776-811 -- WITHOUT a descriptor: no perseus_init / perseus_exit, no global state touched, so a host
+ * that has receivers open can ask (bench.py and the tools used to run init/open/.../exit for this, which tore down
+ * whatever the process had open).  Same outputs as perseus_amd_get_plan + perseus_amd_get_plan_interp; *rate gets
+ * the table rate.  Returns the number of stages or PERSEUS_FPGANOTCFGD. */
+int perseus_amd_plan_for_rate(int sps, int *rate, int decim[4], int ntaps[4], int interp[4], float *taps[4])
+{
+    const int idx = rate_index(sps);
+    if (idx < 0)
+        return PERSEUS_FPGANOTCFGD;
+    ddc_plan pl;
+    memset(&pl, 0, sizeof(pl));
+    plan_build(&pl, k_rates[idx]);
+    if (rate)
+        *rate = k_rates[idx];
+    for (int i = 0; i < pl.nstages; i++) {
+        if (decim)
+            decim[i] = pl.decim[i];
+        if (ntaps)
+            ntaps[i] = pl.ntaps[i];
+        if (interp)
+            interp[i] = pl.interp[i];
+        if (taps && taps[i])
+            memcpy(taps[i], pl.taps[i], sizeof(float) * (size_t)pl.ntaps[i]);
+    }
+    const int n = pl.nstages;
+    plan_free(&pl);
+    return n;
 }
 
 int perseus_amd_get_plan(perseus_descr *d, int decim[4], int ntaps[4], float *taps[4])

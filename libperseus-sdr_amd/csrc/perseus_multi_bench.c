@@ -13,7 +13,7 @@
  *   -T file   first-stage taps, raw float32 (default ../tests/golden/taps_d8_127.f32 next to the binary)
  *   -c        cascade /320 with NCO (taps c320_* from the same directory) instead of the single /8
  *   -G        gather the outputs on GPU 0
- *   -A GiB    size of the per-GPU arena that input, workspace and outputs are cut from (160; 0: separate allocations)
+ *   -A GiB    size of the per-GPU arena that input, workspace and outputs are cut from (72 = a quarter of the HBM; 0: separate allocations)
  * Prints one line per run: aggregate input MS/s (kernel path only), and with -G the with-gather rate
  * and the bytes per second that reached the root per peer link.
  */
@@ -70,7 +70,7 @@ static float *load_f32(const char *dir, const char *name, int *n)
 
 int main(int argc, char **argv)
 {
-    int ng = 0, log2n = 26, steps = 50, warm = 5, cascade = 0, gather = 0, arena_gib = 160, c;
+    int ng = 0, log2n = 26, steps = 50, warm = 5, cascade = 0, gather = 0, arena_gib = 72, c;
     char tapdir[1024];
     {
         char self[1024];

@@ -189,6 +189,8 @@ def test_bench_line_end_to_end_on_the_gpu():
     pl = d["placement"]
     # (four probes when the rule holds; every slot of the arena -- and of a larger one, "grown_after" -- when it does not)
     assert pl is None or ((pl["probe_pairs"] <= 12 or pl["grown_after"]) and pl["first_come_ms"] >= pl["chosen"]["ms"])
+    assert pl is None or pl["arena_GiB"] <= 72                           # a quarter of the HBM at most, never grown by default
+    assert "value_first_come" in d and (pl is None or 0 < d["value_first_come"] <= d["value"] * 1.1)
 
 
 def test_eight_rank_dry_run_of_the_launcher():

@@ -281,6 +281,49 @@ def test_plan_export(L, pkg):
         assert np.allclose(b, b[::-1], atol=1e-9)                     # linear phase
 
 
+def test_plan_for_a_rate_without_touching_open_receivers(L, pkg):
+    """perseus_amd_plan_for_rate (and pkg.api_plan, which bench.py's c320 workload uses): the plan of
+    perseus_set_sampling_rate(rate), nearest-rate rule of perseus-sdr.c:776-811 included, with no descriptor and no init /
+    exit -- a receiver the process has open stays open and configured (round 4's api_plan ran perseus_exit under it)."""
+    d = bring_up(L, 125000)
+    plan = pkg.api_plan(250000)
+    assert [(dd, len(t), l) for dd, t, l in plan][:3] == [(8, 32, 1), (8, 41, 1), (5, 117, 1)]
+    dec, nt = (C.c_int * 4)(), (C.c_int * 4)()
+    assert L.perseus_amd_get_plan(d, dec, nt, None) == 3 and list(dec)[:3] == [8, 8, 10]          # still open, still its own plan
+    assert L.perseus_amd_get_sampling_rate(d) == 125000
+    rate = C.c_int()
+    assert L.perseus_amd_plan_for_rate(260000, C.byref(rate), dec, nt, None, None) == 3 and rate.value == 250000
+    assert L.perseus_amd_plan_for_rate(95500, C.byref(rate), None, None, None, None) == 4 and rate.value == 95000   # midpoint -> lower
+    for r in (48000, 95000, 96000, 125000, 192000, 250000, 500000, 1000000, 1600000, 2000000):
+        assert len(pkg.api_plan(r)) >= 2
+
+
+def test_batch_size_choice_is_the_clients_or_the_librarys_per_stream(L, pkg):
+    """The GPU batch size: the library's pick per stream (2^24 for a free-running on-device source, 2^22 otherwise) unless
+    the client chose one -- and a stream's effective size never becomes the configuration (advisor, round 4: after one
+    unpaced stream a paced one on the same descriptor ran with 2^24-sample batches, 210 ms of latency each)."""
+    d = bring_up(L, 250000)
+    cfg = pkg.AmdConfig()
+    assert L.perseus_amd_get_config(d, C.byref(cfg)) == 0 and cfg.batch_samples == 1 << 22
+    cfg.mode, cfg.pace = 1, 0
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    assert L.perseus_amd_effective_batch(d) == 1 << 24          # unpaced device source: the library's pick
+    cfg.pace = 1
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    assert L.perseus_amd_effective_batch(d) == 1 << 22          # paced: latency counts
+    assert L.perseus_amd_get_config(d, C.byref(cfg)) == 0 and cfg.batch_samples == 1 << 22
+    cfg.pace = 0
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    assert L.perseus_amd_set_batch(d, 1 << 22) == 0             # the client WANTS 2^22, although that is the present value
+    assert L.perseus_amd_effective_batch(d) == 1 << 22
+    assert L.perseus_amd_set_batch(d, 0) == 0                   # ... and hands the choice back
+    assert L.perseus_amd_effective_batch(d) == 1 << 24
+    assert L.perseus_amd_set_batch(d, 12) != 0                  # not a multiple of 8
+    cfg.batch_samples = 1 << 20
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0       # a differing value in set_config is a choice too
+    assert L.perseus_amd_effective_batch(d) == 1 << 20
+
+
 def test_every_reference_rate_has_an_exact_plan(L, O):
     """All ten rates of the reference's FPGA images: integer
     cascades, and rational L/M tails for 48k/95k/96k/192k."""

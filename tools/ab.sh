@@ -11,7 +11,7 @@ if [ "${1:-}" = build ]; then
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $flags -c csrc/ddc_kernels.hip -o /tmp/ab_k.o 2>/tmp/ab_err.txt &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_$name.so /tmp/ab_k.o csrc/ddc_pipeline.o csrc/ddc_multi.o -L/opt/rocm/lib -lrccl &&
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_$name.so /tmp/ab_k.o csrc/ddc_fir_i8.o csrc/ddc_pipeline.o csrc/ddc_multi.o -L/opt/rocm/lib -lrccl &&
       echo "built ab_$name.so ($flags)" || { echo "FAILED $name"; tail -5 /tmp/ab_err.txt; }
   done
 elif [ "${1:-}" = run ]; then
