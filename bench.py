@@ -69,9 +69,9 @@ def parse(argv=None):
     ap.add_argument("--api-batch-log2", type=int, default=0,
                     help="api250k: GPU batch size of the API stream (0 = the library's own choice: 2^24 for an unpaced on-device source)")
     ap.add_argument("--taps-fp16", action="store_true",
-                    help="binary16 taps (BASELINE config 5's fp16 leg).  The 127-/255-tap workloads run on k_fir_i8, which\n"
-                         "then holds the taps on the device as binary16 (2 bytes a tap) and quantises them into its\n"
-                         "matrix operand itself; the vector kernels keep the binary16 VALUES in fp32 registers (their\n"
+                    help="binary16 taps (BASELINE config 5's fp16 leg).  The 127-/255-tap workloads run on k_fir_i8x's plain\n"
+                         "form, which then holds the taps on the device as binary16 (2 bytes a tap) and whose matrix waves\n"
+                         "quantise them into their operand themselves; the vector kernels keep the binary16 VALUES in fp32 registers (their\n"
                          "taps sit in SGPRs in the hot loop: no storage to halve)")
     ap.add_argument("--gather", action="store_true", help="run the gather leg at N=1 too (1-rank RCCL group)")
     ap.add_argument("--no-gather", action="store_true", help="skip the gather leg at N>1")
@@ -750,7 +750,6 @@ def run_rank(a):
                    "k_fir_i8x (int8 matrix cores on the wire bytes%s, fused pair; the tail in line)" % (", NCO folded into the taps" if wl["mix"] else "") if pipe.fused_pair(ns) == 2
                    else "k_fir8 (fused pair + the previous batch's tail as extra blocks of the launch)" if overlap
                    else "k_fir_i8x (int8 matrix cores on the wire bytes%s)" % (", NCO folded into the taps" if wl["mix"] else "") if pipe.on_i8(ns) == 2
-                   else "k_fir_i8 (int8 matrix cores on the wire bytes)" if pipe.on_i8(ns) == 1
                    else "k_fir8") if fused else "k_unpack24" if stages is None else "pipeline")
         traffic, traffic_src = traffic_from_profile(a.workload, kernel_source_sig(), a.log2n, a.taps_fp16, klabel)
         if verified is not None:
@@ -769,9 +768,9 @@ def run_rank(a):
             "config": {"workload": wl["label"], "samples_per_gpu_per_step": ns, "ntaps": wl.get("ntaps"),
                        "input": "LCG bytes seed 12345+rank, device resident",
                        "sharding": "independent stream per GPU, no data-path collective",
-                       "taps": (("binary16 STORAGE: 2 bytes a tap on the device, quantised into int8 digit planes by k_fir_i8's blocks themselves (PDDC_F_TAPS_FP16)" if pipe is not None and pipe.on_i8(ns)
+                       "taps": (("binary16 STORAGE: 2 bytes a tap on the device, quantised into int8 digit planes by k_fir_i8x's matrix waves themselves (PDDC_F_TAPS_FP16)" if pipe is not None and pipe.on_i8(ns)
                                  else "binary16 VALUES held in fp32 registers (PDDC_F_TAPS_FP16)") if a.taps_fp16 else
-                                ("fp32 values as four int8 digit planes, 2^-31 of the largest tap (k_fir_i8 / k_fir_i8x)"
+                                ("fp32 values as four int8 digit planes, 2^-31 of the largest tap (k_fir_i8x)"
                                  if pipe is not None and pipe.on_i8(ns) else "fp32")),
                        "overlap": ("the stage behind the fused pair is carried by the next step's first-stage launch as extra "
                                    "thread blocks (pddc_pipeline_set_overlap); the timed region ends with a fence") if overlap else None},

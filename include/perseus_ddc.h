@@ -70,9 +70,10 @@ extern "C" {
 
 /* pipeline flags */
 #define PDDC_F_MIX         0x1u   /* NCO complex mix before stage 0            */
-#define PDDC_F_TAPS_FP16   0x2u   /* binary16 taps (config 5): rounded to binary16; a /8 first stage of 65..256 taps
-                                     without NCO (k_fir_i8) then holds them on the device AS binary16, 2 bytes a tap,
-                                     and quantises them itself; the other kernels keep the rounded values in fp32 */
+#define PDDC_F_TAPS_FP16   0x2u   /* binary16 taps (config 5): rounded to binary16; a /8 first stage without NCO on the
+                                     matrix cores (k_fir_i8x's plain form) then holds them on the device AS binary16, 2
+                                     bytes a tap, and its matrix waves quantise them themselves; the other kernels keep
+                                     the rounded values in fp32, tuned tables are built on the host from them */
 #define PDDC_F_NO_FAST     0x4u   /* force the generic kernels (testing)       */
 #define PDDC_F_OUT_PACKED24 0x8u  /* process()/push_host() emit 24-bit packed (6 B/sample)
                                      instead of float32: "FPGA emulation"      */
@@ -195,13 +196,11 @@ size_t pddc_pipeline_max_output(const pddc_pipeline *p, size_t nsamples_in);
 size_t pddc_pipeline_next_output(const pddc_pipeline *p, size_t nsamples_in);
 /* 1 if stage 0 runs the fused unpack+mix+polyphase kernel for this geometry   */
 int pddc_pipeline_uses_fused(const pddc_pipeline *p);
-/* 1 if a batch of nsamples_in would run stage 0 on the int8 matrix cores (k_fir_i8: a /8 first stage
- * without the NCO of 129..256 taps, or of 65..128 taps for batches up to 2^25 samples; the wire bytes
- * are the operand, the taps are quantised to 2^-31 of the largest one; same history, same outputs to
- * 1e-7 of full scale)                                                                       */
+/* nonzero if a batch of nsamples_in would run stage 0 on the int8 matrix cores (the wire bytes are the operand, the
+ * taps are quantised to 2^-31 of the largest one; same history, same outputs to 1e-7 of full scale)               */
 int pddc_pipeline_stage0_on_i8(const pddc_pipeline *p, size_t nsamples_in);
-/* Round 4: the return value says WHICH matrix-core kernel: 0 none (k_fir8), 1 k_fir_i8 (65..256 taps, no NCO), 2 k_fir_i8x
- * -- the NCO folded into the taps, y[m] = LO(n0 + 8m) sum_k (h[k] e^{+j theta k}) x_raw[8m - k]: complex taps on the raw
+/* The return value says WHICH kernel: 0 none (k_fir8), 2 k_fir_i8x (1 was round 3's k_fir_i8, retired in round 5: one
+ * kernel family) -- without NCO its plain form, one tap table; with it the NCO folded into the taps, y[m] = LO(n0 + 8m) sum_k (h[k] e^{+j theta k}) x_raw[8m - k]: complex taps on the raw
  * integer planes, one float rotation per output -- which every tuned (PDDC_F_MIX) decimate-by-8 first stage of 1..256
  * taps runs on, i.e. every pipeline the drop-in API builds behind perseus_set_ddc_center_freq (perseus-sdr.c:556-619);
  * with a decimate-by-8 second stage of <= 64 taps behind a first stage of <= 128 and whole 8192-sample tiles, both are one kernel
@@ -238,14 +237,14 @@ int pddc_pipeline_set_option(pddc_pipeline *p, const char *name, int value);
 int pddc_set_tunable(const char *name, int value);
 int pddc_get_tunable(const char *name, int *value);
 int pddc_pipeline_get_option(const pddc_pipeline *p, const char *name, int *value);
-/* The tap operand that kernel reads, as the library builds it (host arithmetic, no device needed; for tests and for
+/* The tap operand k_fir_i8x's plain form reads, as the library builds it (host arithmetic, no device needed; for tests and for
  * hosts that want to look at the quantisation): taps -> H[k] = round(h[k] * 2^E), E = 30 - ceil(log2 max|h|), as four
  * balanced base-256 digits d_j[k] in [-128, 127]; table[j][ks][lane][jj] = d_j[hist - (c - 8 r)] for r = lane & 15,
  * c = 64 ks + 16 (lane >> 4) + jj and 1 <= c - 8 r <= hist, else 0 (the banded Toeplitz matrix in the lane order of
- * v_mfma_i32_16x16x64_i8); 4 * ksteps * 1024 bytes with ksteps = 6 (hist 256) or 4 (hist 128).  *scale turns the
+ * v_mfma_i32_16x16x64_i8); 4 * ksteps * 1024 bytes with ksteps = (120 + hist + 63) / 64, hist = 32, 64, 128 or 256.  *scale turns the
  * integer result into the reference's float, *cterm is the constant that undoes the byte planes' -128 offset.       */
 int pddc_fir_i8_table(const float *taps, int ntaps, int hist, int8_t *table, size_t table_bytes, float *scale, float *cterm);
-/* With PDDC_F_TAPS_FP16 the device holds no such table but the taps as IEEE binary16, and the kernel's blocks quantise
+/* With PDDC_F_TAPS_FP16 (no NCO) the device holds no such table but the taps as IEEE binary16, and the kernel's matrix waves quantise
  * them into their operand registers: out[128 + tt] = binary16(h[hist - tt]) for tt = 1 .. hist, zeros elsewhere,
  * PDDC_FIR_I8_TAPS16_LEN entries (lane (r, kq) reads the 16 values 128 + 64 ks + 16 kq - 8 r + jj of k-step ks as two
  * aligned 16-byte loads); H = llround(value * *two_e), digits as above.  Host arithmetic, no device needed. */

@@ -336,8 +336,8 @@ class Pipeline:
         return bool(ddc_lib().pddc_pipeline_uses_fused_cascade(self._h, nsamples))
 
     def on_i8(self, nsamples: int) -> int:
-        """stage 0 of a batch of nsamples runs on the int8 matrix cores: 0 no (k_fir8), 1 k_fir_i8 (65..256 taps, no NCO),
-        2 k_fir_i8x (NCO folded into the taps)"""
+        """stage 0 of a batch of nsamples runs on the int8 matrix cores: 0 no (k_fir8), 2 k_fir_i8x (plain, or the NCO folded
+        into the taps; 1 was round 3's k_fir_i8, retired)"""
         return int(ddc_lib().pddc_pipeline_stage0_on_i8(self._h, nsamples))
 
     def check(self, stream: int = 0):

@@ -1,14 +1,15 @@
 /*
- * ddc_fir_i8.hip -- the decimate-by-8 first stages on the INT8 matrix cores of gfx950 (MI355X, CDNA4).
+ * ddc_fir_i8.hip -- the first stages on the INT8 matrix cores of gfx950 (MI355X, CDNA4): k_fir_i8x.
  *
- *   k_fir_i8    65..256 taps, no NCO: the wire bytes are the operand planes, the taps four planes of balanced
- *               base-256 digits, int32 accumulation is exact (round 3; BASELINE configs 2 and 5).
- *   k_fir_i8x   the same product with the NCO folded into the TAPS (round 4):
- *                   y[m] = LO(n0 + 8 m) * sum_k (h[k] e^{+j theta k}) x_raw[8 m - k],   theta = 2 pi freg / 2^32,
- *               i.e. complex taps on the raw integer planes (four real band products instead of one) and ONE float
- *               rotation per output, with the exact 32-bit phase; optionally a second decimate-by-8 stage fused behind
- *               it (the cascades' pair: the 1 B/sample intermediate never reaches HBM).  Tiles are handed round the
- *               blocks in chunks of C (1: tile-interleaved, what streams best; the pair: 4), NOTEBOOK.md R4.2.
+ * The wire bytes are the operand planes (a 24-bit sample IS three bytes), the taps four planes of balanced base-256 digits,
+ * int32 accumulation is exact.  Without NCO one tap table; with it the NCO is folded into the TAPS:
+ *       y[m] = LO(n0 + 8 m) * sum_k (h[k] e^{+j theta k}) x_raw[8 m - k],   theta = 2 pi freg / 2^32,
+ * i.e. complex taps on the raw integer planes (four real band products instead of one) and ONE float rotation per output,
+ * with the exact 32-bit phase; optionally a second decimate-by-8 stage fused behind it (the cascades' pair: the 1 B/sample
+ * intermediate never reaches HBM); a decimate-by-10 form.  Tiles are handed round the blocks in chunks of C (1:
+ * tile-interleaved, what streams best; the pair: 4), NOTEBOOK.md R4.2.
+ * (Round 3's k_fir_i8 -- the same product without NCO, eight matrix waves -- lived here until round 5; what it alone
+ * offered, binary16-STORED taps quantised by the matrix waves themselves, is now the plain form's FirI8xArgs::taps16.)
  *
  * Reference anchors: the samples are the 24-bit wire format of examples/perseustest.c:449-455, the tuning word is
  * perseus-sdr.c:584; the arithmetic itself has no reference source (FPGA bitstreams), DESIGN.md 3.
@@ -24,46 +25,21 @@
 
 namespace pddc {
 
-/* ======================================================================== */
-/* k_fir_i8 : 129..256 taps, decimate by 8, packed input, no NCO -- int8 MFMA */
-/* ======================================================================== */
-/* The 255-tap first stage is the one configuration that is bound by vector issue, not by HBM (NOTEBOOK.md rounds 1-3 5 (v)): 17 G
- * multiply-adds per 2^28 samples on a power-capped clock.  fp32 MFMA has the vector unit's own peak; int8 MFMA has
- * thirty times that, and this data fits it exactly: a 24-bit sample is three bytes, a tap quantised to 2^-E (E = 30 -
- * ceil(log2 max|h|), i.e. 31 significant bits on the largest tap) is four balanced base-256 digits, every digit x
- * byte-plane product sum over 256 taps stays below 2^24, so int32 accumulation is EXACT; products of equal weight
- * 256^(i+j) share an accumulator, the three lightest (i + j < 2: below 1.2e-7 of full scale even if every term had the
- * same sign, 2e-9 typical) are dropped, and the four sums are recombined in fp32 once per output.  The unpack is gone:
- * the loader only de-interleaves bytes (v_perm) into six planes (planes 0 and 1 xor 0x80: unsigned -> signed, the
- * offset comes back as one constant per filter).
- *   out[16 n + r] = sum_c T[r][c] X[c][n],  T[r][c] = h[256 - (c - 8 r)] (banded Toeplitz, 16 x 384: two thirds full),
- *   X[c][n] = xp[8192 tile + 128 n + c],    xp = the 256 history samples followed by the batch.
- * v_mfma_i32_16x16x64_i8: 16 output rows, 16 columns, 6 k-steps of 64; 9 plane products per step.  (The first version
- * used 32x32x32: a 32 x 512 band that is half zeros, the k range split over two waves and their partial sums added
- * through LDS: 0.409 ms; this one 0.37.)  A tile = 64 columns x 16 outputs = 8192 inputs (+256).  Persistent block of 12
- * waves per CU: waves 8..11 load -- two tiles ahead, two register sets used alternately so that no register copy waits
- * for a load -- and write the planes of the next tile; waves 0..7 (component x block of 16 columns; ALL 24 tap
- * fragments, 96 VGPRs, resident in registers) run 54 MFMAs per tile, recombine, scale and leave their outputs in LDS;
- * ONE barrier per tile; then they store float2.  Planes and outputs exist twice.  LDS rows are padded (lane stride
- * 144 B / 20 floats): conflict-free.  Measured as stand-alone prototypes first (tools/ubench/fir_i8_planes*.hip).     */
+/* ---- the formulation (round 3; what every form below shares) ----------------------------------------------------------
+ * int8 MFMA has thirty times the vector unit's multiply-add peak, and this data fits it exactly: a 24-bit sample is three
+ * bytes, a tap quantised to 2^-E (E = 30 - ceil(log2 max|h|), i.e. 31 significant bits on the largest tap) is four
+ * balanced base-256 digits, every digit x byte-plane product sum over 256 taps stays below 2^24, so int32 accumulation is
+ * EXACT; products of equal weight 256^(i+j) share an accumulator, the three lightest (i + j < 2: below 1.2e-7 of full
+ * scale even if every term had the same sign, 2e-9 typical) are dropped, and the four sums are recombined in fp32 once
+ * per output.  The unpack is gone: the loaders only de-interleave bytes (v_perm) into six planes (planes 0 and 1 xor
+ * 0x80: unsigned -> signed, the offset comes back as one constant per filter).
+ *   out[16 n + r] = sum_c T[r][c] X[c][n],  T[r][c] = h[HIST - (c - 8 r)] (banded Toeplitz, 16 x (120 + HIST)),
+ *   X[c][n] = xp[8192 tile + 128 n + c],    xp = the HIST history samples followed by the batch.
+ * v_mfma_i32_16x16x64_i8: 16 output rows, 16 columns, k-steps of 64; 9 plane products per step.  LDS rows are padded (lane
+ * stride 144 B / 20 floats): conflict-free.  Measured as stand-alone prototypes first (tools/ubench/fir_i8_planes*.hip). */
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 namespace i8 {
-/* MFMA waves + loader threads per block.  The loaders (global loads, byte de-interleave, plane writes) are the half the
- * kernel sits on, the matrix work has room: 8 + 256 (4 loader waves) 0.3608 ms, 4 + 512 0.3454 ms for 255 taps,
- * 0.3378 -> 0.3250 ms for 127 (same-box A/B, tools/ab_libs.sh). */
-constexpr int NMW = 4, NLT = 512,
-              NB = 8 / NMW;
-/* HIST = 256 (129..256 taps) or 128 (65..128 taps): history samples in front of the batch = the filter's reach */
-template <int HIST>
-struct Geo {
-    static constexpr int TILE = 8192, SPAN = TILE + HIST, PLANE = SPAN + 16 * ((SPAN + 127) / 128), NG = SPAN / 8;
-    static constexpr int KSTEPS = (120 + HIST + 63) / 64;          /* the band is 16 x (8 * 15 + HIST) wide */
-    static constexpr int NQ = (NG + NLT - 1) / NLT;
-    static constexpr size_t LDS_BYTES = 12 * (size_t)PLANE + 4 * (size_t)(20 * 64) * sizeof(float);
-};
-constexpr int OS = 20 * 64, TILE = 8192;
-
 __device__ __forceinline__ int swz(int p) { return p + 16 * (p >> 7); }
 
 /* the 8 bytes at offsets 6 s + O (s = 0..7) of the 48 bytes w[0..11] */
@@ -86,285 +62,10 @@ __device__ __forceinline__ void plane_bytes(const uint32_t (&w)[12], uint32_t &l
     hi = out[1];
 }
 
-/* the loads of one tile: group g of tile t is xp[8192 t + 8 g ..+8) -- history, batch, or (behind the batch) zeros.
- * (Measured and NOT kept, same-box A/B of whole library builds, tools/ab_libs.sh, profiles/r03/i_fir_i8_prototype.txt: a
- * branch-free path for interior tiles -- one base pointer, constant strides -- 0.378 -> 0.399 ms; on top of it the byte
- * de-interleave in 24 instead of 36 v_perm -- 0.409 ms, although the stand-alone prototype gains 2.7 % from it.  With the
- * address arithmetic between them the loads leave spread out; as one burst they are slower.)                      */
-template <int HIST>
-__device__ __forceinline__ void issue_tile(const FirI8Args &a, long long t, uint4 (&raw)[Geo<HIST>::NQ][3], int lt)
-{
-    constexpr int NQ = Geo<HIST>::NQ, NG = Geo<HIST>::NG;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int g = lt + NLT * q;
-        if (g < NG) {
-            const long long b = t * TILE + 8LL * g - HIST;         /* first sample of the group, relative to the batch */
-            const uint4 *p = b < 0 ? reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.hist) + (b + HIST) * 6)
-                                   : reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + b * 6);
-            if (b + 8 <= a.n_in) {
-                raw[q][0] = p[0];
-                raw[q][1] = p[1];
-                raw[q][2] = p[2];
-            } else {
-                raw[q][0] = raw[q][1] = raw[q][2] = make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
-    }
-}
-
-template <int HIST>
-__device__ __forceinline__ void planes_from(const uint4 (&raw)[Geo<HIST>::NQ][3], uint8_t *plane, int lt)
-{
-    constexpr int NQ = Geo<HIST>::NQ, NG = Geo<HIST>::NG, PLANE = Geo<HIST>::PLANE;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int g = lt + NLT * q;
-        if (g < NG) {
-            const uint32_t w[12] = { raw[q][0].x, raw[q][0].y, raw[q][0].z, raw[q][0].w, raw[q][1].x, raw[q][1].y,
-                                     raw[q][1].z, raw[q][1].w, raw[q][2].x, raw[q][2].y, raw[q][2].z, raw[q][2].w };
-            const int at = swz(8 * g);
-            uint32_t lo, hi;
-#define PDDC_PL(C, I, O, X)                                                                       \
-            plane_bytes<O>(w, lo, hi);                                                            \
-            *reinterpret_cast<uint2 *>(plane + (3 * C + I) * PLANE + at) = make_uint2(lo ^ X, hi ^ X);
-            PDDC_PL(0, 0, 0, 0x80808080u)
-            PDDC_PL(0, 1, 1, 0x80808080u)
-            PDDC_PL(0, 2, 2, 0u)
-            PDDC_PL(1, 0, 3, 0x80808080u)
-            PDDC_PL(1, 1, 4, 0x80808080u)
-            PDDC_PL(1, 2, 5, 0u)
-#undef PDDC_PL
-        }
-    }
-}
-/* one loader step: the loads of tile `tn` (if any) go out group by group BETWEEN the conversions of the tile that has
- * arrived -- spread over the whole step instead of one burst */
-template <int HIST>
-__device__ __forceinline__ void load_and_convert(const FirI8Args &a, long long tn, bool have_next,
-                                                 uint4 (&nxt)[Geo<HIST>::NQ][3], const uint4 (&cur)[Geo<HIST>::NQ][3],
-                                                 uint8_t *plane, int lt)
-{
-    constexpr int NQ = Geo<HIST>::NQ, NG = Geo<HIST>::NG, PLANE = Geo<HIST>::PLANE;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int g = lt + NLT * q;
-        if (g < NG) {
-            if (have_next) {
-                const long long b = tn * TILE + 8LL * g - HIST;
-                const uint4 *p = b < 0 ? reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.hist) + (b + HIST) * 6)
-                                       : reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + b * 6);
-                if (b + 8 <= a.n_in) {
-                    nxt[q][0] = p[0];
-                    nxt[q][1] = p[1];
-                    nxt[q][2] = p[2];
-                } else {
-                    nxt[q][0] = nxt[q][1] = nxt[q][2] = make_uint4(0u, 0u, 0u, 0u);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const uint32_t w[12] = { cur[q][0].x, cur[q][0].y, cur[q][0].z, cur[q][0].w, cur[q][1].x, cur[q][1].y,
-                                     cur[q][1].z, cur[q][1].w, cur[q][2].x, cur[q][2].y, cur[q][2].z, cur[q][2].w };
-            const int at = swz(8 * g);
-            uint32_t lo, hi;
-#define PDDC_PL(C, I, O, X)                                                                       \
-            plane_bytes<O>(w, lo, hi);                                                            \
-            *reinterpret_cast<uint2 *>(plane + (3 * C + I) * PLANE + at) = make_uint2(lo ^ X, hi ^ X);
-            PDDC_PL(0, 0, 0, 0x80808080u)
-            PDDC_PL(0, 1, 1, 0x80808080u)
-            PDDC_PL(0, 2, 2, 0u)
-            PDDC_PL(1, 0, 3, 0x80808080u)
-            PDDC_PL(1, 1, 4, 0x80808080u)
-            PDDC_PL(1, 2, 5, 0u)
-#undef PDDC_PL
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
 } // namespace i8
 
-template <int HIST>
-__global__ __launch_bounds__(64 * i8::NMW + i8::NLT, 1) void k_fir_i8(FirI8Args a, long long ntiles)
-{
-    using namespace i8;
-    constexpr int PLANE = Geo<HIST>::PLANE, KSTEPS = Geo<HIST>::KSTEPS, NQ = Geo<HIST>::NQ;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_i8[];
-    /* [2 buffers][2 components][3 planes][PLANE], then [2 buffers][2 components][OS] outputs */
-    float *osum_base = reinterpret_cast<float *>(lds_i8 + 12 * PLANE);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long G = gridDim.x;
-    long long t = blockIdx.x;
-    if (wave >= NMW) {
-        /* ---- loaders (waves 8..11) */
-        const int lt = tid - 64 * NMW;
-        if (blockIdx.x == 0 && a.hist_out) {             /* the next call's history: the batch's last 256 samples */
-            const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(a.in) + (a.n_in - HIST) * 6);
-            if (lt < HIST * 6 / 16)
-                static_cast<uint4 *>(a.hist_out)[lt] = src[lt];
-        }
-        uint4 ra[NQ][3], rb[NQ][3];
-        issue_tile<HIST>(a, t, ra, lt);
-        planes_from<HIST>(ra, lds_i8, lt);
-        if (t + G < ntiles)
-            issue_tile<HIST>(a, t + G, ra, lt);
-        __syncthreads();
-        for (;;) {
-            /* tile t is computed from buffer 0; t + G (in ra) goes to buffer 1, t + 2 G starts towards rb */
-            if (t + G < ntiles)
-                load_and_convert<HIST>(a, t + 2 * G, t + 2 * G < ntiles, rb, ra, lds_i8 + 6 * PLANE, lt);
-            __syncthreads();
-            t += G;
-            if (t >= ntiles)
-                break;
-            if (t + G < ntiles)
-                load_and_convert<HIST>(a, t + 2 * G, t + 2 * G < ntiles, ra, rb, lds_i8, lt);
-            __syncthreads();
-            t += G;
-            if (t >= ntiles)
-                break;
-        }
-        return;
-    }
-    /* ---- MFMA waves (0..7): component x block of 16 columns; the whole tap operand stays in registers */
-    const int comp = wave & 1, nb0 = (wave >> 1) * NB;
-    const int n = lane & 15, kq = lane >> 4;
-    const v4i_t *atab = static_cast<const v4i_t *>(a.atab);
-    v4i_t A[KSTEPS][4];
-    if (a.taps16 == nullptr) {                             /* uniform */
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                A[ks][j] = atab[(j * KSTEPS + ks) * 64 + lane];
-    } else {
-        /* binary16 tap storage: this lane's 16 columns of every k-step, quantised here exactly as fir_i8_build_table
-         * does on the host (H = llround(h 2^E), four balanced base-256 digits).  The device array is laid out for this
-         * read: G[128 + tt] = h[HIST - tt] for tt = 1 .. HIST, zeros around it (kFirI8Taps16Len entries), so that the
-         * 16 values of a k-step -- T[r][c] = G[128 + c - 8 r] -- are two aligned 16-byte loads */
-        const uint4 *g16 = static_cast<const uint4 *>(a.taps16);
-        const float two_e = (float)a.two_e;                 /* a power of two: h 2^E is exact in binary32 */
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const int i0 = (128 + 64 * ks + 16 * kq - 8 * n) >> 3;      /* in units of 8 values */
-            const uint4 lo = g16[i0], hi = g16[i0 + 1];
-            const uint32_t hw[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
-            int w[4][4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                w[0][q] = w[1][q] = w[2][q] = w[3][q] = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int jj = 4 * q + b;
-                    const uint32_t bits = (jj & 1) ? hw[jj >> 1] >> 16 : hw[jj >> 1] & 0xffffu;
-                    _Float16 hv;
-                    const uint16_t b16 = (uint16_t)bits;
-                    __builtin_memcpy(&hv, &b16, 2);
-                    const float x = (float)hv * two_e;
-                    int r = (int)(x + __builtin_copysignf(0.5f, x));   /* llround: exact, |x| <= 2^30 and 11 bits wide */
-                    /* balanced digits: d = the low byte, signed; what is left is (r - d) / 256 = (r + 128) >> 8.  Byte b of
-                     * plane j's word takes the low byte as it is (one v_perm_b32) */
-                    const uint32_t sel = 0x03020100u ^ ((0x04u ^ (uint32_t)b) << (8 * b));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        w[j][q] = (int)__builtin_amdgcn_perm((uint32_t)r, (uint32_t)w[j][q], sel);
-                        r = (r + 128) >> 8;
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                A[ks][j] = v4i_t{ w[j][0], w[j][1], w[j][2], w[j][3] };
-        }
-    }
-    const long long n_out = a.n_in >> 3;
-    __syncthreads();
-    int buf = 0;
-    for (; t < ntiles; t += G, buf ^= 1) {
-        const uint8_t *pb = lds_i8 + buf * 6 * PLANE + 3 * comp * PLANE;
-        float *osum = osum_base + buf * 2 * OS;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int col = 16 * (nb0 + b) + n;
-            v4i_t acc[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc[s] = v4i_t{ 0, 0, 0, 0 };
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const int at = swz(128 * col + 64 * ks + 16 * kq);
-                v4i_t B[3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    B[i] = *reinterpret_cast<const v4i_t *>(pb + i * PLANE + at);
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (i + j >= 2)
-                            acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks][j], B[i], acc[i + j - 2], 0, 0, 0);
-            }
-            /* y = sum_s acc[s] 256^(s+2), as floats (every acc[s] is below 2^24: the conversions are exact).  This lane:
-             * column `col`, rows 4 kq + v -> outputs 16 col + 4 kq + v of the tile, four consecutive ones */
-            float4 y;
-            float *yp = &y.x;
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-                yp[v] = (((float)acc[0][v] * 65536.0f + (float)acc[1][v] * 16777216.0f) +
-                         ((float)acc[2][v] * 4294967296.0f + (float)acc[3][v] * 1099511627776.0f)) * a.scale + a.cterm;
-            *reinterpret_cast<float4 *>(osum + comp * OS + 20 * col + 4 * kq) = y;
-        }
-        __syncthreads();                 /* ONE barrier per tile: the next tile's planes are written, this tile's outputs are in LDS */
-        float2 *dst = reinterpret_cast<float2 *>(a.out) + t * 1024;
-        const long long left = n_out - t * 1024;
-        for (int o = tid; o < 1024; o += 64 * NMW) {
-            const int q = 20 * (o >> 4) + (o & 15);
-            if (o < left)
-                __builtin_nontemporal_store(f32x2{ osum[q], osum[OS + q] }, reinterpret_cast<f32x2 *>(dst + o));
-        }
-    }
-}
-
-bool fir_i8_build_table(const float *taps, int ntaps, int hist, int8_t *table, float *scale, float *cterm, int *exp2)
-{
-    if (!taps || ntaps < 1 || (hist != 128 && hist != 256) || ntaps > hist || !table)
-        return false;
-    double hmax = 0.0;
-    for (int k = 0; k < ntaps; ++k)
-        hmax = std::fmax(hmax, std::fabs((double)taps[k]));
-    if (!(hmax > 0.0) || !std::isfinite(hmax))
-        return false;
-    const int E = 30 - (int)std::ceil(std::log2(hmax));            /* |H| <= 2^30: the top digit stays within +-64 */
-    if (exp2)
-        *exp2 = E;
-    int8_t dig[4][256];
-    long long hsum = 0;
-    for (int k = 0; k < hist; ++k) {
-        long long r = k < ntaps ? std::llround(std::ldexp((double)taps[k], E)) : 0;
-        hsum += r;
-        for (int j = 0; j < 4; ++j) {
-            const long long d = j == 3 ? r : ((r + 128) & 255) - 128;
-            if (d < -128 || d > 127)
-                return false;
-            dig[j][k] = (int8_t)d;
-            r = (r - d) / 256;
-        }
-    }
-    /* lane l of k-step ks holds A[row l & 15][k = 16 (l >> 4) + jj]: T[r][c] = h[hist - (c - 8 r)] */
-    const int ksteps = (120 + hist + 63) / 64;
-    for (int j = 0; j < 4; ++j)
-        for (int ks = 0; ks < ksteps; ++ks)
-            for (int l = 0; l < 64; ++l)
-                for (int jj = 0; jj < 16; ++jj) {
-                    const int r = l & 15, c = 64 * ks + 16 * (l >> 4) + jj, tt = c - 8 * r;
-                    table[(((size_t)j * ksteps + ks) * 64 + l) * 16 + jj] = (tt >= 1 && tt <= hist) ? dig[j][hist - tt] : 0;
-                }
-    /* sample = (v24 << 8) / (INT_MAX - 256): the reference's float (perseustest.c:466-502) */
-    const double unit = std::ldexp(1.0, -E) / 8388607.0;          /* (= 256 / 2147483392: the float the reference divides by) */
-    *scale = (float)unit;
-    *cterm = (float)((double)hsum * 32896.0 * unit);               /* planes 0 and 1 are stored minus 128: 128 + 128*256 */
-    return true;
-}
-
+/* host: the binary16 array the plain form reads with FirI8xArgs::taps16 (values must be binary16-representable):
+ * G[128 + tt] = h[hist - tt] for tt = 1 .. hist, zeros elsewhere */
 void fir_i8_taps16(const float *taps, int ntaps, int hist, uint16_t *out)
 {
     for (int i = 0; i < kFirI8Taps16Len; ++i)
@@ -376,42 +77,6 @@ void fir_i8_taps16(const float *taps, int ntaps, int hist, uint16_t *out)
             __builtin_memcpy(&out[128 + tt], &hv, 2);
         }
     }
-}
-
-template <int HIST>
-static hipError_t launch_fir_i8_t(const FirI8Args &a, hipStream_t s)
-{
-    const long long ntiles = (a.n_in + i8::TILE - 1) / i8::TILE;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static int cus[64] = { 0 };
-    if (cus[dev & 63] == 0) {
-        int v = 0;
-        hipError_t e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess)
-            return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fir_i8<HIST>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)i8::Geo<HIST>::LDS_BYTES);
-        if (e != hipSuccess)
-            return e;
-        cus[dev & 63] = v > 0 ? v : 256;
-    }
-    const long long grid = ntiles < cus[dev & 63] ? ntiles : cus[dev & 63];
-    hipLaunchKernelGGL(k_fir_i8<HIST>, dim3((unsigned)grid), dim3(64 * i8::NMW + i8::NLT), i8::Geo<HIST>::LDS_BYTES, s, a, ntiles);
-    return hipGetLastError();
-}
-
-hipError_t launch_fir_i8(const FirI8Args &a, int hist, hipStream_t s)
-{
-    if (a.n_in <= 0)
-        return hipSuccess;
-    if ((a.n_in & 7) || !a.in || !a.hist || !a.out || (!a.atab && !a.taps16) || (a.hist_out && a.n_in < hist))
-        return hipErrorInvalidValue;
-    if (hist == 256)
-        return launch_fir_i8_t<256>(a, s);
-    if (hist == 128)
-        return launch_fir_i8_t<128>(a, s);
-    return hipErrorInvalidValue;
 }
 
 
@@ -978,7 +643,46 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
      * [-s ; c] the Q planes */
     v4i_t A0[KSTEPS][4];
     v4i_t A1[MODE == 2 ? KSTEPS : 1][4];
-    {
+    if (MODE == 0 && a.taps16 != nullptr) {                 /* uniform */
+        /* binary16 tap storage: this lane's 16 columns of every k-step, quantised here exactly as build_tables_core does on
+         * the host (H = llround(h 2^E), four balanced base-256 digits).  The device array is laid out for this read:
+         * G[128 + tt] = h[HIST - tt] for tt = 1 .. HIST, zeros around it (kFirI8Taps16Len entries), so that the 16 values of
+         * a k-step -- T[r][c] = G[128 + c - 8 r] -- are two aligned 16-byte loads */
+        const uint4 *g16 = static_cast<const uint4 *>(a.taps16);
+        const float two_e = a.two_e;                        /* a power of two: h 2^E is exact in binary32 */
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int i0 = (128 + 64 * ks + 16 * kq - 8 * n) >> 3;      /* in units of 8 values */
+            const uint4 lo = g16[i0], hi = g16[i0 + 1];
+            const uint32_t hw[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+            int w[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                w[0][q] = w[1][q] = w[2][q] = w[3][q] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int jj = 4 * q + b;
+                    const uint32_t bits = (jj & 1) ? hw[jj >> 1] >> 16 : hw[jj >> 1] & 0xffffu;
+                    _Float16 hv;
+                    const uint16_t b16 = (uint16_t)bits;
+                    __builtin_memcpy(&hv, &b16, 2);
+                    const float x = (float)hv * two_e;
+                    int r = (int)(x + __builtin_copysignf(0.5f, x));   /* llround: exact, |x| <= 2^30 and 11 bits wide */
+                    /* balanced digits: d = the low byte, signed; what is left is (r - d) / 256 = (r + 128) >> 8.  Byte b of
+                     * plane j's word takes the low byte as it is (one v_perm_b32) */
+                    const uint32_t sel = 0x03020100u ^ ((0x04u ^ (uint32_t)b) << (8 * b));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        w[j][q] = (int)__builtin_amdgcn_perm((uint32_t)r, (uint32_t)w[j][q], sel);
+                        r = (r + 128) >> 8;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                A0[ks][j] = v4i_t{ w[j][0], w[j][1], w[j][2], w[j][3] };
+        }
+    } else {
         const int tab0 = MODE == 1 ? w0 : 0;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks)
@@ -1155,6 +859,8 @@ __global__ __launch_bounds__(768, 1) void k_fir_i8x_many(FirI8xMany m, long long
     a.taps2 = r.taps2;
     a.hist2 = r.hist2;
     a.hist2_out = r.hist2_out;
+    a.taps16 = r.taps16;
+    a.two_e = r.two_e;
     fir_i8x_block<HIST, MODE, FUSE2, LAYOUT>(a, ntiles, C, (long long)gridDim.x, (long long)blockIdx.x);
 }
 
@@ -1398,7 +1104,10 @@ hipError_t launch_fir_i8x(const FirI8xArgs &a, int hist, bool mix, bool fuse2, h
 {
     if (a.n_in <= 0)
         return hipSuccess;
-    if ((a.n_in & 7) || !a.in || !a.hist || !a.out || !a.atab || (a.hist_out && a.n_in < hist) || !fir_i8x_supported(hist, mix, fuse2))
+    if ((a.n_in & 7) || !a.in || !a.hist || !a.out || (!a.atab && !(a.taps16 && !mix)) || (a.hist_out && a.n_in < hist) ||
+        !fir_i8x_supported(hist, mix, fuse2))
+        return hipErrorInvalidValue;
+    if (a.taps16 && (mix || !(a.two_e > 0.0f)))            /* binary16-stored taps: the untuned form only (tuned tables come from the host) */
         return hipErrorInvalidValue;
     if (fuse2 && ((a.n_in % i8x::TILE) || !a.taps2 || !a.hist2))
         return hipErrorInvalidValue;

@@ -146,39 +146,17 @@ hipError_t launch_gen_tail_many(const GenTailMany &m, int n, hipStream_t s);
 /* n generator streams of nbytes each */
 hipError_t launch_synth_lcg_many(const SynthMany &m, int n, size_t nbytes, hipStream_t s);
 
-/* ---- k_fir_i8: the long packed first stage (65..256 taps, decimate by 8, no NCO) on the INT8 matrix cores -----------
+/* ---- the first stages on the INT8 matrix cores (ddc_fir_i8.hip) -----------------------------------------------------
  * A 24-bit sample is three int8 planes -- the wire bytes -- and taps quantised to 32-bit integers are four balanced
- * base-256 digits: v_mfma_i32_32x32x32_i8 forms the byte-plane products exactly, the planes are recombined once per
- * output (DESIGN.md 4 "k_fir_i8").  History and results as k_fir8's: 256 packed samples in front, out[m] =
- * sum_k h[k] x[8m - k].                                                                                        */
-struct FirI8Args {
-    const void *in;          /* packed batch, 16-byte aligned                                  */
-    const void *hist;        /* the `hist` (128 or 256) packed samples in front of it          */
-    void       *hist_out;    /* receives the batch's last `hist` samples (or NULL; needs n_in >= hist) */
-    float      *out;         /* float2 outputs, n_in / 8                                        */
-    const void *atab;        /* the tap operand table (fir_i8_build_table), kFirI8TableBytes    */
-    long long   n_in;        /* samples, multiple of 8                                          */
-    float       scale;       /* integer result -> float                                         */
-    float       cterm;       /* the planes' unsigned -> signed offset, times the taps' sum      */
-    /* binary16 tap STORAGE (PDDC_F_TAPS_FP16; BASELINE config 5): instead of the operand table the device holds the
-     * taps as IEEE binary16 values -- kFirI8Taps16Len of them, G[128 + tt] = h[hist - tt] for tt = 1 .. hist, zeros
-     * elsewhere (fir_i8_taps16) -- and every block's matrix waves quantise them into their operand registers
-     * themselves: the same integers the host would have put in the table.  atab is NULL then. */
-    const void *taps16;
-    double      two_e;       /* 2^E of fir_i8_build_table                                       */
-};
-constexpr size_t kFirI8TableBytes = 4 * 6 * 64 * 16;       /* (hist 256; 4 k-steps instead of 6 for hist 128) */
-/* host: the operand table for `ntaps` <= hist taps (hist = 128 or 256); false if the taps are all zero */
-bool fir_i8_build_table(const float *taps, int ntaps, int hist, int8_t *table, float *scale, float *cterm,
-                        int *exp2 = nullptr);
+ * base-256 digits: v_mfma_i32_16x16x64_i8 forms the byte-plane products exactly, the planes are recombined once per
+ * output.  History and results as k_fir8's: `hist` packed samples in front, out[m] = sum_k h[k] x[8m - k]. */
 constexpr int kFirI8Taps16Len = 128 + 6 * 64;               /* 1 KB */
-/* host: the binary16 array k_fir_i8 reads with FirI8Args::taps16 (values must be binary16-representable) */
+/* host: the binary16 array k_fir_i8x's plain form reads with FirI8xArgs::taps16 (values must be binary16-representable) */
 void fir_i8_taps16(const float *taps, int ntaps, int hist, uint16_t *out /* kFirI8Taps16Len */);
-hipError_t launch_fir_i8(const FirI8Args &a, int hist, hipStream_t s);
 
-/* ---- k_fir_i8x: the same product with the NCO folded into the taps, and optionally the second decimate-by-8 stage of a
+/* ---- k_fir_i8x: that product, without NCO or with the NCO folded into the taps, and optionally the second decimate-by-8 stage of a
  * cascade fused behind it (ddc_fir_i8.hip).  hist = 32, 64, 128 or 256 packed samples of history (the stage's 8 * ntb);
- * stream state as k_fir8's / k_fir_i8's: packed history, and for the fused pair the 64 first-stage outputs (float2, mixed)
+ * stream state as k_fir8's: packed history, and for the fused pair the 64 first-stage outputs (float2, mixed)
  * in front of the batch.  phase(n) = n * freg + phase_off for EVERY sample the batch's outputs touch, i.e. the history
  * window must have been mixed with the same word (the pipeline routes the one batch behind a retune through k_fir8). */
 struct FirI8xArgs {
@@ -199,6 +177,12 @@ struct FirI8xArgs {
     long long    n_out = 0;         /* outputs to store (0: n_in / 8)                                       */
     int          in_off = 0;        /* batch sample the first output's window ends on: a multiple of 8      */
     int          hist_len = 0;      /* samples the history buffer holds (0: the geometry's `hist`)           */
+    /* binary16 tap STORAGE (PDDC_F_TAPS_FP16 without NCO; BASELINE config 5): instead of the operand table the device holds
+     * the taps as IEEE binary16 values -- kFirI8Taps16Len of them, G[128 + tt] = h[hist - tt] for tt = 1 .. hist, zeros
+     * elsewhere (fir_i8_taps16) -- and every block's matrix waves quantise them into their operand registers themselves:
+     * the same integers fir_i8x_build_tables puts into the table.  atab is not read then. */
+    const void  *taps16 = nullptr;
+    float        two_e = 0.0f;      /* 2^E of fir_i8x_build_tables (exp2)                                    */
 };
 constexpr int kFirI8xTaps2Len = 2 * 68;
 /* n streams (same geometry and batch length), one launch: blockIdx.y is the stream (the gang) */

@@ -14,7 +14,7 @@
  *                (+ a fused second /8 stage, + the previous batch's last stage as extra
  *                blocks of the launch; k_fir8_many: up to eight streams, one launch;
  *                body in fir8_block.inc)
- *   k_fir_i8, k_fir_i8x   the same filter on the INT8 matrix cores, with or without the NCO,
+ *   k_fir_i8x             the same filter on the INT8 matrix cores, with or without the NCO,
  *                optionally with the second /8 stage fused: ddc_fir_i8.hip.  Those are what
  *                a decimate-by-8 first stage runs on unless the pipeline's options say
  *                otherwise; k_fir8 keeps the pair with the carried tail above 2^26 samples.

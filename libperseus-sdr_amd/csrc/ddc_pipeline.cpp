@@ -71,11 +71,10 @@ struct Stage {
     float *d_taps_poly = nullptr; /* rational stage: [L][Kp] polyphase rows g[ph][j] = h[j*L + ph] */
     float *d_taps_seg = nullptr;  /* stage 2 as the fused cascade's third stage: h[k] zero padded to spl*seglen */
     float *d_taps_firp = nullptr; /* k_firp (plain decimators by 4, 5, 8, 10): (h[k], h[k]) zero padded to firp_taps_len */
-    void *d_taps_i8 = nullptr;    /* k_fir_i8 (stage 0, 129..256 taps, /8): the int8 tap operand table, with ...       */
-    float i8_scale = 0.0f, i8_cterm = 0.0f;      /* ... the integer -> float scale and the planes' offset constant     */
-    void *d_taps_f16 = nullptr;   /* PDDC_F_TAPS_FP16: instead of that table the taps as binary16 values (1 KB with padding) -- the only
-                                   * form of them k_fir_i8 reads; its blocks quantise them into their operand registers */
-    double i8_two_e = 0.0;
+    void *d_taps_f16 = nullptr;   /* PDDC_F_TAPS_FP16, stage 0 without NCO: the taps as binary16 values (1 KB with padding) -- the
+                                   * only form of them k_fir_i8x reads then; its matrix waves quantise them into their operand
+                                   * registers themselves (FirI8xArgs::taps16) */
+    float i8_two_e = 0.0f;        /* ... scaled by this power of two first (2^E of fir_i8x_build_tables) */
     bool i8x_ok = false;          /* stage 0: k_fir_i8x can hold these taps (not all zero, finite) */
     int poly_k = 0, poly_kp = 0;
     int ntb = 0;                  /* tap blocks if fused-capable, else 0        */
@@ -174,12 +173,11 @@ struct pddc_pipeline {
      * once, when the pipeline is created, never on the data path) */
     struct Opts {
         int no_i8 = 0;            /* 1: the vector kernels only (k_fir8)                                              */
-        int i8_128 = 1;           /* 65..128 taps without NCO on k_fir_i8 (0: k_fir8)                                 */
         int i8x = 1;              /* tuned first stages (PDDC_F_MIX) on k_fir_i8x (0: k_fir8)                         */
         int i8x_pair = 1;         /* ... and the cascade's first two stages as its fused pair (0: unfused, or k_fir8)  */
-        int i8x_plain = 1;        /* untuned first stages on k_fir_i8x too (0: k_fir_i8 for 65..256 taps, k_fir8 below): at
-                                     2^28 samples 32/48 taps 0.319 against k_fir8's 0.339 ms, 255 taps 0.334 against k_fir_i8's
-                                     0.343; at 2^22 5.9 against 12.9 us (profiles/r04)                                  */
+        int i8x_plain = 1;        /* untuned first stages on k_fir_i8x too (0: k_fir8): at 2^28 samples 32/48 taps 0.319 against
+                                     k_fir8's 0.339 ms; at 2^22 5.9 against 12.9 us (profiles/r04).  Round 3's k_fir_i8, which
+                                     this option used to fall back to, is gone: one kernel family since round 5           */
         int i8x_blocks = 0;       /* persistent grid override of k_fir_i8x (0: one block per CU)                       */
         int i8x_chunk = 0;        /* tiles per chunk of its walk (0: 1, fused pair 4)                                    */
         int i8x_layout = -1;      /* which waves finish a tile (ddc_fir_i8.hip "Who does what"): 0 the matrix waves, 1 the
@@ -338,10 +336,6 @@ static int upload_taps(pddc_pipeline *p, int si)
         hipFree(s.d_taps_firp);
         s.d_taps_firp = nullptr;
     }
-    if (s.d_taps_i8) {
-        hipFree(s.d_taps_i8);
-        s.d_taps_i8 = nullptr;
-    }
     if (s.d_taps_f16) {
         hipFree(s.d_taps_f16);
         s.d_taps_f16 = nullptr;
@@ -354,24 +348,19 @@ static int upload_taps(pddc_pipeline *p, int si)
             hmax = std::fmax(hmax, std::fabs((double)s.taps[k]));
         s.i8x_ok = si == 0 && hmax > 0.0 && std::isfinite(hmax);
     }
-    if (si == 0 && stage_fused_capable(s) && s.ntaps <= i8_hist && (i8_hist == 128 || i8_hist == 256) &&
-        !(p->flags & PDDC_F_NO_FAST)) {
-        /* the long first stage on the int8 matrix cores (k_fir_i8): taps as four planes of balanced base-256 digits */
-        std::vector<int8_t> tab(kFirI8TableBytes);
+    if (si == 0 && s.i8x_ok && stage_fused_capable(s) && s.ntaps <= i8_hist && (p->flags & PDDC_F_TAPS_FP16) &&
+        !(p->flags & (PDDC_F_NO_FAST | PDDC_F_MIX)) && fir_i8x_supported(i8_hist, false, false)) {
+        /* binary16 tap storage on the matrix cores (BASELINE config 5): s.taps hold binary16 values already; the device gets
+         * them as such, 2 bytes a tap, and no operand table (the host's serves for scale and offset constant only) */
+        std::vector<int8_t> tab(fir_i8x_table_bytes(i8_hist, false));
+        float sc = 0.0f, ct[2];
         int e2 = 0;
-        if (fir_i8_build_table(s.taps.data(), s.ntaps, i8_hist, tab.data(), &s.i8_scale, &s.i8_cterm, &e2)) {
-            if (p->flags & PDDC_F_TAPS_FP16) {
-                /* binary16 tap storage (BASELINE config 5): s.taps hold binary16 values already; the device gets them
-                 * as such, 2 bytes a tap, and no table (the host's serves for scale and offset constant only) */
-                std::vector<uint16_t> h16((size_t)kFirI8Taps16Len);
-                fir_i8_taps16(s.taps.data(), s.ntaps, i8_hist, h16.data());
-                HIP_TRY(hipMalloc(&s.d_taps_f16, h16.size() * sizeof(uint16_t)));
-                HIP_TRY(hipMemcpy(s.d_taps_f16, h16.data(), h16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-                s.i8_two_e = std::ldexp(1.0, e2);
-            } else {
-                HIP_TRY(hipMalloc(&s.d_taps_i8, tab.size()));
-                HIP_TRY(hipMemcpy(s.d_taps_i8, tab.data(), tab.size(), hipMemcpyHostToDevice));
-            }
+        if (fir_i8x_build_tables(s.taps.data(), s.ntaps, i8_hist, false, 0u, tab.data(), &sc, ct, &e2)) {
+            std::vector<uint16_t> h16((size_t)kFirI8Taps16Len);
+            fir_i8_taps16(s.taps.data(), s.ntaps, i8_hist, h16.data());
+            HIP_TRY(hipMalloc(&s.d_taps_f16, h16.size() * sizeof(uint16_t)));
+            HIP_TRY(hipMemcpy(s.d_taps_f16, h16.data(), h16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            s.i8_two_e = std::ldexp(1.0f, e2);
         }
     }
     if (s.interp == 1 && !(p->flags & PDDC_F_NO_FAST) && firp_supported(s.decim, s.ntaps)) {
@@ -441,22 +430,24 @@ uint32_t pddc_nco_freg(double center_freq_hz, double adc_clk_hz)
     return (uint32_t)(center_freq_hz / adc_clk_hz * 4.294967296E9);
 }
 
-/* host arithmetic only (no device needed): the tap operand of k_fir_i8, so that its digits can be checked on any machine */
+/* host arithmetic only (no device needed): the plain form's tap operand, so that its digits can be checked on any machine */
 int pddc_fir_i8_table(const float *taps, int ntaps, int hist, int8_t *table, size_t table_bytes, float *scale, float *cterm)
 {
     if (!taps || !table || !scale || !cterm)
         return fail(PDDC_EINVAL, "null argument");
-    if (hist != 128 && hist != 256)
-        return fail(PDDC_EINVAL, "history %d: 128 or 256", hist);
-    const size_t need = (size_t)4 * (size_t)((120 + hist + 63) / 64) * 64 * 16;
+    if (!fir_i8x_supported(hist, false, false))
+        return fail(PDDC_EINVAL, "history %d: 32, 64, 128 or 256", hist);
+    const size_t need = fir_i8x_table_bytes(hist, false);
     if (table_bytes < need)
         return fail(PDDC_ECAPACITY, "table needs %zu bytes, buffer has %zu", need, table_bytes);
-    if (!fir_i8_build_table(taps, ntaps, hist, table, scale, cterm))
+    float ct[2] = { 0.0f, 0.0f };
+    if (!fir_i8x_build_tables(taps, ntaps, hist, false, 0u, table, scale, ct))
         return fail(PDDC_EINVAL, "no int8 form for these taps (1..%d taps, not all zero, finite)", hist);
+    *cterm = ct[0];
     return PDDC_OK;
 }
 
-/* host arithmetic only: the binary16 tap array k_fir_i8 reads under PDDC_F_TAPS_FP16, and the 2^E it scales them with */
+/* ... and k_fir_i8x's operands with the NCO */
 int pddc_fir_i8x_tables(const float *taps, int ntaps, int hist, int mix, uint32_t freg, int8_t *tables, size_t tables_bytes,
                         float *scale, float *ct)
 {
@@ -491,21 +482,22 @@ int pddc_fir_i8x_taps2(const float *taps2, int ntaps2, int mix, uint32_t freg, f
     return PDDC_OK;
 }
 
+/* host arithmetic only: the binary16 tap array k_fir_i8x reads under PDDC_F_TAPS_FP16 (no NCO), and the 2^E it scales them with */
 int pddc_fir_i8_taps16(const float *taps, int ntaps, int hist, uint16_t *out, size_t out_len, double *two_e)
 {
     if (!taps || !out || !two_e)
         return fail(PDDC_EINVAL, "null argument");
-    if (hist != 128 && hist != 256)
-        return fail(PDDC_EINVAL, "history %d: 128 or 256", hist);
+    if (!fir_i8x_supported(hist, false, false))
+        return fail(PDDC_EINVAL, "history %d: 32, 64, 128 or 256", hist);
     if (out_len < (size_t)kFirI8Taps16Len)
         return fail(PDDC_ECAPACITY, "the array has %d entries, buffer has %zu", kFirI8Taps16Len, out_len);
-    std::vector<int8_t> tab(kFirI8TableBytes);
+    std::vector<int8_t> tab(fir_i8x_table_bytes(hist, false));
     std::vector<float> h16(taps, taps + (ntaps > 0 ? ntaps : 0));
     for (float &v : h16)
         v = round_to_half(v);
-    float sc = 0.0f, ct = 0.0f;
+    float sc = 0.0f, ct[2] = { 0.0f, 0.0f };
     int e2 = 0;
-    if (ntaps < 1 || !fir_i8_build_table(h16.data(), ntaps, hist, tab.data(), &sc, &ct, &e2))
+    if (ntaps < 1 || !fir_i8x_build_tables(h16.data(), ntaps, hist, false, 0u, tab.data(), &sc, ct, &e2))
         return fail(PDDC_EINVAL, "no int8 form for these taps (1..%d taps, not all zero, finite)", hist);
     fir_i8_taps16(h16.data(), ntaps, hist, out);
     *two_e = std::ldexp(1.0, e2);
@@ -808,7 +800,6 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
             return e ? atoi(e) : dflt;
         };
         p->opt.no_i8 = getenv("PDDC_NO_I8") ? 1 : 0;
-        p->opt.i8_128 = env_int("PDDC_I8_128", 1);
         p->opt.i8x = env_int("PDDC_I8X", 1);
         p->opt.i8x_pair = env_int("PDDC_I8X_PAIR", 1);
         p->opt.i8x_plain = env_int("PDDC_I8X_PLAIN", 1);
@@ -913,8 +904,6 @@ int pddc_pipeline_destroy(pddc_pipeline *p)
             hipFree(p->st[i].d_taps_seg);
         if (p->st[i].d_taps_firp)
             hipFree(p->st[i].d_taps_firp);
-        if (p->st[i].d_taps_i8)
-            hipFree(p->st[i].d_taps_i8);
         if (p->st[i].d_taps_f16)
             hipFree(p->st[i].d_taps_f16);
         if (p->st[i].d_buf && !p->st[i].buf_in_ws)
@@ -1038,7 +1027,7 @@ static int *option_field(pddc_pipeline *p, const char *name)
     const struct {
         const char *n;
         int *f;
-    } tab[] = { { "no_i8", &p->opt.no_i8 },       { "i8_128", &p->opt.i8_128 },         { "i8x", &p->opt.i8x },
+    } tab[] = { { "no_i8", &p->opt.no_i8 },       { "i8x", &p->opt.i8x },
                 { "i8x_pair", &p->opt.i8x_pair }, { "i8x_plain", &p->opt.i8x_plain },   { "i8x_blocks", &p->opt.i8x_blocks },
                 { "i8x_chunk", &p->opt.i8x_chunk },
                 { "i8x_layout", &p->opt.i8x_layout },
@@ -1249,10 +1238,11 @@ static size_t words_in_window(const pddc_pipeline *p)
     return p->segs.size() - first;
 }
 
-/* Which kernel runs the decimate-by-8 first stage of this batch: 0 the vector kernel (k_fir8), 1 k_fir_i8 (65..256 taps,
- * no NCO: the wire bytes on the int8 matrix cores), 2 k_fir_i8x (the same with the NCO folded into the taps -- every tuned
- * first stage of 1..256 taps whose history window was mixed with the word in force: the one batch behind a retune goes
- * through k_fir8, which re-mixes its packed history with the old word; the two share the stream state).          */
+/* Which kernel runs the decimate-by-8 first stage of this batch: 0 the vector kernel (k_fir8), 2 k_fir_i8x (the wire bytes
+ * on the int8 matrix cores; tuned: the NCO folded into the taps -- every first stage of 1..256 taps whose history window
+ * was mixed with the word in force: the one batch behind a retune goes through k_fir8, which re-mixes its packed history
+ * with the old word; the two share the stream state).  (1 was round 3's k_fir_i8, retired in round 5: its binary16-stored
+ * taps are the plain form's second way to get its operand.)                                                        */
 static int stage0_i8_kind_raw(const pddc_pipeline *p, size_t nsamples)
 {
     const Stage &s0 = p->st[0];
@@ -1260,15 +1250,12 @@ static int stage0_i8_kind_raw(const pddc_pipeline *p, size_t nsamples)
         return 0;
     if (p->flags & PDDC_F_MIX)
         return p->opt.i8x && s0.i8x_ok && fir_i8x_supported(s0.hist, true, false) && words_in_window(p) == 1 ? 2 : 0;
-    if (p->opt.i8x_plain && s0.i8x_ok && !(p->flags & PDDC_F_TAPS_FP16) && fir_i8x_supported(s0.hist, false, false))
+    /* untuned: the plain form -- taps from the host's table, or (PDDC_F_TAPS_FP16) binary16 values the matrix waves
+     * quantise themselves; a pipeline with that flag whose taps have no int8 form keeps the vector kernel */
+    if (p->opt.i8x_plain && s0.i8x_ok && fir_i8x_supported(s0.hist, false, false) &&
+        (!(p->flags & PDDC_F_TAPS_FP16) || s0.d_taps_f16 != nullptr))
         return 2;
-    if (s0.d_taps_i8 == nullptr && s0.d_taps_f16 == nullptr)
-        return 0;
-    /* 65..128 taps: the vector kernel is HBM-bound there too, but since k_fir_i8's loader spreads its loads over the tile
-     * step it streams at least as well -- 2^25: 757 -> 899 GS/s, 2^26: 725 -> 787, 2^27: 761 -> 809, 2^28: 0.3588-0.3616 ->
-     * 0.3464-0.3483 ms (three alternating rounds on one box), 2^30 equal -- and it is the more accurate of the two
-     * (8e-8 against 2.9e-7).  Option i8_128 = 0 forces the vector kernel (development). */
-    return s0.hist == 256 || p->opt.i8_128 ? 1 : 0;
+    return 0;
 }
 
 /* can stages 0 and 1 run as k_fir_i8x's fused pair (given that stage 0 runs on it)?  stage 1 a plain decimate-by-8 of <= 64
@@ -1393,7 +1380,10 @@ static int i8x_prepare(pddc_pipeline *p, bool mix, bool fuse2, hipStream_t s, Fi
         float *t2 = reinterpret_cast<float *>(static_cast<uint8_t *>(sl.h) + kI8xTaps2Off);
         if (fuse2)
             fir_i8x_taps2(p->st[1].taps.data(), p->st[1].ntaps, mix, word, t2);
-        HIP_TRY(hipMemcpyAsync(sl.d, sl.h, kI8xSlotBytes, hipMemcpyHostToDevice, s));
+        /* (binary16-stored taps, no NCO: the matrix waves quantise the device's binary16 array themselves -- no table goes
+         * to the device; the host's serves for scale and offset constant only) */
+        if (!(s0.d_taps_f16 && !mix) || fuse2)
+            HIP_TRY(hipMemcpyAsync(sl.d, sl.h, kI8xSlotBytes, hipMemcpyHostToDevice, s));
         x.cur = nx;
         x.freg = word;
         x.mix = mix;
@@ -1405,6 +1395,11 @@ static int i8x_prepare(pddc_pipeline *p, bool mix, bool fuse2, hipStream_t s, Fi
         x.ct[1] = ct[1];
     }
     q.atab = x.slot[x.cur].d;
+    if (s0.d_taps_f16 && !mix) {
+        q.atab = nullptr;
+        q.taps16 = s0.d_taps_f16;
+        q.two_e = s0.i8_two_e;
+    }
     q.taps2 = fuse2 ? reinterpret_cast<const float *>(static_cast<const uint8_t *>(x.slot[x.cur].d) + kI8xTaps2Off) : nullptr;
     q.scale = x.scale;
     q.ct[0] = x.ct[0];
@@ -1898,9 +1893,6 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
         g->kind = 0;
         g->tail = GenTail{};
         const int i8k = mixed_hist ? 0 : stage0_i8_kind(p, nsamples);
-        if (i8k == 1)
-            return 1;            /* (k_fir_i8 has no many-stream launch: this member runs its own chain on the gang's stream --
-                                    the same bits as alone, which the vector kernel of a shared launch would not give) */
         const int nfirst = (i8k == 2 ? stages01_i8x(p, nsamples) : stages01_fusable(p, nsamples)) ? 2 : 1;
         const int last = p->nstages - 1;
         const bool tail_ok = p->nstages == nfirst ||
@@ -2161,20 +2153,6 @@ int pddc_pipeline_process(pddc_pipeline *p, const void *d_packed, size_t nsample
                 q.out = dst;
                 q.n_in = (long long)nsamples;
                 HIP_TRY(launch_fir_i8x(q, st.hist, mix, false, s, p->opt.i8x_blocks, p->opt.i8x_chunk, p->opt.i8x_layout));
-            } else if (i8kind == 1 && !ov) {
-                /* 65..256 taps, no NCO: the int8 matrix cores (same history, same outputs to 1e-7 of full scale) */
-                FirI8Args q;
-                q.in = d_packed;
-                q.hist = h_in;
-                q.hist_out = a.hist_out;
-                q.out = dst;
-                q.atab = st.d_taps_i8;
-                q.taps16 = st.d_taps_f16;
-                q.two_e = st.i8_two_e;
-                q.n_in = (long long)nsamples;
-                q.scale = st.i8_scale;
-                q.cterm = st.i8_cterm;
-                HIP_TRY(launch_fir_i8(q, st.hist, s));
             } else {
                 HIP_TRY(launch_fir8(st.ntb, p->R, IN_PACKED24, mix, a, s, p->NT));
             }
@@ -3036,7 +3014,6 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
     const int i8kind = stage0_i8_kind(p, nsamples);                    /* what process() would launch for this batch */
     const bool x2 = !fuse3 && i8kind == 2 && stages01_i8x(p, nsamples);
     const bool x1 = !fuse3 && !x2 && !fuse2 && i8kind == 2;
-    const bool i8 = !fuse2 && !fuse3 && i8kind == 1;
     FirI8xArgs qx;
     if (x1 || x2) {
         int rc = i8x_prepare(p, mix, x2, s, qx);
@@ -3050,17 +3027,6 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
         qx.hist2 = p->st[1].d_hist[p->st[1].cur];
         qx.hist2_out = nullptr;
     }
-    FirI8Args q;
-    q.in = d_packed;
-    q.hist = a.hist;
-    q.hist_out = nullptr;
-    q.out = a.out;
-    q.atab = p->st[0].d_taps_i8;
-    q.taps16 = p->st[0].d_taps_f16;
-    q.two_e = p->st[0].i8_two_e;
-    q.n_in = (long long)nsamples;
-    q.scale = p->st[0].i8_scale;
-    q.cterm = p->st[0].i8_cterm;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -3072,8 +3038,6 @@ int pddc_pipeline_time_stage0(pddc_pipeline *p, const void *d_packed, size_t nsa
             HIP_TRY(launch_fir_i8x(qx, p->st[0].hist, mix, x2, s, p->opt.i8x_blocks, p->opt.i8x_chunk, p->opt.i8x_layout));
         else if (fuse2)
             HIP_TRY(launch_fir8_fused2(p->st[0].ntb, p->R, mix, a, s));
-        else if (i8)
-            HIP_TRY(launch_fir_i8(q, p->st[0].hist, s));
         else
             HIP_TRY(launch_fir8(p->st[0].ntb, p->R, IN_PACKED24, mix, a, s, p->NT));
     }

@@ -231,9 +231,9 @@ def test_gang_members_in_overlap_mode_run_chains_of_their_own(pkg, O, dev):
 
 @pytest.mark.parametrize("name", ["d8_127", "d8_255"])
 def test_untuned_long_first_stages_keep_their_bits_in_a_gang(pkg, O, dev, name):
-    """Without the NCO a 65..256-tap first stage runs on k_fir_i8, which has no many-stream launch: in a round of several
-    such a member runs its own chain on the gang's stream -- the bits of a push of its own, which the vector kernel of a
-    shared launch would not give (1e-7 apart)."""
+    """Without the NCO a long first stage runs on k_fir_i8x's plain form, in a gang as one k_fir_i8x_many launch for all its
+    members (until round 5: round 3's k_fir_i8, which had no many-stream launch -- such members ran chains of their own):
+    the bits of a push of its own either way, which the vector kernel of a shared launch would not give (1e-7 apart)."""
     stages = [(8, load_taps(name))]
     seeds = [5, 6, 7]
     ys = run_gang(pkg, [stages] * 3, seeds, SIZES, max(SIZES), mix=False)

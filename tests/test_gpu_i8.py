@@ -1,5 +1,6 @@
-"""GPU tests (-m gpu) of k_fir_i8: the long first stage (65..256 taps, decimate by 8, no NCO) on the int8 matrix cores
-(DESIGN.md 4).  The wire bytes are the operand -- three int8 planes per component --, the taps are four planes of
+"""GPU tests (-m gpu) of k_fir_i8x's PLAIN form: the untuned decimate-by-8 first stage on the int8 matrix cores (DESIGN.md 4;
+until round 5 this file was about round 3's k_fir_i8, whose work -- binary16-stored taps included -- the plain form took
+over).  The wire bytes are the operand -- three int8 planes per component --, the taps are four planes of
 balanced base-256 digits, int32 accumulation is exact; what is left is the tap quantisation (2^-31 of the largest tap)
 and three dropped low-order plane products.  Same bar as every FIR path here: max|y - ref| / max|ref| <= 1e-6 against
 the CPU oracle, on the same stream state as k_fir8 (history, hist_out), so the two kernels can alternate
@@ -24,9 +25,8 @@ def lowpass(ntaps, cutoff):
     return (h / h.sum()).astype(np.float32)
 
 
-def run(pkg, dev, stages, packed, cuts, monkeypatch=None, no_i8_at=(), plain=0):
-    pipe = pkg.Pipeline(stages)
-    pipe.set_option("i8x_plain", plain)          # (0: round 3's k_fir_i8, what this file is about; 1: k_fir_i8x's plain form)
+def run(pkg, dev, stages, packed, cuts, monkeypatch=None, no_i8_at=(), fp16=False):
+    pipe = pkg.Pipeline(stages, taps_fp16=fp16)
     parts, on = [], []
     for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
         if monkeypatch is not None:
@@ -37,25 +37,29 @@ def run(pkg, dev, stages, packed, cuts, monkeypatch=None, no_i8_at=(), plain=0):
     return np.concatenate(parts), on
 
 
-@pytest.mark.parametrize("plain", [0, 1])
-@pytest.mark.parametrize("ntaps", [65, 100, 127, 128, 129, 160, 200, 255, 256])
-def test_i8_first_stage_vs_oracle_ragged_batches(pkg, dev, O, ntaps, plain):
-    """Tap counts over the kernel's whole range; batches of whole tiles (8192), ragged ones, one of a single group of 8
-    behind the history length, and tiny ones (< 256 samples: k_fir8's generic history path on the same state)."""
+@pytest.mark.parametrize("fp16", [False, True])
+@pytest.mark.parametrize("ntaps", [20, 33, 65, 100, 127, 128, 129, 160, 200, 255, 256])
+def test_i8_first_stage_vs_oracle_ragged_batches(pkg, dev, O, ntaps, fp16):
+    """Tap counts over the kernel's whole range (all four history lengths); batches of whole tiles (8192), ragged ones, one
+    of a single group of 8 behind the history length, and tiny ones (below the history: k_fir8's generic history path on the
+    same state).  Both ways the operand reaches the matrix waves: the host's table, and binary16-STORED taps quantised by
+    the waves themselves (PDDC_F_TAPS_FP16; the oracle then filters with the rounded taps)."""
     h = load_taps("d8_255") if ntaps == 255 else load_taps("d8_127") if ntaps == 127 else lowpass(ntaps, 0.05)
-    hist = 128 if ntaps <= 128 else 256
+    if fp16:
+        h = h.astype(np.float16).astype(np.float32)
+    hist = 32 if ntaps <= 32 else 64 if ntaps <= 64 else 128 if ntaps <= 128 else 256
     sizes = [8192 * 3, 8192 + 8, 264, 8, 128, 256, 8192 * 40 + 4096 + 16, 1 << 20, 8192 * 2 - 8]
     cuts = np.concatenate([[0], np.cumsum(sizes)])
     packed = O.lcg_bytes(6 * int(cuts[-1]), 2026)
     ref = O.ddc_chain(packed, [(8, h)])
-    y, on = run(pkg, dev, [(8, h)], packed, cuts, plain=plain)
+    y, on = run(pkg, dev, [(8, h)], packed, cuts, fp16=fp16)
     assert on == [s >= hist for s in sizes]
     assert y.size == ref.size
     assert O.rel_err(y, ref) <= FIR_TOL, (ntaps, O.rel_err(y, ref))
 
 
 def test_i8_and_fp32_kernels_alternate_on_one_stream(pkg, dev, O, monkeypatch):
-    """k_fir_i8 and k_fir8 keep the same stream state (256 packed history samples): switching between them batch by
+    """k_fir_i8x and k_fir8 keep the same stream state (256 packed history samples): switching between them batch by
     batch -- option no_i8 flipped between calls -- still gives the oracle's stream, and the two agree with each other to 1e-6."""
     h = load_taps("d8_255")
     sizes = [1 << 16, 8192 * 5 + 24, 1 << 15, 1 << 17, 8192, 1 << 16]
@@ -105,16 +109,17 @@ def test_i8_binary16_taps_set_taps_and_checkpoint(pkg, dev, O):
     y = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
     assert O.rel_err(y, O.ddc_chain(packed, [(8, h16)])) <= FIR_TOL
     pipe.close()
-    # binary16 STORAGE: with the flag the device holds 2 bytes a tap and the kernel's blocks quantise them into their
+    # binary16 STORAGE: with the flag the device holds 2 bytes a tap and the kernel's matrix waves quantise them into their
     # operand registers; without it the host builds the int8 operand table from the same values -- the same integers,
-    # so the same bits, for both history lengths (65..128 and 129..256 taps) and for taps that need the rounding
+    # so the same bits, for every history length (1..32, ..64, ..128, ..256 taps) and for taps that need the rounding
     # (subnormal binary16 values far below the largest tap)
-    for g in (h16, lowpass(100, 0.05).astype(np.float16).astype(np.float32),
+    for g in (h16, lowpass(100, 0.05).astype(np.float16).astype(np.float32), lowpass(48, 0.05).astype(np.float16).astype(np.float32),
+              lowpass(24, 0.05).astype(np.float16).astype(np.float32),
               (h16 * (1.0 + 0.0 * h16) * np.where(np.arange(h16.size) % 7 == 0, 2.0 ** -14, 1.0)).astype(np.float16).astype(np.float32)):
         outs = []
         for flag in (False, True):
             pipe = pkg.Pipeline([(8, g)], taps_fp16=flag)
-            assert pipe.on_i8(ns)
+            assert pipe.on_i8(ns) == 2
             outs.append(pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1))
             pipe.close()
         assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
@@ -155,10 +160,13 @@ def test_which_first_stages_run_where(pkg, dev):
     p = pkg.Pipeline([(8, h)])
     assert p.on_i8(1 << 20) == 2                                 # untuned: k_fir_i8x's plain form (round 4)
     p.set_option("i8x_plain", 0)
-    assert p.on_i8(1 << 20) == 1                                 # ... or round 3's k_fir_i8 (65..256 taps)
+    assert p.on_i8(1 << 20) == 0                                 # ... or the vector kernel (round 3's k_fir_i8 is gone)
     p.close()
     p = pkg.Pipeline([(8, h)], taps_fp16=True)
-    assert p.on_i8(1 << 20) == 1                                 # binary16 tap STORAGE: k_fir_i8 quantises them itself
+    assert p.on_i8(1 << 20) == 2                                 # binary16 tap STORAGE: the plain form's matrix waves quantise them
+    p.close()
+    p = pkg.Pipeline([(8, h)], taps_fp16=True, mix=True)
+    assert p.on_i8(1 << 20) == 2                                 # ... tuned: tables from the host, built from the rounded values
     p.close()
     p = pkg.Pipeline([(8, load_taps("c320_s1_d8_32"))])
     assert p.on_i8(1 << 20) == 2                                 # short untuned stages too
@@ -216,7 +224,7 @@ def test_int8_path_numeric_floor_in_dbfs(pkg, dev, O, design, fp16):
             packed = b.reshape(-1)
         ref = O.ddc_chain(packed, [(8, h)])
         pipe = pkg.Pipeline([(8, h)], taps_fp16=fp16)
-        assert pipe.on_i8(ns) == (1 if fp16 else 2)            # binary16 STORAGE is k_fir_i8's; otherwise k_fir_i8x's plain form
+        assert pipe.on_i8(ns) == 2                              # k_fir_i8x's plain form either way (binary16 STORAGE: quantised in the kernel)
         y = pipe.process(to_dev(packed, dev)).cpu().numpy().reshape(-1)
         pipe.close()
         err, spur = _floor(y, ref, skip=64)

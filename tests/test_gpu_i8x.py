@@ -164,11 +164,12 @@ def test_checkpoint_resume_and_set_taps_on_the_matrix_core_path(pkg, dev, O):
     b.close()
 
 
-def test_plain_form_agrees_with_k_fir_i8(pkg, dev, O):
-    """Two independent kernels, one arithmetic: the untuned form of k_fir_i8x (the default) and round 3's k_fir_i8 (option
-    i8x_plain = 0) build their operand tables with the same quantisation and accumulate the same exact integers; only
-    the order of the last float additions may differ.  Asserted: they agree to 3e-8 of full scale (a quarter ulp of the
-    fp32 recombination), far inside what either is allowed against the oracle."""
+def test_plain_form_agrees_with_the_vector_kernel(pkg, dev, O):
+    """Two independent kernels, one filter: the untuned form of k_fir_i8x (the default: exact integer accumulation on the
+    matrix cores) and k_fir8 (option i8x_plain = 0: packed fp32 FMAs) on the same stream.  Both within their bars against
+    the oracle -- 2e-7 and 1e-6 -- and within 1e-6 of each other.  (Until round 5 this compared with round 3's k_fir_i8,
+    the same arithmetic in another kernel; that kernel is retired and its binary16-stored taps live on as the plain form's
+    second operand source, compared bit for bit in test_gpu_i8.py.)"""
     for name in ("d8_127", "d8_255"):
         h = load_taps(name)
         n = TILE * 40 + 264
@@ -176,11 +177,10 @@ def test_plain_form_agrees_with_k_fir_i8(pkg, dev, O):
         rec = []
         y_new = run(pkg, dev, [(8, h)], packed, [0, n], mix=False, opts={"i8x_plain": 1}, record=rec)
         y_old = run(pkg, dev, [(8, h)], packed, [0, n], mix=False, opts={"i8x_plain": 0}, record=rec)
-        assert [int(k) for k, _ in rec] == [2, 1]
+        assert [int(k) for k, _ in rec] == [2, 0]
         ref = O.ddc_chain(packed, [(8, h)])
-        scale = np.abs(ref).max()
-        assert np.abs(y_new - y_old).max() <= 3e-8 * scale, np.abs(y_new - y_old).max() / scale
-        assert O.rel_err(y_new, ref) <= 2e-7 and O.rel_err(y_old, ref) <= 2e-7
+        assert O.rel_err(y_new, y_old) <= FIR_TOL
+        assert O.rel_err(y_new, ref) <= 2e-7 and O.rel_err(y_old, ref) <= FIR_TOL
 
 
 def test_untuned_first_stage_on_the_same_kernel(pkg, dev, O):

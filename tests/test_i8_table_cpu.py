@@ -1,5 +1,5 @@
-"""CPU tests of the tap operand of k_fir_i8 (pddc_fir_i8_table, include/perseus_ddc.h: host arithmetic, no GPU).
-The kernel's arithmetic is integer and exact, so all of it can be restated in numpy from the table alone: byte planes of
+"""CPU tests of the tap operand of k_fir_i8x's plain form (pddc_fir_i8_table, include/perseus_ddc.h: host arithmetic, no GPU;
+until round 5 the operand of round 3's k_fir_i8, same layout).  The kernel's arithmetic is integer and exact, so all of it can be restated in numpy from the table alone: byte planes of
 the packed samples, digit planes of the taps, the banded Toeplitz product in the matrix instruction's lane order, the
 nine plane products, the float recombination.  Checked here: the digits reconstruct the quantised taps, the band sits
 where out[m] = sum_k h[k] x[8m - k] needs it, and the restated kernel agrees with the oracle to 1e-6 of full scale -- also
@@ -54,7 +54,7 @@ def test_digits_reconstruct_the_quantised_taps_and_the_band_is_in_place(pkg, nam
 
 
 def restated_kernel(tab, scale, cterm, hist, packed):
-    """what k_fir_i8 computes for a batch that starts a stream (zero history), from the table alone"""
+    """what the plain form computes for a batch that starts a stream (zero history), from the table alone"""
     T = band(tab, hist)
     K = T.shape[2]
     b = packed.reshape(-1, 2, 3).astype(np.int64)

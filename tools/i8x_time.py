@@ -25,8 +25,8 @@ def lowpass(ntaps, cutoff):
     return (h / h.sum()).astype(np.float32)
 
 
-def timeit(stages, opts, ns, steps=30, mix=True):
-    pipe = pkg.Pipeline(stages, mix=mix)
+def timeit(stages, opts, ns, steps=30, mix=True, fp16=False):
+    pipe = pkg.Pipeline(stages, mix=mix, taps_fp16=fp16)
     for k, v in opts.items():
         pipe.set_option(k, v)
     if mix:

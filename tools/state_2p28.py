@@ -29,11 +29,9 @@ for rnd in range(2):
         if sel and not any(s in name for s in sel):
             continue
         o = dict(opts)
-        fp16 = o.pop("taps_fp16", 0)
-        if fp16:
-            continue
+        fp16 = bool(o.pop("taps_fp16", 0))
         try:
-            ms, kind = timeit(stages, o, ns, mix=mix)
+            ms, kind = timeit(stages, o, ns, mix=mix, fp16=fp16)
             print(f"round {rnd} {name:24s} {ms:.4f} ms {ns / ms / 1e6:7.1f} GS/s  kernels (i8, pair, stage0 ms) {kind}", flush=True)
         except Exception as e:
             print(f"round {rnd} {name:24s} FAILED {e}", flush=True)
