@@ -1178,7 +1178,7 @@ static Fir8Sched fir8_schedule(int ntiles, int R, bool fused, int NT = 256, int 
     /* 128-thread blocks: four per CU, tiles half as long (chunks of twice as many) */
     /* small batches (BASELINE config 5's low end): one block per tile up to one block per CU, then about three tiles
      * per block -- a block with a single tile overlaps nothing, its load, filter and store phases just follow each other
-     * (tools/small_batch.sh, 127 taps: 2^22 samples 19.0 -> 14.4 us with 256 instead of 512 blocks, 2^23 22.4 -> 20.2
+     * (bench.py --log2n 22 / 23 --steps 2000, 127 taps: 2^22 samples 19.0 -> 14.4 us with 256 instead of 512 blocks, 2^23 22.4 -> 20.2
      * with 340; x320 cascade 2^21 31.5 -> 25.4) -- and the full two blocks per CU from 1536 tiles on                */
     const int full = kFir8DefaultBlocks * (256 / NT);
     int want = g_fir8_blocks;
@@ -1199,7 +1199,7 @@ static Fir8Sched fir8_schedule(int ntiles, int R, bool fused, int NT = 256, int 
     if (group > 0)
         sc.K = chunk > 0 ? (chunk + group - 1) / group * group : 2 * group;
     /* fused pair: a dynamic chunk starts with a warm-up tile, so only a small share pays (same-box sweep under the
-     * arena placement, tools/sched_sweep_c320.sh: static 0.2897 ms, 5-10 % in chunks of 8 0.2863-0.2867, 20 % 0.293) */
+     * arena placement, a sweep of the fir8_dyn_pct / fir8_chunk tunables: static 0.2897 ms, 5-10 % in chunks of 8 0.2863-0.2867, 20 % 0.293) */
     const int pct = dyn_pct >= 0 ? dyn_pct : (fused ? 8 : 20);
     sc.S = (int)((long long)ntiles * (100 - pct) / 100 / sc.nblocks);
     if (group > 0) {

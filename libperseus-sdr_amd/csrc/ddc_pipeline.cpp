@@ -543,7 +543,7 @@ int pddc_malloc(void **d_ptr, size_t nbytes)
 /* min_bytes: buffers smaller than this are not walked.  A candidate smaller than the probe's 1 GiB is ALLOCATED at
  * 1 GiB (the caller uses its first nbytes): the probe must write past the 256 MB last-level cache to see the HBM, and
  * a 33 MB buffer written once per launch matters as much as a large one -- the fused pair of the x320 cascade, which
- * writes 1/48 of what it reads, runs at 0.292 or 0.330 ms depending on it (tools/placement_probe8.py).           */
+ * writes 1/48 of what it reads, runs at 0.292 or 0.330 ms depending on it (tools/placement_probe.py --mode small).           */
 static int malloc_apart_impl(void **d_ptr, size_t nbytes, const void *d_partner, size_t partner_bytes, int max_candidates,
                              float *ms_best, float *ms_worst, size_t min_bytes, hipStream_t stream = nullptr)
 {

@@ -35,7 +35,7 @@ for f in ("ddc_kernels.hip", "ddc_kernels.h", "fir8_block.inc", "ddc_fir_i8.hip"
 try:
     commit = subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
 except Exception:
-    commit = "unknown (no .git on the GPU box; tools/collect_final.sh fills in the commit the pass is collected into)"
+    commit = "unknown (no .git on the GPU box; tools/evidence.sh collect fills in the commit the pass is collected into)"
 # bench.py reports roofline.traffic only while the kernel source and the launch shape are these
 res["provenance"] = {"kernel_source_sha16": h.hexdigest()[:16], "log2n": 28, "commit": commit,
                      "kernels": kern, "tool": "tools/pmc_traffic.sh"}
