@@ -7,7 +7,7 @@
  * i.e. complex taps on the raw integer planes (four real band products instead of one) and ONE float rotation per output,
  * with the exact 32-bit phase; optionally a second decimate-by-8 stage fused behind it (the cascades' pair: the 1 B/sample
  * intermediate never reaches HBM); a decimate-by-10 form.  Tiles are handed round the blocks in chunks of C (1:
- * tile-interleaved, what streams best; the pair: 4), NOTEBOOK.md R4.2.
+ * tile-interleaved, what streams best; the pair: 4, or 8 with two matrix + two finishing waves from 2^23 samples on), NOTEBOOK.md R4.2.
  * (Round 3's k_fir_i8 -- the same product without NCO, eight matrix waves -- lived here until round 5; what it alone
  * offered, binary16-STORED taps quantised by the matrix waves themselves, is now the plain form's FirI8xArgs::taps16.)
  *
@@ -1052,7 +1052,7 @@ static hipError_t launch_fir_i8x_l(const FirI8xArgs &a, int max_blocks, int chun
         nblk = (nblk + nmany - 1) / nmany;        /* the streams of a round share the CUs */
     if (max_blocks > 0 && nblk > max_blocks)
         nblk = max_blocks;
-    long long C = chunk > 0 ? chunk : FUSE2 ? 4 : 1;
+    long long C = chunk > 0 ? chunk : FUSE2 ? (LAYOUT == 2 ? 8 : 4) : 1;
     if (C > (ntiles + nblk - 1) / nblk)
         C = (ntiles + nblk - 1) / nblk;
     const long long nchunks = (ntiles + C - 1) / C;
@@ -1111,8 +1111,13 @@ hipError_t launch_fir_i8x(const FirI8xArgs &a, int hist, bool mix, bool fuse2, h
         return hipErrorInvalidValue;
     if (fuse2 && ((a.n_in % i8x::TILE) || !a.taps2 || !a.hist2))
         return hipErrorInvalidValue;
-    if (layout < 0)              /* by form: the loaders finish the tile where the finish is heavy (four partial products, the second stage) */
-        layout = (fuse2 || (mix && hist > 128)) ? 1 : 0;
+    /* by form: the loaders finish the tile where the finish is heavy -- the four partial products of 129..256 tuned taps, and
+     * the fused pair's second stage for SMALL batches; from 1024 tiles on (2^23 samples: four tiles per block and more) the
+     * pair runs on two matrix + two finishing waves with chunks of 8 tiles.  Same box, the API's 250 kS/s pair, layout 1 /
+     * chunks of 4 against layout 2 / chunks of 8: 2^22 7.6 / 7.7 us, 2^24 23.9 / 21.4, 2^26 99.7 / 88.5 (k_fir8's pair: 93.7),
+     * 2^28 374 / 336 (profiles/r05/c_pair_layouts.txt) */
+    if (layout < 0)
+        layout = fuse2 ? (a.n_in >= (1LL << 23) ? 2 : 1) : (mix && hist > 128) ? 1 : 0;
     switch (hist) {
     case 32:
         return launch_fir_i8x_h<32>(a, mix, fuse2, max_blocks, chunk, layout, s);

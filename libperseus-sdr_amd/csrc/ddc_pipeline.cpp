@@ -179,7 +179,7 @@ struct pddc_pipeline {
                                      k_fir8's 0.339 ms; at 2^22 5.9 against 12.9 us (profiles/r04).  Round 3's k_fir_i8, which
                                      this option used to fall back to, is gone: one kernel family since round 5           */
         int i8x_blocks = 0;       /* persistent grid override of k_fir_i8x (0: one block per CU)                       */
-        int i8x_chunk = 0;        /* tiles per chunk of its walk (0: 1, fused pair 4)                                    */
+        int i8x_chunk = 0;        /* tiles per chunk of its walk (0: 1; fused pair 4, from 2^23 samples on 8)              */
         int i8x_layout = -1;      /* which waves finish a tile (ddc_fir_i8.hip "Who does what"): 0 the matrix waves, 1 the
                                      loaders, 2 two matrix + two finishing waves; -1: by form (0 without the NCO and for
                                      tuned stages up to 128 taps, 1 for 129..256 tuned taps and for the fused pair)      */
