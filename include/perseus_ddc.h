@@ -50,6 +50,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libperseus_ddc.so is built with -fvisibility=hidden: what this header declares is ALL the library exports (its C++
+ * internals -- kernel stubs, launchers, the pipeline classes -- stay out of the dynamic symbol table) */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define PDDC_OK          0
 #define PDDC_EINVAL     -1   /* bad argument (size, alignment, NULL)          */
@@ -458,6 +463,9 @@ int pddc_plan_unpack(const void *buf, size_t nbytes, pddc_stage_desc *stages /* 
 int pddc_comm_bcast_pipeline(pddc_comm *c, int root, const pddc_stage_desc *stages, int nstages,
                              uint32_t freg, uint32_t flags, pddc_pipeline **out);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif
