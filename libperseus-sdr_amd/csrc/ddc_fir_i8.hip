@@ -717,19 +717,37 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
                     acc[s] = v4i_t{ 0, 0, 0, 0 };
-#pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) {
+                /* The operand reads run ONE k-step ahead of the matrix instructions that use them, in two register sets:
+                 * hipcc left to itself issues a k-step's reads three or four matrix instructions (50-60 cycles) before their
+                 * first use and waits -- the 216 matrix instructions of a tile filled 57 % of these waves' 6000 ticks of work
+                 * (clock probe, NOTEBOOK R5.7), and these waves are the chain the block waits for in this form */
+                constexpr bool PF1 = LAYOUT == 1;               /* (the form's default layout; the others have no registers left) */
+                v4i_t B[PF1 ? 2 : 1][3];
+                auto read_b1 = [&](int ks, v4i_t (&b)[3]) __attribute__((always_inline)) {
                     const int at = swz(pos + 64 * ks);
-                    v4i_t B[3];
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
-                        B[i] = *reinterpret_cast<const v4i_t *>(pb + (3 * comp + i) * PLANE + at);
+                        b[i] = *reinterpret_cast<const v4i_t *>(pb + (3 * comp + i) * PLANE + at);
+                };
+                if (PF1)
+                    read_b1(0, B[0]);
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    if (!PF1)
+                        read_b1(ks, B[0]);
+                    else if (ks + 1 < KSTEPS)
+                        read_b1(ks + 1, B[(ks + 1) & 1]);
+                    if (PF1)
+                        __builtin_amdgcn_sched_barrier(0);
+                    const v4i_t(&b)[3] = B[PF1 ? ks & 1 : 0];
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (i + j >= 2)
-                                acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks][j], B[i], acc[i + j - 2], 0, 0, 0);
+                                acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks][j], b[i], acc[i + j - 2], 0, 0, 0);
+                    if (PF1)
+                        __builtin_amdgcn_sched_barrier(0);
                 }
                 float4 y;
                 float *yp = &y.x;
@@ -743,6 +761,34 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 acc[s] = v4i_t{ 0, 0, 0, 0 };
+            /* (operand reads one k-step ahead of their matrix instructions, two register sets: see mode 1 above) -- for the long
+             * untuned first stage only (six k-steps: there these waves' chain is what the block waits for, 255 taps 0.3451 ->
+             * 0.3369 ms).  Where the loaders are the longer chain the pinned order costs 2 % (two-k-step tuned form 0.3260 ->
+             * 0.3320), and the three-k-step tuned form has no registers for a second set (profiles/r05/f_ab_operand_prefetch.txt) */
+            constexpr bool PF = MODE == 0 && KSTEPS > 4 && !FUSE2;
+            if (PF) {
+                v4i_t B[2][3];
+                auto read_b = [&](int ks, v4i_t (&b)[3]) __attribute__((always_inline)) {
+                    const int at = swz(pos + 64 * ks);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        b[i] = *reinterpret_cast<const v4i_t *>(pb + (3 * w0 + i) * PLANE + at);
+                };
+                read_b(0, B[0]);
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    if (ks + 1 < KSTEPS)
+                        read_b(ks + 1, B[(ks + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (i + j >= 2)
+                                acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks][j], B[ks & 1][i], acc[i + j - 2], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 const int at = swz(pos + 64 * ks);
@@ -773,6 +819,7 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
                                 acc[i + j - 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1[MODE == 2 ? ks : 0][j], BQ[i], acc[i + j - 2], 0, 0, 0);
                             }
                 }
+            }
             }
             /* this lane: its column, rows 4 kq + v -> four consecutive values; mode 2: rows 0..7 are uI, rows 8..15 uQ of the
              * column's eight outputs */
