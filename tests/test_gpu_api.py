@@ -345,6 +345,39 @@ def test_gpu_source_and_cpu_source_are_the_same_stream(L, pkg, O):
     assert outs[0] == outs[1] and len(outs[0]) == 25 * 6144
 
 
+def test_a_streams_batch_size_does_not_stick_to_the_descriptor(L, pkg, O):
+    """Two streams on ONE descriptor: the first free-running (the library picks 2^24-sample GPU batches for an unpaced
+    on-device source), the second paced -- it must get 2^22 again (advisor, round 4: the first stream's effective size used
+    to become the configuration, and the paced stream ran with 210 ms of latency per batch); then the client's explicit
+    choice (perseus_amd_set_batch), which holds for both kinds.  Batch sizes read back as adc_samples / batches."""
+    assert L.perseus_init() == 1
+    d = open_receiver(L, pkg, 0, 250000, 7.1e6, mode=1, max_buffers=400)      # 400 buffers of 1024 outputs = 131 M ADC samples
+    st = pkg.AmdStats()
+    outs, _ = run_all(L, pkg, [d], bufsize=6144)
+    L.perseus_amd_get_stats(d, C.byref(st))
+    assert st.delivered == 400 and st.batches >= 5 and st.adc_samples // st.batches == 1 << 24, (st.adc_samples, st.batches)
+    first = outs[0]
+    cfg = pkg.AmdConfig()
+    assert L.perseus_amd_get_config(d, C.byref(cfg)) == 0 and cfg.batch_samples == 1 << 22     # the configuration was not touched
+    cfg.pace, cfg.max_buffers = 1, 40                                          # 40 buffers at 250 kS/s: 0.16 s of signal
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    assert L.perseus_amd_effective_batch(d) == 1 << 22
+    outs, _ = run_all(L, pkg, [d], bufsize=6144)
+    L.perseus_amd_get_stats(d, C.byref(st))
+    assert st.delivered == 40 and st.adc_samples // st.batches == 1 << 22, (st.adc_samples, st.batches)
+    same = lambda b: O.rel_err(np.frombuffer(b, np.float32), np.frombuffer(first[:len(b)], np.float32)) <= FIR_TOL
+    assert same(outs[0])                                # the same stream from its start, whatever the batches (to the tolerance: the kernels differ by batch size)
+    cfg.pace, cfg.max_buffers = 0, 100
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    assert L.perseus_amd_set_batch(d, 1 << 20) == 0
+    outs, _ = run_all(L, pkg, [d], bufsize=6144)
+    L.perseus_amd_get_stats(d, C.byref(st))
+    assert st.delivered == 100 and st.adc_samples // st.batches == 1 << 20, (st.adc_samples, st.batches)
+    assert same(outs[0])
+    L.perseus_close(d)
+    L.perseus_exit()
+
+
 @pytest.mark.perf
 def test_unpaced_plumbing_client_is_kernel_bound_not_source_bound(pkg, dev, perf_record):
     """with the synthetic stream generated on the device the unpaced client at

@@ -302,6 +302,41 @@ def test_decimate_by_ten_first_stage_on_the_matrix_cores(pkg, dev, O, ntaps):
     assert [int(k) for k, _ in rec].count(0) >= 1 and [int(k) for k, _ in rec].count(2) >= 5, rec
 
 
+def test_decimate_by_ten_retune_storm(pkg, dev, O):
+    """A retune every third batch while the batches' decimation phases cycle through all eight tap delays: every delay's
+    table set is rebuilt for every new word, in the double buffers behind their `left` events (ddc_pipeline.cpp
+    i8x_d10_prepare; until round 5 each rebuild was a hipDeviceSynchronize) -- against the retuned oracle, and the same stream
+    again without waiting between the batches' submissions (the rebuilds then overlap launches still in flight)."""
+    import torch
+    h1, h2 = lowpass(51, 0.04), lowpass(117, 0.08)
+    stages = [(10, h1), (5, h2)]
+    nb = 36
+    sizes = [10240 * 4 + 8 * (1 + k % 9) for k in range(nb)]                     # first outputs on every sample 0 .. 9 of a batch
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    packed = O.lcg_bytes(6 * int(cuts[-1]), 31)
+    words = [O.nco_freg(f) for f in (7.1e6, 14.2e6, 3.55e6, 21.0e6, 1.8e6, 10.1e6)]
+    retune_at = {k: words[(k // 3) % len(words)] for k in range(3, nb, 3)}
+    segs = [(0, FREG)] + [(int(cuts[k]), w) for k, w in sorted(retune_at.items())]
+    ref = O.ddc_chain_retuned(packed, stages, segs)
+    rec = []
+    y = run(pkg, dev, stages, packed, cuts, retune_at=retune_at, record=rec)
+    assert y.size == ref.size and O.rel_err(y, ref) <= FIR_TOL, O.rel_err(y, ref)
+    assert [int(k) for k, _ in rec].count(2) >= nb // 2, rec                      # (the batch behind each retune takes the vector kernel)
+    # the same without a host wait between batches: outputs stay on the device until the end
+    pipe = pkg.Pipeline(stages, mix=True)
+    pipe.set_freg(FREG)
+    d_in = to_dev(packed, dev)
+    outs = []
+    for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if k in retune_at:
+            pipe.set_freg(retune_at[k])
+        outs.append(pipe.process(d_in[6 * a:6 * b]))
+    torch.cuda.synchronize()
+    y2 = np.concatenate([o.cpu().numpy().reshape(-1) for o in outs])
+    pipe.close()
+    assert np.array_equal(y2.view(np.uint32), y.view(np.uint32))
+
+
 def test_decimate_by_ten_walks_and_checkpoint(pkg, dev, O):
     """every walk / grid / layout of the decimate-by-10 form gives the same bits, and a checkpoint taken between batches
     continues them"""
