@@ -297,7 +297,11 @@ def window_positions(n_first, n_count, sched, dtot, width, k_random, seed):
     if sched:
         per_tile = sched["tile"] / dtot                      # outputs per stage-0 tile
         S, nb, nt = sched["S"], sched["nblocks"], sched["ntiles"]
-        seams = [nb * S, nb * S + sched["K"], nt - 1]        # first dynamic chunk, the next one, last tile
+        K = sched["K"]
+        if S < 0:                                            # round-robin walk: chunk j -> block j mod nb, dynamic from chunk -S on
+            seams = [K, 2 * K, nb * K, (nb + 1) * K, -S * K, (-S + 1) * K, nt - 1]
+        else:
+            seams = [nb * S, nb * S + K, nt - 1]             # first dynamic chunk, the next one, last tile
         if S > 0:
             seams += [S, (nb // 2) * S, (nb - 1) * S]        # block-range seams of the static part
         for t in seams:

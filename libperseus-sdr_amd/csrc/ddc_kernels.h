@@ -21,6 +21,8 @@ enum InFmt { IN_PACKED24 = 0, IN_F32C = 1 };
 struct Tunables {
     std::atomic<int> fir8_dyn_pct{ -1 };      /* share of a k_fir8 launch's tiles that go out in dynamic chunks (-1: default) */
     std::atomic<int> fir8_chunk{ 0 };         /* tiles per dynamic chunk (0: default)                                  */
+    std::atomic<int> fir8_walk{ -1 };         /* 1: chunks handed ROUND the blocks (chunk j -> block j mod nblocks, no counter);
+                                               * 0: static runs + dynamic tail; -1: the launcher's default for the form  */
     std::atomic<int> gen_shape_nt{ 0 }, gen_shape_p{ 0 };   /* k_fir_generic block shape override (PDDC_GEN_SHAPE=NT,P) */
     std::atomic<int> no_firp{ 0 };            /* 1: plain decimators by 4/5/10 on k_fir_generic instead of k_firp      */
     std::atomic<int> firp_packed_p{ 0 };

@@ -84,6 +84,7 @@ Tunables &tunables()
         };
         env("PDDC_FIR8_DYN_PCT", t.fir8_dyn_pct);
         env("PDDC_FIR8_CHUNK", t.fir8_chunk);
+        env("PDDC_FIR8_WALK", t.fir8_walk);
         if (const char *e = getenv("PDDC_GEN_SHAPE")) {
             int a = 0, b = 0;
             if (sscanf(e, "%d,%d", &a, &b) == 2) {
@@ -109,7 +110,8 @@ static std::atomic<int> *tunable_by_name(const char *name)
     const struct {
         const char *n;
         std::atomic<int> *v;
-    } tab[] = { { "fir8_dyn_pct", &t.fir8_dyn_pct },   { "fir8_chunk", &t.fir8_chunk },       { "gen_shape_nt", &t.gen_shape_nt },
+    } tab[] = { { "fir8_dyn_pct", &t.fir8_dyn_pct },   { "fir8_chunk", &t.fir8_chunk },       { "fir8_walk", &t.fir8_walk },
+                { "gen_shape_nt", &t.gen_shape_nt },
                 { "gen_shape_p", &t.gen_shape_p },     { "no_firp", &t.no_firp },             { "firp_packed_p", &t.firp_packed_p },
                 { "unpack_blocks", &t.unpack_blocks }, { "debug", &t.debug },                 { "push_three_streams", &t.push_three_streams },
                 { "gang_copy_out", &t.gang_copy_out }, { "gang_gen_inline", &t.gang_gen_inline }, { "gang_solo", &t.gang_solo } };
@@ -936,18 +938,27 @@ struct Fir8Geom {
 
 /* second (fused) decimate-by-8 stage: its input is the tile's TO stage-1
  * outputs, kept in LDS in the same rotated / padded plane layout */
-template <int NTB2, int R>
+template <int NTB2, int R, int NTB = 4>
 struct Fir8Geom2 {
     static constexpr int TO2   = 16 * R;                 /* stage-2 outputs per tile (TO/8)   */
     static constexpr int R2    = TO2 / 64;               /* per lane of waves 0 (I) and 1 (Q) */
     static constexpr int GT2   = 16 * R;                 /* new input groups per tile (TO/8)  */
     static constexpr int NG2   = GT2 + NTB2;
+    /* the PORCH of a chunk's first tile: the 8*NTB2 first-stage outputs in front of it (the second stage's history) are
+     * computed from the 8*NTB2 + NTB input groups in front of the tile, which for that one tile lie -- in the FIRST
+     * stage's padded layout -- in the plane set the second stage is not using                                      */
+    static constexpr int NPG   = 8 * NTB2 + NTB;
+    static constexpr int PORCH = (8 + 8 * NPG + 4 * (NPG / 8) + 8 + 3) & ~3;
     /* plain layout (offset 8 + position): the second stage is ~3 % of the work, a
      * 2-way bank conflict on its reads is cheaper than the LDS a pad would cost  */
-    static constexpr int PLANE = NTB2 > 0 ? 8 + 8 * NG2 + 8 : 0;
+    static constexpr int PLANE0 = 8 + 8 * NG2 + 8;
+    static constexpr int PLANE = NTB2 > 0 ? (PLANE0 > PORCH ? PLANE0 : PORCH) : 0;
+    /* the second stage's outputs of BT tiles leave in ONE burst of BT*TO2*8 bytes (fir8_block.inc "store_tile2") */
+    static constexpr int BT    = R == 4 ? (NTB <= 4 ? 16 : 12) : 8;
+    static constexpr int BURST = NTB2 > 0 ? BT * 2 * TO2 : 0;
     /* two plane SETS, alternating tile by tile (the history of tile t+1 is carried into the other set while all four
-     * waves may still be reading tile t's), and two staging areas for the two halves of the tap sum */
-    static constexpr int LDS_FLT = NTB2 > 0 ? 4 * PLANE + 4 * TO2 : 0;
+     * waves may still be reading tile t's), two staging areas for the two halves of the tap sum, the burst buffer */
+    static constexpr int LDS_FLT = NTB2 > 0 ? 4 * PLANE + 4 * TO2 + BURST : 0;
 };
 
 size_t fir8_lds_bytes(int ntb, int R)
@@ -1202,6 +1213,18 @@ static Fir8Sched fir8_schedule(int ntiles, int R, bool fused, int NT = 256, int 
      * arena placement, a sweep of the fir8_dyn_pct / fir8_chunk tunables: static 0.2897 ms, 5-10 % in chunks of 8 0.2863-0.2867, 20 % 0.293) */
     const int pct = dyn_pct >= 0 ? dyn_pct : (fused ? 8 : 20);
     sc.S = (int)((long long)ntiles * (100 - pct) / 100 / sc.nblocks);
+    /* the round-robin walk (S = -1: chunk j -> block j mod nblocks; fir8_block.inc), not with the fused third stage */
+    if (group == 0 && tunables().fir8_walk.load() == 1) {
+        if (chunk <= 0 && fused)
+            sc.K = 16;
+        const long long nd = ((long long)ntiles + sc.K - 1) / sc.K;
+        long long jd = nd * (100 - (dyn_pct >= 0 ? dyn_pct : 0)) / 100 / sc.nblocks * sc.nblocks;
+        if (jd < sc.nblocks)
+            jd = sc.nblocks < nd ? sc.nblocks : nd;          /* every block starts with a chunk of its own */
+        if (jd > 0x3fffffff)
+            jd = 0x3fffffff;
+        sc.S = -(int)jd;
+    }
     if (group > 0) {
         sc.S -= sc.S % group;
         if (sc.S == 0 && chunk <= 0)
@@ -1282,7 +1305,7 @@ template <int NTB, int R>
 static hipError_t launch_fir8_fused2_t(bool mix, const Fir8Args &a, hipStream_t s)
 {
     using G = Fir8Geom<NTB, R>;
-    using G2 = Fir8Geom2<8, R>;
+    using G2 = Fir8Geom2<8, R, NTB>;
     const size_t lds = (size_t)(2 * G::PLANE + G2::LDS_FLT) * sizeof(float);
     if (a.n_in <= 0 || a.n_in % G::TI)
         return hipErrorInvalidValue;             /* whole tiles only */
@@ -1326,8 +1349,10 @@ size_t fir8_fused2_lds_bytes(int ntb, int R)
 {
     const int NG = 1024 * R / 8 + ntb;
     const int plane = 8 + 8 * NG + 4 * (NG / 8) + 8;
-    const int plane2 = 8 + 8 * (16 * R + 8) + 8;
-    return (size_t)(2 * plane + 4 * plane2 + 4 * 16 * R) * sizeof(float);
+    const int npg = 64 + ntb, porch = (8 + 8 * npg + 4 * (npg / 8) + 8 + 3) & ~3;
+    const int plane0 = 8 + 8 * (16 * R + 8) + 8, plane2 = plane0 > porch ? plane0 : porch;
+    const int bt = R == 4 ? (ntb <= 4 ? 16 : 12) : 8;
+    return (size_t)(2 * plane + 4 * plane2 + 4 * 16 * R + bt * 2 * 16 * R) * sizeof(float);
 }
 
 bool fir8_fused2_supported(int ntb, int ntb2, int R)
@@ -1386,7 +1411,7 @@ template <int NTB, int R, int SL3>
 static hipError_t launch_fir8_fused3_t(bool mix, const Fir8Args &a, hipStream_t s)
 {
     using G = Fir8Geom<NTB, R>;
-    using G2 = Fir8Geom2<8, R>;
+    using G2 = Fir8Geom2<8, R, NTB>;
     const Fir8Stage3 &q = a.s3;
     const size_t lds = (size_t)(2 * G::PLANE + G2::LDS_FLT) * sizeof(float) + fir8_fused3_lds3(q, G2::TO2);
     constexpr size_t lds_cap = 96u * 1024u;
@@ -1452,7 +1477,7 @@ template <int NTB, int NTB2, int R>
 static hipError_t launch_fir8_many_t(bool mix, const Fir8Many &m, int n, hipStream_t s)
 {
     using G = Fir8Geom<NTB, R>;
-    using G2 = Fir8Geom2<8, R>;
+    using G2 = Fir8Geom2<8, R, NTB>;
     const size_t lds = NTB2 ? (size_t)(2 * G::PLANE + G2::LDS_FLT) * sizeof(float) : (size_t)G::LDS_FLT * sizeof(float);
     const long long n_in = m.a[0].n_in;
     if (n_in <= 0 || (NTB2 && n_in % G::TI))

@@ -76,8 +76,18 @@ def lib() -> C.CDLL:
         L.orc_stage1_f32.restype = C.c_size_t
         L.orc_max_threads.argtypes = []
         L.orc_max_threads.restype = C.c_int
+        L.orc_chain_check.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_uint32, C.c_int, C.c_int,
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(f32p), C.c_void_p, C.c_size_t,
+                                      C.c_double, C.POINTER(CheckStats)]
+        L.orc_chain_check.restype = C.c_longlong
         _lib = L
     return _lib
+
+
+class CheckStats(C.Structure):
+    _fields_ = [("max_err", C.c_double), ("max_ref", C.c_double), ("worst_chunk_ratio", C.c_double),
+                ("n_compared", C.c_longlong), ("n_bad", C.c_longlong), ("first_bad", C.c_longlong),
+                ("chunk_outputs", C.c_longlong)]
 
 
 def _p(a: np.ndarray, ty):
@@ -251,6 +261,33 @@ def ddc_chain(packed: np.ndarray, stages, freg: int = 0, mix: bool = False) -> n
     if r == C.c_size_t(-1).value:
         raise RuntimeError("orc_ddc_chain failed")
     return out[:2 * r]
+
+
+def chain_check(packed: np.ndarray, first_in: int, n_in: int, stages, got_iq: np.ndarray, freg: int = 0,
+                mix: bool = False, tol: float = 1e-6) -> dict:
+    """EVERY output of the batch that starts at absolute sample first_in (n_in samples) of the periodic stream
+    `packed`, `packed`, ... against the double oracle (orc_chain_check; plain decimators).  got_iq: float32 pairs, the
+    batch's outputs in order.  -> {"n": outputs compared, "max_rel_err": max|got-ref| / max|ref| over the whole batch,
+    "worst_chunk_rel_err": the same per chunk of `chunk_outputs` outputs, worst chunk, "n_bad", "first_bad", "ok"}."""
+    b = np.ascontiguousarray(packed, dtype=np.uint8)
+    g = np.ascontiguousarray(got_iq, dtype=np.float32).reshape(-1)
+    ds = [int(st[0]) for st in stages]
+    if any(len(st) > 2 and st[2] and int(st[2]) > 1 for st in stages):
+        raise ValueError("chain_check: plain decimators only")
+    hs = [np.ascontiguousarray(st[1], dtype=np.float32) for st in stages]
+    k = len(ds)
+    Darr = (C.c_int * k)(*ds)
+    Narr = (C.c_int * k)(*[h.size for h in hs])
+    Tarr = (C.POINTER(C.c_float) * k)(*[_p(h, C.c_float) for h in hs])
+    st = CheckStats()
+    n = lib().orc_chain_check(b.ctypes.data, b.size // 6, int(first_in), int(n_in), freg & 0xFFFFFFFF, int(bool(mix)), k,
+                              Darr, Narr, Tarr, g.ctypes.data, g.size // 2, float(tol), C.byref(st))
+    if n < 0:
+        raise RuntimeError("orc_chain_check: bad arguments (or fewer outputs than the batch produces)")
+    rel = st.max_err / st.max_ref if st.max_ref > 0 else st.max_err
+    return {"n": int(n), "max_rel_err": float(rel), "worst_chunk_rel_err": float(st.worst_chunk_ratio),
+            "n_bad": int(st.n_bad), "first_bad": int(st.first_bad), "chunk_outputs": int(st.chunk_outputs),
+            "tol": tol, "ok": bool(st.n_bad == 0 and n > 0)}
 
 
 def resample(x_iq: np.ndarray, taps: np.ndarray, L: int, M: int) -> np.ndarray:

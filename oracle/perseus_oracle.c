@@ -291,6 +291,169 @@ size_t orc_ddc_chain(const uint8_t *packed, size_t ns, uint32_t freg,
 }
 
 /* ------------------------------------------------------------------------
+ * EVERY output of one batch of a cascade against the double oracle (authored; what the full-size GPU tests and
+ * bench.py's `verified` use).  The stream is the packed buffer of ns_buf samples repeated for ever from absolute ADC
+ * sample 0 -- the full-size tests and the bench feed the same batch again and again -- and zero before sample 0
+ * (the oracle's zero initial history: every stage's samples with a negative index are zero).  Compared are the
+ * last stage's outputs M with first_in <= M*Dtot < first_in + n_in: the ones the batch that starts at absolute
+ * sample first_in produces, got_iq[0] being the first of them.  The definition is orc_ddc_chain's (unpack to float as
+ * A2, NCO in double with the exact 32-bit phase of the absolute index, y[m] = sum h[k] x[m*D - k] in double); the work
+ * is cut into chunks of outputs, each computed from its own input span plus the cascade's halo, OpenMP over chunks.
+ * Plain decimators only.  Returns the number of outputs compared, or -1 on bad arguments.
+ */
+long long orc_chain_check(const uint8_t *packed, size_t ns_buf, uint64_t first_in, size_t n_in, uint32_t freg,
+                          int mix_enable, int nstages, const int *D, const int *ntaps, const float *const *taps,
+                          const float *got_iq, size_t n_got, double tol, orc_check_stats *st)
+{
+    if (!packed || !got_iq || !st || ns_buf == 0 || nstages < 1 || nstages > 8)
+        return -1;
+    long long dtot = 1;
+    for (int s = 0; s < nstages; s++) {
+        if (D[s] < 1 || ntaps[s] < 1)
+            return -1;
+        dtot *= D[s];
+    }
+    const long long m_first = (long long)((first_in + (uint64_t)dtot - 1) / (uint64_t)dtot);
+    const long long m_end = (long long)((first_in + n_in + (uint64_t)dtot - 1) / (uint64_t)dtot);
+    const long long n_cmp = m_end - m_first;
+    memset(st, 0, sizeof *st);
+    st->first_bad = -1;
+    if (n_cmp <= 0 || (size_t)n_cmp > n_got)
+        return n_cmp <= 0 ? 0 : -1;
+    long long CH = (1LL << 18) / dtot;            /* about 2^18 ADC samples per chunk */
+    if (CH < 64)
+        CH = 64;
+    const long long nchunks = (n_cmp + CH - 1) / CH;
+    /* spans per level for a chunk of CH outputs: level nstages = the outputs, level 0 = ADC samples */
+    long long span[9];
+    span[nstages] = CH;
+    for (int s = nstages - 1; s >= 0; s--)
+        span[s] = (span[s + 1] - 1) * D[s] + ntaps[s];
+    const double two_pi_over_2p32 = 6.283185307179586476925286766559 / 4294967296.0;
+    const float full_scale = (float)(INT_MAX - 256);
+    double g_err = 0.0, g_ref = 0.0, g_ratio = 0.0;
+    long long g_bad = 0, g_first = -1;
+    int failed = 0;
+#pragma omp parallel
+    {
+        double *buf[2];
+        buf[0] = (double *)malloc(sizeof(double) * 2 * (size_t)span[0]);
+        buf[1] = (double *)malloc(sizeof(double) * 2 * (size_t)span[1]);
+        double t_err = 0.0, t_ref = 0.0, t_ratio = 0.0;
+        long long t_bad = 0, t_first = -1;
+        if (!buf[0] || !buf[1]) {
+#pragma omp atomic write
+            failed = 1;
+        } else {
+#pragma omp for schedule(dynamic, 1)
+            for (long long c = 0; c < nchunks; c++) {
+                long long lo[9], hi[9];            /* inclusive index ranges per level */
+                lo[nstages] = m_first + c * CH;
+                hi[nstages] = lo[nstages] + CH - 1 < m_end - 1 ? lo[nstages] + CH - 1 : m_end - 1;
+                for (int s = nstages - 1; s >= 0; s--) {
+                    lo[s] = lo[s + 1] * D[s] - (ntaps[s] - 1);
+                    hi[s] = hi[s + 1] * D[s];
+                }
+                /* level 0: unpack (A2) and mix */
+                double *x = buf[0];
+                const long long n0 = hi[0] - lo[0] + 1;
+                for (long long i = 0; i < n0; i++) {
+                    const long long n = lo[0] + i;
+                    double xr = 0.0, xi = 0.0;
+                    if (n >= 0) {
+                        const uint8_t *q = packed + 6 * (size_t)((uint64_t)n % (uint64_t)ns_buf);
+                        xr = (double)((float)msb_align24(q) / full_scale);
+                        xi = (double)((float)msb_align24(q + 3) / full_scale);
+                        if (mix_enable) {
+                            const uint32_t ph = (uint32_t)((uint64_t)n * (uint64_t)freg);
+                            const double a = two_pi_over_2p32 * (double)ph;
+                            const double cc = cos(a), ss = -sin(a);
+                            const double r = xr * cc - xi * ss, im = xr * ss + xi * cc;
+                            xr = r;
+                            xi = im;
+                        }
+                    }
+                    x[2 * i] = xr;
+                    x[2 * i + 1] = xi;
+                }
+                /* the stages: y[m] = sum_k h[k] x[m*D - k]; indices below zero hold zeros at every level */
+                int cur = 0;
+                for (int s = 0; s < nstages; s++) {
+                    const double *in = buf[cur];
+                    double *out = buf[cur ^ 1];
+                    const float *h = taps[s];
+                    const int nt = ntaps[s], d = D[s];
+                    for (long long m = lo[s + 1]; m <= hi[s + 1]; m++) {
+                        double ar = 0.0, ai = 0.0;
+                        if (m >= 0) {
+                            const double *top = in + 2 * (m * d - lo[s]);
+                            for (int k = 0; k < nt; k++) {
+                                ar += (double)h[k] * top[-2 * k];
+                                ai += (double)h[k] * top[-2 * k + 1];
+                            }
+                        }
+                        out[2 * (m - lo[s + 1])] = ar;
+                        out[2 * (m - lo[s + 1]) + 1] = ai;
+                    }
+                    cur ^= 1;
+                }
+                const double *ref = buf[cur];
+                const long long nn = hi[nstages] - lo[nstages] + 1;
+                const float *g = got_iq + 2 * (lo[nstages] - m_first);
+                double c_err = 0.0, c_ref = 0.0;
+                for (long long i = 0; i < 2 * nn; i++) {
+                    const double r = fabs(ref[i]);
+                    if (r > c_ref)
+                        c_ref = r;
+                }
+                for (long long i = 0; i < 2 * nn; i++) {
+                    const double e = fabs((double)g[i] - ref[i]);
+                    if (!(e <= tol * c_ref)) {               /* also NaN */
+                        t_bad++;
+                        const long long idx = lo[nstages] - m_first + i / 2;
+                        if (t_first < 0 || idx < t_first)
+                            t_first = idx;
+                    }
+                    if (e > c_err || e != e)
+                        c_err = e != e ? INFINITY : e;
+                }
+                if (c_err > t_err)
+                    t_err = c_err;
+                if (c_ref > t_ref)
+                    t_ref = c_ref;
+                const double ratio = c_ref > 0.0 ? c_err / c_ref : c_err;
+                if (ratio > t_ratio)
+                    t_ratio = ratio;
+            }
+        }
+#pragma omp critical
+        {
+            if (t_err > g_err)
+                g_err = t_err;
+            if (t_ref > g_ref)
+                g_ref = t_ref;
+            if (t_ratio > g_ratio)
+                g_ratio = t_ratio;
+            g_bad += t_bad;
+            if (t_first >= 0 && (g_first < 0 || t_first < g_first))
+                g_first = t_first;
+        }
+        free(buf[0]);
+        free(buf[1]);
+    }
+    if (failed)
+        return -1;
+    st->max_err = g_err;
+    st->max_ref = g_ref;
+    st->worst_chunk_ratio = g_ratio;
+    st->n_compared = n_cmp;
+    st->n_bad = g_bad;
+    st->first_bad = g_first;
+    st->chunk_outputs = CH;
+    return n_cmp;
+}
+
+/* ------------------------------------------------------------------------
  * CPU baseline: unpack + one decimating FIR, float accumulate.  Chunks of
  * outputs are independent (the input is read with its halo), so OpenMP
  * splits the output range.  Each thread unpacks its input span into a

@@ -96,6 +96,24 @@ size_t orc_ddc_chain(const uint8_t *packed, size_t nsamples,
                      const float *const *taps, const int *interp,
                      float *out_iq, size_t out_capacity);
 
+/* ---- every output of one batch against the double oracle (authored) ----
+ * The stream = `packed` (ns_buf samples) repeated for ever from absolute sample 0, zeros before it; compared are the
+ * last stage's outputs M with first_in <= M*Dtot < first_in + n_in (what the batch starting at first_in produces),
+ * got_iq[0] the first of them.  Same definition as orc_ddc_chain, computed in chunks (OpenMP).  An output is BAD when
+ * |got - ref| > tol * (max |ref| of its chunk of `chunk_outputs` outputs) or NaN.  Plain decimators only.
+ * Returns the number of outputs compared (-1: bad arguments / n_got too small).                                  */
+typedef struct {
+    double    max_err;            /* max |got - ref| over all outputs (I and Q separately)          */
+    double    max_ref;            /* max |ref|                                                      */
+    double    worst_chunk_ratio;  /* max over chunks of (chunk max err / chunk max |ref|)           */
+    long long n_compared, n_bad;
+    long long first_bad;          /* batch-relative index of the first bad output, -1: none          */
+    long long chunk_outputs;
+} orc_check_stats;
+long long orc_chain_check(const uint8_t *packed, size_t ns_buf, uint64_t first_in, size_t n_in, uint32_t freg,
+                          int mix_enable, int nstages, const int *D, const int *ntaps, const float *const *taps,
+                          const float *got_iq, size_t n_got, double tol, orc_check_stats *st);
+
 /* ---- CPU baseline fast path (float accumulate, OpenMP over chunks) ------
  * unpack + single-stage decimate-by-D, the work bench.py times beside the
  * GPU kernel.  Same definition as the chain above with one stage and no mix,

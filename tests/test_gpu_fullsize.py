@@ -148,6 +148,92 @@ def test_tuned_matrix_core_stages_at_full_size(pkg, O, dev, case):
     assert v["ok"] and v["max_rel_err"] <= 1e-6, v
 
 
+# ---- EVERY output at the bench's size (round 5 review: sparse lane-level corruption is what this code base has actually
+# seen -- lanes 48..63 of a finishing wave, 5-6 thousand wrong outputs in 600 tiles -- and windows cannot see it) -------
+EVERY = {
+    # name: (stages builder, mix, log2 of the batch, pipeline options, taps_fp16, tunables)
+    "d8_127_headline_2p28":      (lambda pkg: [(8, _taps("d8_127"))], False, 28, {}, False, {}),
+    "d8_255_binary16_taps_2p28": (lambda pkg: [(8, _taps("d8_255"))], False, 28, {}, True, {}),
+    "tuned_127_2p27":            (lambda pkg: [(8, _taps("d8_127"))], True, 27, {}, False, {}),
+    "tuned_255_2p26":            (lambda pkg: [(8, _taps("d8_255"))], True, 26, {}, False, {}),
+    "i8x_pair_c320_2p26":        (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(250000)], True, 26, {}, False, {}),
+    "c320_2p28":                 (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(250000)], True, 28, {}, False, {}),
+    "c320_2p28_static_walk":     (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(250000)], True, 28, {}, False, {"fir8_walk": 0}),
+    "c320_2p28_round_robin":     (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(250000)], True, 28, {}, False,
+                                  {"fir8_walk": 1, "fir8_dyn_pct": 10}),
+    "vector_127_2p27":           (lambda pkg: [(8, _taps("d8_127"))], True, 27, {"no_i8": 1}, False, {}),
+    "d10_plan_1M6_2p27":         (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(1600000)], True, 27, {}, False, {}),
+}
+
+
+def _taps(name):
+    from conftest import load_taps
+    return load_taps(name)
+
+
+@pytest.mark.parametrize("case", list(EVERY))
+def test_every_output_at_bench_size(pkg, O, dev, tune, case):
+    """ALL outputs of the second batch (real history, second decimation phase where the batch is not a multiple of the
+    decimation) against the double oracle, <= 1e-6 of the chunk's largest reference value each -- not windows.  The
+    headline launch (127 taps, 2^28 samples), BASELINE config 5's binary16-stored leg, the tuned matrix-core forms, the
+    fused pair on the matrix cores at its largest batch, the x320 step (config 3) under the walks the vector pair knows, the
+    vector first stage and a decimate-by-10 plan.  oracle/perseus_oracle.c orc_chain_check: chunks of about 2^18 ADC
+    samples with their halos, OpenMP."""
+    import torch
+    mk, mix, lg, opts, fp16, tun = EVERY[case]
+    for k, v in tun.items():
+        tune(k, v)
+    stages = mk(pkg)
+    ns = 1 << lg
+    freg = 381178347
+    d_in = pkg.synth_lcg(6 * ns, 12345, 0, dev)
+    pipe = pkg.Pipeline(stages, mix=mix, taps_fp16=fp16)
+    if mix:
+        pipe.set_freg(freg)
+    for k, v in opts.items():
+        pipe.set_option(k, v)
+    out = torch.empty((pipe.max_output(ns) + 8, 2), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    n = 0
+    for _ in range(2):
+        n = pipe.process_ptr(d_in.data_ptr(), ns, out.data_ptr(), out.shape[0], st)
+    pipe.fence(st)
+    torch.cuda.synchronize()
+    kinds = (pipe.on_i8(ns), pipe.fused_pair(ns))
+    pipe.close()
+    if case.startswith(("d8_", "tuned_")):
+        assert kinds[0] == 2, kinds                        # the matrix-core kernel
+    if case.startswith("i8x_pair"):
+        assert kinds == (2, 2), kinds
+    if case.startswith("c320_2p28"):
+        assert kinds[1] == 1, kinds                        # the vector pair
+    packed = d_in.cpu().numpy()
+    got = out[:n].cpu().numpy()
+    del d_in, out
+    ref_stages = [(d, (t.astype(np.float16).astype(np.float32) if fp16 else t)) for d, t in stages]
+    r = O.chain_check(packed, ns, ns, ref_stages, got, freg=freg, mix=mix, tol=1e-6)
+    assert r["n"] == n and r["ok"] and r["max_rel_err"] <= 1e-6, (case, kinds, r)
+
+
+def test_every_output_check_sees_one_wrong_lane(pkg, O, dev):
+    """the checker on the GPU path: ONE output of 2^24 nudged by 3e-6 of full scale is found and located"""
+    import torch
+    ns = 1 << 27
+    stages = [(8, _taps("d8_127"))]
+    d_in = pkg.synth_lcg(6 * ns, 12345, 0, dev)
+    pipe = pkg.Pipeline(stages)
+    out = torch.empty((pipe.max_output(ns) + 8, 2), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    n = pipe.process_ptr(d_in.data_ptr(), ns, out.data_ptr(), out.shape[0], st)
+    torch.cuda.synchronize()
+    pipe.close()
+    got = out[:n].cpu().numpy()
+    k = 9_876_543
+    got[k, 0] += 3e-6 * float(np.abs(got).max())
+    r = O.chain_check(d_in.cpu().numpy(), 0, ns, stages, got)
+    assert not r["ok"] and r["n_bad"] == 1 and r["first_bad"] == k, r
+
+
 def test_first_batch_from_zero_history_at_full_size(pkg, O, dev):
     v, _, _ = _run(pkg, O, dev, "d8_127", steps=1)
     assert v["ok"], v

@@ -174,3 +174,39 @@ def test_retuned_nco_is_a_phase_accumulator(O):
     for (a, w), b in zip(segs, [s[0] for s in segs[1:]] + [4000]):
         ww = w if w < 2 ** 31 else w - 2 ** 32
         assert np.allclose(step[a:b - 1], ww, atol=1e-3 * 2 ** 32 / (2 * np.pi) * 1e-6 + 2.0)
+
+
+@pytest.mark.parametrize("case", ["d8", "c320", "d10x4"])
+def test_chain_check_agrees_with_the_chain(O, case):
+    """orc_chain_check -- every output of one batch of the periodic stream, in chunks with their halos (what the
+    full-size GPU tests and bench.py's `verified` use) -- is the same definition as orc_ddc_chain: the chain's float32
+    result over two periods of the stream passes for both batches, at a batch length that is not a multiple of the
+    decimation (the second batch starts in another phase), and ONE wrong output anywhere is found and located."""
+    rng = np.random.default_rng(7)
+
+    def lp(n, c):
+        k = np.arange(n) - (n - 1) / 2.0
+        h = np.sinc(2 * c * k) * np.hamming(n)
+        return (h / h.sum()).astype(np.float32)
+
+    stages = {"d8": [(8, lp(127, 0.05))], "c320": [(8, lp(32, 0.05)), (8, lp(41, 0.05)), (5, lp(117, 0.08))],
+              "d10x4": [(10, lp(54, 0.04)), (4, lp(93, 0.1))]}[case]
+    dtot = int(np.prod([d for d, _ in stages]))
+    ns = 8 * 70000 + (8 if case != "d8" else 0)                 # c320 / d10x4: not a multiple of the decimation
+    packed = O.lcg_bytes(6 * ns, 4711)
+    mix = case != "d8"
+    freg = 381178347
+    y = O.ddc_chain(np.concatenate([packed, packed]), stages, freg=freg, mix=mix).reshape(-1, 2)
+    m1 = -(-ns // dtot)
+    for first, seg in ((0, y[:m1]), (ns, y[m1:])):
+        r = O.chain_check(packed, first, ns, stages, seg, freg=freg, mix=mix)
+        assert r["n"] == seg.shape[0] and r["ok"] and r["max_rel_err"] < 2e-7, r     # float32 rounding of the chain's result
+    bad = y[m1:].copy()
+    k = int(rng.integers(0, bad.shape[0]))
+    bad[k, 1] += 4e-6 * np.abs(y).max()
+    r = O.chain_check(packed, ns, ns, stages, bad, freg=freg, mix=mix)
+    assert not r["ok"] and r["n_bad"] == 1 and r["first_bad"] == k, (r, k)
+    bad[k, 1] = np.nan
+    assert not O.chain_check(packed, ns, ns, stages, bad, freg=freg, mix=mix)["ok"]
+    with pytest.raises(RuntimeError):
+        O.chain_check(packed, ns, ns, stages, bad[:-1], freg=freg, mix=mix)       # fewer outputs than the batch makes
