@@ -25,7 +25,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
-DDC_LIB = os.path.join(_HERE, "libperseus_ddc.so")
+# (tools/ab.sh points the ctypes binding at an alternative build of the kernel library -- same-box A/B measurements -- through
+# PDDC_DDC_LIB instead of overwriting the product; nothing else reads it)
+DDC_LIB = os.environ.get("PDDC_DDC_LIB") or os.path.join(_HERE, "libperseus_ddc.so")
 SDR_LIB = os.path.join(_HERE, "libperseus-sdr.so")
 
 PDDC_OK, PDDC_EINVAL, PDDC_ENODEV, PDDC_EHIP, PDDC_ENOMEM, PDDC_ECAPACITY, PDDC_ESTATE, PDDC_ECOMM = 0, -1, -2, -3, -4, -5, -6, -7

@@ -345,8 +345,18 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
         const float *uA = arr, *uB = arr + AS;
         const f32x2 PDDC_CONSTANT *gre = (const f32x2 PDDC_CONSTANT *)a.taps2;
         const f32x2 PDDC_CONSTANT *gim = (const f32x2 PDDC_CONSTANT *)(a.taps2 + kTaps2Len);
+        /* Packed fp32 only where the wave that runs this issues the matrix instructions itself (LAYOUT 0).  The finishing
+         * waves of LAYOUT 2 take ONE float per instruction, like the loaders of LAYOUT 1: that they have no matrix wave on
+         * their SIMD rests on waves w, w + 4, w + 8 sharing one (tools/ubench/wave_simd.hip) -- measured, not guaranteed
+         * (round 5 advisor) -- and packed fp32 beside a matrix wave is the code shape that delivered wrong lanes 48..63
+         * (`rotate` above).  The same four partial sums in the same order: the same bits either way.                     */
+        constexpr bool PK = LAYOUT == 0;
         f32x2 ra_[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, ib_[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
         f32x2 ia_[2] = { { 0.f, 0.f }, { 0.f, 0.f } }, rb_[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
+        float sra[4] = { 0.f, 0.f, 0.f, 0.f }, srb[4] = { 0.f, 0.f, 0.f, 0.f }, sia[4] = { 0.f, 0.f, 0.f, 0.f },
+              sib[4] = { 0.f, 0.f, 0.f, 0.f };
+        const float PDDC_CONSTANT *gref = (const float PDDC_CONSTANT *)a.taps2;
+        const float PDDC_CONSTANT *gimf = (const float PDDC_CONSTANT *)(a.taps2 + kTaps2Len);
         /* (hipcc waits for every float4 pair: sixteen exposed LDS latencies, 4200 cycles per tile on the clock probe -- the
          * reason why LAYOUT 1 gives this work to waves that can keep the reads in flight) */
         constexpr int S2B = LAYOUT == 2 ? 8 : 1;  /* (matrix waves: no registers for more -- batches of 4 spill 12, of 8 47) */
@@ -363,23 +373,48 @@ __device__ __forceinline__ void fir_i8x_block(const FirI8xArgs &a, long long nti
 #pragma unroll
             for (int jj = 0; jj < S2B; ++jj) {
                 const int j = jb + jj;
-                const f32x2 xa[2] = { { xA[jj].x, xA[jj].y }, { xA[jj].z, xA[jj].w } },
-                            xb[2] = { { xB[jj].x, xB[jj].y }, { xB[jj].z, xB[jj].w } };
+                if (PK) {
+                    const f32x2 xa[2] = { { xA[jj].x, xA[jj].y }, { xA[jj].z, xA[jj].w } },
+                                xb[2] = { { xB[jj].x, xB[jj].y }, { xB[jj].z, xB[jj].w } };
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const f32x2 gr = gre[2 * j + e];
-                    ra_[e] = __builtin_elementwise_fma(gr, xa[e], ra_[e]);
-                    if (WHOLE)
-                        rb_[e] = __builtin_elementwise_fma(gr, xb[e], rb_[e]);
-                    if (MIX) {
-                        const f32x2 gi = gim[2 * j + e];
-                        ib_[e] = __builtin_elementwise_fma(gi, xb[e], ib_[e]);
+                    for (int e = 0; e < 2; ++e) {
+                        const f32x2 gr = gre[2 * j + e];
+                        ra_[e] = __builtin_elementwise_fma(gr, xa[e], ra_[e]);
                         if (WHOLE)
-                            ia_[e] = __builtin_elementwise_fma(gi, xa[e], ia_[e]);
+                            rb_[e] = __builtin_elementwise_fma(gr, xb[e], rb_[e]);
+                        if (MIX) {
+                            const f32x2 gi = gim[2 * j + e];
+                            ib_[e] = __builtin_elementwise_fma(gi, xb[e], ib_[e]);
+                            if (WHOLE)
+                                ia_[e] = __builtin_elementwise_fma(gi, xa[e], ia_[e]);
+                        }
+                    }
+                } else {
+                    const float *xa = &xA[jj].x, *xb = &xB[jj].x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gr = gref[4 * j + e];
+                        sra[e] = __builtin_fmaf(gr, xa[e], sra[e]);
+                        srb[e] = __builtin_fmaf(gr, xb[e], srb[e]);
+                        if (MIX) {
+                            const float gi = gimf[4 * j + e];
+                            sib[e] = __builtin_fmaf(gi, xb[e], sib[e]);
+                            sia[e] = __builtin_fmaf(gi, xa[e], sia[e]);
+                        }
                     }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!PK) {
+            ra_[0] = f32x2{ sra[0], sra[1] };
+            ra_[1] = f32x2{ sra[2], sra[3] };
+            rb_[0] = f32x2{ srb[0], srb[1] };
+            rb_[1] = f32x2{ srb[2], srb[3] };
+            ia_[0] = f32x2{ sia[0], sia[1] };
+            ia_[1] = f32x2{ sia[2], sia[3] };
+            ib_[0] = f32x2{ sib[0], sib[1] };
+            ib_[1] = f32x2{ sib[2], sib[3] };
         }
         const int op = 8 * p + 64, q = 20 * (op >> 4) + (op & 15);
         const float g0r = a.taps2[64], g0i = a.taps2[kTaps2Len + 64];

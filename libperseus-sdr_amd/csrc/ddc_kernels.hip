@@ -1171,8 +1171,9 @@ static int g_fir8_blocks = 0;       /* override (development) */
  * chunks of K tiles.  Measured (profiles/r01/v7_schedule_sweep.txt): 127 taps R=4
  * 0.398 -> 0.385 ms with 15-25 % dynamic in 4-tile chunks, 255 taps R=8 0.538 ->
  * 0.511 ms with 25 % in 2-tile chunks; single-tile chunks lose (one atomic per
- * tile on one address).  The fused pair pays a warm-up tile per chunk: round 1 saw no
- * gain and kept it static; with the buffers placed (round 2) 8 % in chunks of 8 is worth 1 %.
+ * tile on one address).  A chunk of the fused pair starts with a PORCH (the second stage's history
+ * computed from the 544 samples in front of the chunk: 0.37 of a tile's time; rounds 1-5 recomputed the whole
+ * tile in front): 8 % in chunks of 8.  Large batches of the pair take the round-robin walk below instead.
  * Development overrides: PDDC_FIR8_DYN_PCT (share of the tiles handed out
  * dynamically), PDDC_FIR8_CHUNK (K).                                              */
 struct Fir8Sched {
@@ -1209,16 +1210,23 @@ static Fir8Sched fir8_schedule(int ntiles, int R, bool fused, int NT = 256, int 
     sc.K = chunk > 0 ? chunk : (fused ? 8 : (R == 4 ? 4 : 2) * (256 / NT));
     if (group > 0)
         sc.K = chunk > 0 ? (chunk + group - 1) / group * group : 2 * group;
-    /* fused pair: a dynamic chunk starts with a warm-up tile, so only a small share pays (same-box sweep under the
-     * arena placement, a sweep of the fir8_dyn_pct / fir8_chunk tunables: static 0.2897 ms, 5-10 % in chunks of 8 0.2863-0.2867, 20 % 0.293) */
+    /* fused pair: a dynamic chunk starts with a porch, so only a small share pays (round 2, same-box sweep under the
+     * arena placement with whole warm-up tiles: static 0.2897 ms, 5-10 % in chunks of 8 0.2863-0.2867, 20 % 0.293) */
     const int pct = dyn_pct >= 0 ? dyn_pct : (fused ? 8 : 20);
     sc.S = (int)((long long)ntiles * (100 - pct) / 100 / sc.nblocks);
-    /* the round-robin walk (S = -1: chunk j -> block j mod nblocks; fir8_block.inc), not with the fused third stage */
-    if (group == 0 && tunables().fir8_walk.load() == 1) {
+    /* The round-robin walk (S = -JD: chunk j -> block j mod nblocks for j < JD, the rest from the counter; fir8_block.inc).
+     * Default for the fused pair from 64 tiles per block on (2^27 samples): chunks of 16 / 32 tiles, a porch each (0.37 of a
+     * tile's time), 10 % of them dynamic.  Same box, 2^28 samples, the pair's kernel with its write stream in the read
+     * stream's HBM extent class / in another (profiles/r06/b_ab_walks.txt): static runs + dynamic tail 0.299-0.312 /
+     * 0.287-0.288 ms, round robin 0.295-0.298 / 0.288-0.291 -- it is the placement-insensitive one (3 % against 5-8 %), and
+     * what a host gets without placing anything is the first figure.  Not with the fused third stage.               */
+    const int walk = tunables().fir8_walk.load();
+    if (group == 0 && (walk == 1 || (walk < 0 && fused && ntiles >= 64 * sc.nblocks))) {
         if (chunk <= 0 && fused)
-            sc.K = 16;
+            sc.K = ntiles >= 128 * sc.nblocks ? 32 : 16;
+        const int rr_pct = dyn_pct >= 0 ? dyn_pct : (fused ? 10 : 0);
         const long long nd = ((long long)ntiles + sc.K - 1) / sc.K;
-        long long jd = nd * (100 - (dyn_pct >= 0 ? dyn_pct : 0)) / 100 / sc.nblocks * sc.nblocks;
+        long long jd = nd * (100 - rr_pct) / 100 / sc.nblocks * sc.nblocks;
         if (jd < sc.nblocks)
             jd = sc.nblocks < nd ? sc.nblocks : nd;          /* every block starts with a chunk of its own */
         if (jd > 0x3fffffff)

@@ -62,7 +62,10 @@ def _run(pkg, O, dev, name, steps=2, corrupt=None):
 def test_bench_shape_windows_vs_oracle(pkg, O, dev, name):
     v, sched, n = _run(pkg, O, dev, name)
     assert sched["ntiles"] == NS // sched["tile"] and sched["nblocks"] == 512
-    assert sched["S"] > 0 and sched["nblocks"] * sched["S"] < sched["ntiles"]          # static part + dynamic tail
+    if name == "c320":       # the vector pair at this size: chunks handed round the blocks, the last ones from the counter
+        assert sched["S"] < 0 and -sched["S"] % sched["nblocks"] == 0 and -sched["S"] * sched["K"] < sched["ntiles"]
+    else:
+        assert sched["S"] > 0 and sched["nblocks"] * sched["S"] < sched["ntiles"]      # static part + dynamic tail
     assert v["windows"] >= 24 and v["n_outputs"] == n
     assert v["ok"] and v["max_rel_err"] <= 1e-6, v
 

@@ -1,32 +1,48 @@
 #!/bin/bash
-# A/B builds of libperseus_ddc.so that differ in -D flags of ddc_kernels.hip, measured on ONE box (boxes differ by
-# a few %).   Build here (no GPU):  tools/ab.sh build base: prioU2F0:"-DPDDC_PRIO_U=2 -DPDDC_PRIO_F=0" ...
-#            Run on the GPU box:    gpurun -- bash tools/ab.sh run      (WLS="d8_127 d8_255" REPS=3 STEPS=200)
+# Same-box A/B of builds of the kernel library (boxes differ by a few %, so two versions are only ever compared on ONE box,
+# alternating).  The alternatives are built NEXT TO the product (libperseus-sdr_amd/ab_<name>.so) and selected through
+# PDDC_DDC_LIB, which the ctypes binding honours -- the product library is never overwritten.
+#   build here (no GPU):   tools/ab.sh build <spec> ...
+#        name            the working tree
+#        name@REV        the tree of git revision REV (HEAD, HEAD~2, a hash)
+#        name:FLAGS      the working tree with extra compiler flags (e.g. nopad:"-DX=1"); name@REV:FLAGS works too
+#   run on the GPU box:    gpurun -- bash tools/ab.sh run [REPS] -- <command ...>      (e.g. python tools/state_2p28.py "pair api k_fir8")
+#        every line the command prints comes back prefixed with the build's name
 set -u
-cd "$(dirname "$0")/../libperseus-sdr_amd"
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+PKG="$ROOT/libperseus-sdr_amd"
 if [ "${1:-}" = build ]; then
   shift
-  make -C csrc >/dev/null || exit 1
-  rm -f ab_*.so
   for spec in "$@"; do
-    name=${spec%%:*}; flags=${spec#*:}
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $flags -c csrc/ddc_kernels.hip -o /tmp/ab_k.o 2>/tmp/ab_err.txt &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_$name.so /tmp/ab_k.o csrc/ddc_fir_i8.o csrc/ddc_pipeline.o csrc/ddc_multi.o -L/opt/rocm/lib -lrccl &&
-      echo "built ab_$name.so ($flags)" || { echo "FAILED $name"; tail -5 /tmp/ab_err.txt; }
+    flags=""; case "$spec" in *:*) flags=${spec#*:}; spec=${spec%%:*};; esac
+    rev=""; case "$spec" in *@*) rev=${spec#*@}; spec=${spec%%@*};; esac
+    name=$spec
+    T=$(mktemp -d)
+    mkdir -p "$T/libperseus-sdr_amd"
+    if [ -n "$rev" ]; then
+      (cd "$ROOT" && git archive "$rev" libperseus-sdr_amd/csrc include) | tar -x -C "$T" || { echo "FAILED $name: no such revision $rev"; continue; }
+    else
+      cp -r "$PKG/csrc" "$T/libperseus-sdr_amd/csrc" && cp -r "$ROOT/include" "$T/include" && rm -f "$T"/libperseus-sdr_amd/csrc/*.o
+    fi
+    if make -s -C "$T/libperseus-sdr_amd/csrc" EXTRA="$flags" ../libperseus_ddc.so >"$T/log.txt" 2>&1; then
+      cp "$T/libperseus-sdr_amd/libperseus_ddc.so" "$PKG/ab_$name.so" && echo "built ab_$name.so (${rev:-working tree}${flags:+, $flags})"
+    else
+      echo "FAILED $name"; tail -15 "$T/log.txt"
+    fi
+    rm -rf "$T"
   done
 elif [ "${1:-}" = run ]; then
-  cp libperseus_ddc.so /tmp/keep.so
-  for rep in $(seq 1 ${REPS:-3}); do
-    for f in ab_*.so; do
-      cp $f libperseus_ddc.so
-      for wl in ${WLS:-d8_127 d8_255}; do
-        echo -n "$f $wl: "
-        (cd .. && timeout 200 python bench.py --no-cpu --no-verify --workload $wl --steps ${STEPS:-200} --warmup 10 ${EXTRA:-} 2>/dev/null | tail -1 |
-          python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['kernel_ms'])")
-      done
+  shift
+  reps=2
+  if [ "${1:-}" != "--" ]; then reps=$1; shift; fi
+  [ "${1:-}" = "--" ] && shift
+  cd "$ROOT"
+  for rep in $(seq 1 "$reps"); do
+    for f in "$PKG"/ab_*.so; do
+      n=$(basename "$f" .so); n=${n#ab_}
+      PDDC_DDC_LIB="$f" timeout "${AB_TIMEOUT:-600}" "$@" 2>&1 | grep -v amdgpu.ids | sed "s/^/[$n] /"
     done
   done
-  cp /tmp/keep.so libperseus_ddc.so
 else
-  echo "usage: $0 build name:flags ... | run"; exit 2
+  echo "usage: $0 build <name[@rev][:flags]> ... | run [reps] -- <command>"; exit 2
 fi

@@ -25,11 +25,10 @@ if [ "${1:-}" = build ]; then
   done
   rm -rf $T
 elif [ "${1:-}" = run ]; then
-  cp libperseus_ddc.so /tmp/keep.so
+  # (the alternatives are selected through PDDC_DDC_LIB: the product library is never overwritten -- the slp build is
+  # KNOWN to deliver wrong outputs)
   for v in nopad slp pad; do
-    cp ab_$v.so libperseus_ddc.so
     echo "=== $v"
-    (cd .. && timeout 600 python tools/repeat_bits.py ${2:-40} 2>&1 | tail -20)
+    (cd .. && PDDC_DDC_LIB="$PWD/libperseus-sdr_amd/ab_$v.so" timeout 600 python tools/repeat_bits.py ${2:-40} 2>&1 | tail -20)
   done
-  cp /tmp/keep.so libperseus_ddc.so
 fi

@@ -32,21 +32,19 @@ def main():
     pkg.check(L.pddc_synth_lcg(arena.data_ptr(), 6 * NS, 12345, 0, st))
     # (name, workload, options, tunables)
     walks = [("static+dyn (default)", {}),
-             ("dyn 100 % K=2", {"fir8_dyn_pct": 100, "fir8_chunk": 2}),
-             ("dyn 100 % K=4", {"fir8_dyn_pct": 100, "fir8_chunk": 4}),
-             ("dyn 100 % K=8", {"fir8_dyn_pct": 100, "fir8_chunk": 8}),
-             ("dyn 100 % K=16", {"fir8_dyn_pct": 100, "fir8_chunk": 16}),
-             ("dyn 100 % K=32", {"fir8_dyn_pct": 100, "fir8_chunk": 32}),
-             ("round robin K=1", {"fir8_walk": 1, "fir8_chunk": 1}),
-             ("round robin K=2", {"fir8_walk": 1, "fir8_chunk": 2}),
-             ("round robin K=4", {"fir8_walk": 1, "fir8_chunk": 4}),
+             ("static+dyn, walk 0", {"fir8_walk": 0}),
+             ("static only", {"fir8_walk": 0, "fir8_dyn_pct": 0}),
              ("round robin K=8", {"fir8_walk": 1, "fir8_chunk": 8}),
              ("round robin K=16", {"fir8_walk": 1, "fir8_chunk": 16}),
-             ("round robin K=32", {"fir8_walk": 1, "fir8_chunk": 32})]
+             ("round robin K=16 dyn 10", {"fir8_walk": 1, "fir8_chunk": 16, "fir8_dyn_pct": 10}),
+             ("round robin K=16 dyn 25", {"fir8_walk": 1, "fir8_chunk": 16, "fir8_dyn_pct": 25}),
+             ("round robin K=32", {"fir8_walk": 1, "fir8_chunk": 32}),
+             ("round robin K=32 dyn 10", {"fir8_walk": 1, "fir8_chunk": 32, "fir8_dyn_pct": 10}),
+             ("round robin K=64 dyn 10", {"fir8_walk": 1, "fir8_chunk": 64, "fir8_dyn_pct": 10})]
     cases = [("vector 127 (no_i8)", "d8_127", {"no_i8": 1}), ("pair c320 k_fir8", "c320", {})]
     slots = [1, 4, 6, 8]
     ref_out = {}
-    for rnd in range(2):
+    for rnd in range(3):
         for cname, wlname, opts in cases:
             wl = bench.workload_def(wlname)
             for wname, tun in walks:
@@ -62,7 +60,7 @@ def main():
                 if not ok:
                     for k in tun:
                         try:
-                            pkg.set_tunable(k, -1 if k == "fir8_dyn_pct" else 0)
+                            pkg.set_tunable(k, -1 if k in ("fir8_dyn_pct", "fir8_walk") else 0)
                         except Exception:
                             pass
                     continue
@@ -78,8 +76,8 @@ def main():
                     side = arena.data_ptr() + o * slot + (2 << 30)
                     if cascade:
                         pipe.set_workspace(side, ws, NS)
-                    pipe.time_stage0(arena.data_ptr(), NS, side + ws, 40, st)
-                    res.append(pipe.time_stage0(arena.data_ptr(), NS, side + ws, 40, st))
+                    pipe.time_stage0(arena.data_ptr(), NS, side + ws, 30, st)
+                    res.append(pipe.time_stage0(arena.data_ptr(), NS, side + ws, 100, st))
                 sch = pipe.schedule(NS)
                 # the result must not depend on the walk: one batch from zero history against the default walk's
                 side = arena.data_ptr() + 1 * slot + (2 << 30)
@@ -103,7 +101,7 @@ def main():
                       f"  S={sch['S']} K={sch['K']} nblk={sch['nblocks']} {same}", flush=True)
                 pipe.close()
                 for k in tun:
-                    pkg.set_tunable(k, -1 if k == "fir8_dyn_pct" else 0)
+                    pkg.set_tunable(k, -1 if k in ("fir8_dyn_pct", "fir8_walk") else 0)
 
 
 if __name__ == "__main__":
