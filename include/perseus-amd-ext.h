@@ -60,7 +60,9 @@ typedef struct {
     const char *file_path;    /* FILE: raw 24-bit packed capture, no header       */
     int         pace;         /* 1: real-time pacing at the nominal sample rate   */
     int         gpu_device;   /* DDC: HIP device index (-1: descriptor index % n) */
-    uint32_t    batch_samples;/* DDC: ADC-rate samples per GPU batch (mult. of 8) */
+    uint32_t    batch_samples;/* DDC: ADC-rate samples per GPU batch: 0 = the library picks per stream (the default;
+                                 perseus_amd_effective_batch says what), else the client's choice: a multiple
+                                 of 8, at most PERSEUS_AMD_BATCH_MAX */
     int         drop_every;   /* fault injection, 0 = off                         */
     uint64_t    max_buffers;  /* stop the source after this many transfers (0 = unbounded;
                                  a FILE source also stops at end of file)          */
@@ -102,14 +104,18 @@ typedef struct {
 int perseus_amd_get_config(perseus_descr *descr, perseus_amd_config *cfg);
 int perseus_amd_set_config(perseus_descr *descr, const perseus_amd_config *cfg);
 
-/* The GPU batch size the next stream will use: cfg.batch_samples if the client chose one (set_config, PERSEUS_AMD_BATCH);
- * otherwise the library's pick for the kind of source -- 2^22 samples, or 2^24 for a free-running (unpaced) on-device source */
+/* The library's picks, and the largest batch a client may ask for (a batch is a pinned host buffer of 6 bytes a sample
+ * and a device buffer of the same size, twice: 2^28 samples are 1.6 GB each) */
+#define PERSEUS_AMD_BATCH_DEFAULT        (1u << 22)     /* 52 ms of signal: a paced, real-time source must not wait longer */
+#define PERSEUS_AMD_BATCH_UNPACED_DEVICE (1u << 24)     /* a free-running on-device source: only the launch chain to amortise */
+#define PERSEUS_AMD_BATCH_MAX            (1u << 28)
+/* The GPU batch size the next stream will use: cfg.batch_samples if the client chose one (set_config, set_batch,
+ * PERSEUS_AMD_BATCH); otherwise (cfg.batch_samples == 0) the library's pick for the kind of source */
 uint32_t perseus_amd_effective_batch(perseus_descr *descr);
-/* The explicit form of the choice: batch_samples > 0 (a multiple of 8) is the client's batch size from the next stream on,
- * whatever value is in force now; 0 hands the choice back to the library.  (set_config takes a batch_samples that DIFFERS
- * from the present value as the client's choice and the same value as "no change"; the effective size of a stream never
- * writes cfg.batch_samples, so a descriptor that streamed unpaced at 2^24 starts its next, paced stream at 2^22 again.)
- * Not while streaming (PERSEUS_ASYNCSTARTED). */
+/* The same choice as cfg.batch_samples without a get_config / set_config round: batch_samples > 0 (a multiple of 8, at most
+ * PERSEUS_AMD_BATCH_MAX) is the client's batch size from the next stream on; 0 hands the choice back to the library.  The
+ * effective size of a stream never writes cfg.batch_samples, so a descriptor that streamed unpaced at 2^24 starts its
+ * next, paced stream at 2^22 again.  Not while streaming (PERSEUS_ASYNCSTARTED). */
 int perseus_amd_set_batch(perseus_descr *descr, uint32_t batch_samples);
 
 /* state introspection (for tests and tools) */

@@ -230,7 +230,7 @@ int pddc_fir_i8x_d10_tables(const float *taps, int ntaps, int delay, uint32_t fr
 /* ... and the fused second stage's taps: out[i] = Re g2[64 - i], out[68 + i] = Im g2[64 - i], i = 0 .. 64,
  * g2[k] = h2[k] e^{+j 8 theta k} (a first-stage output is 8 input samples); 136 floats */
 int pddc_fir_i8x_taps2(const float *taps2, int ntaps2, int mix, uint32_t freg, float *out, size_t out_len);
-/* Kernel selection is API state, not environment: name = "no_i8", "i8_128", "i8x", "i8x_pair", "i8x_plain", "i8x_blocks",
+/* Kernel selection is API state, not environment: name = "no_i8", "i8x", "i8x_pair", "i8x_plain", "i8x_blocks",
  * "i8x_chunk", "i8x_layout", "i8x_pair_max_log2", "no_fuse2", "fuse3" (the PDDC_* environment variables of the same names
  * are read once, when the pipeline is created).
  * PDDC_ESTATE while overlap mode holds a tail back (fence first), PDDC_EINVAL for an unknown name.                  */

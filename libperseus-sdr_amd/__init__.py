@@ -325,7 +325,7 @@ class Pipeline:
         return int(ddc_lib().pddc_pipeline_uses_fused_pair(self._h, nsamples))
 
     def set_option(self, name: str, value: int):
-        """kernel selection as API state: no_i8, i8_128, i8x, i8x_pair, i8x_plain, i8x_blocks, no_fuse2, fuse3"""
+        """kernel selection as API state: no_i8, i8x, i8x_pair, i8x_plain, i8x_blocks, no_fuse2, fuse3"""
         check(ddc_lib().pddc_pipeline_set_option(self._h, name.encode(), int(value)))
 
     def get_option(self, name: str) -> int:

@@ -1071,7 +1071,7 @@ static void default_config(perseus_descr *d)
     d->cfg.lcg_seed = 12345u + (uint32_t)d->index;
     d->cfg.pace = 1;
     d->cfg.gpu_device = -1;
-    d->cfg.batch_samples = 1u << 22;
+    d->cfg.batch_samples = 0;                   /* 0: the library picks per stream (effective_batch) */
     d->batch_auto = 1;
     if ((e = getenv("PERSEUS_AMD_MODE"))) {
         if (strcmp(e, "ddc") == 0)
@@ -1094,9 +1094,14 @@ static void default_config(perseus_descr *d)
     }
     if ((e = getenv("PERSEUS_AMD_PACE")))
         d->cfg.pace = atoi(e) != 0;
-    if ((e = getenv("PERSEUS_AMD_BATCH")) && atol(e) >= 8) {
-        d->cfg.batch_samples = (uint32_t)(atol(e) / 8 * 8);
-        d->batch_auto = 0;
+    if ((e = getenv("PERSEUS_AMD_BATCH"))) {     /* a client's choice: 8 .. PERSEUS_AMD_BATCH_MAX, rounded down to a multiple of 8 */
+        const long long v = atoll(e) / 8 * 8;
+        if (v >= 8 && v <= (long long)PERSEUS_AMD_BATCH_MAX) {
+            d->cfg.batch_samples = (uint32_t)v;
+            d->batch_auto = 0;
+        } else {
+            dbgprintf(1, "PERSEUS_AMD_BATCH=%s ignored: not in 8 .. %u", e, PERSEUS_AMD_BATCH_MAX);
+        }
     }
     if ((e = getenv("PERSEUS_AMD_DROP")))
         d->cfg.drop_every = atoi(e);
@@ -1634,18 +1639,16 @@ int perseus_amd_set_config(perseus_descr *d, const perseus_amd_config *cfg)
         return errorset(PERSEUS_ERRPARAM, "bad mode %d", cfg->mode);
     if (cfg->source < PERSEUS_AMD_SRC_LCG || cfg->source > PERSEUS_AMD_SRC_FILE)
         return errorset(PERSEUS_ERRPARAM, "bad source %d", cfg->source);
-    if (cfg->batch_samples < 8 || cfg->batch_samples % 8)
-        return errorset(PERSEUS_ERRPARAM, "batch_samples must be a positive multiple of 8");
+    if (cfg->batch_samples % 8 || cfg->batch_samples > PERSEUS_AMD_BATCH_MAX)
+        return errorset(PERSEUS_ERRPARAM, "batch_samples must be 0 (the library picks) or a multiple of 8 up to %u", PERSEUS_AMD_BATCH_MAX);
     if (cfg->ep_packet_size < 0 || cfg->ep_packet_size > 1024)
         return errorset(PERSEUS_ERRPARAM, "bad endpoint packet size %d", cfg->ep_packet_size);
     /* the strings are copied into the descriptor -- unless they already ARE the descriptor's
      * copies (get_config -> modify -> set_config hands them back) */
     const char *fp = cfg->file_path, *fs = cfg->fault_script;
-    /* A batch size that differs from the present one is the client's choice.  (The same value back -- get_config, change
-     * another field, set_config -- leaves the choice where it was; a client that WANTS the present value, or the library's
-     * pick again, says so with perseus_amd_set_batch.) */
-    if (cfg->batch_samples != d->cfg.batch_samples)
-        d->batch_auto = 0;
+    /* batch_samples: 0 = the library picks per stream, anything else is the client's choice (get_config reports 0 while the
+     * choice is the library's, so get_config -> change another field -> set_config leaves it there) */
+    d->batch_auto = cfg->batch_samples == 0;
     d->cfg = *cfg;
     if (d->cfg.ep_packet_size == 0)
         d->cfg.ep_packet_size = 512;
@@ -1673,9 +1676,11 @@ int perseus_amd_set_config(perseus_descr *d, const perseus_amd_config *cfg)
 static uint32_t effective_batch(const perseus_descr *d)
 {
     const int gpu_source = d->cfg.source == PERSEUS_AMD_SRC_LCG && !d->cfg.cpu_source;
-    if (d->batch_auto && !d->cfg.pace && gpu_source && d->cfg.mode != PERSEUS_AMD_MODE_WIRE)
-        return 1u << 24;
-    return d->cfg.batch_samples;
+    if (!d->batch_auto && d->cfg.batch_samples)
+        return d->cfg.batch_samples;
+    if (!d->cfg.pace && gpu_source && d->cfg.mode != PERSEUS_AMD_MODE_WIRE)
+        return PERSEUS_AMD_BATCH_UNPACED_DEVICE;
+    return PERSEUS_AMD_BATCH_DEFAULT;
 }
 
 uint32_t perseus_amd_effective_batch(perseus_descr *d) { return d ? (d->streaming ? d->batch_eff : effective_batch(d)) : 0; }
@@ -1686,11 +1691,11 @@ int perseus_amd_set_batch(perseus_descr *d, uint32_t batch_samples)
         return errorset(PERSEUS_NULLDESCR, "null descriptor");
     if (d->streaming)
         return errorset(PERSEUS_ASYNCSTARTED, "cannot reconfigure while streaming");
-    if (batch_samples % 8)
-        return errorset(PERSEUS_ERRPARAM, "batch_samples must be a multiple of 8 (0: the library picks)");
+    if (batch_samples % 8 || batch_samples > PERSEUS_AMD_BATCH_MAX)
+        return errorset(PERSEUS_ERRPARAM, "batch_samples must be a multiple of 8 up to %u (0: the library picks)", PERSEUS_AMD_BATCH_MAX);
     if (batch_samples == 0) {
         d->batch_auto = 1;
-        d->cfg.batch_samples = 1u << 22;
+        d->cfg.batch_samples = 0;
     } else {
         d->batch_auto = 0;
         d->cfg.batch_samples = batch_samples;
@@ -1779,7 +1784,10 @@ int perseus_amd_plan_for_rate(int sps, int *rate, int decim[4], int ntaps[4], in
         return PERSEUS_FPGANOTCFGD;
     ddc_plan pl;
     memset(&pl, 0, sizeof(pl));
-    plan_build(&pl, k_rates[idx]);
+    if (plan_build(&pl, k_rates[idx]) <= 0) {       /* (0: no plan for the rate, or no memory for its taps) */
+        plan_free(&pl);
+        return PERSEUS_FPGANOTCFGD;
+    }
     if (rate)
         *rate = k_rates[idx];
     for (int i = 0; i < pl.nstages; i++) {

@@ -247,11 +247,13 @@ int main(int argc, char **argv)
         (void)pddc_comm_rccl_version(&rccl_run, &rccl_hdr);
         printf("{\"metric\": \"input MS/s through unpack+decimate, 1/2/4/8 GPU; %% HBM-roofline\", \"value\": %.1f, \"unit\": \"MS/s\", \"n_gpus\": %d, \"steps\": %d, "
                "\"warmup\": %d, \"ms_per_step\": %.4f, \"higher_is_better\": true, \"scaling\": \"weak\", \"vs_baseline\": null, "
-               "\"dtype\": \"f32\", \"data\": \"synthetic\", \"host\": \"C (perseus_multi_bench, one process, pddc_comm_init_all)\", "
+               "\"dtype\": \"%s\", \"data\": \"synthetic\", \"host\": \"C (perseus_multi_bench, one process, pddc_comm_init_all)\", "
                "\"config\": {\"workload\": \"%s\", \"samples_per_gpu_per_step\": %zu, \"input\": \"LCG bytes seed 12345+gpu, device "
                "resident\", \"sharding\": \"independent stream per GPU, no data-path collective\"}, \"rccl\": {\"running\": %d, "
                "\"header\": %d}",
-               total / t_kernel / 1e6, ng, steps, warm, t_kernel / steps * 1e3, label, ns, rccl_run, rccl_hdr);
+               total / t_kernel / 1e6, ng, steps, warm, t_kernel / steps * 1e3,
+               /* the arithmetic the first-stage kernel of THIS run computes in (bench.py's rule) */
+               pddc_pipeline_stage0_on_i8(pipe[0], ns) > 0 ? "i8xi8->i32, f32 out" : "f32", label, ns, rccl_run, rccl_hdr);
         if (gather)
             printf(", \"gather\": {\"workload\": \"every GPU's output gathered on GPU 0 (pddc_comm_gather_async)\", \"value\": %.1f, "
                    "\"unit\": \"MS/s\", \"ms_per_step\": %.4f, \"out_bytes_per_rank_per_step\": %zu, \"root_ingest_GBps\": %.2f, "

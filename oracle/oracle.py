@@ -76,6 +76,9 @@ def lib() -> C.CDLL:
         L.orc_stage1_f32.restype = C.c_size_t
         L.orc_max_threads.argtypes = []
         L.orc_max_threads.restype = C.c_int
+        L.orc_stream_f32_callback_style.argtypes = [u8p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int, C.c_int,
+                                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(f32p), f32p, C.c_size_t]
+        L.orc_stream_f32_callback_style.restype = C.c_size_t
         L.orc_chain_check.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_size_t, C.c_uint32, C.c_int, C.c_int,
                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(f32p), C.c_void_p, C.c_size_t,
                                       C.c_double, C.POINTER(CheckStats)]
@@ -260,6 +263,27 @@ def ddc_chain(packed: np.ndarray, stages, freg: int = 0, mix: bool = False) -> n
                             len(ds), Darr, Narr, Tarr, Larr, _p(out, C.c_float), max(n, 1))
     if r == C.c_size_t(-1).value:
         raise RuntimeError("orc_ddc_chain failed")
+    return out[:2 * r]
+
+
+def stream_callback_style(packed: np.ndarray, stages, freg: int = 0, mix: bool = False, buf_bytes: int = 6144) -> np.ndarray:
+    """The chain as the reference would run it on a CPU: ONE thread, callbacks of buf_bytes, each unpacked the way
+    examples/perseustest.c:466-502 does and pushed through streaming float FIR stages.  float32 I/Q."""
+    b = np.ascontiguousarray(packed, dtype=np.uint8)
+    ds = [int(st[0]) for st in stages]
+    hs = [np.ascontiguousarray(st[1], dtype=np.float32) for st in stages]
+    k = len(ds)
+    n = b.size // 6
+    for d in ds:
+        n = (n + d - 1) // d
+    out = np.empty(2 * (n + 8), dtype=np.float32)
+    Darr = (C.c_int * k)(*ds)
+    Narr = (C.c_int * k)(*[h.size for h in hs])
+    Tarr = (C.POINTER(C.c_float) * k)(*[_p(h, C.c_float) for h in hs])
+    r = lib().orc_stream_f32_callback_style(_p(b, C.c_uint8), b.size, buf_bytes, freg & 0xFFFFFFFF, int(bool(mix)), k, Darr,
+                                            Narr, Tarr, _p(out, C.c_float), n + 8)
+    if r == C.c_size_t(-1).value:
+        raise RuntimeError("orc_stream_f32_callback_style failed")
     return out[:2 * r]
 
 

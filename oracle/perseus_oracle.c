@@ -459,6 +459,30 @@ long long orc_chain_check(const uint8_t *packed, size_t ns_buf, uint64_t first_i
  * splits the output range.  Each thread unpacks its input span into a
  * private planar float buffer first (so the FIR inner loop vectorises).
  */
+/* four packed samples -> planar floats, the bytes placed as msb_align24 places them (A1), by two-source byte shuffles
+ * (GCC vector extensions: pshufb / vpermt2b on x86); reads 32 bytes from p */
+typedef uint8_t orc_v16u8 __attribute__((vector_size(16)));
+typedef int32_t orc_v4i32 __attribute__((vector_size(16)));
+typedef float orc_v4f32 __attribute__((vector_size(16)));
+static inline void unpack4_planar(const uint8_t *p, float *xi, float *xq, float full_scale)
+{
+    orc_v16u8 v0, v1;
+    memcpy(&v0, p, 16);
+    memcpy(&v1, p + 8, 16);
+    /* I of samples 0..3 at byte offsets 0, 6, 12, 18; Q at 3, 9, 15, 21 (offset b >= 16 is byte b - 8 of v1: index 16 + b - 8);
+     * byte 0 of every lane is masked to zero afterwards */
+    const orc_v16u8 mi = { 0, 0, 1, 2, 0, 6, 7, 8, 0, 12, 13, 14, 0, 26, 27, 28 };
+    const orc_v16u8 mq = { 0, 3, 4, 5, 0, 9, 10, 11, 0, 15, 24, 25, 0, 29, 30, 31 };
+    const orc_v4i32 keep = { (int32_t)0xffffff00, (int32_t)0xffffff00, (int32_t)0xffffff00, (int32_t)0xffffff00 };
+    const orc_v4i32 vi = (orc_v4i32)__builtin_shuffle(v0, v1, mi) & keep;
+    const orc_v4i32 vq = (orc_v4i32)__builtin_shuffle(v0, v1, mq) & keep;
+    const orc_v4f32 fs = { full_scale, full_scale, full_scale, full_scale };
+    const orc_v4f32 fi = __builtin_convertvector(vi, orc_v4f32) / fs;
+    const orc_v4f32 fq = __builtin_convertvector(vq, orc_v4f32) / fs;
+    memcpy(xi, &fi, 16);
+    memcpy(xq, &fq, 16);
+}
+
 int orc_max_threads(void)
 {
 #ifdef _OPENMP
@@ -499,9 +523,19 @@ size_t orc_stage1_f32(const uint8_t *packed, size_t ns, const float *taps,
             /* inputs needed: [m0*D-(ntaps-1), (m1-1)*D] */
             const long long first = (long long)(m0 * D) - (ntaps - 1);
             const long long last = (long long)((m1 - 1) * D);
-            for (long long i = first; i <= last; i++) {
+            long long i = first;
+            for (; i <= last && i < 0; i++) {
+                xi[i - first] = 0.0f;
+                xq[i - first] = 0.0f;
+            }
+            /* four samples (24 bytes) a step through byte shuffles; the last samples of the buffer one by one (the
+             * 16-byte loads must stay inside it) */
+            const long long vec_end = (long long)ns - 6 < last + 1 ? (long long)ns - 6 : last + 1;
+            for (; i + 4 <= vec_end; i += 4)
+                unpack4_planar(packed + 6 * (size_t)i, xi + (i - first), xq + (i - first), full_scale);
+            for (; i <= last; i++) {
                 size_t j = (size_t)(i - first);
-                if (i < 0 || (size_t)i >= ns) {
+                if ((size_t)i >= ns) {
                     xi[j] = 0.0f;
                     xq[j] = 0.0f;
                 } else {
@@ -528,4 +562,128 @@ size_t orc_stage1_f32(const uint8_t *packed, size_t ns, const float *taps,
     }
     free(hr);
     return nout;
+}
+
+/* ------------------------------------------------------------------------
+ * CPU baseline, the way the reference runs: ONE thread, the stream delivered in callbacks of
+ * buf_bytes (6144: perseus-in.c:206-207 -> examples/perseustest.c:466-502), each callback unpacks its buffer as
+ * user_data_callback_c_f does (one sample at a time, float = int / (INT_MAX - 256)), mixes it (authored: a double phasor
+ * stepped per sample, re-seeded from the exact 32-bit phase at every callback) and pushes it through the streaming FIR
+ * chain (authored: each stage keeps its last ntaps - 1 samples and its decimation phase), float accumulation, planar
+ * lines so that the tap loop vectorises.  Returns the number of outputs written to out_iq (capacity out_cap complex
+ * samples), (size_t)-1 on bad arguments.  Same definition as orc_ddc_chain, so the result agrees with it to float
+ * rounding (tests/test_oracle.py).
+ */
+typedef struct {
+    float *li, *lq;      /* the line: ntaps - 1 history samples, then the callback's new ones */
+    float *hr;           /* taps reversed */
+    int    nt, d;
+    long long next;      /* index, relative to the first new sample, of the sample the next output's window ends on */
+} orc_stream_stage;
+
+size_t orc_stream_f32_callback_style(const uint8_t *packed, size_t nbytes, size_t buf_bytes, uint32_t freg, int mix_enable,
+                                     int nstages, const int *D, const int *ntaps, const float *const *taps, float *out_iq,
+                                     size_t out_cap)
+{
+    if (nstages < 1 || nstages > 8 || buf_bytes < 6)
+        return (size_t)-1;
+    const size_t bs = buf_bytes / 6;                     /* samples a callback */
+    orc_stream_stage st[8];
+    memset(st, 0, sizeof st);
+    size_t cap = bs;
+    int bad = 0;
+    for (int s = 0; s < nstages; s++) {
+        st[s].nt = ntaps[s];
+        st[s].d = D[s];
+        st[s].li = (float *)calloc((size_t)ntaps[s] + cap, sizeof(float));
+        st[s].lq = (float *)calloc((size_t)ntaps[s] + cap, sizeof(float));
+        st[s].hr = (float *)malloc(sizeof(float) * (size_t)ntaps[s]);
+        if (!st[s].li || !st[s].lq || !st[s].hr) {
+            bad = 1;
+            break;
+        }
+        for (int k = 0; k < ntaps[s]; k++)
+            st[s].hr[k] = taps[s][ntaps[s] - 1 - k];
+        cap = cap / (size_t)D[s] + 1;
+    }
+    float *yi = (float *)malloc(sizeof(float) * (bs + 1)), *yq = (float *)malloc(sizeof(float) * (bs + 1));
+    size_t n_out = 0;
+    if (bad || !yi || !yq)
+        goto done;
+    {
+        const float full_scale = (float)(INT_MAX - 256);
+        const double two_pi_over_2p32 = 6.283185307179586476925286766559 / 4294967296.0;
+        const double astep = two_pi_over_2p32 * (double)freg;
+        const double sc = cos(astep), ss = -sin(astep);                    /* exp(-j astep) */
+        uint64_t n_abs = 0;
+        for (size_t off = 0; off + 6 <= nbytes; off += buf_bytes) {
+            const size_t nb = (nbytes - off < buf_bytes ? nbytes - off : buf_bytes) / 6;
+            /* the callback: unpack (A2) [+ mix] into stage 0's line */
+            float *xi = st[0].li + (st[0].nt - 1), *xq = st[0].lq + (st[0].nt - 1);
+            const uint8_t *p = packed + off;
+            if (mix_enable) {
+                const double a0 = two_pi_over_2p32 * (double)(uint32_t)(n_abs * (uint64_t)freg);
+                double c = cos(a0), sn = -sin(a0);                       /* (a double phasor: 1024 float steps drift to 2e-5) */
+                for (size_t k = 0; k < nb; k++) {
+                    const float xr = (float)msb_align24(p + 6 * k) / full_scale, xim = (float)msb_align24(p + 6 * k + 3) / full_scale;
+                    xi[k] = (float)(xr * c - xim * sn);
+                    xq[k] = (float)(xr * sn + xim * c);
+                    const double c2 = c * sc - sn * ss;
+                    sn = c * ss + sn * sc;
+                    c = c2;
+                }
+            } else {
+                for (size_t k = 0; k < nb; k++) {
+                    xi[k] = (float)msb_align24(p + 6 * k) / full_scale;
+                    xq[k] = (float)msb_align24(p + 6 * k + 3) / full_scale;
+                }
+            }
+            n_abs += nb;
+            size_t n_in = nb;
+            for (int s = 0; s < nstages; s++) {
+                orc_stream_stage *g = &st[s];
+                const int nt = g->nt;
+                size_t m = 0;
+                long long pos = g->next;
+                for (; pos < (long long)n_in; pos += g->d, m++) {
+                    const float *wi = g->li + pos, *wq = g->lq + pos;      /* window [pos - (nt-1), pos] of the new samples */
+                    float ar = 0.0f, ai = 0.0f;
+#pragma omp simd reduction(+ : ar, ai)
+                    for (int k = 0; k < nt; k++) {
+                        ar += g->hr[k] * wi[k];
+                        ai += g->hr[k] * wq[k];
+                    }
+                    yi[m] = ar;
+                    yq[m] = ai;
+                }
+                g->next = pos - (long long)n_in;
+                memmove(g->li, g->li + n_in, sizeof(float) * (size_t)(nt - 1));
+                memmove(g->lq, g->lq + n_in, sizeof(float) * (size_t)(nt - 1));
+                if (s + 1 < nstages) {
+                    memcpy(st[s + 1].li + (st[s + 1].nt - 1), yi, sizeof(float) * m);
+                    memcpy(st[s + 1].lq + (st[s + 1].nt - 1), yq, sizeof(float) * m);
+                } else {
+                    for (size_t k = 0; k < m; k++) {
+                        if (n_out >= out_cap) {
+                            n_out = (size_t)-1;
+                            goto done;
+                        }
+                        out_iq[2 * n_out] = yi[k];
+                        out_iq[2 * n_out + 1] = yq[k];
+                        n_out++;
+                    }
+                }
+                n_in = m;
+            }
+        }
+    }
+done:
+    for (int s = 0; s < nstages; s++) {
+        free(st[s].li);
+        free(st[s].lq);
+        free(st[s].hr);
+    }
+    free(yi);
+    free(yq);
+    return bad ? (size_t)-1 : n_out;
 }

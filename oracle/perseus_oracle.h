@@ -126,6 +126,12 @@ size_t orc_stage1_f32(const uint8_t *packed, size_t nsamples,
 void orc_unpack24_f32_callback_style(const uint8_t *in, size_t nbytes,
                                      float *out_iq, size_t buf_bytes);
 int orc_max_threads(void);
+/* the whole chain the way the reference would run it on a CPU: ONE thread, callbacks of buf_bytes (6144), each unpacked
+ * as user_data_callback_c_f does, [mixed,] pushed through streaming float FIR stages (plain decimators).  Outputs
+ * written (capacity out_cap complex samples) or (size_t)-1. */
+size_t orc_stream_f32_callback_style(const uint8_t *packed, size_t nbytes, size_t buf_bytes, uint32_t freg, int mix_enable,
+                                     int nstages, const int *D, const int *ntaps, const float *const *taps, float *out_iq,
+                                     size_t out_cap);
 
 #ifdef __cplusplus
 }

@@ -1,12 +1,11 @@
 """Test scaffolding for bench.py's launcher path (tests/test_bench_contract.py): NOT part of the measurement tool.
-bench.py, started with PDDC_BENCH_RANK_HOOK=bench_dry_rank:run and this directory on PYTHONPATH, calls run() in every
-rank instead of its own rank body -- so `python bench.py --gpus N` (parent starts N children, gloo rendezvous, rank 0
-relays ONE JSON line) can be exercised where no GPU exists."""
+tests/bench_dry.py imports bench.py, replaces its rank body by run() below and calls its main() -- so `python bench.py
+--gpus N` (parent starts N children, gloo rendezvous, rank 0 relays ONE JSON line) can be exercised where no GPU exists."""
 import time
 
 
 def run(a, bench):
-    """The rank body for PDDC_BENCH_RANK_HOOK=bench_dry_rank:run (bench.py main): launcher / rendezvous / relay on
+    """The rank body tests/bench_dry.py puts in place of bench.run_rank: launcher / rendezvous / relay on
     CPU.  No GPU exists there, so nothing is measured: the CPU oracle stands in for the pipeline only to give the
     ranks distinct data to gather, the line says so and claims a value of 0."""
     import importlib

@@ -87,5 +87,8 @@ int main(int argc, char **argv)
     }
     printf("ok: %ld batches, %llu bytes delivered, %ld buffers in place, %ld gathered, %ld idle steps\n", batches,
            (unsigned long long)consumed, in_place, gathered, stalls);
+    free(buf);
+    free(live);
+    free(slot);
     return 0;
 }

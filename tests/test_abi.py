@@ -143,3 +143,30 @@ def test_no_getenv_on_the_data_path():
         for name in ("ddc_kernels.hip", "fir8_block.inc", "ddc_fir_i8.hip", "ddc_pipeline.cpp", "ddc_kernels.h"):
             src = open(os.path.join(csrc, name)).read()
             assert ("#ifdef " + forbidden) not in src and ("defined(" + forbidden) not in src, (name, forbidden)
+
+
+def test_experiment_patches_apply_to_their_commits(tmp_path):
+    """tools/ubench/*.patch are the experiments the notebooks quote (probes, ablations, layouts tried and not adopted).  Every
+    one of them is listed in tools/ubench/PATCHES.json with the commit whose tree it applies to, and `git apply --check`
+    agrees -- a patch nothing can apply to any more is a dead file (round 5 review)."""
+    import glob
+    import json
+    import shutil
+    if shutil.which("git") is None or not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("no git history here (the GPU box gets a snapshot without .git)")
+    base = json.load(open(os.path.join(ROOT, "tools", "ubench", "PATCHES.json")))
+    patches = sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "tools", "ubench", "*.patch")))
+    assert patches == sorted(k for k in base if k.endswith(".patch")), "PATCHES.json and tools/ubench/*.patch differ"
+    for name in patches:
+        commit = base[name]
+        if subprocess.run(["git", "-C", ROOT, "cat-file", "-e", commit + "^{commit}"], capture_output=True).returncode:
+            pytest.skip(f"commit {commit} is not in this clone (shallow history)")
+        tree = tmp_path / name
+        tree.mkdir()
+        ar = subprocess.run(["git", "-C", ROOT, "archive", commit, "libperseus-sdr_amd/csrc", "tools", "bench.py"], capture_output=True)
+        assert ar.returncode == 0, ar.stderr[-300:]
+        subprocess.run(["tar", "-x", "-C", str(tree)], input=ar.stdout, check=True)
+        subprocess.run(["git", "init", "-q", str(tree)], check=True)
+        r = subprocess.run(["git", "-C", str(tree), "apply", "--check", os.path.join(ROOT, "tools", "ubench", name)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (name, commit, r.stderr[-500:])

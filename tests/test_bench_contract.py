@@ -31,8 +31,13 @@ def test_defaults_follow_the_contract(monkeypatch):
 def test_cpu_baseline_leg_fields():
     b = _bench()
     r = b.cpu_baseline("d8_127", 0.2)
-    assert set(r) == {"value", "unit", "cores", "kind", "sample", "cpu_model"} and r["cpu_model"]
+    assert set(r) == {"value", "unit", "cores", "kind", "sample", "cpu_model", "single_thread"} and r["cpu_model"]
     assert r["unit"] == "MS/s" and r["kind"] == "port" and r["cores"] >= 1 and r["value"] > 0
+    # beside the all-core figure the single-thread, 6144-byte-callback leg (the reference's own way of running)
+    s1 = r["single_thread"]
+    assert s1["cores"] == 1 and s1["unit"] == "MS/s" and 0 < s1["value"] and "6144-byte callbacks" in s1["sample"]
+    rc = b.cpu_baseline("c320", 0.2)
+    assert rc["single_thread"]["value"] > 0 and rc["value"] > 0 and "one single-threaded streaming float chain per core" in rc["sample"]
     r1 = b.cpu_baseline("unpack", 0.1)
     assert r1["cores"] == 1 and r1["value"] > 0
 
@@ -94,10 +99,11 @@ def test_traffic_is_reported_only_with_matching_provenance(tmp_path, monkeypatch
     assert b.traffic_from_profile("d8_127", sig, 28, False)[0] is None
 
 
+DRY = os.path.join(ROOT, "tests", "bench_dry.py")     # bench.py with its rank body replaced (the CPU stand-in lives in tests/)
+
+
 def _dry_env():
-    """bench.py's rank body replaced by tests/bench_dry_rank.py (the CPU stand-in lives in tests/, not in bench.py)"""
-    env = dict(os.environ, PDDC_BENCH_RANK_HOOK="bench_dry_rank:run")
-    env["PYTHONPATH"] = os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", "")
+    env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     return env
 
@@ -106,7 +112,7 @@ def test_plain_command_launcher_two_ranks_gloo():
     """`python bench.py --gpus 2` as a plain command: the parent starts the ranks itself (it never
     imports torch), relays ONE JSON line.  On CPU the children run the gloo plumbing mode."""
     env = _dry_env()
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    p = subprocess.run([sys.executable, DRY, "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--workload", "c320"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -123,7 +129,7 @@ def test_driver_style_launch_under_torch_distributed_run():
     env = _dry_env()
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_bench()._free_port()),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                        DRY, "--gpus", "2", "--steps", "2", "--warmup", "1"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
@@ -151,7 +157,6 @@ def test_launcher_reports_failure_when_ranks_fail():
         pytest.skip("GPU present")
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
-    env.pop("PDDC_BENCH_RANK_HOOK", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode != 0 and "no CPU path" in p.stderr
@@ -197,7 +202,7 @@ def test_eight_rank_dry_run_of_the_launcher():
     """The driver's N = 8 shape on CPU: eight gloo ranks through the plain-command launcher, one JSON line, every rank's
     block gathered and checked on rank 0 (8 ranks, not 2)."""
     env = _dry_env()
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
+    p = subprocess.run([sys.executable, DRY, "--gpus", "8", "--steps", "1", "--warmup", "0",
                         "--workload", "c320", "--log2n", "12"], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -209,16 +214,20 @@ def test_eight_rank_dry_run_of_the_launcher():
 
 def test_launcher_tears_the_other_ranks_down_when_one_dies(tmp_path):
     """a rank that dies before rendezvous must not leave the others waiting for their own timeouts."""
-    hook = tmp_path / "dying_rank.py"
-    hook.write_text("import os, sys, time\n"
-                    "def run(a, bench):\n"
+    wrap = tmp_path / "bench_dying.py"             # bench.py with a rank body of which rank 1 dies before the rendezvous
+    wrap.write_text("import os, sys, time\n"
+                    f"sys.path.insert(0, {ROOT!r})\n"
+                    "import bench\n"
+                    "def run(a):\n"
                     "    if os.environ['RANK'] == '1':\n"
                     "        sys.exit(7)\n"
-                    "    time.sleep(600)\n")
-    env = dict(os.environ, PDDC_BENCH_RANK_HOOK="dying_rank:run", PYTHONPATH=str(tmp_path))
+                    "    time.sleep(600)\n"
+                    "bench.run_rank = run\n"
+                    "bench.main()\n")
+    env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     t0 = __import__("time").time()
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1"],
+    p = subprocess.run([sys.executable, str(wrap), "--gpus", "3", "--steps", "1"],
                        capture_output=True, text=True, timeout=120, env=env)
     assert p.returncode == 7 and __import__("time").time() - t0 < 60
 
@@ -228,6 +237,7 @@ def test_bench_holds_no_cpu_stand_in():
     only in the cpu_baseline leg and in the parity check of the GPU's output."""
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "run_rank_dry" not in src and "PDDC_BENCH_BACKEND" not in src
+    assert "PDDC_BENCH_RANK_HOOK" not in src and src.count("os.environ.get(") <= 6   # no hook that swaps the rank body from the environment
     assert src.count("from oracle import oracle") == 2            # cpu_baseline() and the verification of the last step
 
 

@@ -358,7 +358,7 @@ def test_a_streams_batch_size_does_not_stick_to_the_descriptor(L, pkg, O):
     assert st.delivered == 400 and st.batches >= 5 and st.adc_samples // st.batches == 1 << 24, (st.adc_samples, st.batches)
     first = outs[0]
     cfg = pkg.AmdConfig()
-    assert L.perseus_amd_get_config(d, C.byref(cfg)) == 0 and cfg.batch_samples == 1 << 22     # the configuration was not touched
+    assert L.perseus_amd_get_config(d, C.byref(cfg)) == 0 and cfg.batch_samples == 0           # the configuration was not touched (0: the library picks)
     cfg.pace, cfg.max_buffers = 1, 40                                          # 40 buffers at 250 kS/s: 0.16 s of signal
     assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
     assert L.perseus_amd_effective_batch(d) == 1 << 22

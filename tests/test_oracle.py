@@ -210,3 +210,28 @@ def test_chain_check_agrees_with_the_chain(O, case):
     assert not O.chain_check(packed, ns, ns, stages, bad, freg=freg, mix=mix)["ok"]
     with pytest.raises(RuntimeError):
         O.chain_check(packed, ns, ns, stages, bad[:-1], freg=freg, mix=mix)       # fewer outputs than the batch makes
+
+
+@pytest.mark.parametrize("case", ["d8_127", "c320"])
+def test_callback_style_stream_is_the_same_chain(O, case):
+    """bench.py's single-thread CPU leg (orc_stream_f32_callback_style: 6144-byte callbacks as perseus-in.c:206-207
+    delivers them, each unpacked as examples/perseustest.c:466-502 does, streaming float FIR stages) computes the chain the
+    double oracle defines -- to float accumulation -- for a stream that does not end on a buffer or decimation boundary,
+    and the vectorised unpack of the all-core leg (orc_stage1_f32) is bit-identical to a scalar float FIR on the scalar unpack."""
+    stages = {"d8_127": [(8, load_taps("d8_127"))],
+              "c320": [(8, load_taps("c320_s1_d8_32")), (8, load_taps("c320_s2_d8_64")), (5, load_taps("c320_s3_d5_161"))]}[case]
+    mix = case == "c320"
+    ns = 1024 * 37 + 8 * 11
+    packed = O.lcg_bytes(6 * ns, 99)
+    ref = O.ddc_chain(packed, stages, freg=381178347, mix=mix)
+    got = O.stream_callback_style(packed, stages, freg=381178347, mix=mix)
+    assert got.size == ref.size
+    assert O.rel_err(got, ref) < 3e-6          # float accumulation and a float phasor recurrence (a CPU baseline, not the parity oracle)
+    if case == "d8_127":
+        y = O.stage1_f32(packed, stages[0][1], 8, 2)
+        assert O.rel_err(y, ref) < 3e-6
+        x = O.unpack24_f32(packed).reshape(-1, 2)
+        h = stages[0][1]
+        m = 3000                                # one output by hand from the scalar unpack: same products, same taps
+        want = float(np.dot(h.astype(np.float64), x[8 * m - np.arange(h.size), 0].astype(np.float64)))
+        assert abs(float(y[2 * m]) - want) < 1e-5

@@ -304,24 +304,35 @@ def test_batch_size_choice_is_the_clients_or_the_librarys_per_stream(L, pkg):
     unpaced stream a paced one on the same descriptor ran with 2^24-sample batches, 210 ms of latency each)."""
     d = bring_up(L, 250000)
     cfg = pkg.AmdConfig()
-    assert L.perseus_amd_get_config(d, C.byref(cfg)) == 0 and cfg.batch_samples == 1 << 22
+    assert L.perseus_amd_get_config(d, C.byref(cfg)) == 0 and cfg.batch_samples == 0      # 0: the library picks
     cfg.mode, cfg.pace = 1, 0
     assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
     assert L.perseus_amd_effective_batch(d) == 1 << 24          # unpaced device source: the library's pick
     cfg.pace = 1
     assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
     assert L.perseus_amd_effective_batch(d) == 1 << 22          # paced: latency counts
-    assert L.perseus_amd_get_config(d, C.byref(cfg)) == 0 and cfg.batch_samples == 1 << 22
+    assert L.perseus_amd_get_config(d, C.byref(cfg)) == 0 and cfg.batch_samples == 0
     cfg.pace = 0
     assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
-    assert L.perseus_amd_set_batch(d, 1 << 22) == 0             # the client WANTS 2^22, although that is the present value
+    assert L.perseus_amd_set_batch(d, 1 << 22) == 0             # the client WANTS 2^22
     assert L.perseus_amd_effective_batch(d) == 1 << 22
     assert L.perseus_amd_set_batch(d, 0) == 0                   # ... and hands the choice back
     assert L.perseus_amd_effective_batch(d) == 1 << 24
     assert L.perseus_amd_set_batch(d, 12) != 0                  # not a multiple of 8
+    assert L.perseus_amd_set_batch(d, (1 << 28) + 8) != 0       # a 1.6 GB pinned buffer is the limit (advisor, round 5)
+    # the same choice through set_config: the value the library's default happens to be IS a choice when the client names it
+    # (round 5 advisor: set_config used to read "equal to the present value" as "no change")
+    cfg.batch_samples = 1 << 22
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    assert L.perseus_amd_effective_batch(d) == 1 << 22
+    assert L.perseus_amd_get_config(d, C.byref(cfg)) == 0 and cfg.batch_samples == 1 << 22
+    cfg.batch_samples = 0
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0 and L.perseus_amd_effective_batch(d) == 1 << 24
     cfg.batch_samples = 1 << 20
-    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0       # a differing value in set_config is a choice too
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
     assert L.perseus_amd_effective_batch(d) == 1 << 20
+    cfg.batch_samples = (1 << 28) + 8
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) != 0
 
 
 def test_every_reference_rate_has_an_exact_plan(L, O):
@@ -634,3 +645,80 @@ def test_output_segments_against_a_byte_queue(tmp_path):
                                         (4, 60000, 12288, 419432), (5, 100000, 16320, 33000), (6, 100000, 510, 1100)):
         p = subprocess.run([exe, str(seed), str(steps), str(bufsize), str(worst)], capture_output=True, text=True, timeout=300)
         assert p.returncode == 0 and p.stdout.startswith("ok:"), (seed, p.stdout[-300:], p.stderr[-300:])
+
+
+def test_api_layer_and_out_segments_under_asan_and_ubsan(pkg, O, tmp_path):
+    """The CPU build of the API layer (perseus_api.c with out_segments.h) and its C client under AddressSanitizer +
+    UndefinedBehaviorSanitizer: the wire-mode paths -- BASELINE config 1 (6144-byte buffers, the reference's unpack in the
+    client), several receivers, a fault script, the control FIFO, a file source that ends mid-buffer, the 510-byte endpoint
+    sizes -- and the byte-queue model of the delivery path.  CPU only (sanitizers never run on the GPU box); the outputs must
+    still be bit-equal to the oracle's."""
+    import shutil
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    csrc = os.path.join(ROOT, "libperseus-sdr_amd", "csrc")
+    san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+    exe = tmp_path / "plumb_asan"
+    cc = subprocess.run(["gcc", *san, "-std=gnu11", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                         os.path.join(csrc, "perseus_api.c"), os.path.join(csrc, "perseus_plumbing.c"),
+                         "-L" + os.path.dirname(pkg.SDR_LIB), "-lperseus_ddc", "-lm", "-o", str(exe)], capture_output=True, text=True)
+    if cc.returncode != 0:
+        pytest.skip("no AddressSanitizer runtime here: " + cc.stderr[-200:])
+    env = dict(os.environ, PERSEUS_AMD_PACE="0", ASAN_OPTIONS="detect_leaks=1:exitcode=67", UBSAN_OPTIONS="print_stacktrace=1",
+               LD_LIBRARY_PATH=os.path.dirname(pkg.SDR_LIB) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for k in ("PERSEUS_AMD_MODE", "PERSEUS_AMD_DEVICES", "PERSEUS_AMD_FAULTS", "PERSEUS_AMD_SOURCE"):
+        env.pop(k, None)
+
+    def run(args, extra_env=None, timeout=120):
+        p = subprocess.run([str(exe), *args], env=dict(env, **(extra_env or {})), capture_output=True, text=True, timeout=timeout)
+        assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr and \
+            "LeakSanitizer" not in p.stderr, p.stderr[-3000:]
+        return p
+
+    # config 1: the plumbing check, float and int32 outputs bit-equal to the oracle
+    out = tmp_path / "c1.f32"
+    p = run(["-s", "95000", "-m", "6", "-p", "-o", str(out), "-t", "10", "-d", "3"])
+    assert p.returncode == 0, p.stderr[-1000:]
+    got = np.fromfile(out, dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), O.unpack24_f32(O.lcg_bytes(6 * 6144, 12345)).view(np.uint32))
+    # three receivers, int32
+    out3 = tmp_path / "rx"
+    p = run(["-N", "3", "-m", "7", "-o", str(out3), "-t", "10", "-d", "0"])
+    assert p.returncode == 0 and "3 receivers: 21504 samples" in p.stderr, p.stderr[-1000:]
+    for i in range(3):
+        assert np.array_equal(np.fromfile(str(out3) + f".{i}", dtype=np.int32), O.unpack24_i32(O.lcg_bytes(7 * 6144, 12345 + i)))
+    # transfer faults: short / timed-out / out-of-sequence / failed transfers are dropped, the stream ends at the EOF
+    p = run(["-s", "95000", "-o", "none", "-t", "10", "-d", "3"],
+            {"PERSEUS_AMD_FAULTS": "short%7,timeout@9,oos@12,error@20,eof@200"})
+    assert p.returncode == 0, p.stderr[-1000:]
+    # a file source that ends in the middle of a buffer
+    src = tmp_path / "cap.bin"
+    O.lcg_bytes(6144 * 5 + 600, 77).tofile(src)
+    outf = tmp_path / "file.f32"
+    p = run(["-s", "95000", "-p", "-o", str(outf), "-t", "10", "-d", "0"], {"PERSEUS_AMD_SOURCE": f"file:{src}"})
+    assert p.returncode == 0, p.stderr[-1000:]
+    got = np.fromfile(outf, dtype=np.float32)
+    assert got.size >= 2 * 1024 * 5 and np.array_equal(got[:2 * 1024 * 5].view(np.uint32),
+                                                       O.unpack24_f32(O.lcg_bytes(6144 * 5, 77)).view(np.uint32))
+    # the control FIFO while streaming (examples/fifo.c's commands)
+    fifo = str(tmp_path / "ctl")
+    pp = subprocess.Popen([str(exe), "-s", "2000000", "-o", "none", "-t", "20", "-d", "0", "-F", fifo, "-a"],
+                          env=dict(env, PERSEUS_AMD_PACE="1"), stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while not os.path.exists(fifo) and time.time() - t0 < 20:
+        time.sleep(0.01)
+    with open(fifo, "w") as f:
+        for line in ("7.05\n", "att 2\n", "7100000\n"):
+            f.write(line)
+            f.flush()
+            time.sleep(0.1)
+        f.write("quit\n")
+    _, err = pp.communicate(timeout=60)
+    assert "ERROR: AddressSanitizer" not in err and "runtime error:" not in err, err[-3000:]
+    assert pp.returncode == 0 and "final NCO word: 381178347" in err, err[-1000:]
+    # the delivery path's byte-queue model
+    oseg = str(tmp_path / "oseg_asan")
+    subprocess.run(["gcc", *san, "-Wall", "-Wextra", "-I", csrc, "-o", oseg, os.path.join(ROOT, "tests", "out_segments_test.c")], check=True)
+    for seed, steps, bufsize, worst in ((1, 40000, 6144, 13104), (3, 20000, 12288, 104920), (6, 30000, 510, 1100)):
+        p = subprocess.run([oseg, str(seed), str(steps), str(bufsize), str(worst)], capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode == 0 and p.stdout.startswith("ok:") and "runtime error:" not in p.stderr, (seed, p.stdout[-300:], p.stderr[-1500:])

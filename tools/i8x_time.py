@@ -47,11 +47,12 @@ def timeit(stages, opts, ns, steps=30, mix=True, fp16=False):
     torch.cuda.synchronize()
     L = pkg.ddc_lib()
     if hasattr(L, "pddc_i8x_probe_dump") and os.environ.get("I8X_PROBE"):
-        L.pddc_i8x_probe_dump()                  # (timing builds with -DI8X_PROBE: clears what the warm-up left)
+        L.pddc_i8x_probe_dump.argtypes = [__import__("ctypes").c_int]
+        L.pddc_i8x_probe_dump(1)                 # (probe builds, tools/ubench/i8x_probe_r05.patch: clears what the warm-up left)
         pipe.process_ptr(d_in.data_ptr(), ns, out.data_ptr(), out.shape[0], st)
         torch.cuda.synchronize()
         print("probe of one launch:", flush=True)
-        L.pddc_i8x_probe_dump()
+        L.pddc_i8x_probe_dump(0)
     kind = (pipe.on_i8(ns), pipe.fused_pair(ns))
     k0 = pipe.time_stage0(d_in.data_ptr(), ns, out.data_ptr(), steps, st)
     kind = kind + (round(k0, 4),)

@@ -1,7 +1,7 @@
 # randomized stress of the stream state machine against the oracle: random plans, cuts, NCO words retuned
 # between batches (phase-continuous), scheduler settings (PDDC_FIR8_BLOCKS / DYN_PCT / CHUNK / R), caller-provided
 # workspaces, checkpoint/restore hops to a fresh pipeline in mid-stream, overlap mode (the last stage carried by the next
-# launch), the int8 matrix-core first stage switched on and off between batches (PDDC_NO_I8 / PDDC_I8_128), and binary16
+# launch), the int8 matrix-core first stage switched on and off between batches (options no_i8 / i8x_plain), and binary16
 # tap storage (one case in four).
 # Usage: python tools/stress_gpu.py [n]
 import sys, os, importlib
@@ -64,13 +64,12 @@ for it in range(n_iter):
     parts = []
     for k, ((a, b), w) in enumerate(zip(zip(cuts[:-1], cuts[1:]), words)):
         pipe.set_freg(w)
-        i8 = int(rng.integers(0, 3))                       # the int8 first stage: library's choice / off / forced on (<= 128 taps)
-        os.environ.pop("PDDC_NO_I8", None)
-        os.environ.pop("PDDC_I8_128", None)
-        if i8 == 1:
-            os.environ["PDDC_NO_I8"] = "1"
-        elif i8 == 2:
-            os.environ["PDDC_I8_128"] = "1"
+        # the first stage's kernel, switched between batches through the pipeline's options (kernel selection is state, not
+        # environment): the library's choice / the vector kernels only / the matrix-core kernel's plain form off (tuned only)
+        i8 = int(rng.integers(0, 3))
+        pipe.fence()
+        pipe.set_option("no_i8", 1 if i8 == 1 else 0)
+        pipe.set_option("i8x_plain", 0 if i8 == 2 else 1)
         parts.append(pipe.process(torch.from_numpy(packed[6 * a:6 * b].copy()).to(dev)).cpu().numpy().reshape(-1))
         act = int(rng.integers(0, 6))
         if act == 0 and use_ws:
