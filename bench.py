@@ -435,7 +435,36 @@ def arena_plan(free_bytes, in_bytes, out_bytes, ws_bytes, arena_gib):
 
 
 # ----------------------------------------------------------------------------------------
+def wall_budget(world, steps, warmup, log2n, arena_rest_s=3.0, settle_ms=250.0, verify_all=True, gather=True):
+    """What a run of this bench SHOULD take on the wall, by phase, in seconds -- so that the first real 8-GPU run has a
+    figure to be boring against (round 5 review, item 7).  Constants: a 2^28-sample step 0.31 ms, scaled with the batch;
+    process start with torch + RCCL 25 s (a fresh box pages the image in: up to 2 min more); an arena of 72 GiB allocates in
+    about 1 s; 582 probe launches; the every-output check of one 2^28-sample batch about 3 s of 128 threads, shared by
+    the ranks of a node; a gather step is bound by ONE xGMI link per peer (~153 GB/s nominal, 100 assumed here) for the
+    decimate-by-8 output, by the kernel for the /320 cascade; each gather leg runs 200 + W untimed and K timed steps."""
+    step = 0.31e-3 * 2.0 ** (log2n - 28)
+    out8 = 8.0 * 2.0 ** log2n / 8.0
+    b = {"start_import_rendezvous": 25.0, "arena_alloc_and_rest": 1.0 + arena_rest_s, "placement_probes": 582 * step + 0.2,
+         "settle_warmup_timed": settle_ms * 1e-3 + (8 + warmup + steps) * step,
+         "verify": (1.5 + (3.0 * world if verify_all else 0.3)) * 2.0 ** (log2n - 28)}
+    if gather and world > 1:
+        link = max(step, out8 / 100e9)
+        b["gather_leg_this_workload"] = (200 + warmup + steps) * link + 1.0
+        b["gather_leg_c320"] = (200 + warmup + steps) * max(step, out8 / 40 / 100e9) + 2.0
+    if world == 1:
+        b["cpu_baseline"] = 16.0
+    b["total"] = round(sum(b.values()), 1)
+    return {k: round(v, 2) for k, v in b.items()}
+
+
 def run_rank(a):
+    t_phase = [time.perf_counter()]
+    phases = {}
+
+    def phase(name):                      # wall seconds of the phase that just ended (this rank's host clock)
+        now = time.perf_counter()
+        phases[name] = round(phases.get(name, 0.0) + now - t_phase[0], 2)
+        t_phase[0] = now
     import numpy as np
     import torch
     pkg = importlib.import_module("libperseus-sdr_amd")
@@ -496,6 +525,7 @@ def run_rank(a):
     # time reported next to it.  --placement full scans every slot for three input places (1.5 s; what round 2 did).
     # A receiver allocates once and runs for hours; 288 GB of HBM make this affordable.
     placement = None
+    phase("setup")
     arena = None
     in_bytes, out_bytes = 6 * ns, out_rows * 8
     # a cascade's inter-stage buffers come from the arena too (pddc_pipeline_set_workspace): the fused pair of the
@@ -626,6 +656,7 @@ def run_rank(a):
     out = outbox[0]
     d_in = inbox[0]
 
+    phase("placement")
     # untimed settle: sustained-load clocks, not boost.  Eight calibration steps, then settle_ms worth of
     # launches queued back to back with NO host synchronisation in between (every idle gap, however short,
     # lets the power management raise the clock again for the next few milliseconds), running straight
@@ -737,9 +768,12 @@ def run_rank(a):
     if pipe is not None:
         pipe.check(stream)                              # a kernel-side failure flag (fused cascade) fails the run
 
+    phase("settle_warmup_timed")
     # ---- parity of what was just timed (outside the timed region, every rank its own stream)
     verified = None
     if not a.no_verify:
+        if world > 1:                                   # the checker's OpenMP team: this rank's share of the node's cores
+            os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // world)))
         from oracle import oracle as O
         if rank == 0:
             O.build()                                   # one rank (re)builds the checker, the others wait for it
@@ -786,6 +820,7 @@ def run_rank(a):
             verified = {"windows": len(starts), "window_outputs": 4096, "mismatching_words": bad, "ok": bad == 0,
                         "metric": "bit-exact vs the CPU oracle (examples/perseustest.c:466-502)"}
 
+    phase("verify")
     names = grp.all_gather_object(torch.cuda.get_device_name(dev))
     per_rank_ms = [float(v) * 1e3 / a.steps for v in grp.all_gather_object(dt)]
     oks = grp.all_gather_object(None if verified is None else bool(verified["ok"]))
@@ -871,12 +906,34 @@ def run_rank(a):
             at2 = (at + out_bytes + 255) & ~255
             spare = arena[at2:(bo + 1) * slot]                                   # the rest of that slot
         g = guarded_gather_legs(a, pkg, shard, grp, dev, stream, ns, d_in, wl, pipe, out, out2, spare)
+        phase("gather_legs")
         if res is not None:
             res["gather"] = g
+            # the three figures the 1 / 2 / 4 / 8-GPU question is about, side by side (round 5 review, item 7): the kernels
+            # alone (what `value` is: no data-path collective), and the same step with every rank's output landing on rank 0
+            tw, tc = g.get("this_workload") or {}, g.get("c320") or {}
+            res["scaling_legs"] = {
+                "kernel_only": {"value": res["value"], "unit": "MS/s", "ms_per_step": res["ms_per_step"]},
+                "with_gather_" + ("c320" if a.workload.startswith("c320") else "d8"): {
+                    "value": tw.get("value"), "unit": "MS/s", "ms_per_step": tw.get("ms_per_step"),
+                    "per_link_GBps": tw.get("per_link_GBps"),
+                    "expected": ("link-bound: every peer's %.0f MB per step cross ONE xGMI link to rank 0 (~153 GB/s nominal "
+                                 "each, SURVEY.md 8e)" % (tw.get("out_bytes_per_rank_per_step", 0) / 1e6)) if tw else None},
+                "with_gather_c320": ({"value": tc.get("value"), "unit": "MS/s", "ms_per_step": tc.get("ms_per_step"),
+                                      "per_link_GBps": tc.get("per_link_GBps"),
+                                      "expected": "kernel-bound: 6.7 MB per rank and step, the gather disappears under the next step's kernels"}
+                                     if tc else None)}
     elif res is not None and grp.comm_error and stages is not None and not a.no_gather:
         res["gather"] = {"skipped": "the gather is RCCL by definition and no communicator exists: " + grp.comm_error}
     if res is not None and world == 1 and not a.no_cpu:
         res["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_seconds)
+        phase("cpu_baseline")
+    if res is not None:
+        # rank 0's wall clock by phase beside what the phases should take (wall_budget): a first 8-GPU run that strays from
+        # its budget says where
+        res["phases_s"] = dict(phases, total=round(sum(phases.values()), 2))
+        res["wall_budget_s"] = wall_budget(world, a.steps, a.warmup, a.log2n, a.arena_rest_s, a.settle_ms,
+                                           not a.no_verify_all, grp.comm is not None and not a.no_gather)
     finish(grp, res)
 
 

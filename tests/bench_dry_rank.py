@@ -40,8 +40,10 @@ def run(a, bench):
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": wl["label"], "samples_per_gpu_per_step": ns},
-               "dry_run": "PDDC_BENCH_BACKEND=gloo: launcher/rendezvous plumbing test on CPU, the oracle stands in "
+               "dry_run": "launcher/rendezvous plumbing test on CPU (gloo), the oracle stands in "
                           "for the HIP pipeline, nothing is measured",
+               # what the REAL run of this shape (the driver's arguments, 2^28 samples a rank) should take on the wall
+               "wall_budget_s": bench.wall_budget(world, 20, 5, 28),
                "ranks_seen": world, "devices": hosts,
                "gather": {"this_workload": {"root_blocks_match_each_ranks_stream": ok}},
                "roofline": None, "cpu_baseline": None}

@@ -210,6 +210,12 @@ def test_eight_rank_dry_run_of_the_launcher():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["devices"] == [f"cpu:{r}" for r in range(8)]
     assert d["gather"]["this_workload"]["root_blocks_match_each_ranks_stream"] is True
+    # the wall-time budget of the real 8-GPU run (driver's arguments): every phase named, the whole well inside the few
+    # minutes the driver allows a bench -- the gather legs are the link-bound part (225 steps of 268 MB per link)
+    wb = d["wall_budget_s"]
+    assert set(wb) >= {"start_import_rendezvous", "arena_alloc_and_rest", "placement_probes", "settle_warmup_timed", "verify",
+                       "gather_leg_this_workload", "gather_leg_c320", "total"}
+    assert 1.0 < wb["gather_leg_this_workload"] < 10 and wb["total"] < 120 and abs(wb["total"] - sum(v for k, v in wb.items() if k != "total")) < 0.5
 
 
 def test_launcher_tears_the_other_ranks_down_when_one_dies(tmp_path):
