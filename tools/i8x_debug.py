@@ -34,6 +34,33 @@ for rep in range(15):
         if bad.size:
             ex = np.abs(y[bad, 0] - r[bad, 0]) > 1e-5
             ey = np.abs(y[bad, 1] - r[bad, 1]) > 1e-5
+            if os.environ.get("I8X_DEBUG_WHICH"):
+                # which operand did the wrong x take?  x = fma(-v, s, u c) with (u + j v) = ref / (c + j s), LO = c + j s = exp(-j theta)
+                m_abs = (pos + bad).astype(np.uint64)
+                ph = ((m_abs * np.uint64(8)) * np.uint64(FREG)) & np.uint64(0xFFFFFFFF)
+                th = 2.0 * np.pi * ph.astype(np.float64) / 4294967296.0
+                c, sn = np.cos(th), -np.sin(th)
+                z = (r[bad, 0].astype(np.float64) + 1j * r[bad, 1]) / (c + 1j * sn)
+                u, v = z.real, z.imag
+                xb = y[bad, 0].astype(np.float64)
+                cand = {"u*c (right)": -v * sn + u * c, "u*s": -v * sn + u * sn, "v*c": -v * sn + v * c, "v*s": -v * sn + v * sn,
+                        "0": -v * sn, "-v*s only, product = previous output's u*c": None}
+                # the same thread's previous output (o - 512 for NPT = 512) and next one
+                for name, val in cand.items():
+                    if val is not None:
+                        print(f"      x_bad == -v*s + {name:12s}: max |diff| {np.abs(xb - val).max():.3e}  median {np.median(np.abs(xb - val)):.3e}")
+                for d in (-512, 512, -1024, 1024):
+                    j = bad + d
+                    ok = (j >= 0) & (j < r.shape[0])
+                    if ok.all():
+                        mj = (pos + j).astype(np.uint64)
+                        phj = ((mj * np.uint64(8)) * np.uint64(FREG)) & np.uint64(0xFFFFFFFF)
+                        thj = 2.0 * np.pi * phj.astype(np.float64) / 4294967296.0
+                        cj, sj = np.cos(thj), -np.sin(thj)
+                        zj = (r[j, 0].astype(np.float64) + 1j * r[j, 1]) / (cj + 1j * sj)
+                        for nm, val in ((f"u[{d:+d}]*c[{d:+d}]", zj.real * cj), (f"u*c[{d:+d}]", u * cj), (f"u[{d:+d}]*c", zj.real * c),
+                                        (f"u*s[{d:+d}]", u * sj)):
+                            print(f"      x_bad == -v*s + {nm:16s}: median |diff| {np.median(np.abs(xb - (-v * sn + val))):.3e}")
             print(f"   x only {int((ex & ~ey).sum())}, y only {int((~ex & ey).sum())}, both {int((ex & ey).sum())}; lanes {np.unique(bad % 64)[:70].tolist()}; o>>6 {np.unique((bad % 1024) >> 6).tolist()}")
             tiles = np.unique(bad // 1024)
             for tl in tiles[:0]:
