@@ -795,6 +795,11 @@ def run_rank(a):
                                           sched)
             verified["n_outputs_ok"] = bool(n_last == verified["n_outputs"])
             verified["ok"] = bool(verified["ok"] and verified["n_outputs_ok"])
+            # what this parity is parity WITH: the unpack is pinned to the reference bit for bit; the NCO mix and
+            # the FIR have no reference arithmetic (they live in FPGA bitstreams) -- the oracle is this repository's definition
+            verified["pinned"] = ("unpack: bit-exact against the reference's compiled callbacks (tests/test_reference_client.py); "
+                                  "NCO + FIR: UNPINNED -- no reference arithmetic exists, the double oracle (cross-checked against "
+                                  "scipy.signal.upfirdn to 1e-12) is the definition")
             # ... and EVERY output of that step (oracle/perseus_oracle.c orc_chain_check: chunks with their halos on the host's
             # cores; 2^28 samples take a couple of seconds on 128 threads): sparse lane-level damage is what windows miss
             if not a.no_verify_all and (os.cpu_count() or 1) >= 16 and all(len(st) < 3 or not st[2] or int(st[2]) <= 1

@@ -1,11 +1,11 @@
 #!/bin/bash
 # The measurement pass of a round, one script (rounds 2-4 each had their own rNN_final.sh / collect_rNN.sh):
-#   on the GPU box:   gpurun --timeout 2400 -- bash tools/evidence.sh run r05      -> gpurun_out/r05_final/
-#   here, afterwards: bash tools/evidence.sh collect r05                           -> profiles/r05/, profiles/pmc_traffic.json
+#   on the GPU box:   gpurun --timeout 2400 -- bash tools/evidence.sh run r06      -> gpurun_out/r05_final/
+#   here, afterwards: bash tools/evidence.sh collect r06                           -> profiles/r05/, profiles/pmc_traffic.json
 # The kernels must not change after `run`: profiles/pmc_traffic.json records the SHA-256 of the kernel sources it was
 # measured on and bench.py refuses the traffic figure for any other source.
 set -u
-MODE=${1:-run}; R=${2:-r05}
+MODE=${1:-run}; R=${2:-r06}
 F=gpurun_out/${R}_final; P=profiles/$R
 line() { python3 - "$1" "$2" <<'PY'
 import json, sys
@@ -37,6 +37,9 @@ if [ "$MODE" = run ]; then
   bash tools/trace_gaps.sh d8_127 $F/trace_d8_127 --steps 200 --warmup 5 > $F/trace_d8_127.txt 2>&1
   cp $(find $F/trace_d8_127/prof -name "*kernel_stats.csv" | head -1) $F/kernel_stats_d8_127.csv 2>/dev/null
   bash tools/trace_gaps.sh c320 $F/trace_c320 --steps 200 --warmup 5 > $F/trace_c320.txt 2>&1
+  # (round 6) the pair's kernel under its walks with the write side in four arena slots, the config-5 sweep on the shipped kernels
+  python tools/walk_probe.py pair > $F/walk_probe_pair.txt 2>&1
+  python tools/sweep_config5.py --out $F/sweep_config5.json > $F/sweep_config5.txt 2>&1
   # 5. every first-stage form on this box, the ten rate plans, the C hosts
   python tools/state_2p28.py > $F/state_2p28.txt 2>&1
   python tools/plan_rates.py --log2n 28 > $F/plan_rates.txt 2>&1
@@ -67,6 +70,8 @@ d["provenance"]["commit"] = head + (" + uncommitted changes under csrc/ (committ
 json.dump(d, open("profiles/pmc_traffic.json", "w"), indent=1)
 PY
   cp profiles/pmc_traffic.json $P/z_pmc_traffic_all_workloads.json
+  [ -f $F/sweep_config5.json ] && cp $F/sweep_config5.json $P/sweep_config5.json && grep -v amdgpu.ids $F/sweep_config5.txt > $P/sweep_config5.txt
+  [ -f $F/walk_probe_pair.txt ] && grep -v amdgpu.ids $F/walk_probe_pair.txt > $P/z_walk_probe_pair.txt
   for t in state_2p28 plan_rates plan_rates_overlap api_receivers; do [ -f $F/$t.txt ] && grep -v amdgpu.ids $F/$t.txt > $P/z_$t.txt; done
   for t in d8_127 d8_127_nco d8_255_nco; do [ -f $F/pmc_i8x_$t/pmc_summary.txt ] && cp $F/pmc_i8x_$t/pmc_summary.txt $P/z_pmc_summary_i8x_$t.txt; done
   for w in d8_127 c320; do
