@@ -236,7 +236,7 @@ int pddc_fir_i8x_taps2(const float *taps2, int ntaps2, int mix, uint32_t freg, f
  * PDDC_ESTATE while overlap mode holds a tail back (fence first), PDDC_EINVAL for an unknown name.                  */
 int pddc_pipeline_set_option(pddc_pipeline *p, const char *name, int value);
 /* Process-wide development knobs of the launchers (tile schedule of k_fir8, block shapes, gang plumbing): "fir8_dyn_pct",
- * "fir8_chunk", "gen_shape_nt", "gen_shape_p", "no_firp", "firp_packed_p", "unpack_blocks", "debug", "push_three_streams",
+ * "fir8_chunk", "fir8_walk" (1: chunks handed round the blocks, 0: static runs + dynamic tail, -1: the launcher's default), "gen_shape_nt", "gen_shape_p", "no_firp", "firp_packed_p", "unpack_blocks", "debug", "push_three_streams",
  * "gang_copy_out", "gang_gen_inline", "gang_solo".  Their PDDC_<NAME> environment variables are read once, at first use;
  * no library call on the data path looks at the environment.                                                         */
 int pddc_set_tunable(const char *name, int value);
