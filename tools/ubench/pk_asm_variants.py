@@ -18,6 +18,8 @@ hipcc's own pipeline (cc1as, lld, clang-offload-bundler, the host object's .hip_
     pad_vgpr_<n>  no instruction changed: the clean two-k-step kernel (48 taps) given n VGPRs (the failing kernel has 155); run with
               `python tools/i8x_debug.py 48 1`
     as_fma    the multiply as v_pk_fma_f32 .., 0 with the same op_sel on src1
+    vmcnt0_before  `s_waitcnt vmcnt(0)` in front of the multiply: the wave's own global loads (the next tile's, issued just
+              before the finishing code) have all returned -- is a load's register write part of it?
     mfma_zero_reg  the packed code untouched; the MATRIX waves' accumulation-starting instructions read their zero from four
               registers instead of the inline constant 0 (the wrong product is exactly 0.0: does the neighbour's constant leak?)
 usage: python tools/ubench/pk_asm_variants.py build       (here, no GPU)   -> libperseus-sdr_amd/ab_<variant>.so
@@ -100,6 +102,8 @@ def edit(lines, variant):
         elif variant == "as_fma":               # the same product as a packed FMA with a zero addend: is it the multiply, or VOP3P's src1?
             seg[0:1] = [f"\tv_pk_fma_f32 v[{m.group(1)}:{m.group(2)}], v[{m.group(3)}:{m.group(4)}], v[{m.group(5)}:{m.group(6)}], 0 "
                         f"op_sel:[0,1,0] op_sel_hi:[0,0,0]"]
+        elif variant == "vmcnt0_before":        # no global load of this wave in flight while the multiply reads its operands
+            seg = ["\ts_waitcnt vmcnt(0)"] + seg
         elif variant == "nop_before":           # idle cycles between the VALU instructions that make c and s and the multiply
             seg = ["\ts_nop 3"] + seg
         out += seg
