@@ -164,6 +164,8 @@ EVERY = {
     "c320_2p28_static_walk":     (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(250000)], True, 28, {}, False, {"fir8_walk": 0}),
     "c320_2p28_round_robin":     (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(250000)], True, 28, {}, False,
                                   {"fir8_walk": 1, "fir8_dyn_pct": 10}),
+    "pair_48_56_taps_2p27_round_robin": (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(500000)][:2], True, 27, {"no_i8": 1}, False,
+                                         {"fir8_walk": 1}),          # eight tap blocks in the first stage: porch of 72 groups, bursts of 12 tiles
     "vector_127_2p27":           (lambda pkg: [(8, _taps("d8_127"))], True, 27, {"no_i8": 1}, False, {}),
     "d10_plan_1M6_2p27":         (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(1600000)], True, 27, {}, False, {}),
 }

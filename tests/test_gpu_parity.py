@@ -539,19 +539,29 @@ def test_long_tile_runs_per_block_all_variants(pkg, dev, O, monkeypatch):
             pipe.close()
 
 
-@pytest.mark.parametrize("dyn,chunk", [("100", "1"), ("100", "3"), ("60", "2"), ("0", "5"), ("100", "64")])
-def test_tile_scheduler_variants(pkg, dev, O, monkeypatch, tune, dyn, chunk):
+@pytest.mark.parametrize("dyn,chunk,walk", [("100", "1", 0), ("100", "3", 0), ("60", "2", 0), ("0", "5", 0), ("100", "64", 0),
+                                            ("0", "1", 1), ("0", "3", 1), ("40", "2", 1), ("-1", "0", 1), ("0", "64", 1), ("100", "4", 1)])
+def test_tile_scheduler_variants(pkg, dev, O, monkeypatch, tune, dyn, chunk, walk):
     """k_fir8 hands part of the tiles out dynamically (atomic chunk counter, the
-    history of a chunk's first tile re-read from global memory, a warm-up tile for
-    the fused pair).  Every schedule must give the same stream: all-dynamic with
+    history of a chunk's first tile re-read from global memory; the fused pair's
+    chunks start with a porch: the second stage's history computed from the 544
+    samples in front).  Every schedule must give the same stream: all-dynamic with
     single-tile chunks, odd chunk sizes, mostly static, one chunk larger than the
-    batch; several launches in a row check that the counters are left at zero."""
+    batch -- and the round-robin walk (chunk j -> block j mod nblocks, fir8_walk 1)
+    with single-tile chunks, odd chunks, a dynamic tail, its default chunk, chunks
+    larger than the batch, everything from the counter; the pair also with a 48-tap
+    first stage (eight tap blocks: a porch of 72 groups, bursts of 12 tiles);
+    several launches in a row check that the counters are left at zero."""
     tune("fir8_dyn_pct", int(dyn))
     tune("fir8_chunk", int(chunk))
+    tune("fir8_walk", walk)
     monkeypatch.setenv("PDDC_FIR8_BLOCKS", "5")
     h1, h2 = load_taps("c320_s1_d8_32"), load_taps("c320_s2_d8_64")
+    k48 = np.arange(48) - 23.5
+    h48 = np.sinc(0.1 * k48) * np.hamming(48)
+    h48 = (h48 / h48.sum()).astype(np.float32)
     for stages, mix, R in (([(8, load_taps("d8_127"))], False, "4"), ([(8, load_taps("d8_255"))], True, "8"),
-                           ([(8, h1), (8, h2)], True, "4"), ([(8, h1), (8, h2)], False, "8")):
+                           ([(8, h1), (8, h2)], True, "4"), ([(8, h1), (8, h2)], False, "8"), ([(8, h48), (8, h2)], True, "4")):
         monkeypatch.setenv("PDDC_FIR8_R", R)
         tile = 1024 * int(R)
         cuts = [0, 23 * tile, 23 * tile + 2 * tile, 60 * tile + (0 if len(stages) == 2 else 8 * 41)]
