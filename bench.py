@@ -1071,9 +1071,9 @@ def run_api250k(a):
     res = {
         "metric": BASELINE_METRIC, "value": round(ns / ms / 1e3, 1), "unit": "MS/s", "n_gpus": 1, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        # (the pair of the 250 kS/s plan runs on the matrix-core kernel for whole-tile batches up to 2^26 samples -- the
+        # (the pair of the 250 kS/s plan runs on the matrix-core kernel for whole-tile batches up to 2^25 samples -- the
         # pipeline's i8x_pair_max_log2 -- and on the vector pair above)
-        "dtype": "i8xi8->i32, f32 out" if (ns <= (1 << 26) and ns % 8192 == 0) else "f32", "data": "synthetic",
+        "dtype": "i8xi8->i32, f32 out" if (ns <= (1 << 25) and ns % 8192 == 0) else "f32", "data": "synthetic",
         "config": {"workload": "drop-in API: perseus_init/open/firmware_download/set_sampling_rate(250000)/set_ddc_center_freq(7.1 MHz)/"
                                "start_async_input(12288 B, C callback) in libperseus-sdr_amd/perseus_plumbing; on-device LCG source, unpaced, "
                                "float32 buffers (mode ddc)",

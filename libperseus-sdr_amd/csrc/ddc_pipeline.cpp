@@ -183,8 +183,9 @@ struct pddc_pipeline {
         int i8x_layout = -1;      /* which waves finish a tile (ddc_fir_i8.hip "Who does what"): 0 the matrix waves, 1 the
                                      loaders, 2 two matrix + two finishing waves; -1: by form (0 without the NCO and for
                                      tuned stages up to 128 taps, 1 for 129..256 tuned taps and for the fused pair)      */
-        int i8x_pair_max_log2 = 26;   /* the fused pair up to 2^26-sample batches: 3.6x k_fir8's pair at 2^22, 1.8x at
-                                         2^24, level at 2^26 and 2^28 -- where k_fir8 carries the tail (profiles/r04)   */
+        int i8x_pair_max_log2 = 25;   /* the fused pair on the matrix cores up to 2^25-sample batches: 3.6x k_fir8's pair at 2^22, 1.6x at
+                                       * 2^24, 1.14x at 2^25; at 2^26 k_fir8's pair -- bursts, porch, round 6 -- is 8-10 % ahead (83 against
+                                       * 92 us, profiles/r06/f_pair_crossover.txt), at 2^28 7 % and carries the tail in its launch */
         int no_fuse2 = 0, fuse3 = 0;
     } opt;
     /* k_fir_i8x's operands follow the tuning word: they are rebuilt on the host when the word, the taps or the form
@@ -806,7 +807,7 @@ int pddc_pipeline_create(pddc_pipeline **out, int device, const pddc_stage_desc 
         p->opt.i8x_blocks = env_int("PDDC_I8X_BLOCKS", 0);
         p->opt.i8x_chunk = env_int("PDDC_I8X_CHUNK", 0);
         p->opt.i8x_layout = env_int("PDDC_I8X_LAYOUT", -1);
-        p->opt.i8x_pair_max_log2 = env_int("PDDC_I8X_PAIR_MAX_LOG2", 26);
+        p->opt.i8x_pair_max_log2 = env_int("PDDC_I8X_PAIR_MAX_LOG2", 25);
         p->opt.no_fuse2 = getenv("PDDC_NO_FUSE2") ? 1 : 0;
         p->opt.fuse3 = env_int("PDDC_FUSE3", 0);
     }

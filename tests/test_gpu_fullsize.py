@@ -131,6 +131,8 @@ def test_tuned_matrix_core_stages_at_full_size(pkg, O, dev, case):
     d_in = pkg.synth_lcg(6 * ns, 12345, 0, dev)
     pipe = pkg.Pipeline(stages, mix=True)
     pipe.set_freg(wl["freg"])
+    if case == "pair_2p26":                  # (the default hands 2^26-sample batches to the vector pair since round 6)
+        pipe.set_option("i8x_pair_max_log2", 26)
     assert pipe.on_i8(ns) == 2 and pipe.fused_pair(ns) == (2 if case == "pair_2p26" else 0)
     out = torch.empty((pipe.max_output(ns) + 8, 2), dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
@@ -159,7 +161,9 @@ EVERY = {
     "d8_255_binary16_taps_2p28": (lambda pkg: [(8, _taps("d8_255"))], False, 28, {}, True, {}),
     "tuned_127_2p27":            (lambda pkg: [(8, _taps("d8_127"))], True, 27, {}, False, {}),
     "tuned_255_2p26":            (lambda pkg: [(8, _taps("d8_255"))], True, 26, {}, False, {}),
-    "i8x_pair_c320_2p26":        (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(250000)], True, 26, {}, False, {}),
+    "i8x_pair_c320_2p25":        (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(250000)], True, 25, {}, False, {}),
+    "i8x_pair_c320_2p26_opt_in": (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(250000)], True, 26, {"i8x_pair_max_log2": 26}, False, {}),
+    "vector_pair_c320_2p26":     (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(250000)], True, 26, {}, False, {}),
     "c320_2p28":                 (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(250000)], True, 28, {}, False, {}),
     "c320_2p28_static_walk":     (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(250000)], True, 28, {}, False, {"fir8_walk": 0}),
     "c320_2p28_round_robin":     (lambda pkg: [(d, t) for d, t, _l in pkg.api_plan(250000)], True, 28, {}, False,
@@ -210,7 +214,7 @@ def test_every_output_at_bench_size(pkg, O, dev, tune, case):
         assert kinds[0] == 2, kinds                        # the matrix-core kernel
     if case.startswith("i8x_pair"):
         assert kinds == (2, 2), kinds
-    if case.startswith("c320_2p28"):
+    if case.startswith(("c320_2p28", "vector_pair")):
         assert kinds[1] == 1, kinds                        # the vector pair
     packed = d_in.cpu().numpy()
     got = out[:n].cpu().numpy()
