@@ -1117,8 +1117,16 @@ __device__ __forceinline__ void fir_window_tap_outer(const float *base, const fl
  *                 equal static shares one block finished 15-25 % before its
  *                 neighbour, which then ran alone and badly overlapped); the
  *                 dynamic tail lets them finish together.
+ *   round robin : (S < 0, round 6; the fused pair's default from 2^27 samples on) no
+ *                 static runs: the batch is chunks of K tiles, chunk j goes to block
+ *                 j mod nblk for the first JD = -S chunks and comes from the counter
+ *                 after that -- all blocks read and write ONE window of the batch,
+ *                 which is what the pair's small write stream wants (fir8_block.inc
+ *                 "store_tile2", NOTEBOOK R6.1).
  * The first tile of a chunk takes its history from global memory (the previous
- * 8*NTB input samples, or p.hist for tile 0), prefetched with the tile itself.
+ * 8*NTB input samples, or p.hist for tile 0), prefetched with the tile itself --
+ * fused pair: with them the PORCH, the 8*NTB2 sample groups whose first-stage
+ * outputs are the second stage's history.
  * The counter is taken one tile ahead (thread 0, published through LDS) so its
  * latency is never waited for, and the last block to leave resets it.
  *

@@ -24,6 +24,8 @@ for rep in range(15):
     pipe = pkg.Pipeline([(8, h)], mix=True)
     pipe.set_option("i8x_layout", layout)
     pipe.set_option("i8x_chunk", chunk)
+    if os.environ.get("I8X_BLOCKS"):                     # a smaller persistent grid: fewer CUs busy, the chip off its power cap
+        pipe.set_option("i8x_blocks", int(os.environ["I8X_BLOCKS"]))
     pipe.set_freg(FREG)
     pos = 0
     for a, b in zip(cuts[:-1], cuts[1:]):
