@@ -27,6 +27,9 @@ for it in range(n_iter):
     chunk_k = int(rng.choice([1, 2, 3, 4, 8])) if dyn >= 0 else 0
     pkg.set_tunable("fir8_dyn_pct", dyn)                      # (process-wide launcher knobs: API state, not environment)
     pkg.set_tunable("fir8_chunk", chunk_k)
+    # the walk (round 6), drawn from a generator of its own so that the other draws stay those of the earlier runs:
+    # the launcher's default / static runs + dynamic tail / chunks handed round the blocks
+    pkg.set_tunable("fir8_walk", int(np.random.default_rng(11000 + it).choice([-1, 0, 1, 1])))
     os.environ["PDDC_FIR8_DYN_PCT"], os.environ["PDDC_FIR8_CHUNK"] = str(dyn), str(chunk_k)   # (for the report line below)
     os.environ["PDDC_FIR8_R"] = str(int(rng.choice([4, 8])))
     mix = bool(rng.integers(0, 2))
