@@ -104,6 +104,8 @@ def edit(lines, variant):
                         f"op_sel:[0,1,0] op_sel_hi:[0,0,0]"]
         elif variant == "vmcnt0_before":        # no global load of this wave in flight while the multiply reads its operands
             seg = ["\ts_waitcnt vmcnt(0)"] + seg
+        elif variant == "nop15_before":         # sixteen idle cycles: a quarter-rate v_mul_lo_u32 three instructions up has drained
+            seg = ["\ts_nop 15"] + seg
         elif variant == "nop_before":           # idle cycles between the VALU instructions that make c and s and the multiply
             seg = ["\ts_nop 3"] + seg
         out += seg
