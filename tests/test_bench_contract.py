@@ -188,6 +188,12 @@ def test_bench_line_end_to_end_on_the_gpu():
     assert rf["traffic"] is None and rf["traffic_source"]        # the offline PMC figure is for 2^28 launches only
     v = d["verified"]
     assert v["ok"] is True and v["windows"] >= 20 and v["max_rel_err"] <= 1e-6 and "max|y-ref|" in v["metric"]
+    # every output of the last timed step, not only windows (hosts with 16 cores or more), and what the parity is pinned to
+    if (os.cpu_count() or 1) >= 16:
+        ev = v["every_output"]
+        assert ev["ok"] is True and ev["compared"] == v["n_outputs"] == (1 << 24) // 8 and ev["bad"] == 0 and ev["max_rel_err"] <= 1e-6
+    assert "UNPINNED" in v["pinned"] and "bit-exact" in v["pinned"]
+    assert d["cpu_baseline"]["single_thread"]["cores"] == 1 and d["phases_s"]["total"] > 0 and d["wall_budget_s"]["total"] > 0
     assert d["config"]["taps"].startswith("fp32")          # (fp32 values; on the int8 kernel: as four digit planes)
     # placement by the rule: a handful of probed pairs, the first-come time next to the chosen one (2^24-sample launches
     # live in the last-level cache, so there may be nothing to choose -- then no search is made at all)
