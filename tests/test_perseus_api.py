@@ -298,6 +298,21 @@ def test_plan_for_a_rate_without_touching_open_receivers(L, pkg):
         assert len(pkg.api_plan(r)) >= 2
 
 
+@pytest.mark.parametrize("value,want", [("262144", 1 << 18), ("262150", 262144), ("7", 1 << 24), ("0", 1 << 24), ("-5", 1 << 24),
+                                         (str((1 << 28) + 8), 1 << 24), ("junk", 1 << 24)])
+def test_batch_size_from_the_environment_is_bounded(L, pkg, monkeypatch, value, want):
+    """PERSEUS_AMD_BATCH (read when a descriptor is opened): a value in 8 .. PERSEUS_AMD_BATCH_MAX is the client's choice,
+    rounded down to a multiple of 8; anything else -- zero, negative, below 8, above 2^28 (a 1.6 GB pinned buffer), not a
+    number -- is ignored and the library picks (round 5 advisor)."""
+    monkeypatch.setenv("PERSEUS_AMD_BATCH", value)
+    d = bring_up(L, 250000)
+    cfg = pkg.AmdConfig()
+    assert L.perseus_amd_get_config(d, C.byref(cfg)) == 0
+    cfg.mode, cfg.pace = 1, 0
+    assert L.perseus_amd_set_config(d, C.byref(cfg)) == 0
+    assert L.perseus_amd_effective_batch(d) == want
+
+
 def test_batch_size_choice_is_the_clients_or_the_librarys_per_stream(L, pkg):
     """The GPU batch size: the library's pick per stream (2^24 for a free-running on-device source, 2^22 otherwise) unless
     the client chose one -- and a stream's effective size never becomes the configuration (advisor, round 4: after one
