@@ -117,6 +117,9 @@ __global__ __launch_bounds__(768, 1) void k(const uint4 *__restrict__ in, unsign
             }
             // the product's registers, by name (v[40:41] = (u, v) from LDS, v[78:79] = (s, c), v[96:97] = the products)
             float plo, phi, u, e_lo, e_hi;
+            // (a sweep of the multiply's issue time against the matrix waves' instruction stream: 0 .. 31 idle cycles, by tile)
+            for (int d = (t + 5 * o4) & 31; d > 0; --d)
+                asm volatile("s_nop 0");
             asm volatile("v_mov_b32 v78, %3\n\tv_mov_b32 v79, %4\n\t"
                          "ds_read2st64_b32 v[40:41], %5 offset1:20\n\t"
                          "s_waitcnt lgkmcnt(0)\n\t"
